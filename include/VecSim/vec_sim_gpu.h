@@ -1,0 +1,53 @@
+/*
+ * VecSim/vec_sim_gpu.h -- additions to the reference C API that the GPU back end needs.
+ *
+ * Nothing in the reference can express more than one query per call (the Python binding loops
+ * single queries, src/python_bindings/bindings.cpp:182-190), and one query cannot fill an MI355X:
+ * the batched entry point below is the only new *query* call.  The rest is ingest/measurement
+ * plumbing.  Existing structs keep their layout; all knobs come through these calls or the
+ * VECSIM_GPU_* environment variables.
+ */
+#pragma once
+#include "vec_sim.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nq queries, `queryStride` bytes apart (>= VecSimParams_GetQueryBlobSize).  replies[i] receives
+ * exactly what VecSimIndex_TopKQuery(index, query_i, k, queryParams, order) would return.
+ * Returns 0, or non-zero after a GPU failure (replies untouched). */
+int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                               size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                               VecSimQueryReply **replies);
+
+/* n new vectors at once; labels[i] must not exist yet (returns the number added, -1 on error) */
+long VecSimIndex_AddVectorsBulk(VecSimIndex *index, const void *blobs, const size_t *labels, size_t n);
+
+/* append n synthetic fp32 rows generated on the device (labels = internal ids); element j of row i
+ * is synth(seed, i*dim + j) in U[-1,1), reproducible on the host (oracle/vso.c:vso_synth_f32) */
+long VecSimIndex_AddSyntheticVectors(VecSimIndex *index, size_t n, uint64_t seed);
+
+/* device selection for indexes created afterwards on this thread/process (default: $VECSIM_GPU_DEVICE or 0) */
+int VecSimGpu_SetDevice(int device);
+int VecSimGpu_DeviceCount(void);
+const char *VecSimGpu_LastError(void);
+
+/* HIP-event timing of the dominant scan kernel since the last reset (bench.py roofline leg) */
+typedef struct {
+    double scan_ms;
+    uint64_t scan_launches;
+    uint64_t scan_rows;
+    uint64_t scan_bytes;
+    double other_ms;
+    uint64_t candidates;
+    uint64_t fallbacks;
+    char scan_kernel[64];
+} VecSimGpuStats;
+void VecSimGpu_ResetStats(VecSimIndex *index);
+void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out);
+int VecSimGpu_SetOption(VecSimIndex *index, const char *name, long value);
+
+#ifdef __cplusplus
+}
+#endif

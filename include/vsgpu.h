@@ -1,0 +1,111 @@
+/*
+ * vsgpu.h -- the thin C-ABI shim between the C++ host index code and the HIP (gfx950) kernels.
+ *
+ * Everything that touches the GPU goes through these entry points: plain pointers, sizes and POD
+ * structs only -- no C++ types, no torch types.  The host library (libvecsim_amd.so, C API in
+ * VecSim/vec_sim.h) is the only in-tree caller; a reference maintainer would bind the same entry
+ * points from DistanceCalculatorCommon / BruteForceIndex.
+ *
+ * What each group replaces in the reference (paths relative to src/VecSim/):
+ *   table_*      the device mirror of DataBlocksContainer          containers/data_blocks_container.h:18-47,
+ *                (rows packed `row_bytes` apart, ids dense [0,n))   containers/data_block.cpp:13-36
+ *   topk         BruteForceIndex::topKQuery's scan + score filter   algorithms/brute_force/brute_force.h:242-291
+ *   range        BruteForceIndex::rangeQuery's scan                 brute_force.h:293-326
+ *   scores       BFS_BatchIterator::calculateScores / calcDistance  brute_force/bfs_batch_iterator.h:24-41,
+ *                                                                   vec_sim_index.h:175-190
+ * The arithmetic of every distance is the reference's AVX-512 tier (or its scalar tier below the
+ * choosers' minimum dims): spaces/L2_space.cpp:185-516, spaces/IP_space.cpp:435-889.
+ */
+#ifndef VSGPU_H
+#define VSGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types / metrics: numeric values equal VecSimType / VecSimMetric (vec_sim_common.h:60-69,87) */
+enum { VSGPU_F32 = 0, VSGPU_F64 = 1, VSGPU_BF16 = 2, VSGPU_F16 = 3, VSGPU_I8 = 4, VSGPU_U8 = 5 };
+enum { VSGPU_L2 = 0, VSGPU_IP = 1, VSGPU_COSINE = 2 };
+/* which reference ISA tier's summation order the kernels reproduce */
+enum { VSGPU_TIER_AVX512 = 0, VSGPU_TIER_SCALAR = 1, VSGPU_TIER_AVX512_BF16 = 2 };
+
+enum {
+    VSGPU_OK = 0,
+    VSGPU_ERR_NO_DEVICE = 1,   /* no HIP device / runtime failure: the product never falls back to CPU */
+    VSGPU_ERR_HIP = 2,
+    VSGPU_ERR_ARG = 3,
+    VSGPU_ERR_UNSUPPORTED = 4,
+    VSGPU_ERR_OOM = 5
+};
+
+typedef struct vsgpu_ctx vsgpu_ctx;     /* one per (process, device): stream, scratch, timers */
+typedef struct vsgpu_table vsgpu_table; /* device-resident rows of one Flat index */
+
+/* ---- runtime ---- */
+int vsgpu_device_count(void);                 /* 0 when no GPU is visible */
+const char *vsgpu_last_error(void);           /* thread-local message of the last failure */
+vsgpu_ctx *vsgpu_ctx_create(int device);      /* NULL on failure (see vsgpu_last_error) */
+void vsgpu_ctx_destroy(vsgpu_ctx *ctx);
+int vsgpu_ctx_device(const vsgpu_ctx *ctx);
+int vsgpu_ctx_sync(vsgpu_ctx *ctx);
+
+/* ---- device table (mirror of DataBlocksContainer) ---- */
+/* row_bytes = storedDataSize (dim*sizeof(T), +4 for int8/uint8 Cosine: utils/vec_utils.cpp:296-302).
+ * `metric` here is the *kernel* metric: fp Cosine indexes pass VSGPU_IP (spaces.cpp:27-30,53-56). */
+vsgpu_table *vsgpu_table_create(vsgpu_ctx *ctx, int type, int metric, int tier, size_t dim,
+                                size_t row_bytes);
+void vsgpu_table_destroy(vsgpu_table *t);
+size_t vsgpu_table_size(const vsgpu_table *t);
+size_t vsgpu_table_bytes(const vsgpu_table *t);          /* device bytes held */
+int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t n);  /* ids n_old .. n_old+n-1 */
+int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row);   /* updateElement */
+int vsgpu_table_move(vsgpu_table *t, size_t dst_id, size_t src_id);       /* swap-delete copy */
+int vsgpu_table_truncate(vsgpu_table *t, size_t new_size);
+int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row);          /* getElement */
+/* append n synthetic rows generated on the device: element j of row i is
+ * synth(seed, (first_id+i)*dim + j), bit-identical to oracle/vso.c:vso_synth_f32 (fp32 only) */
+int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed);
+
+/* ---- queries ----
+ * `queries`: nq preprocessed query blobs, `qstride` bytes apart, on the HOST (borrowed for the call).
+ *
+ * vsgpu_topk: for every query returns every row whose score <= T_q, T_q = the k-th smallest exact
+ * score over the table (all rows when size < k), ascending by internal id, with the exact
+ * (reference-order) score widened to double.  That set is what the sequential heap of
+ * brute_force.h:264-281 needs to reproduce the reference result.
+ *   ids/scores: [nq][cap]; counts[q] = number written, or VSGPU_COUNT_OVERFLOW when more than cap
+ *   rows tie at or below T_q (caller then uses vsgpu_scores for that query). */
+#define VSGPU_COUNT_OVERFLOW 0xFFFFFFFFu
+int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k,
+               size_t cap, uint32_t *ids, double *scores, uint32_t *counts);
+/* rows with score <= radius, ascending id (brute_force.h:305-318). Same overflow convention. */
+int vsgpu_range(vsgpu_table *t, const void *query, double radius, size_t cap, uint32_t *ids,
+                double *scores, uint32_t *count);
+/* dense exact scores of rows [first, first+n) against one query */
+int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, size_t n, double *scores);
+/* exact scores of an explicit list of rows against one query (getDistanceFrom / ad-hoc BF) */
+int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t *ids, size_t n,
+                    double *scores);
+
+/* ---- measurement hooks (bench.py roofline leg) ----
+ * HIP-event time of the dominant scan kernel, accumulated per ctx on the stream it runs on. */
+typedef struct {
+    double scan_ms;        /* sum of scan-kernel durations since the last reset */
+    uint64_t scan_launches;
+    uint64_t scan_rows;    /* rows streamed by those launches */
+    uint64_t scan_bytes;   /* rows * row_bytes (the algorithmic bytes of SURVEY.md §8d) */
+    double other_ms;       /* probe + select + rerank kernels */
+    uint64_t candidates;   /* candidate pairs that reached the exact re-rank */
+    uint64_t fallbacks;    /* queries answered through the dense fallback */
+    char scan_kernel[64];  /* name of the kernel timed as "scan" */
+} vsgpu_stats;
+void vsgpu_stats_reset(vsgpu_ctx *ctx);
+void vsgpu_stats_get(vsgpu_ctx *ctx, vsgpu_stats *out);
+/* knobs: "mfma" (0/1: allow the MFMA filter stage), "dense_pairs", "probe_div", "cand_cap" */
+int vsgpu_set_option(vsgpu_ctx *ctx, const char *name, long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+/*
+ * vso.h -- CPU ORACLE for the VecSim distance-kernel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call it, and only as
+ * the checker.  The product (vectorsimilarity_amd/) never links or imports it.
+ *
+ * What it restates (reference = RedisAI/VectorSimilarity, paths relative to src/VecSim/):
+ *   - scalar kernels              spaces/L2/L2.cpp:76-174, spaces/IP/IP.cpp:185-286
+ *   - AVX-512 tier kernels        spaces/L2/L2_AVX512F_FP32.h:21-59, IP/IP_AVX512F_FP32.h:19-56,
+ *                                 L2/L2_AVX512F_FP64.h:21-59 (+IP twin), L2|IP/..._AVX512F_FP16.h,
+ *                                 L2/L2_AVX512BW_VBMI2_BF16.h:40-78, IP/IP_AVX512BW_VBMI2_BF16.h,
+ *                                 IP/IP_AVX512_BF16_VL_BF16.h:14-47, ..._VNNI_INT8.h / _UINT8.h
+ *   - tier choice                 spaces/L2_space.cpp:185-516, spaces/IP_space.cpp:435-889
+ *   - normalisation               spaces/normalize/normalize_naive.h:24-88, compute_norm.h:18-31
+ *   - bf16 / fp16 conversions     types/bfloat16.h:23-39, types/float16.h:33-117
+ *   - Flat top-K / range scans    algorithms/brute_force/brute_force.h:242-326
+ *
+ * Parity pin: checked against the reference's own known-answer tests (tests/unit/test_spaces.cpp,
+ * test_bruteforce.cpp, test_int8.cpp ... restated as data in tests/golden/) by tests/test_oracle*.py.
+ * The reference itself cannot be compiled in the build image without writing stand-in headers for
+ * the un-vendored cpu_features dependency (every kernel header includes it through
+ * spaces/space_includes.h:13-16), so there is no oracle/_ref; the "AVX-512 order" variants are
+ * restated from the source lines above and cross-checked against an independent AVX-512
+ * intrinsics implementation of the same published algorithm (vso_fast.c) on the host CPU.
+ */
+#ifndef VSO_H
+#define VSO_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* numeric values match VecSimType / VecSimMetric (vec_sim_common.h:60-69,87) */
+enum { VSO_F32 = 0, VSO_F64 = 1, VSO_BF16 = 2, VSO_F16 = 3, VSO_I8 = 4, VSO_U8 = 5 };
+enum { VSO_L2 = 0, VSO_IP = 1, VSO_COSINE = 2 };
+/* arithmetic profile = which ISA tier of the reference is being restated */
+enum {
+    VSO_TIER_AVX512 = 0, /* gcc-11 build on an AVX-512F/BW/VL/VNNI/VBMI2 host, avx512_bf16 masked off */
+    VSO_TIER_SCALAR = 1, /* "no optimisation" kernels */
+    VSO_TIER_AVX512_BF16 = 2 /* as AVX512 plus the vdpbf16ps tier for bf16 IP */
+};
+
+size_t vso_elem_size(int type);
+/* bytes of one stored row / query blob: dim*elem (+4 for int8/uint8 Cosine)   vec_utils.cpp:296-302 */
+size_t vso_blob_size(int type, int metric, size_t dim);
+
+/* one distance, result widened to double (float results widen exactly) */
+double vso_distance(int type, int metric, int tier, size_t dim, const void *a, const void *b);
+/* 1 when the (type,metric,dim,tier) combination resolves to the scalar kernel */
+int vso_uses_scalar(int type, int metric, int tier, size_t dim);
+
+/* n distances query-vs-rows; rows are `stride` bytes apart */
+void vso_scan(int type, int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride,
+              const void *query, double *out);
+
+/* in-place normalisation exactly as VecSim_Normalize (vec_sim.cpp:238-254) */
+void vso_normalize(void *blob, size_t dim, int type);
+
+/* conversions (bit-exact restatements) */
+uint16_t vso_f32_to_bf16(float f);
+float vso_bf16_to_f32(uint16_t h);
+uint16_t vso_f32_to_f16(float f);
+float vso_f16_to_f32(uint16_t h);
+
+/* Flat top-K with the reference's sequential heap semantics (brute_force.h:257-288).
+ * scores[i] belongs to internal id i, labels[i] is its label (NULL => label == id).
+ * Writes min(k,n) results ascending by (score,label); returns the count. */
+size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, size_t k,
+                       size_t *out_labels, double *out_scores);
+/* range scan: score <= radius, in id order (brute_force.h:305-318); returns count */
+size_t vso_range_replay(const double *scores, const size_t *labels, size_t n, double radius,
+                        size_t *out_labels, double *out_scores);
+
+/* whole Flat query on host rows (scan + replay) */
+size_t vso_flat_topk(int type, int metric, int tier, size_t dim, const void *rows, size_t n,
+                     size_t stride, const size_t *labels, const void *query, size_t k,
+                     size_t *out_labels, double *out_scores);
+
+/* ---- timing leg (bench.py cpu_baseline, kind "port") ----
+ * Same arithmetic as VSO_TIER_AVX512, written with AVX-512 intrinsics when the host has them
+ * (falls back to the portable lanes code otherwise).  nq queries, `threads` OpenMP threads, one
+ * query per thread at a time (mirrors bindings.cpp:250-283).  Returns 1 if the intrinsics path ran. */
+int vso_flat_topk_batch_fast(int type, int metric, size_t dim, const void *rows, size_t n,
+                             size_t stride, const void *queries, size_t nq, size_t qstride,
+                             size_t k, int threads, size_t *out_labels, double *out_scores);
+int vso_has_avx512(void);
+
+/* deterministic synthetic data shared with the device generator (vsgpu_fill_uniform):
+ * value(seed, idx) is a pure function, so any row can be re-created on the host. */
+uint32_t vso_hash32(uint64_t seed, uint64_t idx);
+float vso_synth_f32(uint64_t seed, uint64_t idx);           /* U[-1,1) */
+void vso_synth_rows_f32(uint64_t seed, uint64_t first_elem, size_t count, float *out);
+int8_t vso_synth_i8(uint64_t seed, uint64_t idx);           /* uniform [-128,127] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

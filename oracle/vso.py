@@ -1,0 +1,183 @@
+"""ctypes loader for the CPU oracle (oracle/libvso.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (vectorsimilarity_amd) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libvso.so")
+
+F32, F64, BF16, F16, I8, U8 = range(6)
+L2, IP, COSINE = range(3)
+TIER_AVX512, TIER_SCALAR, TIER_AVX512_BF16 = range(3)
+
+NP_DTYPE = {F32: np.float32, F64: np.float64, BF16: np.uint16, F16: np.uint16, I8: np.int8,
+            U8: np.uint8}
+
+
+def build(force=False):
+    """Compile oracle/libvso.so from the C restatement (gcc + make)."""
+    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso.h", "Makefile")]
+    if (not force and os.path.exists(_LIB)
+            and os.path.getmtime(_LIB) >= max(os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        vp, sz, dbl, i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
+        L.vso_blob_size.restype = sz
+        L.vso_blob_size.argtypes = [i, i, sz]
+        L.vso_distance.restype = dbl
+        L.vso_distance.argtypes = [i, i, i, sz, vp, vp]
+        L.vso_distance_fast.restype = dbl
+        L.vso_distance_fast.argtypes = [i, i, sz, vp, vp]
+        L.vso_uses_scalar.restype = i
+        L.vso_uses_scalar.argtypes = [i, i, i, sz]
+        L.vso_scan.restype = None
+        L.vso_scan.argtypes = [i, i, i, sz, vp, sz, sz, vp, vp]
+        L.vso_normalize.restype = None
+        L.vso_normalize.argtypes = [vp, sz, i]
+        L.vso_f32_to_bf16.restype = C.c_uint16
+        L.vso_f32_to_bf16.argtypes = [C.c_float]
+        L.vso_bf16_to_f32.restype = C.c_float
+        L.vso_bf16_to_f32.argtypes = [C.c_uint16]
+        L.vso_f32_to_f16.restype = C.c_uint16
+        L.vso_f32_to_f16.argtypes = [C.c_float]
+        L.vso_f16_to_f32.restype = C.c_float
+        L.vso_f16_to_f32.argtypes = [C.c_uint16]
+        L.vso_topk_replay.restype = sz
+        L.vso_topk_replay.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.vso_range_replay.restype = sz
+        L.vso_range_replay.argtypes = [vp, vp, sz, dbl, vp, vp]
+        L.vso_flat_topk.restype = sz
+        L.vso_flat_topk.argtypes = [i, i, i, sz, vp, sz, sz, vp, vp, sz, vp, vp]
+        L.vso_flat_topk_batch_fast.restype = i
+        L.vso_flat_topk_batch_fast.argtypes = [i, i, sz, vp, sz, sz, vp, sz, sz, sz, i, vp, vp]
+        L.vso_has_avx512.restype = i
+        L.vso_has_avx512_bf16.restype = i
+        L.vso_probe_dpbf16.restype = None
+        L.vso_probe_dpbf16.argtypes = [vp, vp, vp]
+        L.vso_hash32.restype = C.c_uint32
+        L.vso_hash32.argtypes = [C.c_uint64, C.c_uint64]
+        L.vso_synth_f32.restype = C.c_float
+        L.vso_synth_f32.argtypes = [C.c_uint64, C.c_uint64]
+        L.vso_synth_rows_f32.restype = None
+        L.vso_synth_rows_f32.argtypes = [C.c_uint64, C.c_uint64, sz, vp]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def blob_size(vtype, metric, dim):
+    return lib().vso_blob_size(vtype, metric, dim)
+
+
+def distance(vtype, metric, a, b, dim=None, tier=TIER_AVX512):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if dim is None:
+        dim = a.size
+    return lib().vso_distance(vtype, metric, tier, dim, _ptr(a), _ptr(b))
+
+
+def distance_fast(vtype, metric, a, b, dim=None):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if dim is None:
+        dim = a.size
+    return lib().vso_distance_fast(vtype, metric, dim, _ptr(a), _ptr(b))
+
+
+def scan(vtype, metric, rows, query, dim, tier=TIER_AVX512):
+    """rows: 2-D C-contiguous array, one stored blob per row (raw bytes view allowed)."""
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    n = rows.shape[0]
+    out = np.empty(n, dtype=np.float64)
+    lib().vso_scan(vtype, metric, tier, dim, _ptr(rows), n, rows.strides[0], _ptr(query), _ptr(out))
+    return out
+
+
+def normalize(blob, dim, vtype):
+    """In place; for int8/uint8 the array must have dim+4 bytes."""
+    assert blob.flags["C_CONTIGUOUS"]
+    lib().vso_normalize(_ptr(blob), dim, vtype)
+    return blob
+
+
+def topk_replay(scores, k, labels=None):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    n = scores.size
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+    kk = max(1, min(k, n))
+    ol = np.empty(kk, dtype=np.uint64)
+    osc = np.empty(kk, dtype=np.float64)
+    c = lib().vso_topk_replay(_ptr(scores), None if lab is None else _ptr(lab), n, k, _ptr(ol),
+                              _ptr(osc))
+    return ol[:c].copy(), osc[:c].copy()
+
+
+def range_replay(scores, radius, labels=None):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    n = scores.size
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+    ol = np.empty(max(n, 1), dtype=np.uint64)
+    osc = np.empty(max(n, 1), dtype=np.float64)
+    c = lib().vso_range_replay(_ptr(scores), None if lab is None else _ptr(lab), n, radius,
+                               _ptr(ol), _ptr(osc))
+    return ol[:c].copy(), osc[:c].copy()
+
+
+def flat_topk(vtype, metric, rows, query, k, dim, labels=None, tier=TIER_AVX512):
+    rows = np.ascontiguousarray(rows)
+    scores = scan(vtype, metric, rows, query, dim, tier)
+    return topk_replay(scores, k, labels)
+
+
+def flat_topk_batch_fast(vtype, metric, rows, queries, k, dim, threads=1):
+    """Timing leg: returns (labels[nq,k] uint64, scores[nq,k] f64, used_intrinsics)."""
+    rows = np.ascontiguousarray(rows)
+    queries = np.ascontiguousarray(queries)
+    nq = queries.shape[0]
+    ol = np.empty((nq, k), dtype=np.uint64)
+    osc = np.empty((nq, k), dtype=np.float64)
+    fast = lib().vso_flat_topk_batch_fast(vtype, metric, dim, _ptr(rows), rows.shape[0],
+                                          rows.strides[0], _ptr(queries), nq, queries.strides[0],
+                                          k, threads, _ptr(ol), _ptr(osc))
+    return ol, osc, bool(fast)
+
+
+def synth_rows_f32(seed, first_row, nrows, dim):
+    out = np.empty((nrows, dim), dtype=np.float32)
+    lib().vso_synth_rows_f32(seed, first_row * dim, nrows * dim, _ptr(out))
+    return out
+
+
+def f32_to_bf16(a):
+    a = np.asarray(a, dtype=np.float32)
+    f = lib().vso_f32_to_bf16
+    return np.array([f(float(x)) for x in a.ravel()], dtype=np.uint16).reshape(a.shape)
+
+
+def f32_to_f16(a):
+    a = np.asarray(a, dtype=np.float32)
+    f = lib().vso_f32_to_f16
+    return np.array([f(float(x)) for x in a.ravel()], dtype=np.uint16).reshape(a.shape)

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/kat_spaces.json and kat_flat.json: the reference's OWN known-answer tests for
+the hot path, restated as data (inputs + the expected values the reference asserts).
+
+Nothing here is computed by our oracle or our kernels: every expected value is the closed form
+the reference test states.  Sources (paths under /root/reference/tests/unit/):
+  test_spaces.cpp:69-154    L2 "no optimisation" answers         -> l2_noopt
+  test_spaces.cpp:157-283   IP answers, bf16/fp16 normalisation  -> ip_noopt, normalize
+  test_spaces.cpp:286-322   int8/uint8 Cosine of a vector with itself ~ 0
+  test_spaces.cpp:684-779, 878-879, 1073-1074, 1249-1250, 1404-1405
+                            "every SIMD tier == scalar kernel" on v[i]=i, v2[i]=i+1.5 for every
+                            residual; both sides are exact in fp arithmetic, so the expected value
+                            is the exact real number: L2 = 2.25*d, IP = 1 - sum i(i+1.5)
+  test_bruteforce.cpp:747-812   Flat top-k on {i,i,i,i} vectors (L2 closed form / IP id set)
+  test_bruteforce.cpp:1389-1419 Cosine ranking: rank r <-> label n-r
+  test_int8.cpp:366-386         tie order pinned: {50,49,51,48,52,...}
+Run:  python tests/golden/make_kats.py
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def spaces():
+    cases = []
+    # --- no-optimisation answers ---
+    a = [i + 1.5 for i in range(5)]
+    cases.append(dict(name="float_l2_no_opt", type="f32", metric="L2", tier="scalar", a=a, b=a, expect=0.0,
+                      src="test_spaces.cpp:69-81"))
+    cases.append(dict(name="double_l2_no_opt", type="f64", metric="L2", tier="scalar", a=a, b=a, expect=0.0,
+                      src="test_spaces.cpp:83-95"))
+    sa = [0.5 + i * 0.25 for i in range(4)]
+    sb = [i * 0.25 for i in range(4)]
+    # bf16/fp16 of multiples of 0.25 are exact; expected = fp32 L2 of the same values = 4*0.25
+    cases.append(dict(name="bf16_l2_no_opt", type="bf16", metric="L2", tier="scalar", a=sa, b=sb, expect=1.0,
+                      src="test_spaces.cpp:97-113"))
+    cases.append(dict(name="fp16_l2_no_opt", type="f16", metric="L2", tier="scalar", a=sa, b=sb, expect=1.0,
+                      src="test_spaces.cpp:115-131"))
+    ia = [i + 1 for i in range(5)]
+    ib = [i + 2 for i in range(5)]
+    cases.append(dict(name="int8_l2_no_opt", type="i8", metric="L2", tier="scalar", a=ia, b=ib, expect=5.0,
+                      src="test_spaces.cpp:133-144"))
+    cases.append(dict(name="uint8_l2_no_opt", type="u8", metric="L2", tier="scalar", a=ia, b=ib, expect=5.0,
+                      src="test_spaces.cpp:146-154"))
+    ip = 1.0 - sum(x * y for x, y in zip(sa, sb))
+    cases.append(dict(name="bf16_ip_no_opt", type="bf16", metric="IP", tier="scalar", a=sa, b=sb, expect=ip,
+                      src="test_spaces.cpp:233-249"))
+    cases.append(dict(name="fp16_ip_no_opt", type="f16", metric="IP", tier="scalar", a=sa, b=sb, expect=ip,
+                      src="test_spaces.cpp:251-267"))
+    cases.append(dict(name="int8_ip_no_opt", type="i8", metric="IP", tier="scalar", a=[1, 0, 0, 0], b=[1, 0, 0, 0],
+                      expect=0.0, src="test_spaces.cpp:269-275"))
+    cases.append(dict(name="uint8_ip_no_opt", type="u8", metric="IP", tier="scalar", a=[1, 0, 0, 0], b=[1, 0, 0, 0],
+                      expect=0.0, src="test_spaces.cpp:277-283"))
+    # --- SIMD tier == scalar on exactly-summable inputs, every residual ---
+    def exact(d):
+        l2 = 2.25 * d
+        ipv = 1.0 - sum(i * (i + 1.5) for i in range(d))
+        return l2, ipv
+    for typ, lo, hi in (("f32", 8, 64), ("f64", 4, 32), ("bf16", 32, 64), ("f16", 16, 64)):
+        for d in range(lo, hi + 1):
+            l2, ipv = exact(d)
+            v = [float(i) for i in range(d)]
+            w = [i + 1.5 for i in range(d)]
+            for tier in ("avx512", "scalar"):
+                cases.append(dict(name=f"{typ}_l2_simd_eq_scalar_d{d}_{tier}", type=typ, metric="L2", tier=tier,
+                                  a=v, b=w, expect=l2, src="test_spaces.cpp:684-779 (param dims)"))
+                cases.append(dict(name=f"{typ}_ip_simd_eq_scalar_d{d}_{tier}", type=typ, metric="IP", tier=tier,
+                                  a=v, b=w, expect=ipv, src="test_spaces.cpp:781-876 (param dims)"))
+    # bf16 IP through the vdpbf16ps tier as well (test_spaces.cpp:1184-1247)
+    for d in range(32, 65):
+        l2, ipv = exact(d)
+        cases.append(dict(name=f"bf16_ip_dpbf16_d{d}", type="bf16", metric="IP", tier="avx512_bf16",
+                          a=[float(i) for i in range(d)], b=[i + 1.5 for i in range(d)], expect=ipv,
+                          src="test_spaces.cpp:1184-1247"))
+    norm = [dict(name="bf16_normalize", type="bf16", input=[4.0] * 4, expect=[0.5] * 4, src="test_spaces.cpp:191-211"),
+            dict(name="fp16_normalize", type="f16", input=[4.0] * 4, expect=[0.5] * 4, src="test_spaces.cpp:213-231")]
+    return dict(distance=cases, normalize=norm)
+
+
+def flat():
+    cases = []
+    n, k, dim = 100, 11, 4
+    # L2: vectors {i,i,i,i}, query {50..}: rank r -> |id-50| = (r+1)//2, score 4*((r+1)//2)^2
+    cases.append(dict(name="bf_search_l2", metric="L2", dim=dim, n=n, k=k, query_value=50,
+                      vector_rule="label i -> [i]*dim", types=["f32", "f64", "bf16", "f16"],
+                      block_sizes=[1, 12, 1024],
+                      expect_absdiff=[(r + 1) // 2 for r in range(k)],
+                      expect_scores=[4.0 * ((r + 1) // 2) ** 2 for r in range(k)],
+                      src="test_bruteforce.cpp:781-812"))
+    # IP: query {50..}: the 11 largest ids win (most negative 1 - 200*i)
+    cases.append(dict(name="bf_search_ip", metric="IP", dim=dim, n=n, k=k, query_value=50,
+                      vector_rule="label i -> [i]*dim", types=["f32", "f64"],
+                      block_sizes=[1, 12, 1024],
+                      expect_id_set=list(range(n - k, n)), src="test_bruteforce.cpp:747-779"))
+    # int8 L2 with ties: ascending score, then ascending label
+    cases.append(dict(name="int8_search_by_score", metric="L2", dim=dim, n=n, k=k, query_value=50,
+                      vector_rule="label i -> [i]*dim", types=["i8", "u8"],
+                      expect_labels=[50, 49, 51, 48, 52, 47, 53, 46, 54, 45, 55],
+                      expect_scores=[4.0 * (50 - i) ** 2 for i in [50, 49, 51, 48, 52, 47, 53, 46, 54, 45, 55]],
+                      src="test_int8.cpp:366-386"))
+    cases.append(dict(name="int8_search_by_id", metric="L2", dim=dim, n=n, k=k, query_value=50,
+                      vector_rule="label i -> [i]*dim", types=["i8", "u8"], order="BY_ID",
+                      expect_labels=list(range(45, 56)),
+                      expect_scores=[4.0 * (50 - i) ** 2 for i in range(45, 56)],
+                      src="test_int8.cpp:333-347"))
+    # Cosine: f[0] = i/n, rest 1.0, labels 1..n; query all ones: rank r -> label n-r
+    cases.append(dict(name="bf_cosine", metric="Cosine", dim=128, n=100, k=10,
+                      vector_rule="label i in 1..n -> [i/n, 1, 1, ...]", query_rule="[1.0]*dim",
+                      types=["f32", "f64"], expect_labels=[100 - r for r in range(10)],
+                      src="test_bruteforce.cpp:1389-1419"))
+    # heap/tie semantics probed on the compiled reference during the survey:
+    # scan order (label,dist) = (5,16),(9,16),(1,4),(2,16),(0,16)
+    cases.append(dict(name="tie_probe", scan=[[5, 16.0], [9, 16.0], [1, 4.0], [2, 16.0], [0, 16.0]],
+                      expect={"2": [1, 5], "3": [1, 5, 9]}, src="SURVEY.md §8(a) A10 [probed]"))
+    return dict(cases=cases)
+
+
+if __name__ == "__main__":
+    with open(os.path.join(HERE, "kat_spaces.json"), "w") as f:
+        json.dump(spaces(), f, indent=0)
+    with open(os.path.join(HERE, "kat_flat.json"), "w") as f:
+        json.dump(flat(), f, indent=1)
+    print("wrote kat_spaces.json, kat_flat.json")

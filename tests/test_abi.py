@@ -1,0 +1,82 @@
+"""CPU: the drop-in boundary.  (1) our public structs have the reference's layout (fixture from the
+reference header), (2) both shared libraries load and export every symbol the headers declare,
+(3) without a GPU the product refuses to build an index -- no CPU fallback."""
+import ctypes as C
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLD)
+
+
+def test_struct_layout_matches_reference_fixture():
+    from make_abi_layout import probe
+    ours = json.loads(probe(os.path.join(ROOT, "include", "VecSim", "vec_sim_common.h")))
+    with open(os.path.join(GOLD, "abi_layout.json")) as f:
+        ref = json.load(f)
+    assert ours == ref
+
+
+def test_ctypes_mirror_matches_header():
+    from vectorsimilarity_amd import _capi
+    with open(os.path.join(GOLD, "abi_layout.json")) as f:
+        ref = json.load(f)
+    assert C.sizeof(_capi.BFParams) == ref["sizeof(BFParams)"]
+    assert C.sizeof(_capi.HNSWParams) == ref["sizeof(HNSWParams)"]
+    assert C.sizeof(_capi.SVSParams) == ref["sizeof(SVSParams)"]
+    assert C.sizeof(_capi.TieredIndexParams) == ref["sizeof(TieredIndexParams)"]
+    assert C.sizeof(_capi.AlgoParams) == ref["sizeof(AlgoParams)"]
+    assert C.sizeof(_capi.VecSimParams) == ref["sizeof(VecSimParams)"]
+    assert _capi.VecSimParams.logCtx.offset == ref["offsetof(VecSimParams,logCtx)"]
+    assert C.sizeof(_capi.VecSimQueryParams) == ref["sizeof(VecSimQueryParams)"]
+    assert _capi.VecSimQueryParams.timeoutCtx.offset == ref["offsetof(VecSimQueryParams,timeoutCtx)"]
+    assert C.sizeof(_capi.VecSimIndexBasicInfo) == ref["sizeof(VecSimIndexBasicInfo)"]
+
+
+def _declared(header):
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b((?:VecSim|vsgpu)[A-Za-z_0-9]*)\s*\(", txt)) - {"VecSim_OK"}
+
+
+def test_libraries_export_every_declared_symbol():
+    from vectorsimilarity_amd import _capi
+    L = _capi.load()
+    G = C.CDLL(_capi.GPU_LIB_PATH)
+    inc = os.path.join(ROOT, "include")
+    declared = set()
+    for h in ("VecSim/vec_sim.h", "VecSim/query_results.h", "VecSim/vec_sim_gpu.h"):
+        declared |= _declared(os.path.join(inc, h))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    gdecl = _declared(os.path.join(inc, "vsgpu.h"))
+    assert gdecl == set(_capi.GPU_EXPORTS), gdecl ^ set(_capi.GPU_EXPORTS)
+    for name in sorted(gdecl):
+        assert hasattr(G, name), name
+
+
+def test_no_gpu_means_no_index():
+    from vectorsimilarity_amd import VecSim, _capi
+    if _capi.load().VecSimGpu_DeviceCount() > 0:
+        pytest.skip("a GPU is visible")
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, 16, VecSim.VecSimMetric_L2
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        VecSim.BFIndex(p)
+
+
+def test_product_never_references_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "vectorsimilarity_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or fn == "Makefile":
+                txt = open(os.path.join(base, fn)).read()
+                if re.search(r"(import|from)\s+oracle|libvso|vso_[a-z]+\(|#include\s+\"vso", txt):
+                    bad.append(fn)
+    assert not bad, bad

@@ -1,0 +1,280 @@
+"""GPU: parity of the HIP path with the oracle, through the C API (ctypes -> libvecsim_amd.so ->
+libvsgpu.so).  Bit-exact labels, order and scores for every type/metric the reference supports.
+Tolerance: NONE (0 ulp) -- the kernels reproduce the reference's AVX-512 / scalar summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import METRICS, TYPES, encode, random_vectors, stored_rows
+from vectorsimilarity_amd import VecSim
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_index(typ, metric, dim, block=0):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric, p.blockSize = TYPES[typ], dim, METRICS[metric], block
+    return VecSim.BFIndex(p)
+
+
+def kernel_metric(typ, metric):
+    if metric == "Cosine" and typ not in ("i8", "u8"):
+        return METRICS["IP"]
+    return METRICS[metric]
+
+
+def oracle_topk(vso, typ, metric, rows, q, k, labels=None):
+    st = stored_rows(vso, rows, typ, metric)
+    qq = stored_rows(vso, q[None, :], typ, metric)[0]
+    return vso.flat_topk(TYPES[typ], kernel_metric(typ, metric), st, qq, k, rows.shape[1], labels)
+
+
+CASES = [(t, m, d) for t in ("f32", "f16", "bf16", "f64", "i8", "u8") for m in ("L2", "IP", "Cosine")
+         for d in (4, 17, 33, 64, 100, 128)]
+
+
+@pytest.mark.parametrize("typ,metric,dim", CASES)
+def test_all_scores_bit_exact(vso, typ, metric, dim):
+    """k = n returns every row: checks every distance and the full (score,label) order"""
+    rng = np.random.default_rng(dim * 7 + len(typ))
+    n = 300
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 3, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    for i in range(n):
+        ix.add_vector(rows[i], i)
+    assert ix.index_size() == n
+    labels, dists = ix.knn_query(q, n)
+    for j in range(3):
+        el, es = oracle_topk(vso, typ, metric, rows, q[j], n)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (typ, metric, dim, j)
+        assert np.array_equal(dists[j], es), (typ, metric, dim, j)
+
+
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [
+    ("f32", "L2", 128, 100_000, 1, 10),      # BASELINE config 1
+    ("f32", "L2", 128, 100_000, 7, 10),
+    ("f32", "IP", 96, 50_000, 16, 5),
+    ("f32", "Cosine", 200, 30_000, 9, 100),
+    ("f16", "L2", 128, 40_000, 5, 10),
+    ("bf16", "IP", 128, 40_000, 5, 10),
+    ("i8", "Cosine", 128, 60_000, 12, 100),
+    ("u8", "L2", 64, 60_000, 3, 10),
+])
+def test_filtered_scan_path(vso, typ, metric, dim, n, nq, k):
+    """probe -> threshold -> filtered scan (forced by dense_pairs=0) == dense path == oracle"""
+    rng = np.random.default_rng(n + dim)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["fallbacks"] == 0 and "filter" in st["scan_kernel"], st
+    ix.set_option("dense_pairs", 1 << 40)
+    l2, d2 = ix.knn_query(q, k)
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2)
+    for j in range(nq):
+        el, es = oracle_topk(vso, typ, metric, rows, q[j], k)
+        assert np.array_equal(l1[j], el.astype(np.int64)), (typ, metric, j)
+        assert np.array_equal(d1[j], es), (typ, metric, j)
+
+
+def test_reference_flat_kats_through_c_api(vso):
+    with open(os.path.join(GOLD, "kat_flat.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        if c["name"] == "tie_probe":
+            continue
+        for typ in c["types"]:
+            for bs in c.get("block_sizes", [0]):
+                n, dim, k = c["n"], c["dim"], c["k"]
+                ix = make_index(typ, c["metric"], dim, bs)
+                if c["name"] == "bf_cosine":
+                    for i in range(1, n + 1):
+                        v = np.ones(dim)
+                        v[0] = i / n
+                        ix.add_vector(encode(vso, v, typ), i)
+                    q = encode(vso, np.ones(dim), typ)
+                else:
+                    for i in range(n):
+                        ix.add_vector(encode(vso, [i] * dim, typ), i)
+                    q = encode(vso, [c["query_value"]] * dim, typ)
+                order = VecSim.BY_ID if c.get("order") == "BY_ID" else VecSim.BY_SCORE
+                labels, dists = ix.knn_query(q, k, order=order)
+                labels, dists = labels[0], dists[0]
+                if "expect_labels" in c:
+                    assert list(labels) == c["expect_labels"], (c["name"], typ, bs)
+                if "expect_scores" in c:
+                    assert list(dists) == c["expect_scores"], (c["name"], typ, bs)
+                if "expect_absdiff" in c:
+                    assert [abs(int(x) - 50) for x in labels] == c["expect_absdiff"], (c["name"], typ)
+                if "expect_id_set" in c:
+                    assert sorted(int(x) for x in labels) == c["expect_id_set"], (c["name"], typ)
+                # k = 0 sanity (test_bruteforce.cpp:809)
+                l0, _ = ix.knn_query(q, 0)
+                assert l0.shape == (1, 0)
+
+
+def test_ties_follow_the_sequential_heap(vso):
+    """many equal scores: earlier ids win, the largest *label* is evicted (brute_force.h:272-279)"""
+    rng = np.random.default_rng(5)
+    dim, n = 16, 5000
+    base = rng.integers(-3, 4, (40, dim)).astype(np.float32)
+    rows = base[rng.integers(0, 40, n)]            # heavy duplication => massive ties
+    labels = rng.permutation(n).astype(np.uint64) + 7
+    q = base[:4] + 0.0
+    ix = make_index("f32", "L2", dim)
+    for i in range(n):
+        ix.add_vector(rows[i], int(labels[i]))
+    for force in (0, 1 << 40):
+        ix.set_option("dense_pairs", force)
+        for k in (1, 3, 50, 400):
+            got_l, got_d = ix.knn_query(q, k)
+            for j in range(4):
+                el, es = vso.flat_topk(0, 0, rows, q[j], k, dim, labels)
+                assert np.array_equal(got_l[j], el.astype(np.int64)), (force, k, j)
+                assert np.array_equal(got_d[j], es)
+
+
+def test_all_identical_vectors_overflow_fallback(vso):
+    """every row ties at T_k: candidate lists overflow and the dense fallback must still be exact"""
+    dim, n, k = 32, 30000, 10
+    rows = np.tile(np.linspace(-1, 1, dim, dtype=np.float32), (n, 1))
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.set_option("cand_cap", 64)
+    q = np.zeros((2, dim), dtype=np.float32)
+    ix.reset_stats()
+    l, d = ix.knn_query(q, k)
+    assert ix.stats()["fallbacks"] == 2
+    for j in range(2):
+        el, es = vso.flat_topk(0, 0, rows, q[j], k, dim)
+        assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es)
+
+
+def test_delete_and_overwrite_keep_the_device_mirror_coherent(vso):
+    rng = np.random.default_rng(9)
+    dim, n = 24, 3000
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix = make_index("f32", "L2", dim, block=128)
+    host = {}
+    order = []                                   # internal id -> label (swap-delete model)
+    for i in range(n):
+        assert ix.add_vector(rows[i], i) == 1
+        host[i] = rows[i]
+        order.append(i)
+    for lab in rng.choice(n, 700, replace=False):
+        lab = int(lab)
+        assert ix.delete_vector(lab) == 1
+        pos = order.index(lab)
+        order[pos] = order[-1]
+        order.pop()
+        del host[lab]
+    assert ix.delete_vector(10 ** 9) == 0
+    for lab in list(host)[:200]:
+        v = rng.uniform(-1, 1, dim).astype(np.float32)
+        assert ix.add_vector(v, lab) == 0            # overwrite
+        host[lab] = v
+    assert ix.index_size() == len(order)
+    cur = np.stack([host[l] for l in order])
+    labs = np.array(order, dtype=np.uint64)
+    q = rng.uniform(-1, 1, (5, dim)).astype(np.float32)
+    got_l, got_d = ix.knn_query(q, 25)
+    for j in range(5):
+        el, es = vso.flat_topk(0, 0, cur, q[j], 25, dim, labs)
+        assert np.array_equal(got_l[j], el.astype(np.int64)) and np.array_equal(got_d[j], es)
+    # getDistanceFrom_Unsafe (brute_force_single.h:202-212)
+    lab = order[17]
+    assert ix.get_distance_from(lab, q[0]) == vso.distance(0, 0, host[lab], q[0])
+    assert np.isnan(ix.get_distance_from(10 ** 9, q[0]))
+
+
+@pytest.mark.parametrize("typ,metric", [("f32", "L2"), ("f32", "Cosine"), ("f64", "L2"), ("i8", "Cosine"), ("bf16", "IP")])
+def test_range_query(vso, typ, metric):
+    rng = np.random.default_rng(13)
+    dim, n = 32, 4000
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 1, dim, typ, vso)[0]
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    st = stored_rows(vso, rows, typ, metric)
+    qq = stored_rows(vso, q[None, :], typ, metric)[0]
+    scores = vso.scan(TYPES[typ], kernel_metric(typ, metric), st, qq, dim)
+    radius = float(np.sort(scores)[150])
+    rl, rs = vso.range_replay(scores if typ == "f64" else scores, float(np.float32(radius)) if typ != "f64" else radius)
+    got_l, got_d = ix.range_query(q, radius, order=VecSim.BY_ID)
+    assert np.array_equal(got_l[0], rl.astype(np.int64)) and np.array_equal(got_d[0], rs)
+    got_l, got_d = ix.range_query(q, radius, order=VecSim.BY_SCORE)
+    assert np.array_equal(np.sort(got_l[0]), np.sort(rl.astype(np.int64)))
+    assert np.all(np.diff(got_d[0]) >= 0)
+    e_l, _ = ix.range_query(q, 0.0 if metric == "L2" else 1e-12)
+    assert e_l.shape[1] <= 1
+
+
+def test_batch_iterator_matches_reference_semantics(vso):
+    rng = np.random.default_rng(17)
+    dim, n = 32, 2500
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, dim).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    scores = vso.scan(0, 0, rows, q, dim)
+    order = np.lexsort((np.arange(n), scores))
+    it = ix.create_batch_iterator(q)
+    seen = []
+    while it.has_next():
+        l, d = it.get_next_results(100)
+        assert np.all(np.diff(d[0]) >= 0)
+        seen.extend(int(x) for x in l[0])
+        assert np.array_equal(d[0], scores[l[0]])
+    assert seen == [int(x) for x in order]       # no ties in random data: global ascending order
+    it.reset()
+    l, d = it.get_next_results(7)
+    assert [int(x) for x in l[0]] == [int(x) for x in order[:7]]
+
+
+def test_timeout_callback_at_launch_granularity():
+    dim, n = 16, 2000
+    rng = np.random.default_rng(1)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rng.uniform(-1, 1, (n, dim)).astype(np.float32), np.arange(n))
+    q = rng.uniform(-1, 1, dim).astype(np.float32)
+    cb = VecSim.set_timeout_callback(lambda ctx: 1)
+    try:
+        l, d, code = ix.knn_query_code(q, 5)
+        assert code == 1 and np.all(l == -1)          # TimedOut, empty (brute_force.h:265-269)
+    finally:
+        VecSim.set_timeout_callback(None)
+    l, d, code = ix.knn_query_code(q, 5)
+    assert code == 0 and np.all(l >= 0)
+    del cb
+
+
+def test_synthetic_rows_match_host_generator(vso):
+    dim, n = 64, 5000
+    ix = make_index("f32", "L2", dim)
+    ix.add_synthetic(n, 47)
+    rows = vso.synth_rows_f32(47, 0, n, dim)
+    q = vso.synth_rows_f32(48, 0, 3, dim)
+    l, d = ix.knn_query(q, 10)
+    for j in range(3):
+        el, es = vso.flat_topk(0, 0, rows, q[j], 10, dim)
+        assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es)
+
+
+def test_empty_and_tiny_indexes(vso):
+    ix = make_index("f32", "L2", 8)
+    l, d = ix.knn_query(np.zeros(8, dtype=np.float32), 5)
+    assert np.all(l == -1) and np.all(d == -1.0)          # padded like wrap_results
+    ix.add_vector(np.ones(8, dtype=np.float32), 42)
+    l, d = ix.knn_query(np.zeros((2, 8), dtype=np.float32), 5)
+    assert list(l[0]) == [42, -1, -1, -1, -1] and d[0, 0] == 8.0
+    rl, _ = ix.range_query(np.zeros(8, dtype=np.float32), 7.9)
+    assert rl.shape[1] == 0

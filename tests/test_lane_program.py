@@ -1,0 +1,58 @@
+"""CPU: the lane tables that drive the exact HIP kernels (vectorsimilarity_amd/csrc/lane_program.h)
+reproduce the oracle bit for bit when walked the way the kernel walks them (tests/helpers/lane_emul.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import random_vectors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HELP = os.path.join(ROOT, "tests", "helpers")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(HELP, "liblane_emul.so")
+    src = os.path.join(HELP, "lane_emul.cpp")
+    hdr = os.path.join(ROOT, "vectorsimilarity_amd", "csrc", "lane_program.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "vectorsimilarity_amd", "csrc"),
+                        "-o", so, src], check=True)
+    L = C.CDLL(so)
+    L.lane_emul.restype = C.c_double
+    L.lane_emul.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    return L
+
+
+DIMS = {"f32": list(range(1, 100)) + [128, 500, 768, 1024],
+        "f64": list(range(1, 50)) + [128, 768],
+        "f16": list(range(1, 100)) + [128, 768],
+        "bf16": list(range(1, 130)) + [768, 1024],
+        "i8": list(range(1, 140)) + [768, 1024],
+        "u8": list(range(1, 140)) + [1024]}
+TCODE = {"f32": 0, "f64": 1, "bf16": 2, "f16": 3, "i8": 4, "u8": 5}
+
+
+@pytest.mark.parametrize("typ", list(DIMS))
+def test_lane_tables_reproduce_oracle(emul, vso, typ):
+    rng = np.random.default_rng(5)
+    t = TCODE[typ]
+    tiers = [0, 1] + ([2] if typ == "bf16" else [])
+    for d in DIMS[typ]:
+        v = random_vectors(rng, 2, d, typ, vso)
+        a, b = np.ascontiguousarray(v[0]), np.ascontiguousarray(v[1])
+        for metric in (0, 1):
+            for tier in tiers:
+                acc = emul.lane_emul(t, metric, tier, d, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+                want = vso.distance(t, metric, a, b, dim=d, tier=tier)
+                if typ in ("i8", "u8"):
+                    got = float(np.float32(acc)) if metric == 0 else float(np.float32(1 - acc))
+                elif typ == "f64":
+                    got = acc if metric == 0 else 1.0 - acc
+                else:
+                    got = acc if metric == 0 else float(np.float32(1.0) - np.float32(acc))
+                assert got == want, (typ, d, metric, tier, got, want)

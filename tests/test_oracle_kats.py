@@ -1,0 +1,156 @@
+"""CPU: pins the oracle against the reference's own known-answer tests (tests/golden/kat_*.json,
+made by tests/golden/make_kats.py from the reference's unit tests) and cross-checks the portable
+lane emulation against an independent AVX-512 intrinsics implementation on the host CPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import METRICS, TIERS, TYPES, encode
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def test_distance_kats(vso):
+    kats = _load("kat_spaces.json")["distance"]
+    assert len(kats) > 500
+    for c in kats:
+        a = encode(vso, c["a"], c["type"])
+        b = encode(vso, c["b"], c["type"])
+        got = vso.distance(TYPES[c["type"]], METRICS[c["metric"]], a, b, dim=len(c["a"]), tier=TIERS[c["tier"]])
+        assert got == c["expect"], (c["name"], got, c["expect"], c["src"])
+
+
+def test_normalize_kats(vso):
+    for c in _load("kat_spaces.json")["normalize"]:
+        v = encode(vso, c["input"], c["type"])
+        vso.normalize(v, len(c["input"]), TYPES[c["type"]])
+        wide = [vso.lib().vso_bf16_to_f32(int(x)) if c["type"] == "bf16" else vso.lib().vso_f16_to_f32(int(x)) for x in v]
+        assert wide == c["expect"], c["name"]
+
+
+def test_int_cosine_self_distance(vso):
+    # test_spaces.cpp:286-322: Cosine(v, v) ~ 0 with the norm stored after the elements
+    rng = np.random.default_rng(123)
+    for typ, t in (("i8", 4), ("u8", 5)):
+        v = np.zeros(8, dtype=np.uint8)
+        v[:4] = rng.integers(0, 256, 4, dtype=np.uint8)
+        vso.normalize(v, 4, t)
+        assert abs(vso.distance(t, 2, v, v, dim=4)) < 1e-6
+
+
+def test_tie_semantics_probe(vso):
+    c = [x for x in _load("kat_flat.json")["cases"] if x["name"] == "tie_probe"][0]
+    labels = np.array([p[0] for p in c["scan"]], dtype=np.uint64)
+    scores = np.array([p[1] for p in c["scan"]], dtype=np.float64)
+    for k, exp in c["expect"].items():
+        got, _ = vso.topk_replay(scores, int(k), labels)
+        assert list(got) == exp
+
+
+def _flat_case(vso, c, typ):
+    n, dim, k = c["n"], c["dim"], c["k"]
+    t, m = TYPES[typ], METRICS[c["metric"]]
+    if c["name"] == "bf_cosine":
+        rows = np.ones((n, dim))
+        rows[:, 0] = np.arange(1, n + 1) / n
+        labels = np.arange(1, n + 1, dtype=np.uint64)
+        q = np.ones(dim)
+    else:
+        rows = np.repeat(np.arange(n)[:, None], dim, axis=1).astype(np.float64)
+        labels = np.arange(n, dtype=np.uint64)
+        q = np.full(dim, c["query_value"], dtype=np.float64)
+    enc = np.stack([encode(vso, r, typ) for r in rows])
+    qe = encode(vso, q, typ)
+    if c["metric"] == "Cosine":
+        for i in range(n):
+            vso.normalize(enc[i], dim, t)
+        vso.normalize(qe, dim, t)
+    got_l, got_s = vso.flat_topk(t, 1 if c["metric"] == "Cosine" else m, enc, qe, k, dim, labels)
+    return got_l, got_s
+
+
+def test_flat_kats(vso):
+    for c in _load("kat_flat.json")["cases"]:
+        if c["name"] == "tie_probe":
+            continue
+        for typ in c["types"]:
+            got_l, got_s = _flat_case(vso, c, typ)
+            if c.get("order") == "BY_ID":
+                o = np.argsort(got_l, kind="stable")
+                got_l, got_s = got_l[o], got_s[o]
+            if "expect_labels" in c:
+                assert list(got_l) == c["expect_labels"], (c["name"], typ)
+            if "expect_scores" in c:
+                assert list(got_s) == c["expect_scores"], (c["name"], typ)
+            if "expect_absdiff" in c:
+                assert [abs(int(x) - 50) for x in got_l] == c["expect_absdiff"], (c["name"], typ)
+            if "expect_id_set" in c:
+                assert sorted(int(x) for x in got_l) == c["expect_id_set"], (c["name"], typ)
+
+
+def test_lanes_match_avx512_intrinsics(vso):
+    """portable 32-lane emulation == hand-written AVX-512 intrinsics (vso_fast.c), bit for bit"""
+    if not vso.lib().vso_has_avx512():
+        pytest.skip("host CPU has no AVX-512F")
+    rng = np.random.default_rng(7)
+    for d in list(range(8, 200)) + [512, 768, 1000, 1024, 1536]:
+        a = rng.uniform(-1, 1, d).astype(np.float32)
+        b = rng.uniform(-1, 1, d).astype(np.float32)
+        for m in (0, 1):
+            assert vso.distance(0, m, a, b) == vso.distance_fast(0, m, a, b), (d, m)
+
+
+def test_scalar_and_lane_orders_differ_in_last_bits(vso):
+    # documents why the oracle must fix a tier (SURVEY.md hard part 1)
+    rng = np.random.default_rng(3)
+    diff = 0
+    for _ in range(50):
+        a = rng.uniform(-1, 1, 768).astype(np.float32)
+        b = rng.uniform(-1, 1, 768).astype(np.float32)
+        diff += vso.distance(0, 0, a, b, tier=0) != vso.distance(0, 0, a, b, tier=1)
+    assert diff > 0
+
+
+def test_dpbf16_emulation_matches_hardware(vso):
+    """vdpbf16ps characterisation: acc += odd product (rounded), then even product (rounded)"""
+    L = vso.lib()
+    if not L.vso_has_avx512_bf16():
+        pytest.skip("host CPU has no avx512_bf16")
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    for d in (32, 40, 64, 96, 127, 768):
+        for _ in range(20):
+            x = vso.f32_to_bf16(rng.uniform(-1, 1, d).astype(np.float32))
+            y = vso.f32_to_bf16(rng.uniform(-1, 1, d).astype(np.float32))
+            # hardware: emulate the kernel structure with the probe primitive
+            acc = np.zeros(16, dtype=np.float32)
+            r = d % 32
+            pos = 0
+            if r:
+                xx = np.zeros(32, dtype=np.uint16); yy = np.zeros(32, dtype=np.uint16)
+                xx[:r] = x[:r]; yy[:r] = y[:r]
+                L.vso_probe_dpbf16(acc.ctypes.data_as(C.c_void_p), xx.ctypes.data_as(C.c_void_p), yy.ctypes.data_as(C.c_void_p))
+                pos = r
+            while pos < d:
+                xx = np.ascontiguousarray(x[pos:pos + 32]); yy = np.ascontiguousarray(y[pos:pos + 32])
+                L.vso_probe_dpbf16(acc.ctypes.data_as(C.c_void_p), xx.ctypes.data_as(C.c_void_p), yy.ctypes.data_as(C.c_void_p))
+                pos += 32
+            t = acc[8:] + acc[:8]
+            u = t[4:] + t[:4]
+            hw = np.float32(1.0) - ((u[0] + u[2]) + (u[1] + u[3]))
+            assert vso.distance(2, 1, x, y, dim=d, tier=2) == float(hw), d
+
+
+def test_synthetic_generator_is_uniform_and_exact(vso):
+    rows = vso.synth_rows_f32(47, 0, 64, 768)
+    assert rows.min() >= -1.0 and rows.max() < 1.0
+    assert abs(rows.mean()) < 0.01 and abs(rows.var() - 1 / 3) < 0.01
+    again = vso.synth_rows_f32(47, 10, 2, 768)
+    assert np.array_equal(again, rows[10:12])

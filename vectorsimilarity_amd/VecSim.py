@@ -1,0 +1,229 @@
+"""Python surface with the names and I/O shapes of the reference's pybind11 module `VecSim`
+(src/python_bindings/bindings.cpp:660-868), bound over the C API with ctypes.
+
+    p = BFParams(); p.type = VecSimType_FLOAT32; p.dim = 128; p.metric = VecSimMetric_L2
+    ix = BFIndex(p); ix.add_vector(v, label); labels, dists = ix.knn_query(q, 10)
+
+`knn_query` returns (labels int64[nq,k], distances float64[nq,k]) padded with -1 like
+wrap_results (bindings.cpp:36-72).  A 2-D query array is answered as ONE batched GPU pass
+(VecSimIndex_TopKQueryBatch) -- the reference loops single queries (bindings.cpp:182-190).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (BY_ID, BY_SCORE, VecSimAlgo_BF, VecSimAlgo_HNSWLIB, VecSimAlgo_SVS,  # noqa: F401
+                    VecSimAlgo_TIERED, VecSimMetric_Cosine, VecSimMetric_IP, VecSimMetric_L2,
+                    VecSimType_BFLOAT16, VecSimType_FLOAT16, VecSimType_FLOAT32,
+                    VecSimType_FLOAT64, VecSimType_INT8, VecSimType_INT32, VecSimType_INT64,
+                    VecSimType_UINT8, BFParams, HNSWParams, VecSimParams, VecSimQueryParams)
+
+_NP = {VecSimType_FLOAT32: np.float32, VecSimType_FLOAT64: np.float64,
+       VecSimType_BFLOAT16: np.uint16, VecSimType_FLOAT16: np.uint16, VecSimType_INT8: np.int8,
+       VecSimType_UINT8: np.uint8}
+_ELEM = {VecSimType_FLOAT32: 4, VecSimType_FLOAT64: 8, VecSimType_BFLOAT16: 2,
+         VecSimType_FLOAT16: 2, VecSimType_INT8: 1, VecSimType_UINT8: 1}
+
+
+def _wrap(lib, replies, num_res):
+    nq = len(replies)
+    labels = np.full((nq, num_res), -1, dtype=np.int64)
+    dists = np.full((nq, num_res), -1.0, dtype=np.float64)
+    for qi, rep in enumerate(replies):
+        it = lib.VecSimQueryReply_GetIterator(rep)
+        j = 0
+        while lib.VecSimQueryReply_IteratorHasNext(it):
+            item = lib.VecSimQueryReply_IteratorNext(it)
+            dists[qi, j] = lib.VecSimQueryResult_GetScore(item)
+            labels[qi, j] = lib.VecSimQueryResult_GetId(item)
+            j += 1
+        lib.VecSimQueryReply_IteratorFree(it)
+        lib.VecSimQueryReply_Free(rep)
+    return labels, dists
+
+
+class BatchIterator:
+    def __init__(self, index, handle):
+        self._index = index  # keep the index alive longer than the iterator
+        self._h = handle
+        self._lib = _capi.load()
+
+    def has_next(self):
+        return bool(self._lib.VecSimBatchIterator_HasNext(self._h))
+
+    def get_next_results(self, n_res, order=BY_SCORE):
+        rep = self._lib.VecSimBatchIterator_Next(self._h, n_res, order)
+        n = self._lib.VecSimQueryReply_Len(rep)
+        return _wrap(self._lib, [rep], n)
+
+    def reset(self):
+        self._lib.VecSimBatchIterator_Reset(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.VecSimBatchIterator_Free(self._h)
+            self._h = None
+
+
+class VecSimIndex:
+    def __init__(self, params):
+        self._lib = _capi.load()
+        self._h = self._lib.VecSimIndex_New(C.byref(params))
+        if not self._h:
+            err = self._lib.VecSimGpu_LastError()
+            raise RuntimeError("VecSimIndex_New failed: %s" % (err.decode() if err else "unsupported parameters"))
+        info = self._lib.VecSimIndex_BasicInfo(self._h)
+        self._type, self._dim, self._metric = info.type, info.dim, info.metric
+        self._qbytes = self._lib.VecSimParams_GetQueryBlobSize(self._type, self._dim, self._metric)
+
+    # ---- helpers ----
+    def _blob(self, a, rows=None):
+        """C-contiguous array of the index dtype (raw u16 for bf16/fp16) holding >= blob bytes per row."""
+        a = np.asarray(a)
+        want = _NP[self._type]
+        if a.dtype != want:
+            if self._type in (VecSimType_BFLOAT16, VecSimType_FLOAT16) and a.dtype.itemsize == 2:
+                a = a.view(np.uint16)
+            else:
+                a = a.astype(want)
+        return np.ascontiguousarray(a)
+
+    def _padded(self, a):
+        """queries/vectors for int8/uint8 Cosine need dim+4 bytes of room (the norm is appended)."""
+        a = self._blob(a)
+        a2 = a.reshape(-1, a.shape[-1])
+        need = self._qbytes
+        have = a2.shape[1] * a2.dtype.itemsize
+        if have >= need:
+            return a2, a2.strides[0]
+        buf = np.zeros((a2.shape[0], need), dtype=np.uint8)
+        buf[:, :have] = a2.view(np.uint8).reshape(a2.shape[0], have)
+        return buf, need
+
+    # ---- reference surface ----
+    def add_vector(self, vector, label):
+        v, _ = self._padded(vector)
+        return self._lib.VecSimIndex_AddVector(self._h, v.ctypes.data_as(C.c_void_p), int(label))
+
+    def add_vectors(self, vectors, labels):
+        """bulk ingest extension (one H2D per 8 MiB instead of one call per vector)"""
+        v = self._blob(vectors)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        assert v.ndim == 2 and v.shape[0] == lab.size
+        n = self._lib.VecSimIndex_AddVectorsBulk(self._h, v.ctypes.data_as(C.c_void_p),
+                                                 lab.ctypes.data_as(C.c_void_p), lab.size)
+        if n < 0:
+            raise RuntimeError("bulk add failed (duplicate label or GPU error)")
+        return n
+
+    def add_synthetic(self, n, seed):
+        r = self._lib.VecSimIndex_AddSyntheticVectors(self._h, n, seed)
+        if r < 0:
+            raise RuntimeError("synthetic fill failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return r
+
+    def delete_vector(self, label):
+        return self._lib.VecSimIndex_DeleteVector(self._h, int(label))
+
+    def knn_query(self, vector, k, query_param=None, order=BY_SCORE):
+        q, stride = self._padded(vector)
+        nq = q.shape[0]
+        qp = C.byref(query_param) if query_param is not None else None
+        if nq == 1:
+            rep = self._lib.VecSimIndex_TopKQuery(self._h, q.ctypes.data_as(C.c_void_p), k, qp, order)
+            return _wrap(self._lib, [rep], k)
+        reps = (C.c_void_p * nq)()
+        rc = self._lib.VecSimIndex_TopKQueryBatch(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k,
+                                                  qp, order, reps)
+        if rc != 0:
+            raise RuntimeError("GPU batched top-k failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return _wrap(self._lib, list(reps), k)
+
+    def knn_query_code(self, vector, k, query_param=None):
+        """(labels, distances, reply code) for a single query -- lets tests see TimedOut"""
+        q, _ = self._padded(vector)
+        qp = C.byref(query_param) if query_param is not None else None
+        rep = self._lib.VecSimIndex_TopKQuery(self._h, q.ctypes.data_as(C.c_void_p), k, qp, BY_SCORE)
+        code = self._lib.VecSimQueryReply_GetCode(rep)
+        lab, d = _wrap(self._lib, [rep], k)
+        return lab, d, code
+
+    def range_query(self, vector, radius, query_param=None, order=BY_SCORE):
+        q, _ = self._padded(vector)
+        qp = C.byref(query_param) if query_param is not None else None
+        rep = self._lib.VecSimIndex_RangeQuery(self._h, q.ctypes.data_as(C.c_void_p), float(radius), qp, order)
+        return _wrap(self._lib, [rep], self._lib.VecSimQueryReply_Len(rep))
+
+    def get_distance_from(self, label, vector):
+        q, _ = self._padded(vector)
+        return self._lib.VecSimIndex_GetDistanceFrom_Unsafe(self._h, int(label), q.ctypes.data_as(C.c_void_p))
+
+    def index_size(self):
+        return self._lib.VecSimIndex_IndexSize(self._h)
+
+    def index_type(self):
+        return self._type
+
+    def create_batch_iterator(self, query_blob, query_param=None):
+        q, _ = self._padded(query_blob)
+        qp = C.byref(query_param) if query_param is not None else None
+        h = self._lib.VecSimBatchIterator_New(self._h, q.ctypes.data_as(C.c_void_p), qp)
+        return BatchIterator(self, h)
+
+    def prefer_adhoc(self, subset, k, initial=True):
+        return bool(self._lib.VecSimIndex_PreferAdHocSearch(self._h, subset, k, initial))
+
+    # ---- measurement ----
+    def reset_stats(self):
+        self._lib.VecSimGpu_ResetStats(self._h)
+
+    def stats(self):
+        s = _capi.VecSimGpuStats()
+        self._lib.VecSimGpu_GetStats(self._h, C.byref(s))
+        return {"scan_ms": s.scan_ms, "scan_launches": s.scan_launches, "scan_rows": s.scan_rows,
+                "scan_bytes": s.scan_bytes, "other_ms": s.other_ms, "candidates": s.candidates,
+                "fallbacks": s.fallbacks, "scan_kernel": s.scan_kernel.decode()}
+
+    def set_option(self, name, value):
+        if self._lib.VecSimGpu_SetOption(self._h, name.encode(), int(value)) != 0:
+            raise ValueError(name)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.VecSimIndex_Free(self._h)
+            self._h = None
+
+
+class BFIndex(VecSimIndex):
+    def __init__(self, params):
+        p = VecSimParams()
+        p.algo = VecSimAlgo_BF
+        p.algoParams.bfParams = params
+        super().__init__(p)
+
+
+def normalize(vector, vtype):
+    """VecSim_Normalize on a copy; int8/uint8 return dim+4 bytes (norm appended)"""
+    lib = _capi.load()
+    a = np.ascontiguousarray(vector)
+    dim = a.size
+    if vtype in (VecSimType_INT8, VecSimType_UINT8):
+        buf = np.zeros(dim + 4, dtype=np.uint8)
+        buf[:dim] = a.view(np.uint8)
+        lib.VecSim_Normalize(buf.ctypes.data_as(C.c_void_p), dim, vtype)
+        return buf
+    out = a.copy()
+    lib.VecSim_Normalize(out.ctypes.data_as(C.c_void_p), dim, vtype)
+    return out
+
+
+def set_timeout_callback(fn):
+    """fn(ctx:int) -> int, or None to clear.  Keep the returned object alive."""
+    lib = _capi.load()
+    if fn is None:
+        lib.VecSim_SetTimeoutCallbackFunction(None)
+        return None
+    cb = _capi.TIMEOUT_CB(fn)
+    lib.VecSim_SetTimeoutCallbackFunction(C.cast(cb, C.c_void_p))
+    return cb

@@ -1,0 +1,319 @@
+// exact_kernels.hpp -- table-driven exact-distance kernels (gfx950).
+//
+// One GPU lane plays one accumulator lane of the reference's SIMD kernel (see lane_program.h):
+// a group of VL lanes owns R stored rows at a time, walks the lane program step by step with
+// element-wide coalesced loads (VL consecutive elements = one contiguous segment per row), keeps
+// R x BT accumulators (BT = queries resident in LDS), and finishes with the halving tree.  The
+// results are bit-identical to the reference's AVX-512 tier (or scalar tier) by construction.
+//
+// Used for: small query batches (HBM-bound up to BT ~ 8-16), dense score vectors (batch iterator,
+// fallback), range queries, and the exact re-rank of the MFMA filter's survivors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// never let the compiler fuse or re-associate: the summation order IS the contract
+#pragma clang fp contract(off)
+
+namespace vsg {
+
+enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5 };
+enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3 };
+enum ScanMode { MODE_DENSE = 0, MODE_FILTER = 1 };
+// how the reduced accumulator becomes a score
+enum Epilogue {
+    EPI_L2 = 0,         // score = acc
+    EPI_ONE_MINUS = 1,  // score = 1 - acc            (IP / fp Cosine: IP.cpp:185-238)
+    EPI_INT_L2 = 2,     // score = float(acc)         (L2.cpp:164-174)
+    EPI_INT_IP = 3,     // score = float(1 - acc)     (IP.cpp:258-262, 273-277)
+    EPI_INT_COS = 4     // score = 1.0f - float(acc) / (norm_row * norm_q)   (IP.cpp:264-271)
+};
+
+template <int EK> struct Elem;
+template <> struct Elem<EK_F32> {
+    using acc_t = float; using score_t = float;
+    static constexpr int VL = 32;
+    __device__ static inline float load(const char *p) { return *reinterpret_cast<const float *>(p); }
+};
+template <> struct Elem<EK_F16> {
+    using acc_t = float; using score_t = float;
+    static constexpr int VL = 32;
+    __device__ static inline float load(const char *p) {
+        return (float)(*reinterpret_cast<const _Float16 *>(p));  // exact widening (float16.h:33-52)
+    }
+};
+template <> struct Elem<EK_BF16> {
+    using acc_t = float; using score_t = float;
+    static constexpr int VL = 16;
+    __device__ static inline float load(const char *p) {
+        return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t *>(p)) << 16);  // bfloat16.h:32-39
+    }
+};
+template <> struct Elem<EK_F64> {
+    using acc_t = double; using score_t = double;
+    static constexpr int VL = 16;
+    __device__ static inline double load(const char *p) { return *reinterpret_cast<const double *>(p); }
+};
+template <> struct Elem<EK_I8> {
+    using acc_t = int; using score_t = float;
+    static constexpr int VL = 32;
+    __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const int8_t *>(p)); }
+};
+template <> struct Elem<EK_U8> {
+    using acc_t = int; using score_t = float;
+    static constexpr int VL = 32;
+    __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const uint8_t *>(p)); }
+};
+
+// one accumulation step; explicit rounding intrinsics so no contraction flag can change it
+template <int OPK> __device__ inline float acc_step(float x, float q, float acc) {
+    if (OPK == OP_L2_FMA) { float t = __fsub_rn(x, q); return __fmaf_rn(t, t, acc); }
+    if (OPK == OP_IP_FMA) { return __fmaf_rn(x, q, acc); }
+    if (OPK == OP_L2_MULADD) { float t = __fsub_rn(x, q); return __fadd_rn(acc, __fmul_rn(t, t)); }
+    return __fadd_rn(acc, __fmul_rn(x, q));
+}
+template <int OPK> __device__ inline double acc_step(double x, double q, double acc) {
+    if (OPK == OP_L2_FMA) { double t = __dsub_rn(x, q); return __fma_rn(t, t, acc); }
+    if (OPK == OP_IP_FMA) { return __fma_rn(x, q, acc); }
+    if (OPK == OP_L2_MULADD) { double t = __dsub_rn(x, q); return __dadd_rn(acc, __dmul_rn(t, t)); }
+    return __dadd_rn(acc, __dmul_rn(x, q));
+}
+template <int OPK> __device__ inline int acc_step(int x, int q, int acc) {
+    if (OPK == OP_L2_FMA || OPK == OP_L2_MULADD) { int t = x - q; return acc + t * t; }
+    return acc + x * q;
+}
+
+__device__ inline float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ inline double add_rn(double a, double b) { return __dadd_rn(a, b); }
+__device__ inline int add_rn(int a, int b) { return a + b; }
+
+struct ScanParams {
+    // table view: row i lives at slabs[i >> slab_shift] + (i & slab_mask) * row_stride
+    const char *const *slabs;
+    uint32_t slab_shift;
+    uint32_t slab_mask;
+    uint32_t row_stride;
+    // work: compact row c in [0, n_compact) maps to table row
+    //   row_ids ? row_ids[c] : row_begin + (c / tile_rows) * tile_step + (c % tile_rows)
+    const uint32_t *row_ids;
+    uint32_t row_begin;
+    uint32_t row_end;  // exclusive bound on table rows (rows >= row_end are skipped)
+    uint32_t n_compact;
+    uint32_t tile_step;  // >= tile_rows; == tile_rows for a contiguous scan
+    // lane program + queries
+    const int32_t *offs;  // [steps][VL]
+    int steps;
+    const void *qperm;    // [nq][steps][VL] acc_t, query values already widened & permuted
+    int nq;
+    // epilogue
+    int mode;
+    int epilogue;
+    uint32_t norm_off;     // byte offset of the row's trailing float norm (EPI_INT_COS)
+    const float *qnorm;    // [nq] query norms (EPI_INT_COS)
+    void *out;             // MODE_DENSE: score_t [nq][out_stride], column = compact row
+    size_t out_stride;
+    const void *tau;       // MODE_FILTER: score_t [nq]
+    uint32_t *counts;      // [nq]
+    uint2 *cand;           // [nq][cap] {table row, score bits}
+    uint32_t cap;
+};
+
+template <typename S> __device__ inline S epilogue_score(int acc, int epi, float nrow, float nq) {
+    if (epi == EPI_INT_L2) return (S)(float)acc;
+    if (epi == EPI_INT_IP) return (S)(float)(1 - acc);
+    float ip = (float)acc;
+    return (S)__fsub_rn(1.0f, __fdiv_rn(ip, __fmul_rn(nrow, nq)));
+}
+template <typename S> __device__ inline S epilogue_score(float acc, int epi, float, float) {
+    return (epi == EPI_ONE_MINUS) ? (S)__fsub_rn(1.0f, acc) : (S)acc;
+}
+template <typename S> __device__ inline S epilogue_score(double acc, int epi, float, float) {
+    return (epi == EPI_ONE_MINUS) ? (S)__dsub_rn(1.0, acc) : (S)acc;
+}
+
+// R rows per lane group per iteration
+template <int EK> struct ScanShape {
+    static constexpr int VL = Elem<EK>::VL;
+    static constexpr int R = 4;
+    static constexpr int GROUPS = 256 / VL;
+    static constexpr int TILE_ROWS = GROUPS * R;
+};
+
+template <int EK, int OPK, int BT>
+__global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
+    using E = Elem<EK>;
+    using acc_t = typename E::acc_t;
+    using score_t = typename E::score_t;
+    constexpr int VL = E::VL;
+    constexpr int R = ScanShape<EK>::R;
+    constexpr int GROUPS = ScanShape<EK>::GROUPS;
+    constexpr int TILE_ROWS = ScanShape<EK>::TILE_ROWS;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *offs_s = reinterpret_cast<int32_t *>(smem);
+    acc_t *q_s = reinterpret_cast<acc_t *>(smem + (((size_t)P.steps * VL * 4 + 15) & ~(size_t)15));
+
+    const int steps = P.steps;
+    const int q0 = blockIdx.y * BT;  // first query of this block's tile
+    const int nqt = min(BT, P.nq - q0);
+    for (int i = threadIdx.x; i < steps * VL; i += 256) offs_s[i] = P.offs[i];
+    {
+        const acc_t *qg = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q0 * steps * VL;
+        for (int i = threadIdx.x; i < BT * steps * VL; i += 256)
+            q_s[i] = (i < nqt * steps * VL) ? qg[i] : (acc_t)0;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x % VL;
+    const int grp = threadIdx.x / VL;
+    const uint32_t n_tiles = (P.n_compact + TILE_ROWS - 1) / TILE_ROWS;
+
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const char *rp[R];
+        uint32_t rowid[R];
+        uint32_t comp[R];
+        bool valid[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint32_t c = tile * TILE_ROWS + grp * R + r;
+            uint32_t row;
+            if (P.row_ids) {
+                row = (c < P.n_compact) ? P.row_ids[c] : 0u;
+            } else {
+                row = P.row_begin + tile * P.tile_step + grp * R + r;
+            }
+            valid[r] = (c < P.n_compact) && (row < P.row_end);
+            if (!valid[r]) row = P.row_begin;  // any mapped row; result discarded
+            comp[r] = c;
+            rowid[r] = row;
+            rp[r] = P.slabs[row >> P.slab_shift] + (size_t)(row & P.slab_mask) * P.row_stride;
+        }
+
+        acc_t acc[R][BT];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int b = 0; b < BT; b++) acc[r][b] = (acc_t)0;
+
+#pragma unroll 4
+        for (int s = 0; s < steps; s++) {
+            const int off = offs_s[s * VL + lane];
+            if (off >= 0) {
+                acc_t x[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = E::load(rp[r] + off);
+#pragma unroll
+                for (int b = 0; b < BT; b++) {
+                    const acc_t qv = q_s[(b * steps + s) * VL + lane];
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r][b] = acc_step<OPK>(x[r], qv, acc[r][b]);
+                }
+            }
+        }
+
+        // halving tree: offsets VL/2 .. 1 (== sum0+sum1, then _mm512_reduce_add order)
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int b = 0; b < BT; b++) {
+                acc_t v = acc[r][b];
+#pragma unroll
+                for (int o = VL / 2; o >= 1; o >>= 1) v = add_rn(v, __shfl_down(v, o, VL));
+                acc[r][b] = v;
+            }
+
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (!valid[r]) continue;
+                float nrow = 0.f;
+                if (P.epilogue == EPI_INT_COS) {
+                    const unsigned char *np = reinterpret_cast<const unsigned char *>(rp[r] + P.norm_off);
+                    uint32_t u = (uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) |
+                                 ((uint32_t)np[3] << 24);
+                    nrow = __uint_as_float(u);
+                }
+#pragma unroll
+                for (int b = 0; b < BT; b++) {
+                    if (b >= nqt) break;
+                    const int q = q0 + b;
+                    const float nq = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
+                    const score_t sc = epilogue_score<score_t>(acc[r][b], P.epilogue, nrow, nq);
+                    if (P.mode == MODE_DENSE) {
+                        reinterpret_cast<score_t *>(P.out)[(size_t)q * P.out_stride + comp[r]] = sc;
+                    } else {
+                        const score_t t = reinterpret_cast<const score_t *>(P.tau)[q];
+                        if (sc <= t) {
+                            uint32_t slot = atomicAdd(&P.counts[q], 1u);
+                            if (slot < P.cap) {
+                                uint2 rec;
+                                rec.x = rowid[r];
+                                rec.y = __float_as_uint((float)sc);
+                                P.cand[(size_t)q * P.cap + slot] = rec;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- probe threshold: tau[q] = k-th smallest of M tile minima of a dense probe score matrix ----
+// Any k distinct rows bound the k-th smallest score of the whole table from above, and minima of
+// disjoint tiles belong to distinct rows, so tau >= T_q (the exact k-th smallest) always holds.
+// One 1024-thread workgroup per query; M <= 8192 (power of two), bitonic sort in LDS.
+__global__ __launch_bounds__(1024) void k_probe_threshold(const float *dense, size_t stride,
+                                                          uint32_t n0, uint32_t k, uint32_t M,
+                                                          float *tau) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *v = reinterpret_cast<float *>(smem);
+    const float *src = dense + (size_t)blockIdx.x * stride;
+    const uint32_t ts = (n0 + M - 1) / M;  // rows per tile
+    for (uint32_t t = threadIdx.x; t < M; t += 1024) {
+        float m = INFINITY;
+        const uint32_t lo = t * ts, hi = min(n0, lo + ts);
+        for (uint32_t i = lo; i < hi; i++) {
+            float s = src[i];
+            if (s < m) m = s;  // NaN never wins: a NaN row cannot lower the bound
+        }
+        v[t] = m;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= M; size <<= 1) {
+        for (uint32_t strd = size >> 1; strd > 0; strd >>= 1) {
+            for (uint32_t i = threadIdx.x; i < M / 2; i += 1024) {
+                uint32_t lo = 2 * i - (i & (strd - 1));
+                uint32_t hi = lo + strd;
+                bool asc = ((lo & size) == 0);
+                float a = v[lo], b = v[hi];
+                if ((a > b) == asc) { v[lo] = b; v[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        // number of non-empty tiles
+        uint32_t tiles = (n0 + ts - 1) / ts;
+        tau[blockIdx.x] = (k >= 1 && k <= tiles) ? v[k - 1] : INFINITY;
+    }
+}
+
+// ---- synthetic rows (bench / tests): identical to oracle/vso.c:vso_hash32 / vso_synth_f32 ----
+__device__ inline uint32_t hash32(uint64_t seed, uint64_t idx) {
+    uint64_t x = seed + idx * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+__global__ void k_fill_uniform_f32(float *dst, uint64_t first_elem, uint64_t count, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t strd = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += strd) {
+        uint32_t u = hash32(seed, first_elem + i) >> 8;
+        dst[i] = __fsub_rn(__fmul_rn((float)u, 1.0f / 8388608.0f), 1.0f);
+    }
+}
+
+}  // namespace vsg

@@ -1,0 +1,313 @@
+// c_api.cpp -- extern "C" surface of libvecsim_amd.so (VecSim/vec_sim.h, query_results.h,
+// vec_sim_gpu.h).  Thin: argument checks, dispatch to the index object, reply accessors.
+#include <strings.h>
+
+#include <algorithm>
+#include <cassert>
+#include <cerrno>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "blob_prep.h"
+#include "flat_index.h"
+
+using vsa::FlatIndex;
+
+// ------------------------------------------------------------------ lifetime
+extern "C" VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
+    if (!params) return nullptr;
+    // index_factory.cpp:17-46 swallows construction failures and returns NULL; so do we
+    if (params->algo != VecSimAlgo_BF) {
+        std::fprintf(stderr, "vecsim_amd: only Flat (VecSimAlgo_BF) indexes are built by this back end\n");
+        return nullptr;
+    }
+    const BFParams &bf = params->algoParams.bfParams;
+    if (bf.multi) {
+        std::fprintf(stderr, "vecsim_amd: multi-value Flat indexes are not built yet (SURVEY.md §8f rank 3)\n");
+        return nullptr;
+    }
+    FlatIndex *ix = FlatIndex::create(bf, params->logCtx);
+    if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create GPU index: %s\n", vsgpu_last_error());
+    return ix;
+}
+extern "C" void VecSimIndex_Free(VecSimIndex *index) { delete index; }
+
+extern "C" size_t VecSimIndex_EstimateInitialSize(const VecSimParams *params) {
+    (void)params;
+    return sizeof(FlatIndex);
+}
+extern "C" size_t VecSimIndex_EstimateElementSize(const VecSimParams *params) {
+    if (!params || params->algo != VecSimAlgo_BF) return 0;
+    const BFParams &bf = params->algoParams.bfParams;
+    // stored row + id->label slot (brute_force_factory.cpp:113-135 counts the same two terms)
+    return vsa::blob_bytes(bf.type, bf.dim, bf.metric) + sizeof(labelType);
+}
+
+// ------------------------------------------------------------------ ingest
+extern "C" int VecSimIndex_AddVector(VecSimIndex *index, const void *blob, size_t label) {
+    return index->addVector(blob, label);
+}
+extern "C" int VecSimIndex_DeleteVector(VecSimIndex *index, size_t label) { return index->deleteVector(label); }
+extern "C" size_t VecSimIndex_IndexSize(VecSimIndex *index) { return index->indexSize(); }
+extern "C" long VecSimIndex_AddVectorsBulk(VecSimIndex *index, const void *blobs, const size_t *labels, size_t n) {
+    return index->addBulk(blobs, labels, n);
+}
+extern "C" long VecSimIndex_AddSyntheticVectors(VecSimIndex *index, size_t n, uint64_t seed) {
+    return index->addSynthetic(n, seed);
+}
+
+// ------------------------------------------------------------------ queries
+extern "C" VecSimQueryReply *VecSimIndex_TopKQuery(VecSimIndex *index, const void *queryBlob, size_t k,
+                                                   VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
+    assert((order == BY_ID || order == BY_SCORE) && "Possible order values are only 'BY_ID' or 'BY_SCORE'");
+    VecSimQueryReply *rep = index->topKQuery(queryBlob, k, queryParams);
+    if (order == BY_ID) vsa::sort_reply(rep, BY_ID);
+    return rep;
+}
+extern "C" int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                          size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                          VecSimQueryReply **replies) {
+    if (order != BY_ID && order != BY_SCORE) return -1;
+    return index->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, replies);
+}
+extern "C" VecSimQueryReply *VecSimIndex_RangeQuery(VecSimIndex *index, const void *queryBlob, double radius,
+                                                    VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
+    // same contract as vec_sim.cpp:359-367: C++ exceptions cross the boundary on bad arguments
+    if (order != BY_ID && order != BY_SCORE) throw std::runtime_error("Possible order values are only 'BY_ID' or 'BY_SCORE'");
+    if (radius < 0) throw std::runtime_error("radius must be non-negative");
+    return index->rangeQuery(queryBlob, radius, queryParams, order);
+}
+extern "C" double VecSimIndex_GetDistanceFrom_Unsafe(VecSimIndex *index, size_t label, const void *blob) {
+    return index->getDistanceFrom(label, blob);
+}
+extern "C" bool VecSimIndex_PreferAdHocSearch(VecSimIndex *index, size_t subsetSize, size_t k, bool initial_check) {
+    return index->preferAdHocSearch(subsetSize, k, initial_check);
+}
+
+extern "C" VecSimAdhocBfCtx *VecSimIndex_AdhocBfCtx_New(VecSimIndex *, const void *) { return nullptr; }
+extern "C" void VecSimIndex_AdhocBfCtx_Free(VecSimAdhocBfCtx *) {}
+extern "C" double VecSimIndex_AdhocBfCtx_GetDistanceFrom(VecSimAdhocBfCtx *, size_t) {
+    return std::numeric_limits<double>::quiet_NaN();
+}
+extern "C" void VecSimIndex_AdhocBfCtx_GetExactDistances(VecSimAdhocBfCtx *, const size_t *, double *out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = std::numeric_limits<double>::quiet_NaN();
+}
+
+// ------------------------------------------------------------------ runtime parameter strings
+static bool positive_integer(const VecSimRawParam &p, long long *out) {
+    char *end = nullptr;
+    errno = 0;
+    *out = std::strtoll(p.value, &end, 0);
+    return !(*out <= 0 || *out == LLONG_MAX || errno != 0 || end != p.value + p.valLen);
+}
+extern "C" VecSimResolveCode VecSimIndex_ResolveParams(VecSimIndex *index, VecSimRawParam *rparams, int paramNum,
+                                                       VecSimQueryParams *qparams, VecsimQueryType query_type) {
+    if (!qparams || (!rparams && paramNum != 0)) return VecSimParamResolverErr_NullParam;
+    std::memset(qparams, 0, sizeof *qparams);
+    for (int i = 0; i < paramNum; i++) {
+        const VecSimRawParam &p = rparams[i];
+        if (!strcasecmp(p.name, "BATCH_SIZE")) {
+            if (query_type != QUERY_TYPE_HYBRID) return VecSimParamResolverErr_InvalidPolicy_NHybrid;
+            if (qparams->batchSize != 0) return VecSimParamResolverErr_AlreadySet;
+            long long v;
+            if (!positive_integer(p, &v)) return VecSimParamResolverErr_BadValue;
+            qparams->batchSize = (size_t)v;
+        } else if (!strcasecmp(p.name, "HYBRID_POLICY")) {
+            if (query_type != QUERY_TYPE_HYBRID) return VecSimParamResolverErr_InvalidPolicy_NHybrid;
+            if (qparams->searchMode != 0) return VecSimParamResolverErr_AlreadySet;
+            if (!strcasecmp(p.value, VECSIM_POLICY_BATCHES)) qparams->searchMode = HYBRID_BATCHES;
+            else if (!strcasecmp(p.value, VECSIM_POLICY_ADHOC_BF)) qparams->searchMode = HYBRID_ADHOC_BF;
+            else return VecSimParamResolverErr_InvalidPolicy_NExits;
+        } else {
+            // EF_RUNTIME / EPSILON / RERANK / SVS knobs exist only for graph indexes (vec_sim.cpp:47-165);
+            // on a Flat index they, like any unknown name, are rejected
+            return VecSimParamResolverErr_UnknownParam;
+        }
+    }
+    if (qparams->searchMode == HYBRID_ADHOC_BF && qparams->batchSize > 0)
+        return VecSimParamResolverErr_InvalidPolicy_AdHoc_With_BatchSize;
+    if (qparams->searchMode != 0) index->setLastMode(qparams->searchMode);
+    return VecSimParamResolver_OK;
+}
+
+// ------------------------------------------------------------------ blobs
+extern "C" void VecSim_Normalize(void *blob, size_t dim, VecSimType type) { vsa::normalize_blob(blob, dim, type); }
+extern "C" size_t VecSimParams_GetQueryBlobSize(VecSimType type, size_t dim, VecSimMetric metric) {
+    return vsa::blob_bytes(type, dim, metric);
+}
+
+// ------------------------------------------------------------------ info
+extern "C" VecSimIndexDebugInfo VecSimIndex_DebugInfo(VecSimIndex *index) { return index->debugInfo(); }
+extern "C" VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index) { return index->basicInfo(); }
+extern "C" VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index) { return index->statsInfo(); }
+extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *) { return nullptr; }
+extern "C" void VecSimTieredIndex_GC(VecSimIndex *) {}
+extern "C" void VecSimTieredIndex_AcquireSharedLocks(VecSimIndex *) {}
+extern "C" void VecSimTieredIndex_ReleaseSharedLocks(VecSimIndex *) {}
+
+// ------------------------------------------------------------------ process-wide hooks
+extern "C" void VecSim_SetMemoryFunctions(VecSimMemoryFunctions) {
+    // host bookkeeping uses the C++ allocator; vector bytes live in HBM (pass-through)
+}
+extern "C" void VecSim_SetTimeoutCallbackFunction(timeoutCallbackFunction cb) { vsa::globals().timeout_cb = cb; }
+extern "C" void VecSim_SetLogCallbackFunction(logCallbackFunction cb) { vsa::globals().log_cb = cb; }
+extern "C" void VecSim_SetTestLogContext(const char *, const char *) {}
+extern "C" void VecSim_SetWriteMode(VecSimWriteMode mode) { vsa::globals().write_mode = mode; }
+extern "C" void VecSim_UpdateThreadPoolSize(size_t n) {
+    vsa::globals().write_mode = n == 0 ? VecSim_WriteInPlace : VecSim_WriteAsync;
+}
+extern "C" size_t VecSim_GetSharedMemory(void) { return 0; }
+
+// ------------------------------------------------------------------ GPU extension
+extern "C" int VecSimGpu_SetDevice(int device) {
+    if (device < 0 || device >= vsgpu_device_count()) return -1;
+    vsa::globals().device = device;
+    return 0;
+}
+extern "C" int VecSimGpu_DeviceCount(void) { return vsgpu_device_count(); }
+extern "C" const char *VecSimGpu_LastError(void) { return vsgpu_last_error(); }
+extern "C" void VecSimGpu_ResetStats(VecSimIndex *index) { vsgpu_stats_reset(index->gpu()); }
+extern "C" void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out) {
+    static_assert(sizeof(VecSimGpuStats) == sizeof(vsgpu_stats), "stats structs must stay in sync");
+    vsgpu_stats s;
+    vsgpu_stats_get(index->gpu(), &s);
+    std::memcpy(out, &s, sizeof s);
+}
+extern "C" int VecSimGpu_SetOption(VecSimIndex *index, const char *name, long value) {
+    return vsgpu_set_option(index->gpu(), name, value);
+}
+
+// ------------------------------------------------------------------ replies
+extern "C" int64_t VecSimQueryResult_GetId(const VecSimQueryResult *item) { return item ? (int64_t)item->id : (int64_t)INVALID_ID; }
+extern "C" double VecSimQueryResult_GetScore(const VecSimQueryResult *item) {
+    return item ? item->score : std::numeric_limits<double>::quiet_NaN();
+}
+extern "C" size_t VecSimQueryReply_Len(VecSimQueryReply *r) { return r->results.size(); }
+extern "C" VecSimQueryReply_Code VecSimQueryReply_GetCode(VecSimQueryReply *r) { return r->code; }
+extern "C" void VecSimQueryReply_Free(VecSimQueryReply *r) { delete r; }
+extern "C" VecSimQueryReply_Iterator *VecSimQueryReply_GetIterator(VecSimQueryReply *r) {
+    return new VecSimQueryReply_Iterator{r, 0};
+}
+extern "C" bool VecSimQueryReply_IteratorHasNext(VecSimQueryReply_Iterator *it) { return it->pos < it->reply->results.size(); }
+extern "C" VecSimQueryResult *VecSimQueryReply_IteratorNext(VecSimQueryReply_Iterator *it) {
+    if (it->pos >= it->reply->results.size()) return nullptr;
+    return &it->reply->results[it->pos++];
+}
+extern "C" void VecSimQueryReply_IteratorReset(VecSimQueryReply_Iterator *it) { it->pos = 0; }
+extern "C" void VecSimQueryReply_IteratorFree(VecSimQueryReply_Iterator *it) { delete it; }
+
+// ------------------------------------------------------------------ batch iterator
+// Behaviour of brute_force/bf_batch_iterator.h:61-199: all scores once (on the GPU), then per call
+// either a bounded max-heap pass (few results out of many remaining) or an nth_element partition.
+extern "C" VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *queryBlob,
+                                                        VecSimQueryParams *queryParams) {
+    return index->newBatchIterator(queryBlob, queryParams);
+}
+
+using ScoredLabel = std::pair<double, size_t>;
+
+static VecSimQueryReply *next_by_heap(VecSimBatchIterator *it, size_t n_res) {
+    auto *rep = new VecSimQueryReply();
+    auto &sc = it->scores;
+    std::priority_queue<ScoredLabel> best;             // max-heap on (score, label)
+    std::unordered_map<size_t, size_t> slot_of_label;  // label -> position in sc
+    double upper = std::numeric_limits<double>::lowest();
+    for (size_t i = it->valid_start; i < sc.size(); i++) {
+        if (best.size() >= n_res) {
+            if (!(sc[i].first < upper)) continue;
+            slot_of_label.erase(best.top().second);
+            best.pop();
+        }
+        best.emplace(sc[i].first, sc[i].second);
+        slot_of_label[sc[i].second] = i;
+        upper = best.top().first;
+    }
+    const size_t got = best.size();
+    rep->results.resize(got);
+    for (size_t i = got; i-- > 0;) {
+        rep->results[i].score = best.top().first;
+        rep->results[i].id = best.top().second;
+        best.pop();
+    }
+    // retire the returned entries: survivors sitting in the first `got` live slots move, in order,
+    // into the slots (beyond that prefix) vacated by returned entries
+    std::vector<size_t> taken;
+    taken.reserve(got);
+    for (auto &kv : slot_of_label) taken.push_back(kv.second);
+    std::sort(taken.begin(), taken.end());
+    const size_t next_start = it->valid_start + got;
+    size_t hole = std::lower_bound(taken.begin(), taken.end(), next_start) - taken.begin();
+    size_t t = 0;
+    for (size_t pos = it->valid_start; pos < next_start; pos++) {
+        if (t < taken.size() && taken[t] == pos) {
+            t++;
+        } else {
+            sc[taken[hole++]] = sc[pos];
+        }
+    }
+    it->valid_start = next_start;
+    return rep;
+}
+
+static VecSimQueryReply *next_by_select(VecSimBatchIterator *it, size_t n_res) {
+    auto *rep = new VecSimQueryReply();
+    auto &sc = it->scores;
+    const size_t remaining = sc.size() - it->valid_start;
+    n_res = std::min(n_res, remaining);
+    auto first = sc.begin() + (std::ptrdiff_t)it->valid_start;
+    std::nth_element(first, first + (std::ptrdiff_t)n_res, sc.end());
+    rep->results.reserve(n_res);
+    for (size_t i = it->valid_start; i < it->valid_start + n_res; i++)
+        rep->results.push_back(VecSimQueryResult{sc[i].second, sc[i].first});
+    it->valid_start += n_res;
+    return rep;
+}
+
+extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, size_t n_results,
+                                                      VecSimQueryReply_Order order) {
+    assert((order == BY_ID || order == BY_SCORE) && "Possible order values are only 'BY_ID' or 'BY_SCORE'");
+    auto timed_out_reply = []() {
+        auto *r = new VecSimQueryReply();
+        r->code = VecSim_QueryReply_TimedOut;
+        return r;
+    };
+    if (!it->scored) {
+        if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
+        std::vector<double> s;
+        if (it->index->allScores(it->query.data(), s)) {
+            std::fprintf(stderr, "vecsim_amd: GPU score pass failed: %s\n", vsgpu_last_error());
+            return timed_out_reply();
+        }
+        it->label_count = s.size();
+        it->scores.resize(s.size());
+        for (size_t i = 0; i < s.size(); i++) it->scores[i] = ScoredLabel(s[i], it->index->labelOf(i));
+        it->scored = true;
+    }
+    if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
+    VecSimQueryReply *rep;
+    if ((it->label_count - it->returned) / 1000 > n_results) {
+        rep = next_by_heap(it, n_results);  // already ascending by score
+    } else {
+        rep = next_by_select(it, n_results);
+        if (order == BY_SCORE) vsa::sort_reply(rep, BY_SCORE);
+        else if (order == BY_SCORE_THEN_ID) vsa::sort_reply(rep, BY_SCORE_THEN_ID);
+    }
+    it->returned += rep->results.size();
+    if (order == BY_ID) vsa::sort_reply(rep, BY_ID);
+    return rep;
+}
+extern "C" bool VecSimBatchIterator_HasNext(VecSimBatchIterator *it) { return it->returned < it->label_count; }
+extern "C" void VecSimBatchIterator_Free(VecSimBatchIterator *it) { delete it; }
+extern "C" void VecSimBatchIterator_Reset(VecSimBatchIterator *it) {
+    it->scores.clear();
+    it->scored = false;
+    it->valid_start = 0;
+    it->returned = 0;
+}

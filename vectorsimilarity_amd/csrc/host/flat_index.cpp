@@ -1,0 +1,432 @@
+// flat_index.cpp -- see flat_index.h
+#include "flat_index.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+#include "blob_prep.h"
+
+namespace vsa {
+
+Globals &globals() {
+    static Globals g;
+    return g;
+}
+
+// utils/vec_utils.cpp:100-130 -- same comparators, same std::sort, same input order => same output
+void sort_reply(VecSimQueryReply *rep, VecSimQueryReply_Order order) {
+    auto &r = rep->results;
+    switch (order) {
+    case BY_ID:
+        std::sort(r.begin(), r.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
+        break;
+    case BY_SCORE:
+        std::sort(r.begin(), r.end(),
+                  [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.score < b.score; });
+        break;
+    case BY_SCORE_THEN_ID:
+        std::sort(r.begin(), r.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
+            return a.score == b.score ? a.id < b.id : a.score < b.score;
+        });
+        break;
+    }
+}
+
+static int resolve_device() {
+    int d = globals().device;
+    if (d >= 0) return d;
+    if (const char *e = std::getenv("VECSIM_GPU_DEVICE")) return std::atoi(e);
+    if (const char *e = std::getenv("LOCAL_RANK")) {
+        int n = vsgpu_device_count();
+        if (n > 0) return std::atoi(e) % n;
+    }
+    return 0;
+}
+
+static int resolve_tier() {
+    if (const char *e = std::getenv("VECSIM_GPU_TIER")) {
+        if (!std::strcmp(e, "scalar")) return VSGPU_TIER_SCALAR;
+        if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
+    }
+    return VSGPU_TIER_AVX512;
+}
+
+FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
+    if (p.dim == 0 || p.type > VecSimType_UINT8 || p.metric > VecSimMetric_Cosine) return nullptr;
+    vsgpu_ctx *ctx = vsgpu_ctx_create(resolve_device());
+    if (!ctx) return nullptr;
+    FlatIndex *ix = new FlatIndex();
+    ix->type_ = p.type;
+    ix->metric_ = p.metric;
+    ix->dim_ = p.dim;
+    ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
+    ix->stored_bytes_ = blob_bytes(p.type, p.dim, p.metric);
+    ix->query_bytes_ = ix->stored_bytes_;
+    ix->log_ctx_ = logCtx;
+    ix->ctx_ = ctx;
+    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    if (!ix->table_) {
+        vsgpu_ctx_destroy(ctx);
+        ix->ctx_ = nullptr;
+        delete ix;
+        return nullptr;
+    }
+    return ix;
+}
+
+FlatIndex::~FlatIndex() {
+    if (table_) vsgpu_table_destroy(table_);
+    if (ctx_) vsgpu_ctx_destroy(ctx_);
+}
+
+void FlatIndex::log(const char *level, const char *fmt, ...) const {
+    logCallbackFunction cb = globals().log_cb;
+    if (!cb) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    cb(log_ctx_, level, buf);
+}
+
+// ---- ingest ----
+void FlatIndex::stageRow(const void *processed) {
+    const char *p = static_cast<const char *>(processed);
+    staged_.insert(staged_.end(), p, p + stored_bytes_);
+    staged_rows_++;
+}
+
+int FlatIndex::flush() {
+    if (staged_rows_ == 0) return 0;
+    int rc = vsgpu_table_append(table_, staged_.data(), staged_rows_);
+    if (rc) {
+        log("warning", "device append failed: %s", vsgpu_last_error());
+        return rc;
+    }
+    staged_.clear();
+    staged_rows_ = 0;
+    return 0;
+}
+
+int FlatIndex::addVector(const void *blob, size_t label) {
+    auto it = label_to_id_.find(label);
+    if (it != label_to_id_.end()) {
+        // Overwrite.  The reference copies the caller's blob as-is here, without the storage
+        // preprocessing (brute_force_single.h:139-143 -> updateElement).  fp blobs have exactly the
+        // stored size, so we do the same; for int8/uint8 Cosine the reference would read 4 bytes
+        // past the caller's blob for the norm -- we recompute the norm instead.
+        if (flush()) return 0;
+        if (metric_ == VecSimMetric_Cosine && is_int_type(type_)) {
+            std::vector<char> tmp(stored_bytes_);
+            std::memcpy(tmp.data(), blob, dim_);
+            normalize_blob(tmp.data(), dim_, type_);
+            vsgpu_table_write(table_, it->second, tmp.data());
+        } else {
+            vsgpu_table_write(table_, it->second, blob);
+        }
+        return 0;
+    }
+    // appendVector (brute_force.h:175-193): preprocess for storage, next id, maps
+    if (metric_ == VecSimMetric_Cosine) {
+        std::vector<char> tmp(stored_bytes_);
+        std::memcpy(tmp.data(), blob, dim_ * type_size(type_));
+        normalize_blob(tmp.data(), dim_, type_);
+        stageRow(tmp.data());
+    } else {
+        stageRow(blob);
+    }
+    const uint32_t id = (uint32_t)count_++;
+    if (id_to_label_.size() < count_) {
+        // grow metadata by whole blocks, like growByBlock() (brute_force.h:109-117)
+        id_to_label_.resize(id_to_label_.size() + block_size_);
+    }
+    id_to_label_[id] = label;
+    label_to_id_[label] = id;
+    if (staged_.size() >= ((size_t)8 << 20)) flush();
+    return 1;
+}
+
+long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
+    const size_t in_bytes = dim_ * type_size(type_);
+    for (size_t i = 0; i < n; i++)
+        if (label_to_id_.count(labels[i])) return -1;
+    for (size_t i = 0; i < n; i++) addVector(static_cast<const char *>(blobs) + i * in_bytes, labels[i]);
+    return flush() ? -1 : (long)n;
+}
+
+long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
+    if (type_ != VecSimType_FLOAT32 || metric_ == VecSimMetric_Cosine) return -1;
+    if (flush()) return -1;
+    const size_t first = count_;
+    for (size_t i = 0; i < n; i++)
+        if (label_to_id_.count(first + i)) return -1;
+    if (vsgpu_table_append_synthetic(table_, n, seed)) return -1;
+    count_ += n;
+    size_t cap = ((count_ + block_size_ - 1) / block_size_) * block_size_;
+    id_to_label_.resize(cap);
+    label_to_id_.reserve(count_);
+    for (size_t i = 0; i < n; i++) {
+        id_to_label_[first + i] = first + i;
+        label_to_id_[first + i] = (uint32_t)(first + i);
+    }
+    return (long)n;
+}
+
+int FlatIndex::deleteVector(size_t label) {
+    auto it = label_to_id_.find(label);
+    if (it == label_to_id_.end()) return 0;
+    if (flush()) return 0;
+    const uint32_t id = it->second;
+    label_to_id_.erase(it);
+    // removeVector (brute_force.h:196-224): move the last row into the hole, shrink by one
+    const uint32_t last = (uint32_t)(--count_);
+    if (id != last) {
+        const size_t last_label = id_to_label_[last];
+        id_to_label_[id] = last_label;
+        label_to_id_[last_label] = id;
+        vsgpu_table_move(table_, id, last);
+    }
+    vsgpu_table_truncate(table_, count_);
+    if (count_ % block_size_ == 0) {
+        // shrinkByBlock (brute_force.h:119-137): keep at most one spare block of metadata
+        if (count_ == 0) id_to_label_.clear();
+        else if (id_to_label_.size() >= count_ + 2 * block_size_) id_to_label_.resize(id_to_label_.size() - block_size_);
+        id_to_label_.shrink_to_fit();
+    }
+    return 1;
+}
+
+// ---- queries ----
+std::vector<char> FlatIndex::preprocessQuery(const void *query) const {
+    std::vector<char> q(query_bytes_);
+    std::memcpy(q.data(), query, dim_ * type_size(type_));
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(q.data(), dim_, type_);
+    return q;
+}
+
+// The sequential heap of brute_force.h:257-288 replayed over the GPU's candidate rows (all rows
+// with score <= T_k, ascending internal id): insert iff score < heap top or heap not full; evict the
+// largest (score,label).  SURVEY.md §8a row A10 proves this equals the full scan.
+void FlatIndex::replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const {
+    using Item = std::pair<double, size_t>;
+    std::priority_queue<Item> heap;  // std::less<pair>: max-heap on (score, label)
+    double upper = std::numeric_limits<double>::lowest();
+    for (size_t i = 0; i < n; i++) {
+        const double s = scores[i];
+        if (s < upper || heap.size() < k) {
+            heap.emplace(s, id_to_label_[ids[i]]);
+            if (heap.size() > k) heap.pop();
+            upper = heap.top().first;
+        }
+    }
+    rep->results.resize(heap.size());
+    for (size_t i = rep->results.size(); i-- > 0;) {
+        rep->results[i].score = heap.top().first;
+        rep->results[i].id = heap.top().second;
+        heap.pop();
+    }
+}
+
+int FlatIndex::allScores(const void *processed_query, std::vector<double> &scores) {
+    if (flush()) return -1;
+    scores.resize(count_);
+    if (count_ == 0) return 0;
+    return vsgpu_scores(table_, processed_query, 0, count_, scores.data());
+}
+
+int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
+                              VecSimQueryReply_Order order, VecSimQueryReply **out) {
+    void *tctx = qp ? qp->timeoutCtx : nullptr;
+    last_mode_ = STANDARD_KNN;
+    if (nq == 0) return 0;
+    std::vector<VecSimQueryReply *> reps(nq);
+    for (auto &r : reps) r = new VecSimQueryReply();
+    auto finish = [&]() {
+        for (size_t q = 0; q < nq; q++) out[q] = reps[q];
+        return 0;
+    };
+    if (k == 0) return finish();
+    // the reference polls the timeout callback once per scanned vector (brute_force.h:265); the GPU
+    // path polls at launch granularity: before the scan and after it
+    if (timed_out(tctx)) {
+        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+        return finish();
+    }
+    if (flush()) {
+        for (auto *r : reps) delete r;
+        return -1;
+    }
+    if (count_ == 0) return finish();
+    // preprocess queries into one contiguous buffer
+    std::vector<char> qbuf(nq * query_bytes_);
+    const size_t in_bytes = dim_ * type_size(type_);
+    for (size_t q = 0; q < nq; q++) {
+        char *dst = qbuf.data() + q * query_bytes_;
+        std::memcpy(dst, static_cast<const char *>(queries) + q * stride, in_bytes);
+        if (metric_ == VecSimMetric_Cosine) normalize_blob(dst, dim_, type_);
+    }
+    const size_t kk = std::min(k, count_);
+    const size_t cap = std::max<size_t>(2 * kk, kk + 64);
+    std::vector<uint32_t> ids(nq * cap), counts(nq);
+    std::vector<double> sc(nq * cap);
+    int rc = vsgpu_topk(table_, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
+    if (rc) {
+        log("warning", "GPU top-k failed: %s", vsgpu_last_error());
+        for (auto *r : reps) delete r;
+        return rc;
+    }
+    if (timed_out(tctx)) {
+        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+        return finish();
+    }
+    std::vector<double> all;
+    std::vector<uint32_t> all_ids;
+    for (size_t q = 0; q < nq; q++) {
+        if (counts[q] == VSGPU_COUNT_OVERFLOW) {
+            // more than `cap` rows tie at the k-th score: replay over every row's GPU score
+            rc = vsgpu_scores(table_, qbuf.data() + q * query_bytes_, 0, count_, (all.resize(count_), all.data()));
+            if (rc) {
+                for (auto *r : reps) delete r;
+                return rc;
+            }
+            if (all_ids.size() != count_) {
+                all_ids.resize(count_);
+                for (size_t i = 0; i < count_; i++) all_ids[i] = (uint32_t)i;
+            }
+            replay(all_ids.data(), all.data(), count_, k, reps[q]);
+        } else {
+            replay(ids.data() + q * cap, sc.data() + q * cap, counts[q], k, reps[q]);
+        }
+        if (order == BY_ID) sort_reply(reps[q], BY_ID);
+    }
+    return finish();
+}
+
+VecSimQueryReply *FlatIndex::topKQuery(const void *query, size_t k, VecSimQueryParams *qp) {
+    VecSimQueryReply *rep = nullptr;
+    int rc = topKQueryBatch(query, 1, 0, k, qp, BY_SCORE, &rep);
+    if (rc) {
+        // no CPU fallback: report loudly and return an empty reply flagged as failed
+        std::fprintf(stderr, "vecsim_amd: GPU top-k query failed: %s\n", vsgpu_last_error());
+        rep = new VecSimQueryReply();
+        rep->code = VecSim_QueryReply_TimedOut;
+    }
+    return rep;
+}
+
+VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
+                                        VecSimQueryReply_Order order) {
+    auto *rep = new VecSimQueryReply();
+    void *tctx = qp ? qp->timeoutCtx : nullptr;
+    last_mode_ = RANGE_QUERY;
+    if (timed_out(tctx)) {
+        rep->code = VecSim_QueryReply_TimedOut;
+        return rep;
+    }
+    if (flush() || count_ == 0) return rep;
+    std::vector<char> q = preprocessQuery(query);
+    size_t cap = 1024;
+    std::vector<uint32_t> ids;
+    std::vector<double> sc;
+    uint32_t cnt = 0;
+    for (;;) {
+        ids.resize(cap);
+        sc.resize(cap);
+        int rc = vsgpu_range(table_, q.data(), radius, cap, ids.data(), sc.data(), &cnt);
+        if (rc) {
+            std::fprintf(stderr, "vecsim_amd: GPU range query failed: %s\n", vsgpu_last_error());
+            rep->code = VecSim_QueryReply_TimedOut;
+            return rep;
+        }
+        if (cnt != VSGPU_COUNT_OVERFLOW) break;
+        if (cap >= count_) {  // cannot overflow at full capacity; defensive
+            cnt = 0;
+            break;
+        }
+        cap = std::min(count_, cap * 16);
+    }
+    if (timed_out(tctx)) {
+        rep->code = VecSim_QueryReply_TimedOut;
+        return rep;
+    }
+    rep->results.resize(cnt);
+    for (uint32_t i = 0; i < cnt; i++) {
+        rep->results[i].id = id_to_label_[ids[i]];
+        rep->results[i].score = sc[i];
+    }
+    sort_reply(rep, order);
+    return rep;
+}
+
+double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
+    auto it = label_to_id_.find(label);
+    if (it == label_to_id_.end()) return std::numeric_limits<double>::quiet_NaN();
+    if (flush()) return std::numeric_limits<double>::quiet_NaN();
+    // "Unsafe": the blob is used as given (caller normalises for Cosine), brute_force_single.h:202-212
+    std::vector<char> q(query_bytes_);
+    std::memcpy(q.data(), blob, query_bytes_);
+    uint32_t id = it->second;
+    double s = std::numeric_limits<double>::quiet_NaN();
+    if (vsgpu_scores_of(table_, q.data(), &id, 1, &s)) return std::numeric_limits<double>::quiet_NaN();
+    return s;
+}
+
+// scripts/BF_batches_clf.py decision tree as evaluated in brute_force.h:380-451
+bool FlatIndex::preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) {
+    (void)k;
+    const size_t n = count_;
+    subsetSize = std::min(subsetSize, n);
+    const size_t d = dim_;
+    const float r = (n == 0) ? 0.0f : (float)subsetSize / (float)n;
+    bool adhoc;
+    if (n <= 5500) adhoc = true;
+    else if (d <= 300) adhoc = (r <= 0.15) || (r <= 0.35 && d > 75 && n <= 550000);
+    else adhoc = (r <= 0.55) || (d > 750 && r <= 0.75);
+    last_mode_ = adhoc ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
+    return adhoc;
+}
+
+VecSimIndexBasicInfo FlatIndex::basicInfo() const {
+    VecSimIndexBasicInfo b{};
+    b.algo = VecSimAlgo_BF;
+    b.metric = metric_;
+    b.type = type_;
+    b.isMulti = false;
+    b.isTiered = false;
+    b.isDisk = false;
+    b.blockSize = block_size_;
+    b.dim = dim_;
+    return b;
+}
+VecSimIndexStatsInfo FlatIndex::statsInfo() const {
+    VecSimIndexStatsInfo s{};
+    s.memory = id_to_label_.capacity() * sizeof(size_t) + staged_.capacity() + (table_ ? vsgpu_table_bytes(table_) : 0);
+    return s;
+}
+VecSimIndexDebugInfo FlatIndex::debugInfo() const {
+    VecSimIndexDebugInfo d{};
+    d.commonInfo.basicInfo = basicInfo();
+    d.commonInfo.indexSize = count_;
+    d.commonInfo.indexLabelCount = count_;
+    d.commonInfo.memory = statsInfo().memory;
+    d.commonInfo.lastMode = last_mode_;
+    return d;
+}
+
+VecSimBatchIterator *FlatIndex::newBatchIterator(const void *query, VecSimQueryParams *qp) {
+    auto *it = new VecSimBatchIterator();
+    it->index = this;
+    it->query = preprocessQuery(query);
+    it->timeout_ctx = qp ? qp->timeoutCtx : nullptr;
+    it->label_count = count_;
+    return it;
+}
+
+}  // namespace vsa

@@ -1,0 +1,141 @@
+// flat_index.h -- host side of the Flat (brute-force) index: labels, block bookkeeping, blob
+// preprocessing, reply construction.  Vector bytes live in HBM behind vsgpu_table; every distance
+// comes back from the gfx950 kernels through include/vsgpu.h.
+//
+// Mirrors the behaviour of the reference's BruteForceIndex / BruteForceIndex_Single
+// (algorithms/brute_force/brute_force.h:175-326, brute_force_single.h:135-212) for the calls on the
+// hot path and the calls either side of it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "VecSim/vec_sim.h"
+#include "VecSim/vec_sim_gpu.h"
+#include "vsgpu.h"
+
+// Reply objects (reference: query_result_definitions.h:25-39)
+struct VecSimQueryResult {
+    size_t id;
+    double score;
+};
+struct VecSimQueryReply {
+    std::vector<VecSimQueryResult> results;
+    VecSimQueryReply_Code code = VecSim_QueryReply_OK;
+};
+struct VecSimQueryReply_Iterator {
+    VecSimQueryReply *reply;
+    size_t pos;
+};
+
+namespace vsa {
+struct Globals {
+    timeoutCallbackFunction timeout_cb = nullptr;  // default: never times out (vec_sim_interface.cpp:78)
+    logCallbackFunction log_cb = nullptr;
+    VecSimWriteMode write_mode = VecSim_WriteAsync;
+    int device = -1;  // -1: $VECSIM_GPU_DEVICE or 0
+};
+Globals &globals();
+inline bool timed_out(void *ctx) {
+    timeoutCallbackFunction cb = globals().timeout_cb;
+    return cb && cb(ctx) != 0;
+}
+void sort_reply(VecSimQueryReply *rep, VecSimQueryReply_Order order);
+}  // namespace vsa
+
+// The C API's opaque index type
+struct VecSimIndexInterface {
+    virtual ~VecSimIndexInterface() = default;
+    virtual int addVector(const void *blob, size_t label) = 0;
+    virtual int deleteVector(size_t label) = 0;
+    virtual size_t indexSize() const = 0;
+    virtual size_t indexLabelCount() const = 0;
+    virtual VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) = 0;
+    virtual int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
+                               VecSimQueryReply_Order order, VecSimQueryReply **out) = 0;
+    virtual VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
+                                         VecSimQueryReply_Order order) = 0;
+    virtual double getDistanceFrom(size_t label, const void *blob) = 0;
+    virtual VecSimBatchIterator *newBatchIterator(const void *query, VecSimQueryParams *qp) = 0;
+    virtual bool preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) = 0;
+    virtual VecSimIndexBasicInfo basicInfo() const = 0;
+    virtual VecSimIndexStatsInfo statsInfo() const = 0;
+    virtual VecSimIndexDebugInfo debugInfo() const = 0;
+    virtual long addBulk(const void *blobs, const size_t *labels, size_t n) = 0;
+    virtual long addSynthetic(size_t n, uint64_t seed) = 0;
+    virtual vsgpu_ctx *gpu() = 0;
+    virtual void setLastMode(VecSearchMode m) = 0;
+};
+
+namespace vsa {
+
+class FlatIndex final : public VecSimIndexInterface {
+public:
+    // returns nullptr (with VecSimGpu_LastError set) when the GPU context cannot be created
+    static FlatIndex *create(const BFParams &p, void *logCtx);
+    ~FlatIndex() override;
+
+    int addVector(const void *blob, size_t label) override;
+    int deleteVector(size_t label) override;
+    size_t indexSize() const override { return count_; }
+    size_t indexLabelCount() const override { return count_; }
+    VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) override;
+    int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
+                       VecSimQueryReply_Order order, VecSimQueryReply **out) override;
+    VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
+                                 VecSimQueryReply_Order order) override;
+    double getDistanceFrom(size_t label, const void *blob) override;
+    VecSimBatchIterator *newBatchIterator(const void *query, VecSimQueryParams *qp) override;
+    bool preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) override;
+    VecSimIndexBasicInfo basicInfo() const override;
+    VecSimIndexStatsInfo statsInfo() const override;
+    VecSimIndexDebugInfo debugInfo() const override;
+    long addBulk(const void *blobs, const size_t *labels, size_t n) override;
+    long addSynthetic(size_t n, uint64_t seed) override;
+    vsgpu_ctx *gpu() override { return ctx_; }
+    void setLastMode(VecSearchMode m) override { last_mode_ = m; }
+
+    // used by the batch iterator
+    int allScores(const void *processed_query, std::vector<double> &scores);
+    size_t labelOf(size_t id) const { return id_to_label_[id]; }
+    size_t queryBytes() const { return query_bytes_; }
+    std::vector<char> preprocessQuery(const void *query) const;
+
+private:
+    FlatIndex() = default;
+    int flush();  // push host-staged rows to the device table
+    void stageRow(const void *processed);
+    void log(const char *level, const char *fmt, ...) const;
+    void replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const;
+
+    VecSimType type_ = VecSimType_FLOAT32;
+    VecSimMetric metric_ = VecSimMetric_L2;
+    size_t dim_ = 0, block_size_ = DEFAULT_BLOCK_SIZE;
+    size_t stored_bytes_ = 0, query_bytes_ = 0;
+    void *log_ctx_ = nullptr;
+    vsgpu_ctx *ctx_ = nullptr;
+    vsgpu_table *table_ = nullptr;
+    size_t count_ = 0;  // vectors in the index (device rows + staged rows)
+    std::vector<size_t> id_to_label_;
+    std::unordered_map<size_t, uint32_t> label_to_id_;
+    std::vector<char> staged_;  // rows appended but not yet uploaded
+    size_t staged_rows_ = 0;
+    mutable VecSearchMode last_mode_ = EMPTY_MODE;
+};
+
+}  // namespace vsa
+
+// "next n best" cursor (reference: batch_iterator.h, brute_force/bf_batch_iterator.h:24-199)
+struct VecSimBatchIterator {
+    vsa::FlatIndex *index;
+    std::vector<char> query;  // processed query, owned
+    void *timeout_ctx;
+    std::vector<std::pair<double, size_t>> scores;  // (score, label) of every vector, lazily filled
+    bool scored = false;
+    size_t valid_start = 0;
+    size_t label_count = 0;
+    size_t returned = 0;
+};

@@ -1,0 +1,164 @@
+// lane_program.h -- host-side description of the summation order each kernel must reproduce.
+//
+// The reference picks one SIMD kernel per (type, metric, dim) (spaces/L2_space.cpp:185-516,
+// spaces/IP_space.cpp:435-889) and every such kernel is a set of independent accumulator lanes,
+// each consuming a fixed subsequence of the vector elements in increasing order, followed by a
+// fixed halving-tree horizontal add.  A "lane program" writes that down as a table:
+//
+//     offs[step * vl + lane] = byte offset (inside the row) of the element that virtual lane `lane`
+//                              consumes at `step`, or -1 when the lane idles in that step.
+//
+// The exact-distance HIP kernels are table driven: one GPU lane plays one virtual lane, walks the
+// steps in order, then the group reduces with __shfl_down offsets vl/2 .. 1, which is the
+// _mm512_reduce_add_ps / _pd tree of gcc 11 (avx512fintrin.h:16112-16121).  Host code only; no
+// distance is ever computed here.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "vsgpu.h"
+
+namespace vsg {
+
+struct LaneProgram {
+    int vl = 32;        // virtual lanes per row (32: fp32/fp16/int8/uint8, 16: fp64/bf16)
+    int steps = 0;      // table height
+    bool fused = true;  // true: acc = fma(a,b,acc); false: acc = acc + a*b (scalar tier, L2.cpp:76-133)
+    bool is_l2 = true;  // L2: (x-q)^2 terms; otherwise x*q terms
+    int elem_bytes = 4;
+    bool scalar_tier = false;
+    std::vector<int32_t> offs;  // steps * vl
+};
+
+inline int elem_bytes_of(int type) {
+    switch (type) {
+    case VSGPU_F32: return 4;
+    case VSGPU_F64: return 8;
+    case VSGPU_BF16:
+    case VSGPU_F16: return 2;
+    default: return 1;
+    }
+}
+
+// Minimum dims below which the x86 choosers keep the scalar kernel:
+// fp32 <8 (L2_space.cpp:215-217, IP_space.cpp twin), fp64 <4 (:274-276), bf16 <32 (:329-331),
+// fp16 <16 for the AVX512F tier (:397-402; dims 8..15 would be the F16C tier, not restated: we
+// use the scalar order there and say so in DESIGN.md).
+inline bool uses_scalar_tier(int type, int tier, size_t dim) {
+    if (tier == VSGPU_TIER_SCALAR) return true;
+    switch (type) {
+    case VSGPU_F32: return dim < 8;
+    case VSGPU_F64: return dim < 4;
+    case VSGPU_BF16: return dim < 32;
+    case VSGPU_F16: return dim < 16;
+    default: return false;  // integer kernels are exact in any order
+    }
+}
+
+inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, size_t dim) {
+    LaneProgram p;
+    p.elem_bytes = elem_bytes_of(type);
+    p.is_l2 = (kernel_metric == VSGPU_L2);
+    p.vl = (type == VSGPU_F64 || type == VSGPU_BF16) ? 16 : 32;
+    const int vl = p.vl;
+    const int eb = p.elem_bytes;
+    auto new_step = [&]() {
+        p.offs.insert(p.offs.end(), (size_t)vl, -1);
+        return p.steps++;
+    };
+    auto put = [&](int step, int lane, size_t elem) {
+        p.offs[(size_t)step * vl + lane] = (int32_t)(elem * eb);
+    };
+
+    if (type == VSGPU_I8 || type == VSGPU_U8) {
+        // exact integer sums: any order gives the reference's integer (IP_AVX512F_BW_VL_VNNI_INT8.h
+        // :29-60 accumulates in int32 lanes; L2.cpp:149-162 in long long).  Plain striding.
+        p.fused = true;
+        for (size_t e = 0; e < dim; e += vl) {
+            int s = new_step();
+            for (int j = 0; j < vl && e + j < dim; j++) put(s, j, e + j);
+        }
+        return p;
+    }
+
+    if (uses_scalar_tier(type, tier, dim)) {
+        // one sequential chain, separate multiply and add
+        p.fused = false;
+        p.scalar_tier = true;
+        for (size_t e = 0; e < dim; e++) put(new_step(), 0, e);
+        return p;
+    }
+
+    if (type == VSGPU_F32 || type == VSGPU_F16 || type == VSGPU_F64) {
+        // two accumulators of h lanes each (h = 16 for 32-bit math, 8 for fp64):
+        // L2_AVX512F_FP32.h:21-59, L2_AVX512F_FP16.h, L2_AVX512F_FP64.h:21-59 and the IP twins.
+        const size_t h = vl / 2, chunk = vl;
+        const size_t residual = dim % chunk, rh = residual % h;
+        size_t pos = 0;
+        if (residual) {
+            int s = new_step();
+            for (size_t j = 0; j < rh; j++) put(s, (int)j, j);  // masked head -> sum0
+            pos = rh;
+            if (residual >= h) {  // one full h-block -> sum1
+                for (size_t j = 0; j < h; j++) put(s, (int)(h + j), pos + j);
+                pos += h;
+            }
+        }
+        for (; pos < dim; pos += chunk) {
+            int s = new_step();
+            for (size_t j = 0; j < chunk; j++) put(s, (int)j, pos + j);  // lanes 0..h-1 sum0, rest sum1
+        }
+        return p;
+    }
+
+    // bf16, 16 fp32 lanes, one accumulator
+    const size_t residual = dim % 32;
+    size_t pos = 0;
+    if (tier == VSGPU_TIER_AVX512_BF16 && !p.is_l2) {
+        // vdpbf16ps (IP_AVX512_BF16_VL_BF16.h:14-47): lane j takes the pair (2j, 2j+1), the odd
+        // element first, each accumulated with its own rounding (characterised on hardware, see
+        // oracle/vso.c).
+        if (residual) {
+            int s1 = new_step(), s0 = new_step();
+            for (int j = 0; j < 16; j++) {
+                if ((size_t)(2 * j + 1) < residual) put(s1, j, 2 * j + 1);
+                if ((size_t)(2 * j) < residual) put(s0, j, 2 * j);
+            }
+            pos = residual;
+        }
+        for (; pos < dim; pos += 32) {
+            int s1 = new_step(), s0 = new_step();
+            for (int j = 0; j < 16; j++) {
+                put(s1, j, pos + 2 * j + 1);
+                put(s0, j, pos + 2 * j);
+            }
+        }
+        return p;
+    }
+    // VBMI2 tier (L2_AVX512BW_VBMI2_BF16.h:40-78, IP_AVX512BW_VBMI2_BF16.h:38-76)
+    if (residual) {
+        if (residual >= 16) {
+            int s = new_step();
+            for (int j = 0; j < 16; j++) put(s, j, j);
+            pos = 16;
+        }
+        if (residual != 16) {
+            int s = new_step();
+            size_t r = residual % 16;
+            for (size_t j = 0; j < r; j++) put(s, (int)j, pos + j);
+            pos += r;
+        }
+    }
+    for (; pos < dim; pos += 32) {
+        int lo = new_step(), hi = new_step();
+        for (int j = 0; j < 16; j++) {
+            int L = j / 4, w = j % 4;
+            put(lo, j, pos + 8 * L + w);      // unpacklo: elements 0..3 of each 128-bit lane
+            put(hi, j, pos + 8 * L + 4 + w);  // unpackhi: elements 4..7
+        }
+    }
+    return p;
+}
+
+}  // namespace vsg

@@ -1,0 +1,838 @@
+// vsgpu.hip -- implementation of include/vsgpu.h: device table + query orchestration (gfx950).
+//
+// No CPU fallback lives here: if there is no HIP device every entry point fails with
+// VSGPU_ERR_NO_DEVICE and a message.  Host code in this file only moves bytes, builds lane tables,
+// launches kernels and selects among *GPU-computed* scores.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "vsgpu.h"
+#include "lane_program.h"
+#include "exact_kernels.hpp"
+
+using namespace vsg;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(_e == hipErrorOutOfMemory ? VSGPU_ERR_OOM : VSGPU_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+extern "C" const char *vsgpu_last_error(void) { return g_err.c_str(); }
+
+extern "C" int vsgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ context
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct vsgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    vsgpu_stats stats{};
+    // options
+    long opt_mfma = 1;
+    long opt_dense_pairs = 1L << 22;  // nq*n at or below this: dense score matrix + host selection
+    long opt_probe_div = 32;          // probe ~ n / probe_div rows
+    long opt_cand_cap = 8192;         // candidate slots per query
+    int n_cu = 256;
+};
+
+static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return VSGPU_OK;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max(bytes, (size_t)4096);
+    want = (want + 0xFFFF) & ~(size_t)0xFFFF;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return VSGPU_OK;
+}
+static int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
+    if (bytes <= c->pinned_cap) return VSGPU_OK;
+    if (c->pinned) HIPCHK(hipHostFree(c->pinned));
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    size_t want = (std::max(bytes, (size_t)1 << 20) + 0xFFFF) & ~(size_t)0xFFFF;
+    HIPCHK(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinned_cap = want;
+    return VSGPU_OK;
+}
+
+extern "C" vsgpu_ctx *vsgpu_ctx_create(int device) {
+    int n = vsgpu_device_count();
+    if (n <= 0) {
+        fail(VSGPU_ERR_NO_DEVICE, "no HIP device visible: the gfx950 kernels are the only compute path");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        fail(VSGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(VSGPU_ERR_HIP, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    vsgpu_ctx *c = new vsgpu_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess ||
+        hipEventCreate(&c->ev_c) != hipSuccess || hipEventCreate(&c->ev_d) != hipSuccess) {
+        fail(VSGPU_ERR_HIP, "stream/event creation failed on device %d", device);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids})
+        if (b->p) (void)hipFree(b->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    (void)hipEventDestroy(c->ev_a);
+    (void)hipEventDestroy(c->ev_b);
+    (void)hipEventDestroy(c->ev_c);
+    (void)hipEventDestroy(c->ev_d);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int vsgpu_ctx_device(const vsgpu_ctx *c) { return c ? c->device : -1; }
+extern "C" int vsgpu_ctx_sync(vsgpu_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VSGPU_OK;
+}
+extern "C" void vsgpu_stats_reset(vsgpu_ctx *c) {
+    char name[64];
+    memcpy(name, c->stats.scan_kernel, sizeof name);
+    c->stats = vsgpu_stats{};
+    memcpy(c->stats.scan_kernel, name, sizeof name);
+}
+extern "C" void vsgpu_stats_get(vsgpu_ctx *c, vsgpu_stats *out) { *out = c->stats; }
+extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
+    std::string n(name);
+    if (n == "mfma") c->opt_mfma = value;
+    else if (n == "dense_pairs") c->opt_dense_pairs = value;
+    else if (n == "probe_div") c->opt_probe_div = std::max(1L, value);
+    else if (n == "cand_cap") c->opt_cand_cap = std::max(16L, value);
+    else return fail(VSGPU_ERR_ARG, "unknown option %s", name);
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ table
+struct vsgpu_table {
+    vsgpu_ctx *ctx = nullptr;
+    int type = 0, metric = 0, tier = 0;
+    size_t dim = 0, row_bytes = 0;
+    LaneProgram prog;
+    int32_t *d_offs = nullptr;
+    std::vector<char *> slabs;
+    char **d_slabs = nullptr;
+    size_t d_slabs_cap = 0;
+    uint32_t slab_shift = 0;
+    size_t n = 0;
+    int ek = 0, opk = 0, epi = 0;
+    int bt_max = 1;  // largest query tile whose LDS image fits
+};
+
+static size_t acc_bytes(int type) { return type == VSGPU_F64 ? 8 : 4; }
+
+extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, int tier, size_t dim,
+                                           size_t row_bytes) {
+    if (!c) {
+        fail(VSGPU_ERR_ARG, "null context");
+        return nullptr;
+    }
+    if (type < VSGPU_F32 || type > VSGPU_U8 || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
+        row_bytes < dim * (size_t)elem_bytes_of(type)) {
+        fail(VSGPU_ERR_ARG, "bad table parameters (type %d metric %d dim %zu row_bytes %zu)", type, metric,
+             dim, row_bytes);
+        return nullptr;
+    }
+    bool is_int = (type == VSGPU_I8 || type == VSGPU_U8);
+    if (metric == VSGPU_COSINE && !is_int) metric = VSGPU_IP;  // fp Cosine == IP kernel on normalised blobs
+    vsgpu_table *t = new vsgpu_table();
+    t->ctx = c;
+    t->type = type;
+    t->metric = metric;
+    t->tier = tier;
+    t->dim = dim;
+    t->row_bytes = row_bytes;
+    t->prog = build_lane_program(type, metric == VSGPU_L2 ? VSGPU_L2 : VSGPU_IP, tier, dim);
+    t->ek = type;  // ElemKind values equal the type codes
+    bool l2 = (metric == VSGPU_L2);
+    t->opk = t->prog.fused ? (l2 ? OP_L2_FMA : OP_IP_FMA) : (l2 ? OP_L2_MULADD : OP_IP_MULADD);
+    if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
+    else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
+    // LDS budget 64 KiB: offs + BT query images
+    size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
+    size_t q_b = (size_t)t->prog.steps * t->prog.vl * acc_bytes(type);
+    size_t budget = 64 * 1024;
+    if (offs_b + q_b > budget) {
+        fail(VSGPU_ERR_UNSUPPORTED, "dim %zu too large for the table-driven kernel's LDS image", dim);
+        delete t;
+        return nullptr;
+    }
+    size_t fit = (budget - offs_b) / q_b;
+    t->bt_max = fit >= 8 ? 8 : (fit >= 4 ? 4 : 1);
+    if (!t->prog.fused) t->bt_max = 1;  // scalar-tier variants are only instantiated for BT=1
+    // slabs of ~64 MiB, power-of-two row count
+    size_t rows = ((size_t)64 << 20) / row_bytes;
+    uint32_t shift = 0;
+    while (((size_t)2 << shift) <= rows) shift++;
+    if (shift < 6) shift = 6;
+    t->slab_shift = shift;
+    if (hipSetDevice(c->device) != hipSuccess ||
+        hipMalloc((void **)&t->d_offs, std::max<size_t>(16, t->prog.offs.size() * 4)) != hipSuccess ||
+        hipMemcpy(t->d_offs, t->prog.offs.data(), t->prog.offs.size() * 4, hipMemcpyHostToDevice) !=
+            hipSuccess) {
+        fail(VSGPU_ERR_HIP, "lane table upload failed");
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+
+extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    for (char *s : t->slabs) (void)hipFree(s);
+    if (t->d_slabs) (void)hipFree(t->d_slabs);
+    if (t->d_offs) (void)hipFree(t->d_offs);
+    delete t;
+}
+extern "C" size_t vsgpu_table_size(const vsgpu_table *t) { return t->n; }
+extern "C" size_t vsgpu_table_bytes(const vsgpu_table *t) {
+    return t->slabs.size() * (((size_t)1 << t->slab_shift) * t->row_bytes);
+}
+
+static int grow_to(vsgpu_table *t, size_t rows) {
+    const size_t slab_rows = (size_t)1 << t->slab_shift;
+    size_t need = (rows + slab_rows - 1) / slab_rows;
+    bool changed = false;
+    while (t->slabs.size() < need) {
+        char *p = nullptr;
+        HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes));
+        t->slabs.push_back(p);
+        changed = true;
+    }
+    if (changed) {
+        if (t->slabs.size() > t->d_slabs_cap) {
+            // the old pointer table may still be read by nothing: all launches are synchronised per call
+            if (t->d_slabs) HIPCHK(hipFree(t->d_slabs));
+            t->d_slabs = nullptr;
+            size_t cap = std::max<size_t>(64, t->slabs.size() * 2);
+            HIPCHK(hipMalloc((void **)&t->d_slabs, cap * sizeof(char *)));
+            t->d_slabs_cap = cap;
+        }
+        HIPCHK(hipMemcpy(t->d_slabs, t->slabs.data(), t->slabs.size() * sizeof(char *),
+                         hipMemcpyHostToDevice));
+    }
+    return VSGPU_OK;
+}
+static inline char *row_ptr(const vsgpu_table *t, size_t id) {
+    const size_t mask = ((size_t)1 << t->slab_shift) - 1;
+    return t->slabs[id >> t->slab_shift] + (id & mask) * t->row_bytes;
+}
+
+extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t n) {
+    if (n == 0) return VSGPU_OK;
+    HIPCHK(hipSetDevice(t->ctx->device));
+    if (t->n + n > 0xFFFFFFF0ull) return fail(VSGPU_ERR_UNSUPPORTED, "more than 2^32 rows per device table");
+    int rc = grow_to(t, t->n + n);
+    if (rc) return rc;
+    const size_t slab_rows = (size_t)1 << t->slab_shift;
+    const char *src = (const char *)host_rows;
+    size_t id = t->n, left = n;
+    while (left) {
+        size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
+        HIPCHK(hipMemcpy(row_ptr(t, id), src, in_slab * t->row_bytes, hipMemcpyHostToDevice));
+        src += in_slab * t->row_bytes;
+        id += in_slab;
+        left -= in_slab;
+    }
+    t->n += n;
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row) {
+    if (id >= t->n) return fail(VSGPU_ERR_ARG, "row %zu out of range", id);
+    HIPCHK(hipSetDevice(t->ctx->device));
+    HIPCHK(hipMemcpy(row_ptr(t, id), host_row, t->row_bytes, hipMemcpyHostToDevice));
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_table_move(vsgpu_table *t, size_t dst, size_t src) {
+    if (dst >= t->n || src >= t->n) return fail(VSGPU_ERR_ARG, "move %zu <- %zu out of range", dst, src);
+    if (dst == src) return VSGPU_OK;
+    HIPCHK(hipSetDevice(t->ctx->device));
+    HIPCHK(hipMemcpy(row_ptr(t, dst), row_ptr(t, src), t->row_bytes, hipMemcpyDeviceToDevice));
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_table_truncate(vsgpu_table *t, size_t new_size) {
+    if (new_size > t->n) return fail(VSGPU_ERR_ARG, "truncate beyond size");
+    t->n = new_size;  // slabs are kept (the reference frees whole blocks; capacity is not on the query path)
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
+    if (id >= t->n) return fail(VSGPU_ERR_ARG, "row %zu out of range", id);
+    HIPCHK(hipSetDevice(t->ctx->device));
+    HIPCHK(hipMemcpy(host_row, row_ptr(t, id), t->row_bytes, hipMemcpyDeviceToHost));
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
+    if (t->type != VSGPU_F32) return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32 only");
+    if (n == 0) return VSGPU_OK;
+    HIPCHK(hipSetDevice(t->ctx->device));
+    if (t->n + n > 0xFFFFFFF0ull) return fail(VSGPU_ERR_UNSUPPORTED, "more than 2^32 rows per device table");
+    int rc = grow_to(t, t->n + n);
+    if (rc) return rc;
+    const size_t slab_rows = (size_t)1 << t->slab_shift;
+    size_t id = t->n, left = n;
+    while (left) {
+        size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
+        uint64_t count = (uint64_t)in_slab * t->dim;
+        int grid = (int)std::min<uint64_t>((count + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_fill_uniform_f32, dim3(grid), dim3(256), 0, t->ctx->stream,
+                           (float *)row_ptr(t, id), (uint64_t)id * t->dim, count, seed);
+        id += in_slab;
+        left -= in_slab;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    t->n += n;
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ query staging
+// widen one stored element to the accumulator type (host side of the LDS query image only)
+static inline float widen_f16(uint16_t h) {
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (float)v;
+}
+static inline float widen_bf16(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Build [nq][steps][vl] permuted/widened query images in pinned memory and upload them.
+static int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride) {
+    vsgpu_ctx *c = t->ctx;
+    const LaneProgram &pg = t->prog;
+    const size_t per_q = (size_t)pg.steps * pg.vl;
+    const size_t ab = acc_bytes(t->type);
+    const size_t bytes = nq * per_q * ab;
+    int rc = ensure_pinned(c, bytes + nq * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->qperm, bytes);
+    if (rc) return rc;
+    char *dst = (char *)c->pinned;
+    for (size_t q = 0; q < nq; q++) {
+        const char *src = (const char *)queries + q * qstride;
+        for (size_t i = 0; i < per_q; i++) {
+            int32_t off = pg.offs[i];
+            char *o = dst + (q * per_q + i) * ab;
+            switch (t->type) {
+            case VSGPU_F32: {
+                float v = 0;
+                if (off >= 0) memcpy(&v, src + off, 4);
+                memcpy(o, &v, 4);
+                break;
+            }
+            case VSGPU_F64: {
+                double v = 0;
+                if (off >= 0) memcpy(&v, src + off, 8);
+                memcpy(o, &v, 8);
+                break;
+            }
+            case VSGPU_F16:
+            case VSGPU_BF16: {
+                float v = 0;
+                if (off >= 0) {
+                    uint16_t h;
+                    memcpy(&h, src + off, 2);
+                    v = t->type == VSGPU_F16 ? widen_f16(h) : widen_bf16(h);
+                }
+                memcpy(o, &v, 4);
+                break;
+            }
+            case VSGPU_I8: {
+                int v = off >= 0 ? (int)*(const int8_t *)(src + off) : 0;
+                memcpy(o, &v, 4);
+                break;
+            }
+            default: {
+                int v = off >= 0 ? (int)*(const uint8_t *)(src + off) : 0;
+                memcpy(o, &v, 4);
+                break;
+            }
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->qperm.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    if (t->epi == EPI_INT_COS) {
+        float *qn = (float *)((char *)c->pinned + bytes);
+        for (size_t q = 0; q < nq; q++) memcpy(&qn[q], (const char *)queries + q * qstride + t->dim, 4);
+        rc = ensure(c, c->qnorm, nq * 4);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->qnorm.p, qn, nq * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ kernel dispatch
+template <int EK, int OPK, int BT> static void launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((k_exact_scan<EK, OPK, BT>), grid, dim3(256), lds, s, P);
+}
+template <int EK, int OPK> static void launch_scan_bt(int bt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    if (bt == 8) launch_scan_t<EK, OPK, 8>(P, grid, lds, s);
+    else if (bt == 4) launch_scan_t<EK, OPK, 4>(P, grid, lds, s);
+    else launch_scan_t<EK, OPK, 1>(P, grid, lds, s);
+}
+template <int EK> static void launch_scan_op(int opk, int bt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    switch (opk) {
+    case OP_L2_FMA: launch_scan_bt<EK, OP_L2_FMA>(bt, P, grid, lds, s); break;
+    case OP_IP_FMA: launch_scan_bt<EK, OP_IP_FMA>(bt, P, grid, lds, s); break;
+    case OP_L2_MULADD: launch_scan_t<EK, OP_L2_MULADD, 1>(P, grid, lds, s); break;
+    default: launch_scan_t<EK, OP_IP_MULADD, 1>(P, grid, lds, s); break;
+    }
+}
+static void launch_scan(int ek, int opk, int bt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    switch (ek) {
+    case EK_F32: launch_scan_op<EK_F32>(opk, bt, P, grid, lds, s); break;
+    case EK_F64: launch_scan_op<EK_F64>(opk, bt, P, grid, lds, s); break;
+    case EK_BF16: launch_scan_op<EK_BF16>(opk, bt, P, grid, lds, s); break;
+    case EK_F16: launch_scan_op<EK_F16>(opk, bt, P, grid, lds, s); break;
+    case EK_I8: launch_scan_op<EK_I8>(opk, bt, P, grid, lds, s); break;
+    default: launch_scan_op<EK_U8>(opk, bt, P, grid, lds, s); break;
+    }
+}
+static int tile_rows_of(int ek) { return (ek == EK_F64 || ek == EK_BF16) ? (256 / 16) * 4 : (256 / 32) * 4; }
+
+static int pick_bt(const vsgpu_table *t, size_t nq) {
+    int bt = t->bt_max;
+    while (bt > 1 && (size_t)bt / 2 >= nq) bt /= 2;  // 8 -> 4 -> ... while the smaller tile still covers nq
+    if (bt == 2) bt = 4;
+    if (bt > 1 && nq == 1) bt = 1;
+    return bt;
+}
+
+// Fill the table/program part of ScanParams and launch over compact rows.
+static int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
+    vsgpu_ctx *c = t->ctx;
+    P.slabs = t->d_slabs;
+    P.slab_shift = t->slab_shift;
+    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    P.row_stride = (uint32_t)t->row_bytes;
+    P.offs = t->d_offs;
+    P.steps = t->prog.steps;
+    P.qperm = c->qperm.p;
+    P.nq = (int)nq;
+    P.epilogue = t->epi;
+    P.norm_off = (uint32_t)t->dim;
+    P.qnorm = (const float *)c->qnorm.p;
+    const int bt = pick_bt(t, nq);
+    const int tile_rows = tile_rows_of(t->ek);
+    const uint32_t n_tiles = (P.n_compact + tile_rows - 1) / tile_rows;
+    if (n_tiles == 0) return VSGPU_OK;
+    const size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
+    const size_t lds = offs_b + (size_t)bt * t->prog.steps * t->prog.vl * acc_bytes(t->type);
+    const uint32_t q_tiles = (uint32_t)((nq + bt - 1) / bt);
+    uint32_t gx = std::min<uint32_t>(n_tiles, (uint32_t)c->n_cu * 8);
+    if (timed) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    launch_scan(t->ek, t->opk, bt, P, dim3(gx, q_tiles), lds, c->stream);
+    HIPCHK(hipGetLastError());
+    if (timed) HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    return VSGPU_OK;
+}
+
+static void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) {
+        c->stats.scan_ms += ms;
+        c->stats.scan_launches += 1;
+        c->stats.scan_rows += rows;
+        c->stats.scan_bytes += rows * t->row_bytes;
+        (void)passes;
+        snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, "%s", name);
+    }
+}
+
+// ------------------------------------------------------------------ dense scores
+// scores of compact rows (contiguous range or id list) for nq staged queries -> host doubles [nq][n]
+static int dense_to_host(vsgpu_table *t, size_t nq, const uint32_t *d_ids, size_t first, size_t n,
+                         double *out /*[nq][n]*/) {
+    vsgpu_ctx *c = t->ctx;
+    const bool f64 = (t->type == VSGPU_F64);
+    const size_t sb = f64 ? 8 : 4;
+    int rc = ensure(c, c->dense, nq * n * sb);
+    if (rc) return rc;
+    ScanParams P{};
+    P.row_ids = d_ids;
+    P.row_begin = (uint32_t)first;
+    P.row_end = (uint32_t)t->n;
+    P.n_compact = (uint32_t)n;
+    P.tile_step = (uint32_t)tile_rows_of(t->ek);
+    P.mode = MODE_DENSE;
+    P.out = c->dense.p;
+    P.out_stride = n;
+    rc = run_scan(t, P, nq, false);
+    if (rc) return rc;
+    rc = ensure_pinned(c, nq * n * sb);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->pinned, c->dense.p, nq * n * sb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (f64) memcpy(out, c->pinned, nq * n * 8);
+    else {
+        const float *src = (const float *)c->pinned;
+        for (size_t i = 0; i < nq * n; i++) out[i] = (double)src[i];
+    }
+    return VSGPU_OK;
+}
+
+extern "C" int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, size_t n, double *scores) {
+    if (first + n > t->n) return fail(VSGPU_ERR_ARG, "range [%zu,%zu) beyond table size %zu", first, first + n, t->n);
+    if (n == 0) return VSGPU_OK;
+    HIPCHK(hipSetDevice(t->ctx->device));
+    int rc = stage_queries(t, query, 1, 0);
+    if (rc) return rc;
+    // chunk so the dense buffer stays modest
+    const size_t chunk = (size_t)1 << 24;
+    for (size_t off = 0; off < n; off += chunk) {
+        size_t m = std::min(chunk, n - off);
+        rc = dense_to_host(t, 1, nullptr, first + off, m, scores + off);
+        if (rc) return rc;
+    }
+    return VSGPU_OK;
+}
+
+extern "C" int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t *ids, size_t n, double *scores) {
+    if (n == 0) return VSGPU_OK;
+    for (size_t i = 0; i < n; i++)
+        if (ids[i] >= t->n) return fail(VSGPU_ERR_ARG, "row id %u beyond table size %zu", ids[i], t->n);
+    vsgpu_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = stage_queries(t, query, 1, 0);
+    if (rc) return rc;
+    rc = ensure(c, c->ids, n * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->ids.p, ids, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // ids is caller memory: finish the copy before returning paths diverge
+    return dense_to_host(t, 1, (const uint32_t *)c->ids.p, 0, n, scores);
+}
+
+// ------------------------------------------------------------------ selection helpers (host, on GPU scores)
+struct Hit {
+    uint32_t id;
+    double score;
+};
+// keep rows with score <= T (T = k-th smallest), ascending id
+static void select_upto_kth(std::vector<Hit> &hits, size_t k) {
+    if (hits.size() > k) {
+        std::vector<double> s(hits.size());
+        for (size_t i = 0; i < hits.size(); i++) s[i] = hits[i].score;
+        std::nth_element(s.begin(), s.begin() + (k - 1), s.end());
+        const double T = s[k - 1];
+        size_t w = 0;
+        for (size_t i = 0; i < hits.size(); i++)
+            if (hits[i].score <= T) hits[w++] = hits[i];
+        hits.resize(w);
+    }
+    std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
+}
+static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *ids, double *scores, uint32_t *counts) {
+    if (hits.size() > cap) {
+        counts[q] = VSGPU_COUNT_OVERFLOW;
+        return;
+    }
+    counts[q] = (uint32_t)hits.size();
+    for (size_t i = 0; i < hits.size(); i++) {
+        ids[q * cap + i] = hits[i].id;
+        scores[q * cap + i] = hits[i].score;
+    }
+}
+
+// ------------------------------------------------------------------ top-K
+static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
+                           uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride) {
+    // queries [q_first, q_first+q_count) answered from full score vectors
+    const size_t n = t->n;
+    std::vector<double> row(n);
+    std::vector<Hit> hits;
+    for (size_t q = q_first; q < q_first + q_count; q++) {
+        int rc = vsgpu_scores(t, (const char *)queries + q * qstride, 0, n, row.data());
+        if (rc) return rc;
+        hits.resize(n);
+        for (size_t i = 0; i < n; i++) hits[i] = Hit{(uint32_t)i, row[i]};
+        select_upto_kth(hits, k);
+        emit(hits, q, cap, ids, scores, counts);
+    }
+    (void)nq;
+    return VSGPU_OK;
+}
+
+extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                          uint32_t *ids, double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    if (nq == 0) return VSGPU_OK;
+    if (k == 0 || t->n == 0) {
+        for (size_t q = 0; q < nq; q++) counts[q] = 0;
+        return VSGPU_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = t->n;
+    const bool f64 = (t->type == VSGPU_F64);
+
+    // small problems (and fp64): one dense score matrix, selection on the host
+    if (f64 || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k) {
+        if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) {
+            int rc = stage_queries(t, queries, nq, qstride);
+            if (rc) return rc;
+            std::vector<double> all(nq * n);
+            HIPCHK(hipEventRecord(c->ev_c, c->stream));
+            ScanParams P{};
+            // dense_to_host re-records nothing: time it here as the scan
+            rc = ensure(c, c->dense, nq * n * 4);
+            if (rc) return rc;
+            P.row_ids = nullptr;
+            P.row_begin = 0;
+            P.row_end = (uint32_t)n;
+            P.n_compact = (uint32_t)n;
+            P.tile_step = (uint32_t)tile_rows_of(t->ek);
+            P.mode = MODE_DENSE;
+            P.out = c->dense.p;
+            P.out_stride = n;
+            rc = run_scan(t, P, nq, true);
+            if (rc) return rc;
+            rc = ensure_pinned(c, nq * n * 4);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(c->pinned, c->dense.p, nq * n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            account_scan(c, t, n, 1, "k_exact_scan(dense)");
+            const float *src = (const float *)c->pinned;
+            std::vector<Hit> hits;
+            for (size_t q = 0; q < nq; q++) {
+                hits.resize(n);
+                for (size_t i = 0; i < n; i++) hits[i] = Hit{(uint32_t)i, (double)src[q * n + i]};
+                select_upto_kth(hits, k);
+                emit(hits, q, cap, ids, scores, counts);
+            }
+            return VSGPU_OK;
+        }
+        return topk_dense_path(t, nq, k, cap, ids, scores, counts, 0, nq, queries, qstride);
+    }
+
+    // ---- probe -> threshold -> filtered scan ----
+    int rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
+    const int tile_rows = tile_rows_of(t->ek);
+    const size_t total_tiles = (n + tile_rows - 1) / tile_rows;
+    size_t probe_tiles = std::max<size_t>(total_tiles / (size_t)c->opt_probe_div, (64 * k + tile_rows - 1) / tile_rows);
+    probe_tiles = std::min(probe_tiles, total_tiles);
+    const size_t tile_stride = total_tiles / probe_tiles;  // >= 1
+    const size_t n0 = std::min(n, probe_tiles * (size_t)tile_rows);
+    uint32_t M = 1024;
+    while (M < 64 * k && M < 8192) M <<= 1;
+    while (M > 64 && M > n0) M >>= 1;
+
+    rc = ensure(c, c->dense, nq * n0 * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->tau, nq * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->counts, nq * 4);
+    if (rc) return rc;
+    const size_t ccap = (size_t)c->opt_cand_cap;
+    rc = ensure(c, c->cand, nq * ccap * sizeof(uint2));
+    if (rc) return rc;
+
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    {
+        ScanParams P{};
+        P.row_ids = nullptr;
+        P.row_begin = 0;
+        P.row_end = (uint32_t)n;
+        P.n_compact = (uint32_t)n0;
+        P.tile_step = (uint32_t)(tile_stride * tile_rows);
+        P.mode = MODE_DENSE;
+        P.out = c->dense.p;
+        P.out_stride = n0;
+        rc = run_scan(t, P, nq, false);
+        if (rc) return rc;
+    }
+    // rows of the last probe tile may lie beyond the table (skipped, left uninitialised): bound n0
+    // to the rows actually written.  With tile_stride*tile_rows spacing only the final tile can be short.
+    size_t last_tile_first = (probe_tiles - 1) * tile_stride * (size_t)tile_rows;
+    size_t n0_valid = (probe_tiles - 1) * (size_t)tile_rows + std::min<size_t>(tile_rows, n - last_tile_first);
+    hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                       (const float *)c->dense.p, n0, (uint32_t)n0_valid, (uint32_t)k, M, (float *)c->tau.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->counts.p, 0, nq * 4, c->stream));
+    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    {
+        ScanParams P{};
+        P.row_ids = nullptr;
+        P.row_begin = 0;
+        P.row_end = (uint32_t)n;
+        P.n_compact = (uint32_t)n;
+        P.tile_step = (uint32_t)tile_rows;
+        P.mode = MODE_FILTER;
+        P.tau = c->tau.p;
+        P.counts = (uint32_t *)c->counts.p;
+        P.cand = (uint2 *)c->cand.p;
+        P.cap = (uint32_t)ccap;
+        rc = run_scan(t, P, nq, true);
+        if (rc) return rc;
+    }
+    std::vector<uint32_t> hcounts(nq);
+    HIPCHK(hipMemcpyAsync(hcounts.data(), c->counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        account_scan(c, t, n, 1, "k_exact_scan(filter)");
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
+    }
+    size_t maxc = 0;
+    for (size_t q = 0; q < nq; q++) maxc = std::max<size_t>(maxc, std::min<size_t>(hcounts[q], ccap));
+    std::vector<uint2> hc(nq * std::max<size_t>(maxc, 1));
+    if (maxc) {
+        HIPCHK(hipMemcpy2DAsync(hc.data(), maxc * sizeof(uint2), c->cand.p, ccap * sizeof(uint2),
+                                maxc * sizeof(uint2), nq, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    std::vector<Hit> hits;
+    for (size_t q = 0; q < nq; q++) {
+        if (hcounts[q] > ccap || hcounts[q] < std::min(k, n)) {
+            // more candidates than slots (heavy ties / adversarial data): exact dense fallback
+            c->stats.fallbacks++;
+            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
+            if (rc) return rc;
+            continue;
+        }
+        c->stats.candidates += hcounts[q];
+        hits.resize(hcounts[q]);
+        for (size_t i = 0; i < hcounts[q]; i++) {
+            uint2 r = hc[q * maxc + i];
+            float f;
+            memcpy(&f, &r.y, 4);
+            hits[i] = Hit{r.x, (double)f};
+        }
+        select_upto_kth(hits, k);
+        emit(hits, q, cap, ids, scores, counts);
+    }
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ range
+extern "C" int vsgpu_range(vsgpu_table *t, const void *query, double radius, size_t cap, uint32_t *ids,
+                           double *scores, uint32_t *count) {
+    vsgpu_ctx *c = t->ctx;
+    *count = 0;
+    if (t->n == 0) return VSGPU_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = t->n;
+    // dense scores, threshold on the host: the comparison is `score <= radius` on the DistType value
+    // (brute_force.h:305-314).  (A filtered scan is used once the table is large.)
+    std::vector<Hit> hits;
+    if (t->type == VSGPU_F64 || n <= ((size_t)1 << 20)) {
+        std::vector<double> row(n);
+        int rc = vsgpu_scores(t, query, 0, n, row.data());
+        if (rc) return rc;
+        const double r = (t->type == VSGPU_F64) ? radius : (double)(float)radius;
+        for (size_t i = 0; i < n; i++)
+            if (row[i] <= r) hits.push_back(Hit{(uint32_t)i, row[i]});
+    } else {
+        int rc = stage_queries(t, query, 1, 0);
+        if (rc) return rc;
+        const size_t ccap = std::max<size_t>((size_t)c->opt_cand_cap, cap);
+        rc = ensure(c, c->tau, 4);
+        if (rc) return rc;
+        rc = ensure(c, c->counts, 4);
+        if (rc) return rc;
+        rc = ensure(c, c->cand, ccap * sizeof(uint2));
+        if (rc) return rc;
+        float rf = (float)radius;
+        HIPCHK(hipMemcpyAsync(c->tau.p, &rf, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->counts.p, 0, 4, c->stream));
+        ScanParams P{};
+        P.row_begin = 0;
+        P.row_end = (uint32_t)n;
+        P.n_compact = (uint32_t)n;
+        P.tile_step = (uint32_t)tile_rows_of(t->ek);
+        P.mode = MODE_FILTER;
+        P.tau = c->tau.p;
+        P.counts = (uint32_t *)c->counts.p;
+        P.cand = (uint2 *)c->cand.p;
+        P.cap = (uint32_t)ccap;
+        rc = run_scan(t, P, 1, true);
+        if (rc) return rc;
+        uint32_t hcount = 0;
+        HIPCHK(hipMemcpyAsync(&hcount, c->counts.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        account_scan(c, t, n, 1, "k_exact_scan(filter)");
+        if (hcount > ccap) {
+            *count = VSGPU_COUNT_OVERFLOW;
+            return VSGPU_OK;
+        }
+        std::vector<uint2> hc(std::max<uint32_t>(hcount, 1));
+        if (hcount) HIPCHK(hipMemcpy(hc.data(), c->cand.p, hcount * sizeof(uint2), hipMemcpyDeviceToHost));
+        hits.resize(hcount);
+        for (uint32_t i = 0; i < hcount; i++) {
+            float f;
+            memcpy(&f, &hc[i].y, 4);
+            hits[i] = Hit{hc[i].x, (double)f};
+        }
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
+    }
+    if (hits.size() > cap) {
+        *count = VSGPU_COUNT_OVERFLOW;
+        return VSGPU_OK;
+    }
+    *count = (uint32_t)hits.size();
+    for (size_t i = 0; i < hits.size(); i++) {
+        ids[i] = hits[i].id;
+        scores[i] = hits[i].score;
+    }
+    return VSGPU_OK;
+}
