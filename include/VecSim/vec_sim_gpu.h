@@ -21,6 +21,23 @@ int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryBlobs, size_
                                size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
                                VecSimQueryReply **replies);
 
+/* Shard-side half of a multi-GPU query: for every query, EVERY local row with score <= T_local
+ * (T_local = the k-th smallest local score; all rows when the shard holds fewer than k), ascending
+ * internal id.  That is the superset the global sequential replay needs.
+ * ids/labels/scores are [nq][cap]; counts[q] = rows written, or 0xFFFFFFFF when more than `cap`
+ * rows tie at or below T_local. */
+int VecSimIndex_TopKCandidatesBatch(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                    size_t k, size_t cap, uint32_t *ids, size_t *labels, double *scores,
+                                    uint32_t *counts);
+
+/* Merge side: `parts` shards' candidate lists (layout [part][nq][cap], counts [part][nq], gids =
+ * the row's internal id in the equivalent single index) -> the reply the reference's sequential
+ * heap would give over the union scanned in gid order.  out_* are [nq][k], padded with -1 / -1.0.
+ * Returns 0, or -1 if any count is the overflow marker. */
+int VecSimGpu_MergeTopK(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels,
+                        const double *scores, const uint32_t *counts, size_t k, int64_t *out_labels,
+                        double *out_scores);
+
 /* n new vectors at once; labels[i] must not exist yet (returns the number added, -1 on error) */
 long VecSimIndex_AddVectorsBulk(VecSimIndex *index, const void *blobs, const size_t *labels, size_t n);
 

@@ -140,6 +140,15 @@ class VecSimIndex:
             raise RuntimeError("GPU batched top-k failed: %s" % self._lib.VecSimGpu_LastError().decode())
         return _wrap(self._lib, list(reps), k)
 
+    def topk_candidates(self, queries, k, cap, ids, labels, scores, counts):
+        """shard-side half of a multi-GPU query (VecSimIndex_TopKCandidatesBatch); fills the arrays"""
+        q, stride = self._padded(queries)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._lib.VecSimIndex_TopKCandidatesBatch(self._h, p(q), q.shape[0], stride, k, cap, p(ids), p(labels),
+                                                       p(scores), p(counts))
+        if rc != 0:
+            raise RuntimeError("GPU candidate pass failed: %s" % self._lib.VecSimGpu_LastError().decode())
+
     def knn_query_code(self, vector, k, query_param=None):
         """(labels, distances, reply code) for a single query -- lets tests see TimedOut"""
         q, _ = self._padded(vector)

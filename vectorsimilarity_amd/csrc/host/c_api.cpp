@@ -77,6 +77,66 @@ extern "C" int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryB
     if (order != BY_ID && order != BY_SCORE) return -1;
     return index->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, replies);
 }
+extern "C" int VecSimIndex_TopKCandidatesBatch(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                               size_t k, size_t cap, uint32_t *ids, size_t *labels, double *scores,
+                                               uint32_t *counts) {
+    return index->topKCandidates(queryBlobs, nq, queryStride, k, cap, ids, labels, scores, counts);
+}
+
+// Global replay over the shards' candidate lists: keep score <= T (k-th smallest of
+// the union), order by the row's id in the equivalent single index, run the sequential heap.
+extern "C" int VecSimGpu_MergeTopK(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels,
+                                   const double *scores, const uint32_t *counts, size_t k, int64_t *out_labels,
+                                   double *out_scores) {
+    struct Cand {
+        uint64_t gid;
+        size_t label;
+        double score;
+    };
+    for (size_t i = 0; i < nq * k; i++) {
+        out_labels[i] = -1;
+        out_scores[i] = -1.0;
+    }
+    for (size_t i = 0; i < parts * nq; i++)
+        if (counts[i] == 0xFFFFFFFFu) return -1;
+    if (k == 0) return 0;
+    std::vector<Cand> c;
+    std::vector<double> tmp;
+    for (size_t q = 0; q < nq; q++) {
+        c.clear();
+        for (size_t p = 0; p < parts; p++) {
+            const size_t base = (p * nq + q) * cap;
+            for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
+        }
+        if (c.size() > k) {
+            tmp.resize(c.size());
+            for (size_t i = 0; i < c.size(); i++) tmp[i] = c[i].score;
+            std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(k - 1), tmp.end());
+            const double T = tmp[k - 1];
+            size_t w = 0;
+            for (size_t i = 0; i < c.size(); i++)
+                if (c[i].score <= T) c[w++] = c[i];
+            c.resize(w);
+        }
+        std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
+        std::priority_queue<std::pair<double, size_t>> heap;
+        double upper = std::numeric_limits<double>::lowest();
+        for (const Cand &x : c) {
+            if (x.score < upper || heap.size() < k) {
+                heap.emplace(x.score, x.label);
+                if (heap.size() > k) heap.pop();
+                upper = heap.top().first;
+            }
+        }
+        for (size_t i = heap.size(); i-- > 0;) {
+            out_labels[q * k + i] = (int64_t)heap.top().second;
+            out_scores[q * k + i] = heap.top().first;
+            heap.pop();
+        }
+    }
+    return 0;
+}
+
 extern "C" VecSimQueryReply *VecSimIndex_RangeQuery(VecSimIndex *index, const void *queryBlob, double radius,
                                                     VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
     // same contract as vec_sim.cpp:359-367: C++ exceptions cross the boundary on bad arguments

@@ -264,14 +264,7 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         return -1;
     }
     if (count_ == 0) return finish();
-    // preprocess queries into one contiguous buffer
-    std::vector<char> qbuf(nq * query_bytes_);
-    const size_t in_bytes = dim_ * type_size(type_);
-    for (size_t q = 0; q < nq; q++) {
-        char *dst = qbuf.data() + q * query_bytes_;
-        std::memcpy(dst, static_cast<const char *>(queries) + q * stride, in_bytes);
-        if (metric_ == VecSimMetric_Cosine) normalize_blob(dst, dim_, type_);
-    }
+    std::vector<char> qbuf = packQueries(queries, nq, stride);
     const size_t kk = std::min(k, count_);
     const size_t cap = std::max<size_t>(2 * kk, kk + 64);
     std::vector<uint32_t> ids(nq * cap), counts(nq);
@@ -307,6 +300,37 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         if (order == BY_ID) sort_reply(reps[q], BY_ID);
     }
     return finish();
+}
+
+// preprocess queries into one contiguous buffer (Cosine: copy + normalise, vec_sim_index.h:397-402)
+std::vector<char> FlatIndex::packQueries(const void *queries, size_t nq, size_t stride) const {
+    std::vector<char> qbuf(nq * query_bytes_);
+    const size_t in_bytes = dim_ * type_size(type_);
+    for (size_t q = 0; q < nq; q++) {
+        char *dst = qbuf.data() + q * query_bytes_;
+        std::memcpy(dst, static_cast<const char *>(queries) + q * stride, in_bytes);
+        if (metric_ == VecSimMetric_Cosine) normalize_blob(dst, dim_, type_);
+    }
+    return qbuf;
+}
+
+int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
+                              size_t *labels, double *scores, uint32_t *counts) {
+    last_mode_ = STANDARD_KNN;
+    if (nq == 0) return 0;
+    if (flush()) return -1;
+    if (k == 0 || count_ == 0) {
+        for (size_t q = 0; q < nq; q++) counts[q] = 0;
+        return 0;
+    }
+    std::vector<char> qbuf = packQueries(queries, nq, stride);
+    int rc = vsgpu_topk(table_, qbuf.data(), nq, query_bytes_, k, cap, ids, scores, counts);
+    if (rc) return rc;
+    for (size_t q = 0; q < nq; q++) {
+        if (counts[q] == VSGPU_COUNT_OVERFLOW) continue;
+        for (uint32_t i = 0; i < counts[q]; i++) labels[q * cap + i] = id_to_label_[ids[q * cap + i]];
+    }
+    return 0;
 }
 
 VecSimQueryReply *FlatIndex::topKQuery(const void *query, size_t k, VecSimQueryParams *qp) {

@@ -56,6 +56,8 @@ struct VecSimIndexInterface {
     virtual VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) = 0;
     virtual int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                                VecSimQueryReply_Order order, VecSimQueryReply **out) = 0;
+    virtual int topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
+                               size_t *labels, double *scores, uint32_t *counts) = 0;
     virtual VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
                                          VecSimQueryReply_Order order) = 0;
     virtual double getDistanceFrom(size_t label, const void *blob) = 0;
@@ -85,6 +87,8 @@ public:
     VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) override;
     int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                        VecSimQueryReply_Order order, VecSimQueryReply **out) override;
+    int topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
+                       size_t *labels, double *scores, uint32_t *counts) override;
     VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
                                  VecSimQueryReply_Order order) override;
     double getDistanceFrom(size_t label, const void *blob) override;
@@ -109,6 +113,7 @@ private:
     int flush();  // push host-staged rows to the device table
     void stageRow(const void *processed);
     void log(const char *level, const char *fmt, ...) const;
+    std::vector<char> packQueries(const void *queries, size_t nq, size_t stride) const;
     void replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const;
 
     VecSimType type_ = VecSimType_FLOAT32;
