@@ -282,3 +282,104 @@ def test_empty_and_tiny_indexes(vso):
     assert list(l[0]) == [42, -1, -1, -1, -1] and d[0, 0] == 8.0
     rl, _ = ix.range_query(np.zeros(8, dtype=np.float32), 7.9)
     assert rl.shape[1] == 0
+
+
+# ---------------------------------------------------------------- MFMA filter path (fp32, wide batches)
+def _fast_oracle(vso, metric, rows, queries, k, dim):
+    """AVX-512 intrinsics twin of the lane oracle (bit-identical, see test_oracle_kats); falls back to
+    the portable code when the host lacks AVX-512"""
+    l, s, _ = vso.flat_topk_batch_fast(0, METRICS[metric], rows, queries, k, dim, threads=min(64, os.cpu_count() or 1))
+    return l.astype(np.int64), s
+
+
+@pytest.mark.parametrize("metric,dim,n,nq,k", [
+    ("L2", 128, 150_000, 64, 10),
+    ("L2", 768, 60_000, 64, 10),
+    ("L2", 256, 100_003, 40, 100),     # ragged last tile, padded query tile
+    ("L2", 384, 50_000, 130, 10),      # three query tiles
+    ("L2", 512, 40_000, 64, 1),
+    ("L2", 1024, 30_000, 17, 10),
+    ("IP", 768, 60_000, 64, 10),
+    ("Cosine", 128, 120_000, 64, 10),
+])
+def test_mfma_filter_path_bit_exact(vso, metric, dim, n, nq, k):
+    rng = np.random.default_rng(dim + n)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    ix = make_index("f32", metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"] == "k_mfma_filter" and st["fallbacks"] == 0, st
+    srows = stored_rows(vso, rows, "f32", metric)
+    sq = stored_rows(vso, q, "f32", metric)
+    el, es = _fast_oracle(vso, "IP" if metric == "Cosine" else metric, srows, sq, k, dim)
+    assert np.array_equal(l1, el)
+    assert np.array_equal(d1, es)
+    # and the exact (no-MFMA) GPU path agrees too
+    ix.set_option("mfma", 0)
+    l2, d2 = ix.knn_query(q, k)
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2)
+
+
+def test_mfma_filter_adversarial_near_duplicates(vso):
+    """rows within the bf16 error band of each other: the filter cannot separate them, the candidate
+    lists overflow and the exact fallback must still give the reference answer (with ties)"""
+    rng = np.random.default_rng(3)
+    dim, n, nq, k = 128, 40_000, 32, 10
+    base = rng.uniform(-1, 1, dim).astype(np.float32)
+    rows = (base[None, :] + rng.integers(-2, 3, (n, dim)).astype(np.float32) * np.float32(2 ** -12)).astype(np.float32)
+    q = (base[None, :] + rng.uniform(-1e-3, 1e-3, (nq, dim)).astype(np.float32)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.set_option("cand_cap", 256)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    assert ix.stats()["fallbacks"] > 0
+    el, es = _fast_oracle(vso, "L2", rows, q, k, dim)
+    assert np.array_equal(l1, el) and np.array_equal(d1, es)
+
+
+def test_mfma_filter_large_magnitudes_and_clusters(vso):
+    """norms far from 1 and clustered data stress the error bound E (a too-small E loses neighbours)"""
+    rng = np.random.default_rng(8)
+    dim, n, nq, k = 256, 80_000, 64, 10
+    centers = rng.normal(0, 50, (20, dim)).astype(np.float32)
+    rows = (centers[rng.integers(0, 20, n)] + rng.normal(0, 1, (n, dim)).astype(np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, 20, nq)] + rng.normal(0, 1, (nq, dim)).astype(np.float32)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    l1, d1 = ix.knn_query(q, k)
+    el, es = _fast_oracle(vso, "L2", rows, q, k, dim)
+    assert np.array_equal(l1, el) and np.array_equal(d1, es)
+
+
+def test_mfma_path_after_delete_and_overwrite(vso):
+    rng = np.random.default_rng(12)
+    dim, n, nq, k = 128, 30_000, 64, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    cur = rows.copy()
+    labels = list(range(n))
+    for lab in rng.choice(n, 300, replace=False):
+        pos = labels.index(int(lab))
+        ix.delete_vector(int(lab))
+        cur[pos] = cur[len(labels) - 1]
+        labels[pos] = labels[-1]
+        labels.pop()
+    cur = cur[:len(labels)]
+    for pos in rng.choice(len(labels), 200, replace=False):
+        v = rng.uniform(-1, 1, dim).astype(np.float32)
+        ix.add_vector(v, labels[pos])
+        cur[pos] = v
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    ix.set_option("dense_pairs", 0)
+    l1, d1 = ix.knn_query(q, k)
+    el, es = _fast_oracle(vso, "L2", cur, q, k, dim)
+    lab = np.array(labels, dtype=np.int64)
+    assert np.array_equal(l1, lab[el]) and np.array_equal(d1, es)

@@ -1,0 +1,308 @@
+// mfma_kernels.hpp -- the HBM-roofline path for fp32 Flat scans with a wide query batch (gfx950).
+//
+// Exact reference-order fp32 distances cost 2 VALU ops per (row, query, element): at B = 64 that is
+// ~12 ms per 10M x 768 scan, 3x the time HBM needs to stream the rows (SURVEY.md §7 hard part 2).
+// So the scan is split:
+//
+//   stage 1 (this file, k_mfma_filter): stream every row ONCE, compute
+//        a = |x|^2 + |q|^2 - 2 <bf16(x), bf16(q)>           (one bf16 MFMA term, fp32 accumulate)
+//     and a rigorous bound E >= |a - s_ref| (s_ref = the reference-order fp32 score), then
+//        probe mode : per (tile, query) min of a + E   -> thresholds tau_q >= T_q   (k_probe_threshold)
+//        filter mode: emit (row, query) when a - E <= tau_q  -> superset of {s_ref <= T_q}
+//   stage 2 (exact_kernels.hpp, k_exact_pairs): reference-order exact score of every survivor.
+//   host: sequential-heap replay (flat_index.cpp) -> bit-identical reply.
+//
+// Data movement (the kernel is HBM-bound; MFMA/VALU/LDS all run far below their peaks):
+//   * rows go HBM -> LDS by `global_load_lds_dwordx4` (no VGPR round trip), 64 rows x 256 B per stage,
+//     whole 256-B row segments per 16 lanes (full-line coalescing), 3-stage ring, counted vmcnt waits
+//     and one raw s_barrier per stage so two stages stay in flight per workgroup;
+//   * the LDS image is XOR-swizzled on the *source* address (slot ^= row & 15) so the MFMA A-operand
+//     reads (ds_read_b128, 16 rows x 32 B per lane group) are bank-conflict free;
+//   * the 64 queries live in VGPRs as bf16 B-operands for the whole kernel (16 per wave);
+//   * fp32 -> bf16 (RNE) is done in registers between the LDS read and the MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "exact_kernels.hpp"
+
+namespace vsg {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+
+enum MfmaMode { MF_PROBE = 0, MF_FILTER = 1 };
+
+constexpr int MF_TILE_ROWS = 64;      // rows per workgroup tile (4 MFMA M-tiles of 16)
+constexpr int MF_KCHUNK = 64;         // floats per stage per row (2 MFMA k-steps of 32)
+constexpr int MF_STAGE_BYTES = MF_TILE_ROWS * MF_KCHUNK * 4;  // 16 KiB
+constexpr int MF_NSTAGE = 3;
+constexpr int MF_QTILE = 64;          // queries per workgroup (16 per wave)
+constexpr int MF_NORM_BYTES = 4 * 2 * 256;  // [wave][parity][64 floats]
+constexpr int MF_LDS_BYTES = MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES;
+
+struct MfmaParams {
+    const char *const *slabs;        // row slabs
+    const float *const *norm_slabs;  // |x|^2 per row, same slab geometry
+    uint32_t slab_shift, slab_mask;
+    uint32_t row_stride;             // bytes (dim*4)
+    uint32_t n_rows;
+    // tiles processed by this launch: tile t (0 <= t < n_tiles) covers rows (tile_first + t*tile_step)*64 ...
+    uint32_t tile_first, tile_step, n_tiles;
+    const uint4 *qfrag;              // [q_tile][wave][KSTEPS][lane] bf16x8 B-operand fragments
+    const float *qn2;                // [q_tiles*64] |q|^2 (0 for padding queries)
+    float cE;                        // E = cE * (|x|^2 + |q|^2) + absE
+    float absE;
+    int is_l2;                       // 1: a = nx2 + nq2 - 2 dot ; 0: a = 1 - dot
+    float *tilemin;                  // MF_PROBE: [q_tiles*64][tilemin_stride]
+    size_t tilemin_stride;
+    const float *tau;                // MF_FILTER: [q_tiles*64] (-inf for padding queries)
+    uint32_t *counts;                // [q_tiles*64]
+    uint2 *cand;                     // [q_tiles*64][cap] {row, lower-bound bits}
+    uint32_t cap;
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_byte_off, char *lds_base) {
+    // 64 lanes x 16 B -> LDS [lds_base + lds_byte_off + lane*16]; lds address is wave-uniform
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc,
+        (__attribute__((address_space(3))) void *)(lds_base + lds_byte_off), 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, char *lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc,
+        (__attribute__((address_space(3))) void *)(lds_base + lds_byte_off), 4, 0, 0);
+}
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
+    constexpr int KCH = KSTEPS / 2;  // stages per row tile
+    static_assert(KSTEPS % 2 == 0 && KCH >= 2, "dim must be a multiple of 64, at least 128");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15;   // A: row inside an M-tile / B,C: query inside the wave's 16
+    const int kq = lane >> 4;    // A,B: which 8 of the 32 k ; C: row quad
+    const int qtile = blockIdx.y;
+
+    // ---- resident query fragments (bf16 B operands) ----
+    bf16x8_t qf[KSTEPS];
+    {
+        const uint4 *src = P.qfrag + ((size_t)(qtile * 4 + wave) * KSTEPS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            uint4 v = src[(size_t)s * 64];
+            qf[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    const int qidx = qtile * MF_QTILE + wave * 16 + m16;
+    float nq2 = P.qn2[qidx];
+    float tau = 0.f;
+    if (MODE == MF_FILTER) tau = P.tau[qidx];
+    // Pin the completion of these ordinary loads HERE, before any LDS-DMA is issued: an empty asm that
+    // consumes the registers makes hipcc place its s_waitcnt now instead of a vmcnt(0) in front of the
+    // first MFMA of every tile (which would drain the two stages in flight once per tile).
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) asm volatile("" : "+v"(qf[s]));
+    asm volatile("" : "+v"(nq2), "+v"(tau));
+
+    // ---- per-lane staging geometry ----
+    // this wave stages rows [16*wave, 16*wave+16) of the tile: instruction t (0..3) covers rows
+    // 16*wave + 4t + lane/16, LDS slot lane%16, source chunk (lane%16) ^ (row%16)
+    const int st_r = lane >> 4;               // 0..3
+    const int st_p = lane & 15;
+    uint32_t src_off[4];                      // byte offset inside the 256-B row segment
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        int r = 16 * wave + 4 * t + st_r;
+        src_off[t] = (uint32_t)((st_p ^ (r & 15)) * 16);
+    }
+    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);  // 4 instr x 1 KiB per wave per stage
+    char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + wave * 512;
+
+    const uint32_t my_first = blockIdx.x;
+    const uint32_t step = gridDim.x;
+
+    // row pointers of a tile (clamped to the last row so tails read valid memory)
+    auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * MF_TILE_ROWS; };
+    const char *rp_cur[4], *rp_nxt[4];
+    const float *np_cur, *np_nxt;
+    auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
+        uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;  // past-the-end prefetches re-read the last tile
+        const uint32_t r0 = tile_row0(tt);
+        // a tile never straddles a slab (slab rows are a power of two >= 64), so the slab lookups are
+        // wave-uniform: scalar loads (lgkmcnt), which do not disturb the counted vmcnt waits below
+        const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
+        const char *sbase = P.slabs[sidx];
+        const float *nbase = P.norm_slabs[sidx];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t row = r0 + 16 * wave + 4 * i + st_r;
+            if (row >= P.n_rows) row = P.n_rows - 1;
+            rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + src_off[i];
+        }
+        uint32_t nrow = r0 + lane;
+        if (nrow >= P.n_rows) nrow = P.n_rows - 1;
+        np = nbase + (nrow & P.slab_mask);
+    };
+
+    // issue the loads of one stage: k-chunk `kc` of the tile whose pointers are given
+    auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm,
+                     uint32_t norm_parity) {
+        const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
+#pragma unroll
+        for (int i = 0; i < 4; i++) glds16(rp[i] + (size_t)kc * (MF_KCHUNK * 4), base + i * 1024, lds);
+        if (with_norm) glds4(np, norm_parity * 256, norm_lds);
+    };
+
+    uint32_t tile = my_first;
+    make_ptrs(tile, rp_cur, np_cur);
+    make_ptrs(tile + step, rp_nxt, np_nxt);
+    uint32_t slot_c = 0;       // slot computed in the current unit
+    uint32_t parity = 0;       // norm ring parity of the current tile
+
+    // prologue: units (tile,0) and (tile,1)
+    issue(rp_cur, np_cur, 0, 0, true, 0);
+    issue(rp_cur, np_cur, 1, 1, false, 0);
+
+    for (; tile < P.n_tiles; tile += step) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            // unit (tile,c) must have landed; only unit (tile,c+1) [5 loads if it opens a tile] may remain
+            if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // refill the slot read in the previous unit with unit +2
+            {
+                uint32_t slot_p = slot_c + 2;
+                if (slot_p >= MF_NSTAGE) slot_p -= MF_NSTAGE;
+                if (c + 2 < KCH) issue(rp_cur, np_cur, c + 2, slot_p, false, 0);
+                else issue(rp_nxt, np_nxt, c + 2 - KCH, slot_p, (c + 2 - KCH) == 0, parity ^ 1u);
+            }
+            const char *sbase = lds + slot_c * MF_STAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const char *rowp = sbase + (mt * 16 + m16) * 256;
+                    const int p0 = (8 * j + 2 * kq) ^ m16;
+                    const int p1 = (8 * j + 2 * kq + 1) ^ m16;
+                    f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+                    f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+                    f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[c * 2 + j], acc[mt], 0, 0, 0);
+                }
+            }
+            slot_c = slot_c + 1 == MF_NSTAGE ? 0 : slot_c + 1;
+        }
+
+        // ---- epilogue: lane holds dot(row = mt*16 + kq*4 + i, query = m16) ----
+        const uint32_t r0 = tile_row0(tile);
+        const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * 256);
+        bool emitted = false;
+        float tmin = INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            f32x4_t n4 = *reinterpret_cast<const f32x4_t *>(nrm + mt * 16 + kq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t row = r0 + mt * 16 + kq * 4 + i;
+                const float nx2 = n4[i];
+                const float ssum = nx2 + nq2;
+                const float dot = acc[mt][i];
+                const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
+                const float E = P.cE * ssum + P.absE;
+                if (MODE == MF_PROBE) {
+                    const float up = a + E;
+                    if (row < P.n_rows && up < tmin) tmin = up;
+                } else {
+                    const float low = a - E;
+                    if (row < P.n_rows && low <= tau) {
+                        uint32_t s = atomicAdd(&P.counts[qidx], 1u);
+                        if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                        emitted = true;
+                    }
+                }
+            }
+        }
+        if (MODE == MF_PROBE) {
+            // min over the 4 row quads (lanes m16, m16+16, m16+32, m16+48)
+            tmin = fminf(tmin, __shfl_xor(tmin, 16));
+            tmin = fminf(tmin, __shfl_xor(tmin, 32));
+            if (kq == 0) P.tilemin[(size_t)qidx * P.tilemin_stride + tile] = tmin;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (__any(emitted)) {
+            // stores/atomics share the VM counter with the staged loads: drain once so the counted
+            // waits of the next tile see only loads
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+
+        // rotate tile state
+#pragma unroll
+        for (int i = 0; i < 4; i++) rp_cur[i] = rp_nxt[i];
+        np_cur = np_nxt;
+        make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
+        parity ^= 1u;
+    }
+    // drain the two stages still in flight before the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// |x|^2 per row in double, rounded once to float (relative error <= 2^-24): feeds the bound E
+__global__ __launch_bounds__(256) void k_row_norms_f32(const char *rows, uint32_t row_stride, uint32_t dim,
+                                                       uint32_t n, float *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *p = reinterpret_cast<const float *>(rows + (size_t)row * row_stride);
+    double s = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        double v = (double)p[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = (float)s;
+}
+
+// ---- stage 2: exact reference-order scores of the surviving (row, query) pairs ----
+// One VL-lane group per pair; pairs of query q are cand[q][0 .. min(counts[q], cap)).
+template <int EK, int OPK>
+__global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
+    using E = Elem<EK>;
+    using acc_t = typename E::acc_t;
+    constexpr int VL = E::VL;
+    constexpr int GROUPS = 256 / VL;
+    const int lane = threadIdx.x % VL;
+    const int grp = threadIdx.x / VL;
+    const int q = blockIdx.y;
+    const uint32_t cnt = min(P.counts[q], P.cap);
+    const acc_t *qv = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q * P.steps * VL;
+    for (uint32_t s = blockIdx.x * GROUPS + grp; s < cnt; s += gridDim.x * GROUPS) {
+        uint2 rec = P.cand[(size_t)q * P.cap + s];
+        const uint32_t row = rec.x;
+        const char *rp = P.slabs[row >> P.slab_shift] + (size_t)(row & P.slab_mask) * P.row_stride;
+        acc_t acc = (acc_t)0;
+        for (int st = 0; st < P.steps; st++) {
+            const int off = P.offs[st * VL + lane];
+            if (off >= 0) acc = acc_step<OPK>(E::load(rp + off), qv[st * VL + lane], acc);
+        }
+#pragma unroll
+        for (int o = VL / 2; o >= 1; o >>= 1) acc = add_rn(acc, __shfl_down(acc, o, VL));
+        if (lane == 0) {
+            float sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
+            rec.y = __float_as_uint(sc);
+            P.cand[(size_t)q * P.cap + s] = rec;
+        }
+    }
+}
+
+}  // namespace vsg

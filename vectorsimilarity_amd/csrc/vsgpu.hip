@@ -17,6 +17,7 @@
 #include "vsgpu.h"
 #include "lane_program.h"
 #include "exact_kernels.hpp"
+#include "mfma_kernels.hpp"
 
 using namespace vsg;
 
@@ -60,12 +61,13 @@ struct vsgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     vsgpu_stats stats{};
     // options
     long opt_mfma = 1;
+    long opt_mfma_min_q = 9;          // narrower batches stay on the exact kernel (one BT=8 pass is HBM-bound)
     long opt_dense_pairs = 1L << 22;  // nq*n at or below this: dense score matrix + host selection
     long opt_probe_div = 32;          // probe ~ n / probe_div rows
     long opt_cand_cap = 8192;         // candidate slots per query
@@ -126,7 +128,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
@@ -152,6 +154,7 @@ extern "C" void vsgpu_stats_get(vsgpu_ctx *c, vsgpu_stats *out) { *out = c->stat
 extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     std::string n(name);
     if (n == "mfma") c->opt_mfma = value;
+    else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
     else if (n == "probe_div") c->opt_probe_div = std::max(1L, value);
     else if (n == "cand_cap") c->opt_cand_cap = std::max(16L, value);
@@ -173,6 +176,11 @@ struct vsgpu_table {
     size_t n = 0;
     int ek = 0, opk = 0, epi = 0;
     int bt_max = 1;  // largest query tile whose LDS image fits
+    // MFMA filter path (fp32, AVX-512-order tier, dim a multiple of 64): |x|^2 per row, slab-parallel
+    bool mfma_ok = false;
+    int ksteps = 0;
+    std::vector<float *> norm_slabs;
+    float **d_norm_slabs = nullptr;
 };
 
 static size_t acc_bytes(int type) { return type == VSGPU_F64 ? 8 : 4; }
@@ -216,6 +224,12 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     size_t fit = (budget - offs_b) / q_b;
     t->bt_max = fit >= 8 ? 8 : (fit >= 4 ? 4 : 1);
     if (!t->prog.fused) t->bt_max = 1;  // scalar-tier variants are only instantiated for BT=1
+    {
+        const size_t ks = dim / 32;
+        t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && dim % 64 == 0 && row_bytes == dim * 4 &&
+                      (ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32));
+        t->ksteps = (int)ks;
+    }
     // slabs of ~64 MiB, power-of-two row count
     size_t rows = ((size_t)64 << 20) / row_bytes;
     uint32_t shift = 0;
@@ -238,7 +252,9 @@ extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
     for (char *s : t->slabs) (void)hipFree(s);
+    for (float *s : t->norm_slabs) (void)hipFree(s);
     if (t->d_slabs) (void)hipFree(t->d_slabs);
+    if (t->d_norm_slabs) (void)hipFree(t->d_norm_slabs);
     if (t->d_offs) (void)hipFree(t->d_offs);
     delete t;
 }
@@ -255,25 +271,54 @@ static int grow_to(vsgpu_table *t, size_t rows) {
         char *p = nullptr;
         HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes));
         t->slabs.push_back(p);
+        if (t->mfma_ok) {
+            float *np = nullptr;
+            HIPCHK(hipMalloc((void **)&np, slab_rows * sizeof(float)));
+            t->norm_slabs.push_back(np);
+        }
         changed = true;
     }
     if (changed) {
         if (t->slabs.size() > t->d_slabs_cap) {
             // the old pointer table may still be read by nothing: all launches are synchronised per call
             if (t->d_slabs) HIPCHK(hipFree(t->d_slabs));
+            if (t->d_norm_slabs) HIPCHK(hipFree(t->d_norm_slabs));
             t->d_slabs = nullptr;
+            t->d_norm_slabs = nullptr;
             size_t cap = std::max<size_t>(64, t->slabs.size() * 2);
             HIPCHK(hipMalloc((void **)&t->d_slabs, cap * sizeof(char *)));
+            if (t->mfma_ok) HIPCHK(hipMalloc((void **)&t->d_norm_slabs, cap * sizeof(float *)));
             t->d_slabs_cap = cap;
         }
         HIPCHK(hipMemcpy(t->d_slabs, t->slabs.data(), t->slabs.size() * sizeof(char *),
                          hipMemcpyHostToDevice));
+        if (t->mfma_ok)
+            HIPCHK(hipMemcpy(t->d_norm_slabs, t->norm_slabs.data(), t->norm_slabs.size() * sizeof(float *),
+                             hipMemcpyHostToDevice));
     }
     return VSGPU_OK;
 }
 static inline char *row_ptr(const vsgpu_table *t, size_t id) {
     const size_t mask = ((size_t)1 << t->slab_shift) - 1;
     return t->slabs[id >> t->slab_shift] + (id & mask) * t->row_bytes;
+}
+
+// recompute |x|^2 of rows [first, first+n) (fp32 tables on the MFMA path only)
+static int update_norms(vsgpu_table *t, size_t first, size_t n) {
+    if (!t->mfma_ok || n == 0) return VSGPU_OK;
+    const size_t slab_rows = (size_t)1 << t->slab_shift;
+    size_t id = first, left = n;
+    while (left) {
+        size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
+        float *np = t->norm_slabs[id >> t->slab_shift] + (id & (slab_rows - 1));
+        hipLaunchKernelGGL(k_row_norms_f32, dim3((unsigned)((in_slab + 3) / 4)), dim3(256), 0, t->ctx->stream,
+                           (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
+        id += in_slab;
+        left -= in_slab;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    return VSGPU_OK;
 }
 
 extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t n) {
@@ -292,6 +337,8 @@ extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t 
         id += in_slab;
         left -= in_slab;
     }
+    rc = update_norms(t, t->n, n);
+    if (rc) return rc;
     t->n += n;
     return VSGPU_OK;
 }
@@ -299,14 +346,14 @@ extern "C" int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row
     if (id >= t->n) return fail(VSGPU_ERR_ARG, "row %zu out of range", id);
     HIPCHK(hipSetDevice(t->ctx->device));
     HIPCHK(hipMemcpy(row_ptr(t, id), host_row, t->row_bytes, hipMemcpyHostToDevice));
-    return VSGPU_OK;
+    return update_norms(t, id, 1);
 }
 extern "C" int vsgpu_table_move(vsgpu_table *t, size_t dst, size_t src) {
     if (dst >= t->n || src >= t->n) return fail(VSGPU_ERR_ARG, "move %zu <- %zu out of range", dst, src);
     if (dst == src) return VSGPU_OK;
     HIPCHK(hipSetDevice(t->ctx->device));
     HIPCHK(hipMemcpy(row_ptr(t, dst), row_ptr(t, src), t->row_bytes, hipMemcpyDeviceToDevice));
-    return VSGPU_OK;
+    return update_norms(t, dst, 1);
 }
 extern "C" int vsgpu_table_truncate(vsgpu_table *t, size_t new_size) {
     if (new_size > t->n) return fail(VSGPU_ERR_ARG, "truncate beyond size");
@@ -339,6 +386,8 @@ extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t s
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    rc = update_norms(t, t->n, n);
+    if (rc) return rc;
     t->n += n;
     return VSGPU_OK;
 }
@@ -594,6 +643,201 @@ static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *i
     }
 }
 
+// D2H of the per-query candidate lists (exact scores already in place), host-side selection of
+// {score <= T_k} in id order; queries whose list overflowed fall back to a dense exact pass.
+static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
+                           uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride);
+static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                              size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n;
+    std::vector<uint32_t> hcounts(nq);
+    HIPCHK(hipMemcpyAsync(hcounts.data(), c->counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        account_scan(c, t, n, 1, scan_name);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
+    }
+    size_t maxc = 0;
+    for (size_t q = 0; q < nq; q++) maxc = std::max<size_t>(maxc, std::min<size_t>(hcounts[q], ccap));
+    std::vector<uint2> hc(nq * std::max<size_t>(maxc, 1));
+    if (maxc) {
+        HIPCHK(hipMemcpy2DAsync(hc.data(), maxc * sizeof(uint2), c->cand.p, ccap * sizeof(uint2),
+                                maxc * sizeof(uint2), nq, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    std::vector<Hit> hits;
+    for (size_t q = 0; q < nq; q++) {
+        if (hcounts[q] > ccap || hcounts[q] < std::min(k, n)) {
+            // more candidates than slots (heavy ties / adversarial data): exact dense fallback
+            c->stats.fallbacks++;
+            int rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
+            if (rc) return rc;
+            continue;
+        }
+        c->stats.candidates += hcounts[q];
+        hits.resize(hcounts[q]);
+        for (size_t i = 0; i < hcounts[q]; i++) {
+            uint2 r = hc[q * maxc + i];
+            float f;
+            memcpy(&f, &r.y, 4);
+            hits[i] = Hit{r.x, (double)f};
+        }
+        select_upto_kth(hits, k);
+        emit(hits, q, cap, ids, scores, counts);
+    }
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ MFMA filter path (fp32, wide batches)
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <int KS> static void launch_mfma_ks(int mode, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE>), grid, dim3(256), MF_LDS_BYTES, s, P);
+    else hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER>), grid, dim3(256), MF_LDS_BYTES, s, P);
+}
+static void launch_mfma(int ksteps, int mode, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_mfma_ks<4>(mode, P, grid, s); break;
+    case 8: launch_mfma_ks<8>(mode, P, grid, s); break;
+    case 12: launch_mfma_ks<12>(mode, P, grid, s); break;
+    case 16: launch_mfma_ks<16>(mode, P, grid, s); break;
+    case 24: launch_mfma_ks<24>(mode, P, grid, s); break;
+    default: launch_mfma_ks<32>(mode, P, grid, s); break;
+    }
+}
+
+static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                     uint32_t *ids, double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, dim = t->dim;
+    const int KS = t->ksteps;
+    const size_t q_tiles = (nq + MF_QTILE - 1) / MF_QTILE, nqp = q_tiles * MF_QTILE;
+    const bool l2 = (t->metric == VSGPU_L2);
+
+    // (1) exact-order query images for the re-rank, (2) bf16 B-operand fragments + |q|^2 for the filter
+    int rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
+    std::vector<uint16_t> frag(nqp * dim, 0);  // [q_tile][wave][kstep][lane][8]
+    std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
+    for (size_t q = 0; q < nq; q++) {
+        const float *src = (const float *)((const char *)queries + q * qstride);
+        double ss = 0;
+        for (size_t i = 0; i < dim; i++) ss += (double)src[i] * (double)src[i];
+        qn2[q] = (float)ss;
+        const size_t qt = q / MF_QTILE, w = (q % MF_QTILE) / 16, nn = q % 16;
+        for (int s = 0; s < KS; s++)
+            for (int kq = 0; kq < 4; kq++) {
+                const size_t lane = (size_t)kq * 16 + nn;
+                uint16_t *dst = &frag[((((qt * 4 + w) * KS + s) * 64) + lane) * 8];
+                for (int j = 0; j < 8; j++) dst[j] = bf16_rne(src[32 * s + 8 * kq + j]);
+            }
+    }
+    rc = ensure(c, c->qfrag, frag.size() * 2);
+    if (rc) return rc;
+    rc = ensure(c, c->qn2, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->tau, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->counts, nqp * 4);
+    if (rc) return rc;
+    const size_t ccap = (size_t)c->opt_cand_cap;
+    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+
+    // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
+    const double u = std::ldexp(1.0, -24);
+    const double cq = std::ldexp(1.0, -8) * (1.0 + std::ldexp(1.0, -10)) + (double)dim * std::ldexp(1.0, -22) * 1.01;
+    const double gref = ((double)dim / 32.0 + 12.0) * u;
+    const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
+    const float absE = l2 ? 1e-30f : 1e-6f;
+
+    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    const uint32_t tile_step = total_tiles / probe_tiles;
+    uint32_t M = 64;
+    while (M < probe_tiles) M <<= 1;
+
+    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
+    if (rc) return rc;
+
+    MfmaParams P{};
+    P.slabs = t->d_slabs;
+    P.norm_slabs = t->d_norm_slabs;
+    P.slab_shift = t->slab_shift;
+    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    P.row_stride = (uint32_t)t->row_bytes;
+    P.n_rows = (uint32_t)n;
+    P.qfrag = (const uint4 *)c->qfrag.p;
+    P.qn2 = (const float *)c->qn2.p;
+    P.cE = cE;
+    P.absE = absE;
+    P.is_l2 = l2 ? 1 : 0;
+    P.tau = (const float *)c->tau.p;
+    P.counts = (uint32_t *)c->counts.p;
+    P.cand = (uint2 *)c->cand.p;
+    P.cap = (uint32_t)ccap;
+    const uint32_t wg_cap = (uint32_t)c->n_cu * 2;
+
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    {   // probe: strided tiles -> per (tile, query) upper bounds
+        MfmaParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = tile_step;
+        Q.n_tiles = probe_tiles;
+        Q.tilemin = (float *)c->dense.p;
+        Q.tilemin_stride = probe_tiles;
+        launch_mfma(KS, MF_PROBE, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    {   // filter: every tile once
+        MfmaParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = 1;
+        Q.n_tiles = total_tiles;
+        launch_mfma(KS, MF_FILTER, Q, dim3(std::min(total_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    {   // exact re-rank of the survivors, in place
+        ScanParams S{};
+        S.slabs = t->d_slabs;
+        S.slab_shift = t->slab_shift;
+        S.slab_mask = P.slab_mask;
+        S.row_stride = P.row_stride;
+        S.offs = t->d_offs;
+        S.steps = t->prog.steps;
+        S.qperm = c->qperm.p;
+        S.nq = (int)nq;
+        S.epilogue = t->epi;
+        S.counts = (uint32_t *)c->counts.p;
+        S.cand = (uint2 *)c->cand.p;
+        S.cap = (uint32_t)ccap;
+        dim3 grid(64, (unsigned)nq);
+        if (t->opk == OP_L2_FMA) hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+        else hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+        HIPCHK(hipGetLastError());
+    }
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
+}
+
 // ------------------------------------------------------------------ top-K
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride) {
@@ -664,6 +908,8 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         return topk_dense_path(t, nq, k, cap, ids, scores, counts, 0, nq, queries, qstride);
     }
 
+    if (t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) return topk_mfma(t, queries, nq, qstride, k, cap, ids, scores, counts);
+
     // ---- probe -> threshold -> filtered scan ----
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
@@ -725,43 +971,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         rc = run_scan(t, P, nq, true);
         if (rc) return rc;
     }
-    std::vector<uint32_t> hcounts(nq);
-    HIPCHK(hipMemcpyAsync(hcounts.data(), c->counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    {
-        account_scan(c, t, n, 1, "k_exact_scan(filter)");
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
-    }
-    size_t maxc = 0;
-    for (size_t q = 0; q < nq; q++) maxc = std::max<size_t>(maxc, std::min<size_t>(hcounts[q], ccap));
-    std::vector<uint2> hc(nq * std::max<size_t>(maxc, 1));
-    if (maxc) {
-        HIPCHK(hipMemcpy2DAsync(hc.data(), maxc * sizeof(uint2), c->cand.p, ccap * sizeof(uint2),
-                                maxc * sizeof(uint2), nq, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    std::vector<Hit> hits;
-    for (size_t q = 0; q < nq; q++) {
-        if (hcounts[q] > ccap || hcounts[q] < std::min(k, n)) {
-            // more candidates than slots (heavy ties / adversarial data): exact dense fallback
-            c->stats.fallbacks++;
-            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
-            if (rc) return rc;
-            continue;
-        }
-        c->stats.candidates += hcounts[q];
-        hits.resize(hcounts[q]);
-        for (size_t i = 0; i < hcounts[q]; i++) {
-            uint2 r = hc[q * maxc + i];
-            float f;
-            memcpy(&f, &r.y, 4);
-            hits[i] = Hit{r.x, (double)f};
-        }
-        select_upto_kth(hits, k);
-        emit(hits, q, cap, ids, scores, counts);
-    }
-    return VSGPU_OK;
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_exact_scan(filter)");
 }
 
 // ------------------------------------------------------------------ range
