@@ -21,6 +21,13 @@ int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryBlobs, size_
                                size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
                                VecSimQueryReply **replies);
 
+/* Same query, results written straight into caller arrays [nq][k] (labels padded with -1, scores with
+ * -1.0, like the reference's Python wrap_results, bindings.cpp:36-72); codes[q] (may be NULL) receives
+ * the VecSimQueryReply_Code.  Saves nq reply objects + iterators per batch for array-oriented callers. */
+int VecSimIndex_TopKQueryBatchArrays(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                     size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                     int64_t *labels, double *scores, int *codes);
+
 /* Shard-side half of a multi-GPU query: for every query, EVERY local row with score <= T_local
  * (T_local = the k-th smallest local score; all rows when the shard holds fewer than k), ascending
  * internal id.  That is the superset the global sequential replay needs.

@@ -383,3 +383,15 @@ def test_mfma_path_after_delete_and_overwrite(vso):
     el, es = _fast_oracle(vso, "L2", cur, q, k, dim)
     lab = np.array(labels, dtype=np.int64)
     assert np.array_equal(l1, lab[el]) and np.array_equal(d1, es)
+
+
+def test_reply_objects_and_array_entry_points_agree():
+    rng = np.random.default_rng(2)
+    dim, n = 64, 5000
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rng.uniform(-1, 1, (n, dim)).astype(np.float32), np.arange(n))
+    q = rng.uniform(-1, 1, (9, dim)).astype(np.float32)
+    for order in (VecSim.BY_SCORE, VecSim.BY_ID):
+        a = ix.knn_query(q, 7, order=order)
+        b = ix.knn_query_replies(q, 7, order=order)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -133,6 +133,20 @@ class VecSimIndex:
         if nq == 1:
             rep = self._lib.VecSimIndex_TopKQuery(self._h, q.ctypes.data_as(C.c_void_p), k, qp, order)
             return _wrap(self._lib, [rep], k)
+        labels = np.empty((nq, k), dtype=np.int64)
+        dists = np.empty((nq, k), dtype=np.float64)
+        rc = self._lib.VecSimIndex_TopKQueryBatchArrays(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k, qp, order,
+                                                        labels.ctypes.data_as(C.c_void_p),
+                                                        dists.ctypes.data_as(C.c_void_p), None)
+        if rc != 0:
+            raise RuntimeError("GPU batched top-k failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return labels, dists
+
+    def knn_query_replies(self, vector, k, query_param=None, order=BY_SCORE):
+        """batched query through the reply-object entry point (VecSimIndex_TopKQueryBatch)"""
+        q, stride = self._padded(vector)
+        nq = q.shape[0]
+        qp = C.byref(query_param) if query_param is not None else None
         reps = (C.c_void_p * nq)()
         rc = self._lib.VecSimIndex_TopKQueryBatch(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k,
                                                   qp, order, reps)

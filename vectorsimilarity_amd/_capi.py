@@ -109,7 +109,7 @@ EXPORTS = [
     "VecSimQueryReply_IteratorNext", "VecSimQueryReply_IteratorHasNext",
     "VecSimQueryReply_IteratorReset", "VecSimQueryReply_IteratorFree", "VecSimBatchIterator_Next",
     "VecSimBatchIterator_HasNext", "VecSimBatchIterator_Free", "VecSimBatchIterator_Reset",
-    "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
+    "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
@@ -202,6 +202,8 @@ def load():
     L.VecSimIndex_TopKQueryBatch.restype = i
     L.VecSimIndex_TopKQueryBatch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i,
                                              C.POINTER(vp)]
+    L.VecSimIndex_TopKQueryBatchArrays.restype = i
+    L.VecSimIndex_TopKQueryBatchArrays.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, vp, vp, vp]
     L.VecSimIndex_TopKCandidatesBatch.restype = i
     L.VecSimIndex_TopKCandidatesBatch.argtypes = [vp, vp, sz, sz, sz, sz, vp, vp, vp, vp]
     L.VecSimGpu_MergeTopK.restype = i

@@ -77,6 +77,24 @@ extern "C" int VecSimIndex_TopKQueryBatch(VecSimIndex *index, const void *queryB
     if (order != BY_ID && order != BY_SCORE) return -1;
     return index->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, replies);
 }
+extern "C" int VecSimIndex_TopKQueryBatchArrays(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                                size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                                int64_t *labels, double *scores, int *codes) {
+    if (order != BY_ID && order != BY_SCORE) return -1;
+    std::vector<VecSimQueryReply *> reps(nq, nullptr);
+    int rc = index->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, reps.data());
+    if (rc) return rc;
+    for (size_t q = 0; q < nq; q++) {
+        const auto &r = reps[q]->results;
+        for (size_t j = 0; j < k; j++) {
+            labels[q * k + j] = j < r.size() ? (int64_t)r[j].id : -1;
+            scores[q * k + j] = j < r.size() ? r[j].score : -1.0;
+        }
+        if (codes) codes[q] = (int)reps[q]->code;
+        delete reps[q];
+    }
+    return 0;
+}
 extern "C" int VecSimIndex_TopKCandidatesBatch(VecSimIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
                                                size_t k, size_t cap, uint32_t *ids, size_t *labels, double *scores,
                                                uint32_t *counts) {

@@ -34,13 +34,12 @@ typedef float f32x8_t __attribute__((ext_vector_type(8)));
 
 enum MfmaMode { MF_PROBE = 0, MF_FILTER = 1 };
 
-constexpr int MF_TILE_ROWS = 64;      // rows per workgroup tile (4 MFMA M-tiles of 16)
-constexpr int MF_KCHUNK = 64;         // floats per stage per row (2 MFMA k-steps of 32)
-constexpr int MF_STAGE_BYTES = MF_TILE_ROWS * MF_KCHUNK * 4;  // 16 KiB
-constexpr int MF_NSTAGE = 3;
+constexpr int MF_TILE_ROWS = 64;      // default rows per workgroup tile (4 MFMA M-tiles of 16)
+constexpr int MF_STAGE_BYTES = 16384; // one ring slot: RT rows x (4096/RT) floats
+constexpr int MF_NSTAGE_MAX = 4;
 constexpr int MF_QTILE = 64;          // queries per workgroup (16 per wave)
 constexpr int MF_NORM_BYTES = 4 * 2 * 256;  // [wave][parity][64 floats]
-constexpr int MF_LDS_BYTES = MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES;
+constexpr int mf_lds_bytes(int nstage) { return nstage * MF_STAGE_BYTES + MF_NORM_BYTES; }
 
 struct MfmaParams {
     const char *const *slabs;        // row slabs
@@ -63,11 +62,13 @@ struct MfmaParams {
     uint32_t cap;
 };
 
+template <int AUX>
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_byte_off, char *lds_base) {
-    // 64 lanes x 16 B -> LDS [lds_base + lds_byte_off + lane*16]; lds address is wave-uniform
+    // 64 lanes x 16 B -> LDS [lds_base + lds_byte_off + lane*16]; lds address is wave-uniform.
+    // AUX = 2 marks the stream non-temporal (every row is read exactly once per launch).
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void *)gsrc,
-        (__attribute__((address_space(3))) void *)(lds_base + lds_byte_off), 16, 0, 0);
+        (__attribute__((address_space(3))) void *)(lds_base + lds_byte_off), 16, 0, AUX);
 }
 __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, char *lds_base) {
     __builtin_amdgcn_global_load_lds(
@@ -75,10 +76,20 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, c
         (__attribute__((address_space(3))) void *)(lds_base + lds_byte_off), 4, 0, 0);
 }
 
-template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
-    constexpr int KCH = KSTEPS / 2;  // stages per row tile
-    static_assert(KSTEPS % 2 == 0 && KCH >= 2, "dim must be a multiple of 64, at least 128");
+// RT = rows per workgroup tile: 64 (stage = 64 rows x 256 B, for any dim % 64 == 0) or 16 (stage = 16 rows
+// x 1 KiB, dim % 256 == 0: every DMA instruction moves 1 KiB of ONE row, which HBM likes better).
+template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64>
+__global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
+    constexpr int MF_NSTAGE = NS;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert(RT == 64 || RT == 16, "tile rows");
+    constexpr int MT = RT / 16;                      // MFMA M-tiles per tile
+    constexpr int KC = (MF_STAGE_BYTES / 4) / RT;    // floats per row per stage: 64 or 256
+    constexpr int SEG = KC * 4;                      // bytes per row per stage: 256 or 1024
+    constexpr int KSUB = KC / 32;                    // MFMA k-steps per stage: 2 or 8
+    static_assert(KSTEPS % KSUB == 0, "dim must be a multiple of the stage width");
+    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
+    static_assert(KCH >= NS - 1, "tile shorter than the ring");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -104,30 +115,32 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
     if (MODE == MF_FILTER) tau = P.tau[qidx];
     // Pin the completion of these ordinary loads HERE, before any LDS-DMA is issued: an empty asm that
     // consumes the registers makes hipcc place its s_waitcnt now instead of a vmcnt(0) in front of the
-    // first MFMA of every tile (which would drain the two stages in flight once per tile).
+    // first MFMA of every tile (which would drain the stages in flight once per tile).
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) asm volatile("" : "+v"(qf[s]));
     asm volatile("" : "+v"(nq2), "+v"(tau));
 
     // ---- per-lane staging geometry ----
-    // this wave stages rows [16*wave, 16*wave+16) of the tile: instruction t (0..3) covers rows
-    // 16*wave + 4t + lane/16, LDS slot lane%16, source chunk (lane%16) ^ (row%16)
-    const int st_r = lane >> 4;               // 0..3
-    const int st_p = lane & 15;
-    uint32_t src_off[4];                      // byte offset inside the 256-B row segment
+    // A stage image is 16 KiB = 16 DMA instructions of 1 KiB; this wave issues instructions 4w..4w+3.
+    // Instruction g, lane l fills LDS byte L = 1024 g + 16 l: row = L / SEG, 16-B slot = (L % SEG)/16,
+    // 256-B window = slot/16, slot-in-window p = slot%16, and its SOURCE chunk is p ^ (row & 15):
+    // the XOR swizzle lives on the source address because the DMA destination is lane-linear.
+    uint32_t st_row[4];   // row inside the tile
+    uint32_t st_off[4];   // byte offset inside the row's stage segment
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        int r = 16 * wave + 4 * t + st_r;
-        src_off[t] = (uint32_t)((st_p ^ (r & 15)) * 16);
+        const uint32_t L = 1024u * (uint32_t)(4 * wave + t) + 16u * (uint32_t)lane;
+        const uint32_t row = L / SEG, slot = (L % SEG) / 16;
+        st_row[t] = row;
+        st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
     }
-    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);  // 4 instr x 1 KiB per wave per stage
+    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
     char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + wave * 512;
 
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
 
-    // row pointers of a tile (clamped to the last row so tails read valid memory)
-    auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * MF_TILE_ROWS; };
+    auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
     const char *rp_cur[4], *rp_nxt[4];
     const float *np_cur, *np_nxt;
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
@@ -140,9 +153,9 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
         const float *nbase = P.norm_slabs[sidx];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t row = r0 + 16 * wave + 4 * i + st_r;
-            if (row >= P.n_rows) row = P.n_rows - 1;
-            rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + src_off[i];
+            uint32_t row = r0 + st_row[i];
+            if (row >= P.n_rows) row = P.n_rows - 1;  // tails read valid memory; masked in the epilogue
+            rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + st_off[i];
         }
         uint32_t nrow = r0 + lane;
         if (nrow >= P.n_rows) nrow = P.n_rows - 1;
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
                      uint32_t norm_parity) {
         const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
 #pragma unroll
-        for (int i = 0; i < 4; i++) glds16(rp[i] + (size_t)kc * (MF_KCHUNK * 4), base + i * 1024, lds);
+        for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
         if (with_norm) glds4(np, norm_parity * 256, norm_lds);
     };
 
@@ -164,41 +177,60 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
     uint32_t slot_c = 0;       // slot computed in the current unit
     uint32_t parity = 0;       // norm ring parity of the current tile
 
-    // prologue: units (tile,0) and (tile,1)
-    issue(rp_cur, np_cur, 0, 0, true, 0);
-    issue(rp_cur, np_cur, 1, 1, false, 0);
+    // prologue: the first NS-1 units.  Unit index u (0-based from the first tile) is (tile + u/KCH, u%KCH).
+#pragma unroll
+    for (int u = 0; u < NS - 1; u++) {
+        if (u < KCH) issue(rp_cur, np_cur, u, u, u == 0, 0);
+        else issue(rp_nxt, np_nxt, u - KCH, u, u == KCH, 1);
+    }
 
     for (; tile < P.n_tiles; tile += step) {
-        f32x4_t acc[4];
+        f32x4_t acc[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
-            // unit (tile,c) must have landed; only unit (tile,c+1) [5 loads if it opens a tile] may remain
-            if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // refill the slot read in the previous unit with unit +2
+            // unit (tile,c) must have landed; the NS-2 younger units (4 loads each, +1 norm load for a
+            // unit that opens a tile) may stay in flight
             {
-                uint32_t slot_p = slot_c + 2;
+                constexpr int AHEAD = NS - 2;
+                int allowed = 4 * AHEAD;
+#pragma unroll
+                for (int a = 1; a <= AHEAD; a++)
+                    if ((c + a) % KCH == 0) allowed += 1;
+                if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (allowed == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            // refill the slot read in the previous unit with unit +(NS-1)
+            {
+                constexpr int D = NS - 1;
+                uint32_t slot_p = slot_c + D;
                 if (slot_p >= MF_NSTAGE) slot_p -= MF_NSTAGE;
-                if (c + 2 < KCH) issue(rp_cur, np_cur, c + 2, slot_p, false, 0);
-                else issue(rp_nxt, np_nxt, c + 2 - KCH, slot_p, (c + 2 - KCH) == 0, parity ^ 1u);
+                const int cc = c + D;
+                if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
+                else if (cc < 2 * KCH) issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, parity ^ 1u);
+                else {
+                    // only when KCH < NS-1 would a unit two tiles ahead be needed; excluded by static_assert
+                }
             }
             const char *sbase = lds + slot_c * MF_STAGE_BYTES;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < KSUB; j++) {
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    const char *rowp = sbase + (mt * 16 + m16) * 256;
-                    const int p0 = (8 * j + 2 * kq) ^ m16;
-                    const int p1 = (8 * j + 2 * kq + 1) ^ m16;
+                for (int mt = 0; mt < MT; mt++) {
+                    const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 2) * 256;
+                    const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
+                    const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
                     f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
                     f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
                     f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[c * 2 + j], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[c * KSUB + j], acc[mt], 0, 0, 0);
                 }
             }
             slot_c = slot_c + 1 == MF_NSTAGE ? 0 : slot_c + 1;
@@ -210,7 +242,7 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
         bool emitted = false;
         float tmin = INFINITY;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
+        for (int mt = 0; mt < MT; mt++) {
             f32x4_t n4 = *reinterpret_cast<const f32x4_t *>(nrm + mt * 16 + kq * 4);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -252,7 +284,7 @@ __global__ __launch_bounds__(256) void k_mfma_filter(MfmaParams P) {
         make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
         parity ^= 1u;
     }
-    // drain the two stages still in flight before the workgroup's LDS is released
+    // drain the stages still in flight before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -303,6 +335,58 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
             P.cand[(size_t)q * P.cap + s] = rec;
         }
     }
+}
+
+
+// ---- stage 3: per-query selection among the exactly re-scored survivors ----
+// One workgroup per query: T = k-th smallest exact score (bitwise search over the order-preserving
+// integer image of the float), then every candidate with score <= T is compacted to out[q][...].
+// The host only sorts those few by id and replays the sequential heap.
+__device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
+    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);  // unsigned order == float order
+}
+__global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
+                                                         uint32_t k, uint2 *out, uint32_t *out_counts,
+                                                         uint32_t out_cap) {
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t wpos;
+    const int q = blockIdx.x;
+    const uint32_t raw = counts[q];
+    if (raw > cap) {  // candidate list overflowed: the host falls back to a dense exact pass
+        if (threadIdx.x == 0) out_counts[q] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t n = raw;
+    const uint2 *c = cand + (size_t)q * cap;
+    uint32_t T = 0xFFFFFFFFu;
+    if (n > k) {
+        T = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t trial = T | (1u << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            const uint32_t total = red[0] + red[1] + red[2] + red[3];
+            if (total < k) T = trial;  // fewer than k keys below `trial`: the k-th smallest has this bit set
+        }
+    }
+    if (threadIdx.x == 0) wpos = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint2 r = c[i];
+        const uint32_t bits = r.y;
+        const bool is_nan = (bits & 0x7FFFFFFFu) > 0x7F800000u;
+        if (!is_nan && float_sort_key(bits) <= T) {
+            const uint32_t p = atomicAdd(&wpos, 1u);
+            if (p < out_cap) out[(size_t)q * out_cap + p] = r;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
 }
 
 }  // namespace vsg

@@ -61,12 +61,14 @@ struct vsgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     vsgpu_stats stats{};
     // options
     long opt_mfma = 1;
+    long opt_mfma_variant = 0;
+    long opt_wg_per_cu = 2;
     long opt_mfma_min_q = 9;          // narrower batches stay on the exact kernel (one BT=8 pass is HBM-bound)
     long opt_dense_pairs = 1L << 22;  // nq*n at or below this: dense score matrix + host selection
     long opt_probe_div = 32;          // probe ~ n / probe_div rows
@@ -87,7 +89,10 @@ static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
 }
 static int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
     if (bytes <= c->pinned_cap) return VSGPU_OK;
-    if (c->pinned) HIPCHK(hipHostFree(c->pinned));
+    if (c->pinned) {
+        HIPCHK(hipStreamSynchronize(c->stream));  // an async copy may still read the old staging buffer
+        HIPCHK(hipHostFree(c->pinned));
+    }
     c->pinned = nullptr;
     c->pinned_cap = 0;
     size_t want = (std::max(bytes, (size_t)1 << 20) + 0xFFFF) & ~(size_t)0xFFFF;
@@ -128,7 +133,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2, &c->sel, &c->selcnt})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
@@ -154,6 +159,8 @@ extern "C" void vsgpu_stats_get(vsgpu_ctx *c, vsgpu_stats *out) { *out = c->stat
 extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     std::string n(name);
     if (n == "mfma") c->opt_mfma = value;
+    else if (n == "mfma_variant") c->opt_mfma_variant = value;
+    else if (n == "wg_per_cu") c->opt_wg_per_cu = std::max(1L, value);
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
     else if (n == "probe_div") c->opt_probe_div = std::max(1L, value);
@@ -418,46 +425,54 @@ static int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t 
     rc = ensure(c, c->qperm, bytes);
     if (rc) return rc;
     char *dst = (char *)c->pinned;
+    const int32_t *offs = pg.offs.data();
     for (size_t q = 0; q < nq; q++) {
         const char *src = (const char *)queries + q * qstride;
-        for (size_t i = 0; i < per_q; i++) {
-            int32_t off = pg.offs[i];
-            char *o = dst + (q * per_q + i) * ab;
-            switch (t->type) {
-            case VSGPU_F32: {
+        char *o = dst + q * per_q * ab;
+        switch (t->type) {
+        case VSGPU_F32: {
+            float *of = (float *)o;
+            for (size_t i = 0; i < per_q; i++) {
                 float v = 0;
-                if (off >= 0) memcpy(&v, src + off, 4);
-                memcpy(o, &v, 4);
-                break;
+                if (offs[i] >= 0) memcpy(&v, src + offs[i], 4);
+                of[i] = v;
             }
-            case VSGPU_F64: {
+            break;
+        }
+        case VSGPU_F64: {
+            double *od = (double *)o;
+            for (size_t i = 0; i < per_q; i++) {
                 double v = 0;
-                if (off >= 0) memcpy(&v, src + off, 8);
-                memcpy(o, &v, 8);
-                break;
+                if (offs[i] >= 0) memcpy(&v, src + offs[i], 8);
+                od[i] = v;
             }
-            case VSGPU_F16:
-            case VSGPU_BF16: {
+            break;
+        }
+        case VSGPU_F16:
+        case VSGPU_BF16: {
+            float *of = (float *)o;
+            const bool f16 = (t->type == VSGPU_F16);
+            for (size_t i = 0; i < per_q; i++) {
                 float v = 0;
-                if (off >= 0) {
+                if (offs[i] >= 0) {
                     uint16_t h;
-                    memcpy(&h, src + off, 2);
-                    v = t->type == VSGPU_F16 ? widen_f16(h) : widen_bf16(h);
+                    memcpy(&h, src + offs[i], 2);
+                    v = f16 ? widen_f16(h) : widen_bf16(h);
                 }
-                memcpy(o, &v, 4);
-                break;
+                of[i] = v;
             }
-            case VSGPU_I8: {
-                int v = off >= 0 ? (int)*(const int8_t *)(src + off) : 0;
-                memcpy(o, &v, 4);
-                break;
-            }
-            default: {
-                int v = off >= 0 ? (int)*(const uint8_t *)(src + off) : 0;
-                memcpy(o, &v, 4);
-                break;
-            }
-            }
+            break;
+        }
+        case VSGPU_I8: {
+            int *oi = (int *)o;
+            for (size_t i = 0; i < per_q; i++) oi[i] = offs[i] >= 0 ? (int)*(const int8_t *)(src + offs[i]) : 0;
+            break;
+        }
+        default: {
+            int *oi = (int *)o;
+            for (size_t i = 0; i < per_q; i++) oi[i] = offs[i] >= 0 ? (int)*(const uint8_t *)(src + offs[i]) : 0;
+            break;
+        }
         }
     }
     HIPCHK(hipMemcpyAsync(c->qperm.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
@@ -651,40 +666,53 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
                               size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
-    std::vector<uint32_t> hcounts(nq);
-    HIPCHK(hipMemcpyAsync(hcounts.data(), c->counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    // GPU: keep, per query, the candidates with exact score <= T_k; only those travel to the host
+    const size_t ocap = cap;
+    int rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
+    if (rc) return rc;
+    rc = ensure(c, c->selcnt, nq * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
+                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)c->sel.p,
+                       (uint32_t *)c->selcnt.p, (uint32_t)ocap);
+    HIPCHK(hipGetLastError());
+    // raw candidate counts ride along (statistics + "fewer than k" sanity check)
+    HIPCHK(hipMemcpyAsync((uint32_t *)c->selcnt.p + nq, c->counts.p, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    rc = ensure_pinned(c, nq * 8 + nq * ocap * sizeof(uint2));
+    if (rc) return rc;
+    uint32_t *hsel = (uint32_t *)c->pinned;
+    uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 8);
+    HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     {
         account_scan(c, t, n, 1, scan_name);
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
     }
-    size_t maxc = 0;
-    for (size_t q = 0; q < nq; q++) maxc = std::max<size_t>(maxc, std::min<size_t>(hcounts[q], ccap));
-    std::vector<uint2> hc(nq * std::max<size_t>(maxc, 1));
-    if (maxc) {
-        HIPCHK(hipMemcpy2DAsync(hc.data(), maxc * sizeof(uint2), c->cand.p, ccap * sizeof(uint2),
-                                maxc * sizeof(uint2), nq, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
+    const uint32_t *hraw = hsel + nq;
     std::vector<Hit> hits;
     for (size_t q = 0; q < nq; q++) {
-        if (hcounts[q] > ccap || hcounts[q] < std::min(k, n)) {
+        if (hraw[q] > ccap || hraw[q] < std::min(k, n)) {
             // more candidates than slots (heavy ties / adversarial data): exact dense fallback
             c->stats.fallbacks++;
-            int rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
+            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
             if (rc) return rc;
             continue;
         }
-        c->stats.candidates += hcounts[q];
-        hits.resize(hcounts[q]);
-        for (size_t i = 0; i < hcounts[q]; i++) {
-            uint2 r = hc[q * maxc + i];
+        c->stats.candidates += hraw[q];
+        if (hsel[q] == VSGPU_COUNT_OVERFLOW) {  // more than `cap` rows tie at or below T_k
+            counts[q] = VSGPU_COUNT_OVERFLOW;
+            continue;
+        }
+        hits.resize(hsel[q]);
+        for (size_t i = 0; i < hsel[q]; i++) {
+            uint2 r = hrec[q * ocap + i];
             float f;
             memcpy(&f, &r.y, 4);
             hits[i] = Hit{r.x, (double)f};
         }
-        select_upto_kth(hits, k);
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
         emit(hits, q, cap, ids, scores, counts);
     }
     return VSGPU_OK;
@@ -699,18 +727,67 @@ static inline uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
-template <int KS> static void launch_mfma_ks(int mode, const MfmaParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE) hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE>), grid, dim3(256), MF_LDS_BYTES, s, P);
-    else hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER>), grid, dim3(256), MF_LDS_BYTES, s, P);
+// Default shapes: the probe always uses 64-row tiles (its per-tile minima must stay <= 8192 per query);
+// the filter uses 16-row x 1-KiB stages with non-temporal DMA when dim % 256 == 0 and the tile is at
+// least as long as the ring (dim >= 512), else 64-row x 256-B stages.  Measured on 10M x 768 (profiles/):
+// 64-row default policy 5.5 ms, 64-row nt 5.16 ms, 16-row nt 4.99 ms.
+template <int KS> static uint32_t launch_filter_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    if constexpr (KS % 8 == 0 && KS >= 16) {
+        Q.n_tiles = (uint32_t)((n + 15) / 16);
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 16>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+                           mf_lds_bytes(3), s, Q);
+    } else {
+        Q.n_tiles = (uint32_t)((n + 63) / 64);
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 64>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+                           mf_lds_bytes(3), s, Q);
+    }
+    return Q.n_tiles;
 }
-static void launch_mfma(int ksteps, int mode, const MfmaParams &P, dim3 grid, hipStream_t s) {
+template <int KS> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64>), grid, dim3(256), mf_lds_bytes(3), s, P);
+}
+// tuning variants of the d=768 filter kernel (option "mfma_variant"): ring depth / cache policy /
+// occupancy / tile shape.  Returns the tile height (rows) of the launched variant, 0 if none matched.
+#define MF_VARIANT(NS_, AUX_, MINW_, RT_)                                                                     \
+    {                                                                                                         \
+        Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                          \
+        dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                         \
+        hipLaunchKernelGGL((k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_>), grid, dim3(256), mf_lds_bytes(NS_), \
+                           s, Q);                                                                             \
+        return RT_;                                                                                           \
+    }
+static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    switch (variant) {
+    case 1: MF_VARIANT(3, 2, 1, 64)
+    case 2: MF_VARIANT(4, 0, 1, 64)
+    case 3: MF_VARIANT(4, 2, 1, 64)
+    case 4: MF_VARIANT(3, 0, 3, 64)
+    case 5: MF_VARIANT(3, 2, 3, 64)
+    case 6: MF_VARIANT(3, 2, 1, 16)
+    case 7: MF_VARIANT(4, 2, 1, 16)
+    case 8: MF_VARIANT(3, 2, 3, 16)
+    case 9: MF_VARIANT(3, 0, 1, 16)
+    default: return 0;
+    }
+}
+static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
     switch (ksteps) {
-    case 4: launch_mfma_ks<4>(mode, P, grid, s); break;
-    case 8: launch_mfma_ks<8>(mode, P, grid, s); break;
-    case 12: launch_mfma_ks<12>(mode, P, grid, s); break;
-    case 16: launch_mfma_ks<16>(mode, P, grid, s); break;
-    case 24: launch_mfma_ks<24>(mode, P, grid, s); break;
-    default: launch_mfma_ks<32>(mode, P, grid, s); break;
+    case 4: launch_filter_ks<4>(P, n, wgs, q_tiles, s); break;
+    case 8: launch_filter_ks<8>(P, n, wgs, q_tiles, s); break;
+    case 12: launch_filter_ks<12>(P, n, wgs, q_tiles, s); break;
+    case 16: launch_filter_ks<16>(P, n, wgs, q_tiles, s); break;
+    case 24: launch_filter_ks<24>(P, n, wgs, q_tiles, s); break;
+    default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
+    }
+}
+static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_probe_ks<4>(P, grid, s); break;
+    case 8: launch_probe_ks<8>(P, grid, s); break;
+    case 12: launch_probe_ks<12>(P, grid, s); break;
+    case 16: launch_probe_ks<16>(P, grid, s); break;
+    case 24: launch_probe_ks<24>(P, grid, s); break;
+    default: launch_probe_ks<32>(P, grid, s); break;
     }
 }
 
@@ -799,7 +876,7 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        launch_mfma(KS, MF_PROBE, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
                            (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
@@ -812,7 +889,9 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.tile_first = 0;
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
-        launch_mfma(KS, MF_FILTER, Q, dim3(std::min(total_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
+        if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
+            launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));

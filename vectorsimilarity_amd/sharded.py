@@ -119,9 +119,10 @@ class ShardedFlatIndex:
         if dev is None:
             dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
         t = torch.from_numpy(rec).to(dev)
-        out = torch.empty((self.world,) + tuple(rec.shape), dtype=torch.int64, device=dev)
+        # concatenated form (world*nq, W): accepted by both RCCL and gloo
+        out = torch.empty((self.world * rec.shape[0], rec.shape[1]), dtype=torch.int64, device=dev)
         self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        return out.cpu().numpy().reshape((self.world,) + tuple(rec.shape))
 
     def knn_query(self, queries, k):
         queries = np.ascontiguousarray(queries)
