@@ -395,3 +395,43 @@ def test_reply_objects_and_array_entry_points_agree():
         a = ix.knn_query(q, 7, order=order)
         b = ix.knn_query_replies(q, 7, order=order)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------- low-precision MFMA filter (bf16 / fp16 / int8)
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [
+    ("bf16", "IP", 768, 24_000, 40, 10),        # BASELINE config 4 shape (scaled down)
+    ("bf16", "L2", 256, 30_000, 130, 10),       # two query tiles of 128
+    ("bf16", "Cosine", 512, 20_000, 33, 5),
+    ("bf16", "L2", 1024, 12_000, 20, 10),
+    ("f16", "L2", 768, 20_000, 40, 10),
+    ("f16", "IP", 256, 30_000, 64, 100),
+    ("f16", "Cosine", 1024, 12_000, 17, 10),
+    ("i8", "Cosine", 1024, 30_000, 70, 100),    # BASELINE config 3 shape (scaled down), norm-carrying rows
+    ("i8", "L2", 512, 40_000, 260, 10),         # two query tiles of 256
+    ("i8", "IP", 768, 30_000, 64, 10),
+])
+def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
+    rng = np.random.default_rng(dim * 3 + n)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"].startswith("k_mfma_filter_lowp"), st
+    # ints are heavy on exact ties (integer scores): the candidate lists may legitimately overflow
+    if typ != "i8":
+        assert st["fallbacks"] == 0, st
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    km = kernel_metric(typ, metric)
+    for j in range(nq):
+        sc = vso.scan(TYPES[typ], km, srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l1[j], el.astype(np.int64)), (typ, metric, dim, j)
+        assert np.array_equal(d1[j], es), (typ, metric, dim, j)
+    ix.set_option("mfma", 0)
+    l2, d2 = ix.knn_query(q[:8], k)
+    assert np.array_equal(l1[:8], l2) and np.array_equal(d1[:8], d2)

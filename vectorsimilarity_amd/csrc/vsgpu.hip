@@ -18,6 +18,7 @@
 #include "lane_program.h"
 #include "exact_kernels.hpp"
 #include "mfma_kernels.hpp"
+#include "mfma_lowp_kernels.hpp"
 
 using namespace vsg;
 
@@ -186,6 +187,9 @@ struct vsgpu_table {
     // MFMA filter path (fp32, AVX-512-order tier, dim a multiple of 64): |x|^2 per row, slab-parallel
     bool mfma_ok = false;
     int ksteps = 0;
+    // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
+    bool lowp_ok = false;
+    int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;
 };
@@ -236,6 +240,22 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && dim % 64 == 0 && row_bytes == dim * 4 &&
                       (ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32));
         t->ksteps = (int)ks;
+        const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
+        if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
+            (dim == 256 || dim == 512 || dim == 768 || dim == 1024) && row_bytes == data_bytes) {
+            t->lowp_ok = true;
+            t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
+            t->lp_ksteps = (int)(dim / 32);
+            t->lp_rt = dim == 256 ? 64 : (dim == 1024 ? 16 : 32);
+            t->lp_qtile = 128;
+        }
+        if (type == VSGPU_I8 && (dim == 512 || dim == 768 || dim == 1024)) {
+            t->lowp_ok = true;
+            t->lp_kind = LP_I8;
+            t->lp_ksteps = (int)(dim / 64);
+            t->lp_rt = dim == 1024 ? 32 : 64;
+            t->lp_qtile = 256;
+        }
     }
     // slabs of ~64 MiB, power-of-two row count
     size_t rows = ((size_t)64 << 20) / row_bytes;
@@ -278,7 +298,7 @@ static int grow_to(vsgpu_table *t, size_t rows) {
         char *p = nullptr;
         HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes));
         t->slabs.push_back(p);
-        if (t->mfma_ok) {
+        if (t->mfma_ok || t->lowp_ok) {
             float *np = nullptr;
             HIPCHK(hipMalloc((void **)&np, slab_rows * sizeof(float)));
             t->norm_slabs.push_back(np);
@@ -294,12 +314,12 @@ static int grow_to(vsgpu_table *t, size_t rows) {
             t->d_norm_slabs = nullptr;
             size_t cap = std::max<size_t>(64, t->slabs.size() * 2);
             HIPCHK(hipMalloc((void **)&t->d_slabs, cap * sizeof(char *)));
-            if (t->mfma_ok) HIPCHK(hipMalloc((void **)&t->d_norm_slabs, cap * sizeof(float *)));
+            if (t->mfma_ok || t->lowp_ok) HIPCHK(hipMalloc((void **)&t->d_norm_slabs, cap * sizeof(float *)));
             t->d_slabs_cap = cap;
         }
         HIPCHK(hipMemcpy(t->d_slabs, t->slabs.data(), t->slabs.size() * sizeof(char *),
                          hipMemcpyHostToDevice));
-        if (t->mfma_ok)
+        if (t->mfma_ok || t->lowp_ok)
             HIPCHK(hipMemcpy(t->d_norm_slabs, t->norm_slabs.data(), t->norm_slabs.size() * sizeof(float *),
                              hipMemcpyHostToDevice));
     }
@@ -312,14 +332,23 @@ static inline char *row_ptr(const vsgpu_table *t, size_t id) {
 
 // recompute |x|^2 of rows [first, first+n) (fp32 tables on the MFMA path only)
 static int update_norms(vsgpu_table *t, size_t first, size_t n) {
-    if (!t->mfma_ok || n == 0) return VSGPU_OK;
+    if (!(t->mfma_ok || t->lowp_ok) || n == 0) return VSGPU_OK;
     const size_t slab_rows = (size_t)1 << t->slab_shift;
     size_t id = first, left = n;
     while (left) {
         size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
         float *np = t->norm_slabs[id >> t->slab_shift] + (id & (slab_rows - 1));
-        hipLaunchKernelGGL(k_row_norms_f32, dim3((unsigned)((in_slab + 3) / 4)), dim3(256), 0, t->ctx->stream,
-                           (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
+        const dim3 g((unsigned)((in_slab + 3) / 4));
+        if (t->mfma_ok)
+            hipLaunchKernelGGL(k_row_norms_f32, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
+        else if (t->lp_kind == LP_I8)
+            hipLaunchKernelGGL(k_row_aux_i8, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, t->metric == VSGPU_COSINE ? 1 : 0,
+                               (uint32_t *)np);
+        else
+            hipLaunchKernelGGL(k_row_norms_h16, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, t->type, (uint32_t *)np);
         id += in_slab;
         left -= in_slab;
     }
@@ -917,6 +946,188 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
 }
 
+// ------------------------------------------------------------------ low-precision MFMA filter path
+template <int LK, int KS, int RT, int NQW>
+static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE)
+        hipLaunchKernelGGL((k_mfma_filter_lowp<LK, KS, MF_PROBE, RT, 8, NQW>), grid, dim3(512), lowp_lds_bytes(8), s, P);
+    else
+        hipLaunchKernelGGL((k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, 8, NQW>), grid, dim3(512), lowp_lds_bytes(8), s, P);
+}
+template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    switch (ks) {
+    case 8: launch_lowp_t<LK, 8, 64, 1>(mode, P, grid, s); break;
+    case 16: launch_lowp_t<LK, 16, 32, 1>(mode, P, grid, s); break;
+    case 24: launch_lowp_t<LK, 24, 32, 1>(mode, P, grid, s); break;
+    default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
+    }
+}
+static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
+    else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
+    else {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_t<LP_I8, 8, 64, 2>(mode, P, grid, s); break;
+        case 12: launch_lowp_t<LP_I8, 12, 64, 2>(mode, P, grid, s); break;
+        default: launch_lowp_t<LP_I8, 16, 32, 2>(mode, P, grid, s); break;
+        }
+    }
+}
+
+static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                     uint32_t *ids, double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, dim = t->dim;
+    const int KS = t->lp_ksteps, RT = t->lp_rt;
+    const size_t QT = (size_t)t->lp_qtile, NQW = QT / 128;
+    const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
+    const bool is_int = (t->lp_kind == LP_I8);
+    const size_t eb = is_int ? 1 : 2;
+    const size_t kelem = is_int ? 64 : 32;        // elements per MFMA k-step
+    const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
+
+    int rc = VSGPU_OK;
+    if (!is_int) {
+        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
+        if (rc) return rc;
+    }
+    // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
+    std::vector<unsigned char> frag(nqp * dim * eb, 0);
+    std::vector<uint32_t> qaux(nqp, 0);
+    std::vector<float> tau0(nqp, -INFINITY);
+    for (size_t q = 0; q < nq; q++) {
+        const unsigned char *src = (const unsigned char *)queries + q * qstride;
+        const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
+        for (int s = 0; s < KS; s++)
+            for (int kq = 0; kq < 4; kq++) {
+                const size_t lane = (size_t)kq * 16 + nn;
+                unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
+                memcpy(dst, src + (kelem * s + per_lane * kq) * eb, 16);
+            }
+        if (is_int) {
+            if (t->epi == EPI_INT_COS) memcpy(&qaux[q], src + dim, 4);
+            else if (t->epi == EPI_INT_L2) {
+                int ss = 0;
+                for (size_t i = 0; i < dim; i++) ss += (int)(int8_t)src[i] * (int)(int8_t)src[i];
+                memcpy(&qaux[q], &ss, 4);
+            }
+        } else {
+            double ss = 0;
+            for (size_t i = 0; i < dim; i++) {
+                uint16_t h;
+                memcpy(&h, src + 2 * i, 2);
+                double v = t->type == VSGPU_BF16 ? (double)widen_bf16(h) : (double)widen_f16(h);
+                ss += v * v;
+            }
+            float f = (float)ss;
+            memcpy(&qaux[q], &f, 4);
+        }
+    }
+    rc = ensure(c, c->qfrag, frag.size());
+    if (rc) return rc;
+    rc = ensure(c, c->qn2, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->tau, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->counts, nqp * 4);
+    if (rc) return rc;
+    const size_t ccap = (size_t)c->opt_cand_cap;
+    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+
+    LowpParams P{};
+    P.slabs = t->d_slabs;
+    P.aux_slabs = (const uint32_t *const *)t->d_norm_slabs;
+    P.slab_shift = t->slab_shift;
+    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    P.row_stride = (uint32_t)t->row_bytes;
+    P.n_rows = (uint32_t)n;
+    P.qfrag = (const uint4 *)c->qfrag.p;
+    P.qaux = (const uint32_t *)c->qn2.p;
+    if (is_int) {
+        P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? LE_I8_IP : LE_I8_COS);
+    } else {
+        P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
+        // bf16*bf16 / fp16*fp16 products are exact in fp32: only accumulation order/rounding differs
+        const double u = std::ldexp(1.0, -24);
+        const double cq = (double)dim * std::ldexp(1.0, -22) * 1.01;
+        const double gref = ((double)dim / 16.0 + 12.0) * u;
+        P.cE = (float)(((cq + 2.0 * gref + 4.0 * u) * 1.001) * (1.0 + 1e-6));
+        P.absE = t->metric == VSGPU_L2 ? 1e-30f : 1e-6f;
+    }
+    P.tau = (const float *)c->tau.p;
+    P.counts = (uint32_t *)c->counts.p;
+    P.cand = (uint2 *)c->cand.p;
+    P.cap = (uint32_t)ccap;
+
+    const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    const uint32_t tile_step = total_tiles / probe_tiles;
+    uint32_t M = 64;
+    while (M < probe_tiles) M <<= 1;
+    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
+    if (rc) return rc;
+    const uint32_t wgs = (uint32_t)c->n_cu * 2;
+
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    {
+        LowpParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = tile_step;
+        Q.n_tiles = probe_tiles;
+        Q.tilemin = (float *)c->dense.p;
+        Q.tilemin_stride = probe_tiles;
+        launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    {
+        LowpParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = 1;
+        Q.n_tiles = total_tiles;
+        launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, wgs), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (!is_int) {
+        ScanParams S{};
+        S.slabs = t->d_slabs;
+        S.slab_shift = t->slab_shift;
+        S.slab_mask = P.slab_mask;
+        S.row_stride = P.row_stride;
+        S.offs = t->d_offs;
+        S.steps = t->prog.steps;
+        S.qperm = c->qperm.p;
+        S.nq = (int)nq;
+        S.epilogue = t->epi;
+        S.counts = (uint32_t *)c->counts.p;
+        S.cand = (uint2 *)c->cand.p;
+        S.cap = (uint32_t)ccap;
+        dim3 grid(64, (unsigned)nq);
+        const bool l2 = (t->opk == OP_L2_FMA);
+        if (t->type == VSGPU_BF16) {
+            if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+            else hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+        } else {
+            if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+            else hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
+                              is_int ? "k_mfma_filter_lowp(i8)" : "k_mfma_filter_lowp(h16)");
+}
+
 // ------------------------------------------------------------------ top-K
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride) {
@@ -987,6 +1198,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         return topk_dense_path(t, nq, k, cap, ids, scores, counts, 0, nq, queries, qstride);
     }
 
+    if (t->lowp_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) return topk_lowp(t, queries, nq, qstride, k, cap, ids, scores, counts);
     if (t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) return topk_mfma(t, queries, nq, qstride, k, cap, ids, scores, counts);
 
     // ---- probe -> threshold -> filtered scan ----

@@ -70,8 +70,10 @@ class ShardedFlatIndex:
         return len(labels)
 
     def add_synthetic_local(self, rows_per_rank, seed):
-        """weak-scaling fill: THIS rank appends rows_per_rank device-generated rows (labels = gids)"""
-        assert self.n_global == 0 and rows_per_rank % self.block == 0 or self.world == 1
+        """weak-scaling fill: THIS rank appends rows_per_rank device-generated rows.  The equivalent
+        single index is the concatenation of the shards in rank order: gid = rank*rows_per_rank + local
+        id, label = gid."""
+        assert self.n_global == 0
         self.local.add_synthetic(rows_per_rank, seed)
         self._synthetic = rows_per_rank
         self.n_global = rows_per_rank * self.world
@@ -79,9 +81,7 @@ class ShardedFlatIndex:
     def locate(self, label):
         """(owner rank, local row) of a label; synthetic fills use label == gid"""
         if self._synthetic is not None:
-            if self.world == 1:
-                return 0, label
-            return block_owner(label, self.block, self.world), gid_to_local(label, self.block, self.world)
+            return label // self._synthetic, label % self._synthetic
         gid = self._label_gid[label]
         return block_owner(gid, self.block, self.world), gid_to_local(gid, self.block, self.world)
 
@@ -104,12 +104,13 @@ class ShardedFlatIndex:
         rec = np.zeros((nq, 1 + 3 * cap), dtype=np.int64)
         rec[:, 0] = counts
         lid = ids.astype(np.int64)
-        gids = ((lid // self.block) * self.world + self.rank) * self.block + lid % self.block
-        rec[:, 1:1 + cap] = gids
-        if self._synthetic is not None and self.world > 1:
-            rec[:, 1 + cap:1 + 2 * cap] = gids          # synthetic shards: label := gid (globally unique)
+        if self._synthetic is not None:
+            gids = self.rank * self._synthetic + lid    # contiguous shards
+            rec[:, 1 + cap:1 + 2 * cap] = gids          # label := gid (globally unique)
         else:
+            gids = ((lid // self.block) * self.world + self.rank) * self.block + lid % self.block
             rec[:, 1 + cap:1 + 2 * cap] = labels.view(np.int64)
+        rec[:, 1:1 + cap] = gids
         rec[:, 1 + 2 * cap:] = scores.view(np.int64)
         return rec
 
