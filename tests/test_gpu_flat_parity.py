@@ -435,3 +435,22 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     ix.set_option("mfma", 0)
     l2, d2 = ix.knn_query(q[:8], k)
     assert np.array_equal(l1[:8], l2) and np.array_equal(d1[:8], d2)
+
+
+@pytest.mark.parametrize("typ,metric,dim", [("bf16", "IP", 256), ("f16", "L2", 256), ("i8", "Cosine", 512), ("i8", "L2", 512)])
+def test_synthetic_fill_lowp_types_matches_host_twin(vso, typ, metric, dim):
+    from vectorsimilarity_amd import synth
+    n, nq, k = 20_000, 12, 10
+    ix = make_index(typ, metric, dim)
+    ix.add_synthetic(n, 47)
+    gen = {"bf16": synth.rows_bf16, "f16": synth.rows_f16, "i8": synth.rows_i8}[typ]
+    rows = gen(47, 0, n, dim)
+    q = gen(48, 0, nq, dim)
+    ix.set_option("dense_pairs", 0)
+    l, d = ix.knn_query(q, k)
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    for j in range(nq):
+        sc = vso.scan(TYPES[typ], kernel_metric(typ, metric), srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es), (typ, j)

@@ -316,4 +316,48 @@ __global__ void k_fill_uniform_f32(float *dst, uint64_t first_elem, uint64_t cou
     }
 }
 
+// bf16 / fp16 rows: the fp32 synthetic value rounded to nearest-even (bf16) or converted by the
+// hardware RNE cvt (fp16); int8 rows: top byte of the hash.  Twins: vectorsimilarity_amd/synth.py.
+__global__ void k_fill_uniform_h16(uint16_t *dst, uint64_t first_elem, uint64_t count, uint64_t seed, int is_bf16) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t strd = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += strd) {
+        uint32_t u = hash32(seed, first_elem + i) >> 8;
+        float f = __fsub_rn(__fmul_rn((float)u, 1.0f / 8388608.0f), 1.0f);
+        if (is_bf16) {
+            uint32_t b = __float_as_uint(f);
+            b += 0x7FFFu + ((b >> 16) & 1u);
+            dst[i] = (uint16_t)(b >> 16);
+        } else {
+            _Float16 h = (_Float16)f;
+            dst[i] = __builtin_bit_cast(uint16_t, h);
+        }
+    }
+}
+// int8 rows, `row_bytes` apart; when with_norm the float norm sqrt(sum x^2) follows the dim bytes
+// (compute_norm.h:18-31: uint64 sum, sqrt in double, narrowed to float).  One wave per row.
+__global__ __launch_bounds__(256) void k_fill_rows_i8(char *rows, uint32_t row_bytes, uint32_t dim, uint64_t first_row,
+                                                      uint32_t n, uint64_t seed, int with_norm) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    char *p = rows + (size_t)r * row_bytes;
+    unsigned long long ss = 0;
+    for (uint32_t i = lane; i < dim; i += 64) {
+        const int8_t v = (int8_t)(hash32(seed, (first_row + r) * (uint64_t)dim + i) >> 24);
+        p[i] = (char)v;
+        ss += (unsigned long long)((int)v * (int)v);
+    }
+    if (with_norm) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) {
+            const float norm = (float)sqrt((double)ss);
+            const uint32_t u = __float_as_uint(norm);
+            unsigned char *np = reinterpret_cast<unsigned char *>(p + dim);
+            np[0] = (unsigned char)u; np[1] = (unsigned char)(u >> 8); np[2] = (unsigned char)(u >> 16); np[3] = (unsigned char)(u >> 24);
+        }
+    }
+}
+
 }  // namespace vsg

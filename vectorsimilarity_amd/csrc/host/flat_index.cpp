@@ -162,7 +162,10 @@ long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
 }
 
 long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
-    if (type_ != VecSimType_FLOAT32 || metric_ == VecSimMetric_Cosine) return -1;
+    // device-generated rows are stored as generated: fp Cosine would need normalisation, so only int8 Cosine
+    // (norm appended by the fill kernel) is accepted among the Cosine indexes
+    if (type_ == VecSimType_FLOAT64 || type_ == VecSimType_UINT8) return -1;
+    if (metric_ == VecSimMetric_Cosine && type_ != VecSimType_INT8) return -1;
     if (flush()) return -1;
     const size_t first = count_;
     for (size_t i = 0; i < n; i++)

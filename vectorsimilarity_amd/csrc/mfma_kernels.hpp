@@ -389,4 +389,46 @@ __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, cons
     if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
 }
 
+
+// Dense variant: the scores of ALL n rows of one query are in `dense` (column = row id); same
+// bitwise k-th search, the survivors (score <= T_k) are compacted as {row, score} records.
+__global__ __launch_bounds__(1024) void k_select_dense_upto_kth(const float *dense, size_t stride, uint32_t n, uint32_t k,
+                                                                uint2 *out, uint32_t *out_counts, uint32_t out_cap) {
+    __shared__ uint32_t red[16];
+    __shared__ uint32_t wpos;
+    const int q = blockIdx.x;
+    const uint32_t *c = reinterpret_cast<const uint32_t *>(dense + (size_t)q * stride);
+    uint32_t T = 0xFFFFFFFFu;
+    if (n > k) {
+        T = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t trial = T | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll 4
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) cnt += (float_sort_key(c[i]) < trial) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) total += red[w];
+            if (total < k) T = trial;
+        }
+    }
+    if (threadIdx.x == 0) wpos = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t bits = c[i];
+        const bool is_nan = (bits & 0x7FFFFFFFu) > 0x7F800000u;
+        if (!is_nan && float_sort_key(bits) <= T) {
+            const uint32_t p = atomicAdd(&wpos, 1u);
+            if (p < out_cap) out[(size_t)q * out_cap + p] = make_uint2(i, bits);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
+}
+
 }  // namespace vsg

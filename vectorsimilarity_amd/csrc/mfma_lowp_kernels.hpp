@@ -70,8 +70,8 @@ struct LowpParams {
 
 constexpr int lowp_lds_bytes(int nwaves) { return 3 * MF_STAGE_BYTES + nwaves * 512; }
 
-template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW>
-__global__ __launch_bounds__(NWAVES * 64) void k_mfma_filter_lowp(LowpParams P) {
+template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1>
+__global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
     constexpr int NS = 3;
@@ -173,7 +173,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_mfma_filter_lowp(LowpParams P) 
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
             // unit c landed; unit c+1 (IPW loads, +1 aux load if it opens the next tile) may stay in flight
-            if (IPW == 2) {
+            if (IPW == 1) {
+                if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else if (IPW == 2) {
                 if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else {

@@ -69,9 +69,10 @@ struct vsgpu_ctx {
     // options
     long opt_mfma = 1;
     long opt_mfma_variant = 0;
+    long opt_lowp_variant = 0;
     long opt_wg_per_cu = 2;
     long opt_mfma_min_q = 9;          // narrower batches stay on the exact kernel (one BT=8 pass is HBM-bound)
-    long opt_dense_pairs = 1L << 22;  // nq*n at or below this: dense score matrix + host selection
+    long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
     long opt_probe_div = 32;          // probe ~ n / probe_div rows
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
@@ -161,6 +162,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     std::string n(name);
     if (n == "mfma") c->opt_mfma = value;
     else if (n == "mfma_variant") c->opt_mfma_variant = value;
+    else if (n == "lowp_variant") c->opt_lowp_variant = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = std::max(1L, value);
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
@@ -403,7 +405,7 @@ extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
     return VSGPU_OK;
 }
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
-    if (t->type != VSGPU_F32) return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32 only");
+    if (t->type == VSGPU_F64 || t->type == VSGPU_U8) return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32/bf16/fp16/int8 only");
     if (n == 0) return VSGPU_OK;
     HIPCHK(hipSetDevice(t->ctx->device));
     if (t->n + n > 0xFFFFFFF0ull) return fail(VSGPU_ERR_UNSUPPORTED, "more than 2^32 rows per device table");
@@ -415,8 +417,16 @@ extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t s
         size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
         uint64_t count = (uint64_t)in_slab * t->dim;
         int grid = (int)std::min<uint64_t>((count + 255) / 256, 8192);
-        hipLaunchKernelGGL(k_fill_uniform_f32, dim3(grid), dim3(256), 0, t->ctx->stream,
-                           (float *)row_ptr(t, id), (uint64_t)id * t->dim, count, seed);
+        if (t->type == VSGPU_F32)
+            hipLaunchKernelGGL(k_fill_uniform_f32, dim3(grid), dim3(256), 0, t->ctx->stream, (float *)row_ptr(t, id),
+                               (uint64_t)id * t->dim, count, seed);
+        else if (t->type == VSGPU_BF16 || t->type == VSGPU_F16)
+            hipLaunchKernelGGL(k_fill_uniform_h16, dim3(grid), dim3(256), 0, t->ctx->stream, (uint16_t *)row_ptr(t, id),
+                               (uint64_t)id * t->dim, count, seed, t->type == VSGPU_BF16 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_fill_rows_i8, dim3((unsigned)((in_slab + 3) / 4)), dim3(256), 0, t->ctx->stream,
+                               row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint64_t)id, (uint32_t)in_slab, seed,
+                               t->row_bytes > t->dim ? 1 : 0);
         id += in_slab;
         left -= in_slab;
     }
@@ -719,6 +729,11 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
     }
+    // copy out of the pinned staging area: the dense fallback below reuses (and may reallocate) it
+    std::vector<uint32_t> hsel_v(hsel, hsel + 2 * nq);
+    std::vector<uint2> hrec_v(hrec, hrec + nq * ocap);
+    hsel = hsel_v.data();
+    hrec = hrec_v.data();
     const uint32_t *hraw = hsel + nq;
     std::vector<Hit> hits;
     for (size_t q = 0; q < nq; q++) {
@@ -745,6 +760,14 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
         emit(hits, q, cap, ids, scores, counts);
     }
     return VSGPU_OK;
+}
+
+// Candidate slots per query: the threshold comes from a sample of `probe_rows` rows, so about
+// k * n / probe_rows rows pass the filter (more with a loose bound); leave 3x headroom.
+static size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows) {
+    double expect = (double)k * (double)n / (double)std::max<size_t>(probe_rows, 1);
+    size_t want = (size_t)std::min(expect * 3.0 + 64.0, 1048576.0);
+    return std::max<size_t>((size_t)c->opt_cand_cap, want);
 }
 
 // ------------------------------------------------------------------ MFMA filter path (fp32, wide batches)
@@ -854,7 +877,10 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     if (rc) return rc;
     rc = ensure(c, c->counts, nqp * 4);
     if (rc) return rc;
-    const size_t ccap = (size_t)c->opt_cand_cap;
+    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -869,9 +895,6 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
     const float absE = l2 ? 1e-30f : 1e-6f;
 
-    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
     const uint32_t tile_step = total_tiles / probe_tiles;
     uint32_t M = 64;
     while (M < probe_tiles) M <<= 1;
@@ -962,6 +985,19 @@ template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams
     default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
     }
 }
+// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024
+static bool launch_lowp_variant(const vsgpu_table *t, int variant, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode != MF_FILTER || variant == 0) return false;
+    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) {
+        if (variant == 1) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_BF16, 24, MF_FILTER, 32, 8, 1, 4>), grid, dim3(512), lowp_lds_bytes(8), s, P); return true; }
+        if (variant == 2) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_BF16, 24, MF_FILTER, 32, 8, 1, 3>), grid, dim3(512), lowp_lds_bytes(8), s, P); return true; }
+    }
+    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
+        if (variant == 1) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_I8, 16, MF_FILTER, 32, 16, 1, 4>), grid, dim3(1024), lowp_lds_bytes(16), s, P); return true; }
+        if (variant == 2) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_I8, 16, MF_FILTER, 32, 16, 1, 1>), grid, dim3(1024), lowp_lds_bytes(16), s, P); return true; }
+    }
+    return false;
+}
 static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
@@ -1031,7 +1067,10 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     if (rc) return rc;
     rc = ensure(c, c->counts, nqp * 4);
     if (rc) return rc;
-    const size_t ccap = (size_t)c->opt_cand_cap;
+    const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
@@ -1064,9 +1103,6 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     P.cand = (uint2 *)c->cand.p;
     P.cap = (uint32_t)ccap;
 
-    const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
     const uint32_t tile_step = total_tiles / probe_tiles;
     uint32_t M = 64;
     while (M < probe_tiles) M <<= 1;
@@ -1095,7 +1131,9 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.tile_first = 0;
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
-        launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, wgs), (unsigned)q_tiles), c->stream);
+        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
+        if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream))
+            launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
@@ -1164,7 +1202,6 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) {
             int rc = stage_queries(t, queries, nq, qstride);
             if (rc) return rc;
-            std::vector<double> all(nq * n);
             HIPCHK(hipEventRecord(c->ev_c, c->stream));
             ScanParams P{};
             // dense_to_host re-records nothing: time it here as the scan
@@ -1180,17 +1217,37 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
             P.out_stride = n;
             rc = run_scan(t, P, nq, true);
             if (rc) return rc;
-            rc = ensure_pinned(c, nq * n * 4);
+            // selection on the GPU: only the rows with score <= T_k travel to the host
+            const size_t ocap = cap;
+            rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(c->pinned, c->dense.p, nq * n * 4, hipMemcpyDeviceToHost, c->stream));
+            rc = ensure(c, c->selcnt, nq * 4);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_select_dense_upto_kth, dim3((unsigned)nq), dim3(1024), 0, c->stream, (const float *)c->dense.p,
+                               n, (uint32_t)n, (uint32_t)std::min(k, n), (uint2 *)c->sel.p, (uint32_t *)c->selcnt.p,
+                               (uint32_t)ocap);
+            HIPCHK(hipGetLastError());
+            rc = ensure_pinned(c, nq * 4 + nq * ocap * sizeof(uint2));
+            if (rc) return rc;
+            uint32_t *hsel = (uint32_t *)c->pinned;
+            uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 4);
+            HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             account_scan(c, t, n, 1, "k_exact_scan(dense)");
-            const float *src = (const float *)c->pinned;
             std::vector<Hit> hits;
             for (size_t q = 0; q < nq; q++) {
-                hits.resize(n);
-                for (size_t i = 0; i < n; i++) hits[i] = Hit{(uint32_t)i, (double)src[q * n + i]};
-                select_upto_kth(hits, k);
+                if (hsel[q] == VSGPU_COUNT_OVERFLOW) {
+                    counts[q] = VSGPU_COUNT_OVERFLOW;
+                    continue;
+                }
+                hits.resize(hsel[q]);
+                for (size_t i = 0; i < hsel[q]; i++) {
+                    float f;
+                    memcpy(&f, &hrec[q * ocap + i].y, 4);
+                    hits[i] = Hit{hrec[q * ocap + i].x, (double)f};
+                }
+                std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
                 emit(hits, q, cap, ids, scores, counts);
             }
             return VSGPU_OK;
@@ -1220,7 +1277,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
     if (rc) return rc;
     rc = ensure(c, c->counts, nq * 4);
     if (rc) return rc;
-    const size_t ccap = (size_t)c->opt_cand_cap;
+    const size_t ccap = candidate_capacity(c, k, n, n0);
     rc = ensure(c, c->cand, nq * ccap * sizeof(uint2));
     if (rc) return rc;
 

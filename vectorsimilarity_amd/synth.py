@@ -27,3 +27,18 @@ def rows_f32(seed, first_row, nrows, dim):
     idx = np.arange(first_row * dim, (first_row + nrows) * dim, dtype=np.uint64)
     u = (hash32(seed, idx) >> np.uint32(8)).astype(np.float32)
     return (u * np.float32(1.0 / 8388608.0) - np.float32(1.0)).reshape(nrows, dim)
+
+
+def rows_bf16(seed, first_row, nrows, dim):
+    """uint16 bf16 bits: the fp32 synthetic values rounded to nearest even"""
+    u = rows_f32(seed, first_row, nrows, dim).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def rows_f16(seed, first_row, nrows, dim):
+    return rows_f32(seed, first_row, nrows, dim).astype(np.float16).view(np.uint16)
+
+
+def rows_i8(seed, first_row, nrows, dim):
+    idx = np.arange(first_row * dim, (first_row + nrows) * dim, dtype=np.uint64)
+    return (hash32(seed, idx) >> np.uint32(24)).astype(np.uint8).view(np.int8).reshape(nrows, dim)
