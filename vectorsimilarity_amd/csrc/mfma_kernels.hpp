@@ -39,7 +39,44 @@ constexpr int MF_STAGE_BYTES = 16384; // one ring slot: RT rows x (4096/RT) floa
 constexpr int MF_NSTAGE_MAX = 4;
 constexpr int MF_QTILE = 64;          // queries per workgroup (16 per wave)
 constexpr int MF_NORM_BYTES = 4 * 2 * 256;  // [wave][parity][64 floats]
-constexpr int mf_lds_bytes(int nstage) { return nstage * MF_STAGE_BYTES + MF_NORM_BYTES; }
+// Candidate emission goes through a small LDS queue (LDS atomics use lgkmcnt, not the VM counter the
+// DMA pipeline is counted on); the queue is flushed to global memory when half full and at kernel end.
+constexpr int MF_EQ_CAP = 384;                     // queued {row, query, score bits} records
+constexpr int MF_EQ_BYTES = 16 + MF_EQ_CAP * 16;
+constexpr int mf_lds_bytes(int nstage) { return nstage * MF_STAGE_BYTES + MF_NORM_BYTES + MF_EQ_BYTES; }
+
+// The queue is touched with inline-asm DS instructions on purpose: for a compiler-visible LDS store or
+// atomic hipcc inserts `s_waitcnt vmcnt(0)` while LDS-DMA writes are in flight (it cannot prove the
+// addresses disjoint), which would drain the staging ring at every emission.
+typedef unsigned int mf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t mf_lds_offset(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ uint32_t mf_queue_reserve(uint32_t eq_n_off) {
+    uint32_t ret, one = 1u;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ret) : "v"(eq_n_off), "v"(one) : "memory");
+    return ret;
+}
+__device__ __forceinline__ void mf_queue_write(uint32_t slot_off, uint32_t row, uint32_t q, uint32_t bits) {
+    mf_u32x4 v = {row, q, bits, 0u};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(slot_off), "v"(v) : "memory");
+}
+
+// all threads of the workgroup: move the queued records to the per-query candidate lists
+template <int NTHREADS>
+__device__ __forceinline__ void mf_flush_queue(uint32_t *eq_n, uint4 *eq, uint32_t *counts, uint2 *cand, uint32_t cap) {
+    const uint32_t n = min(*eq_n, (uint32_t)MF_EQ_CAP);
+    for (uint32_t i = threadIdx.x; i < n; i += NTHREADS) {
+        const uint4 r = eq[i];
+        const uint32_t s = atomicAdd(&counts[r.y], 1u);
+        if (s < cap) cand[(size_t)r.y * cap + s] = make_uint2(r.x, r.z);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) *eq_n = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 struct MfmaParams {
     const char *const *slabs;        // row slabs
@@ -136,6 +173,10 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
     char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + wave * 512;
+    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES);
+    uint4 *eq = reinterpret_cast<uint4 *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES + 16);
+    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
+    if (MODE == MF_FILTER && tid == 0) *eq_n = 0;  // visible to everyone after the first unit's barrier
 
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
@@ -206,6 +247,10 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
+            if (MODE == MF_FILTER && c == 0) {
+                // every wave has finished the previous tile's epilogue: the queue length is final and uniform
+                if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+            }
             // refill the slot read in the previous unit with unit +(NS-1)
             {
                 constexpr int D = NS - 1;
@@ -258,9 +303,14 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 } else {
                     const float low = a - E;
                     if (row < P.n_rows && low <= tau) {
-                        uint32_t s = atomicAdd(&P.counts[qidx], 1u);
-                        if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                        emitted = true;
+                        const uint32_t pos = mf_queue_reserve(eq_n_off);
+                        if (pos < MF_EQ_CAP) {
+                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));
+                        } else {  // queue full (dense survivors): straight to global memory
+                            uint32_t s = atomicAdd(&P.counts[qidx], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            emitted = true;
+                        }
                     }
                 }
             }
@@ -271,10 +321,13 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
             tmin = fminf(tmin, __shfl_xor(tmin, 32));
             if (kq == 0) P.tilemin[(size_t)qidx * P.tilemin_stride + tile] = tmin;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (__any(emitted)) {
-            // stores/atomics share the VM counter with the staged loads: drain once so the counted
-            // waits of the next tile see only loads
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (__any(emitted)) {
+                // stores/atomics share the VM counter with the staged loads: drain once so the counted
+                // waits of the next tile see only loads
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // queue writes land before the next barrier
         }
 
         // rotate tile state
@@ -285,7 +338,11 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         parity ^= 1u;
     }
     // drain the stages still in flight before the workgroup's LDS is released
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (MODE == MF_FILTER) {
+        __builtin_amdgcn_s_barrier();
+        mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+    }
 }
 
 // |x|^2 per row in double, rounded once to float (relative error <= 2^-24): feeds the bound E

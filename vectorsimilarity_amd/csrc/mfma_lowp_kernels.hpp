@@ -68,7 +68,7 @@ struct LowpParams {
     uint32_t cap;
 };
 
-constexpr int lowp_lds_bytes(int nwaves) { return 3 * MF_STAGE_BYTES + nwaves * 512; }
+constexpr int lowp_lds_bytes(int nwaves) { return 3 * MF_STAGE_BYTES + nwaves * 512 + MF_EQ_BYTES; }
 
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
@@ -127,6 +127,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * IPW * 1024);
     char *aux_lds = lds + NS * MF_STAGE_BYTES + wave * 512;
+    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + NWAVES * 512);
+    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + NWAVES * 512 + 16);
+    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
+    if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
 
     const uint32_t step = gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
@@ -184,6 +188,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
+            if (MODE == MF_FILTER && c == 0) {
+                if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
+            }
             {
                 uint32_t slot_p = slot_c + 2;
                 if (slot_p >= NS) slot_p -= NS;
@@ -191,15 +198,26 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 else issue(rp_nxt, ap_nxt, c + 2 - KCH, slot_p, (c + 2 - KCH) == 0, parity ^ 1u);
             }
             const char *sbase = lds + slot_c * MF_STAGE_BYTES;
+            // LDS reads are issued in groups of PF fragments ahead of the MFMAs that consume them, so the
+            // ds_read latency overlaps the matrix pipe instead of serialising with it (hipcc otherwise
+            // emits read -> wait -> mfma per fragment)
+            constexpr int NFRAG = KSUB * MT;
+            constexpr int PF = NFRAG < 8 ? NFRAG : 8;
 #pragma unroll
-            for (int j = 0; j < KSUB; j++) {
+            for (int g = 0; g < NFRAG; g += PF) {
+                u32x4_t afr[PF];
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
+                for (int f = 0; f < PF; f++) {
+                    const int j = (g + f) / MT, mt = (g + f) % MT;
                     const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
                     const int p = (4 * (j % 4) + kq) ^ m16;
-                    const u32x4_t a = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
+                    afr[f] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
+                }
 #pragma unroll
-                    for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(a, qf[nt][c * KSUB + j], acc[mt][nt]);
+                for (int f = 0; f < PF; f++) {
+                    const int j = (g + f) / MT, mt = (g + f) % MT;
+#pragma unroll
+                    for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(afr[f], qf[nt][c * KSUB + j], acc[mt][nt]);
                 }
             }
             slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
@@ -240,9 +258,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     if (MODE == MF_PROBE) {
                         if (row < P.n_rows && up < tmin[nt]) tmin[nt] = up;
                     } else if (row < P.n_rows && low <= tau[nt]) {
-                        uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
-                        if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                        emitted = true;
+                        const uint32_t pos = mf_queue_reserve(eq_n_off);
+                        if (pos < MF_EQ_CAP) {
+                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                        } else {
+                            uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            emitted = true;
+                        }
                     }
                 }
             }
@@ -256,8 +279,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 if (kq == 0) P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + tile] = v;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (__any(emitted)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int i = 0; i < IPW; i++) rp_cur[i] = rp_nxt[i];
@@ -265,7 +289,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         make_ptrs(tile + 2 * step, rp_nxt, ap_nxt);
         parity ^= 1u;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (MODE == MF_FILTER) {
+        __builtin_amdgcn_s_barrier();
+        mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
+    }
 }
 
 // ---- per-row aux values ----
