@@ -136,6 +136,14 @@ def main():
         avg_ms = st["scan_ms"] / launches
         bytes_per_launch = st["scan_bytes"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes, committed summary)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(st["scan_kernel"])
+            if t and t["workload"] == {"rows": args.rows, "dim": args.dim, "batch": args.batch}:
+                traffic = t["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "distances/sec, Flat fp32 L2 top-%d, N=%s d=%d, batch-%d" % (
                 args.topk, "%dM" % (args.rows // 1_000_000) if args.rows % 1_000_000 == 0 else str(args.rows),
@@ -151,7 +159,7 @@ def main():
                        "batch": args.batch, "k": args.topk, "sharding": "rows x %d, all-gather top-K merge" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": st["scan_kernel"], "avg_kernel_ms": avg_ms, "launches": int(st["scan_launches"]),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "other_kernels_ms_per_step":
                              st["other_ms"] / max(1, args.steps)},
