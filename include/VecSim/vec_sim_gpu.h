@@ -52,6 +52,15 @@ long VecSimIndex_AddVectorsBulk(VecSimIndex *index, const void *blobs, const siz
  * is synth(seed, i*dim + j) in U[-1,1), reproducible on the host (oracle/vso.c:vso_synth_f32) */
 long VecSimIndex_AddSyntheticVectors(VecSimIndex *index, size_t n, uint64_t seed);
 
+/* HNSW tooling (tests, benchmarks): the graph the host index built, copied into caller arrays.
+ * info = {n, M, M0, entry (0xFFFFFFFF none), max_level (as uint32, 0xFFFFFFFF none), upper_words}.
+ * Arrays: links0 [n][M0] u32, cnt0 [n] u16, upper_off [n] u32, upper [upper_words] u32 (blocks of 1+M:
+ * count, links), deleted [n] u8, labels [n] u64.  Returns 0, -1 if the index is not an HNSW index. */
+int VecSimGpu_HnswGraphInfo(VecSimIndex *index, uint64_t info[6]);
+int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0, uint32_t *upper_off, uint32_t *upper,
+                            uint8_t *deleted, uint64_t *labels);
+uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
+
 /* device selection for indexes created afterwards on this thread/process (default: $VECSIM_GPU_DEVICE or 0) */
 int VecSimGpu_SetDevice(int device);
 int VecSimGpu_DeviceCount(void);

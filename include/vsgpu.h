@@ -88,6 +88,24 @@ int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, size_t n, doub
 int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t *ids, size_t n,
                     double *scores);
 
+/* ---- HNSW query loops (algorithms/hnsw/hnsw.h:530-613, 1210-1258, 1967-2084) ----
+ * A device snapshot of the graph the host index built (vectors stay in the vsgpu_table): level-0
+ * adjacency [n][2M] + counts, upper-level blocks, deletion flags, labels, entry point.  The search
+ * kernel replays the reference's greedy descent + ef-bounded best-first search, one wavefront per
+ * query, scoring neighbours with the same exact kernels as the Flat path. */
+typedef struct vsgpu_graph vsgpu_graph;
+vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M);
+void vsgpu_graph_destroy(vsgpu_graph *g);
+/* upper_off[i]: index (in blocks of 1+M words) of node i's level-1 block inside `upper`, 0xFFFFFFFF
+ * for level-0-only nodes; block l-1 of a node holds {count, links[M]} of level l. */
+int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *links0, const uint16_t *cnt0,
+                       const uint32_t *upper_off, const uint32_t *upper, size_t upper_words,
+                       const uint8_t *deleted, const uint64_t *labels, uint32_t entry, int max_level);
+/* labels/scores are [nq][k] (ascending score, then label); counts[q] <= k results written.
+ * `dist_evals` (may be NULL) receives the number of distance evaluations of the call. */
+int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef,
+                       uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals);
+
 /* ---- measurement hooks (bench.py roofline leg) ----
  * HIP-event time of the dominant scan kernel, accumulated per ctx on the stream it runs on. */
 typedef struct {

@@ -78,6 +78,15 @@ size_t vso_flat_topk(int type, int metric, int tier, size_t dim, const void *row
                      size_t stride, const size_t *labels, const void *query, size_t k,
                      size_t *out_labels, double *out_scores);
 
+/* ---- HNSW query loops over a given graph (vso_hnsw.c; hnsw.h:530-613, 1210-1258, 1967-2084) ----
+ * graph layout = what VecSimGpu_HnswGraphCopy exports.  Returns the number of results (<= k),
+ * ascending (score, label). */
+size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                       const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                       uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
+                       double *out_scores, uint64_t *dist_evals);
+
 /* ---- timing leg (bench.py cpu_baseline, kind "port") ----
  * Same arithmetic as VSO_TIER_AVX512, written with AVX-512 intrinsics when the host has them
  * (falls back to the portable lanes code otherwise).  nq queries, `threads` OpenMP threads, one

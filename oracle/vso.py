@@ -22,7 +22,7 @@ NP_DTYPE = {F32: np.float32, F64: np.float64, BF16: np.uint16, F16: np.uint16, I
 
 def build(force=False):
     """Compile oracle/libvso.so from the C restatement (gcc + make)."""
-    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso_hnsw.c", "vso.h", "Makefile")]
     if (not force and os.path.exists(_LIB)
             and os.path.getmtime(_LIB) >= max(os.path.getmtime(s) for s in srcs)):
         return _LIB
@@ -68,6 +68,9 @@ def lib():
         L.vso_flat_topk.argtypes = [i, i, i, sz, vp, sz, sz, vp, vp, sz, vp, vp]
         L.vso_flat_topk_batch_fast.restype = i
         L.vso_flat_topk_batch_fast.argtypes = [i, i, sz, vp, sz, sz, vp, sz, sz, sz, i, vp, vp]
+        L.vso_hnsw_search.restype = sz
+        L.vso_hnsw_search.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
+                                      C.c_uint32, i, vp, sz, sz, vp, vp, vp]
         L.vso_has_avx512.restype = i
         L.vso_has_avx512_bf16.restype = i
         L.vso_probe_dpbf16.restype = None
@@ -181,3 +184,18 @@ def f32_to_f16(a):
     a = np.asarray(a, dtype=np.float32)
     f = lib().vso_f32_to_f16
     return np.array([f(float(x)) for x in a.ravel()], dtype=np.uint16).reshape(a.shape)
+
+
+def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512):
+    """graph: dict from vectorsimilarity_amd.VecSim.HNSWIndex.graph(); rows: stored (preprocessed) blobs by id"""
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    ol = np.zeros(max(k, 1), dtype=np.uint64)
+    osc = np.zeros(max(k, 1), dtype=np.float64)
+    ev = C.c_uint64(0)
+    g = graph
+    c = lib().vso_hnsw_search(vtype, metric, tier, dim, _ptr(rows), rows.strides[0], g["n"], _ptr(g["links0"]),
+                              _ptr(g["cnt0"]), g["M0"], _ptr(g["upper_off"]), _ptr(g["upper"]), g["M"],
+                              _ptr(g["deleted"]), _ptr(g["labels"]), g["entry"], g["max_level"], _ptr(query), k, ef,
+                              _ptr(ol), _ptr(osc), C.byref(ev))
+    return ol[:c].copy(), osc[:c].copy(), ev.value

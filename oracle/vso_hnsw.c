@@ -1,0 +1,122 @@
+/*
+ * vso_hnsw.c -- CPU restatement of the reference's HNSW *query* loops.  TEST INFRASTRUCTURE ONLY.
+ *
+ *   searchBottomLayerEP / greedySearchLevel<true>   algorithms/hnsw/hnsw.h:1967-1981, 1210-1258
+ *   searchBottomLayer_WithTimeout                   hnsw.h:1983-2035
+ *   processCandidate                                hnsw.h:530-613
+ *   topKQuery (ef = max(ef, k), drain ascending)    hnsw.h:2037-2084
+ *
+ * The graph is an input (exported from the index under test), distances come from vso_distance (the
+ * pinned kernel oracle).  The two heaps are kept as plain arrays with linear-scan "pop the maximum",
+ * which is trivially the same element std::priority_queue<pair> pops: candidate_set orders by
+ * (-dist, id), top_candidates by (dist, label).  There is no reference fixture for HNSW results (the
+ * reference's own tests check recall against brute force), so parity for this path is: GPU search ==
+ * this restatement on the same graph, bit for bit, plus recall vs the exact Flat answer.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vso.h"
+
+typedef struct { float d; uint32_t id; } cand_t;
+typedef struct { float d; uint64_t label; } top_t;
+
+static const uint32_t *links_at(uint32_t node, int level, const uint32_t *links0, const uint16_t *cnt0, uint32_t M0,
+                                const uint32_t *upper_off, const uint32_t *upper, uint32_t M, uint32_t *cnt) {
+    if (level == 0) {
+        *cnt = cnt0[node];
+        return links0 + (size_t)node * M0;
+    }
+    const uint32_t *blk = upper + ((size_t)upper_off[node] + (size_t)(level - 1)) * (M + 1);
+    *cnt = blk[0];
+    return blk + 1;
+}
+
+size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                       const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                       uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
+                       double *out_scores, uint64_t *dist_evals) {
+    if (n == 0 || k == 0 || entry == 0xFFFFFFFFu) return 0;
+    if (ef < k) ef = k;
+    const char *base = rows;
+    uint64_t evals = 0;
+#define DIST(node) (evals++, (float)vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query))
+    uint32_t cur = entry;
+    float curd = DIST(cur);
+    for (int level = max_level; level > 0; level--) {
+        int changed = 1;
+        while (changed) {
+            changed = 0;
+            uint32_t cnt;
+            const uint32_t *lk = links_at(cur, level, links0, cnt0, M0, upper_off, upper, M, &cnt);
+            for (uint32_t i = 0; i < cnt; i++) {   /* walks the ORIGINAL node's list to its end */
+                float d = DIST(lk[i]);
+                if (d < curd) { curd = d; cur = lk[i]; changed = 1; }
+            }
+        }
+    }
+    uint8_t *visited = calloc(n, 1);
+    cand_t *cand = malloc(((size_t)n + 1) * sizeof(cand_t));
+    top_t *top = malloc((ef + 2) * sizeof(top_t));
+    size_t nc = 0, nt = 0;
+    float lower;
+    if (!deleted[cur]) {
+        float d = DIST(cur);   /* the reference re-evaluates dist(ep) here */
+        lower = d;
+        top[nt].d = d; top[nt].label = labels[cur]; nt++;
+        cand[nc].d = d; cand[nc].id = cur; nc++;
+    } else {
+        lower = 3.402823466e+38f;
+        cand[nc].d = lower; cand[nc].id = cur; nc++;
+    }
+    visited[cur] = 1;
+    while (nc) {
+        /* candidate_set.top(): max of (-d, id) == min d, ties -> larger id */
+        size_t bi = 0;
+        for (size_t i = 1; i < nc; i++)
+            if (cand[i].d < cand[bi].d || (cand[i].d == cand[bi].d && cand[i].id > cand[bi].id)) bi = i;
+        cand_t c = cand[bi];
+        if (c.d > lower && nt >= ef) break;
+        cand[bi] = cand[--nc];
+        uint32_t cnt;
+        const uint32_t *lk = links_at(c.id, 0, links0, cnt0, M0, upper_off, upper, M, &cnt);
+        for (uint32_t j = 0; j < cnt; j++) {
+            uint32_t nb = lk[j];
+            if (visited[nb]) continue;
+            visited[nb] = 1;
+            float d = DIST(nb);
+            if (lower > d || nt < ef) {
+                cand[nc].d = d; cand[nc].id = nb; nc++;
+                if (!deleted[nb]) { top[nt].d = d; top[nt].label = labels[nb]; nt++; }
+                if (nt > ef) {   /* pop the max (d, label) */
+                    size_t mi = 0;
+                    for (size_t i = 1; i < nt; i++)
+                        if (top[i].d > top[mi].d || (top[i].d == top[mi].d && top[i].label > top[mi].label)) mi = i;
+                    top[mi] = top[--nt];
+                }
+                if (nt) {
+                    float mx = top[0].d;
+                    for (size_t i = 1; i < nt; i++) if (top[i].d > mx) mx = top[i].d;
+                    lower = mx;
+                }
+            }
+        }
+    }
+#undef DIST
+    /* pop down to k, then ascending (d, label) */
+    while (nt > k) {
+        size_t mi = 0;
+        for (size_t i = 1; i < nt; i++)
+            if (top[i].d > top[mi].d || (top[i].d == top[mi].d && top[i].label > top[mi].label)) mi = i;
+        top[mi] = top[--nt];
+    }
+    for (size_t i = 0; i < nt; i++)
+        for (size_t j = i + 1; j < nt; j++)
+            if (top[j].d < top[i].d || (top[j].d == top[i].d && top[j].label < top[i].label)) { top_t t = top[i]; top[i] = top[j]; top[j] = t; }
+    for (size_t i = 0; i < nt; i++) { out_labels[i] = top[i].label; out_scores[i] = top[i].d; }
+    if (dist_evals) *dist_evals = evals;
+    free(visited); free(cand); free(top);
+    return nt;
+}

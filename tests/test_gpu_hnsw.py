@@ -1,0 +1,120 @@
+"""GPU: HNSW query loops.  (1) the GPU search equals the CPU restatement of the reference's search loops
+(oracle/vso_hnsw.c) on the SAME graph -- labels, order, scores and even the number of distance
+evaluations, bit for bit; (2) recall@10 against the exact Flat answer, as the reference's own flow tests
+measure it (tests/flow/test_hnsw.py:114-117: recall > 0.9)."""
+import numpy as np
+import pytest
+
+from vectorsimilarity_amd import VecSim
+
+pytestmark = pytest.mark.gpu
+
+
+def build(dim, n, metric, M=16, efc=100, ef=50, seed=3, rows=None, labels=None):
+    rng = np.random.default_rng(seed)
+    if rows is None:
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, dim, metric, M, efc, ef
+    ix = VecSim.HNSWIndex(p)
+    labels = np.arange(n) if labels is None else labels
+    ix.add_vectors(rows, labels)
+    return ix, rows
+
+
+def stored(vso, rows, metric):
+    if metric != VecSim.VecSimMetric_Cosine:
+        return rows
+    out = rows.copy()
+    for i in range(len(out)):
+        vso.normalize(out[i], out.shape[1], 0)
+    return out
+
+
+@pytest.mark.parametrize("metric,dim,n,M,ef,k", [
+    (VecSim.VecSimMetric_L2, 32, 3000, 16, 50, 10),
+    (VecSim.VecSimMetric_L2, 128, 5000, 16, 128, 10),
+    (VecSim.VecSimMetric_IP, 64, 3000, 8, 40, 5),
+    (VecSim.VecSimMetric_Cosine, 100, 3000, 12, 64, 20),
+    (VecSim.VecSimMetric_L2, 20, 2000, 4, 10, 10),
+])
+def test_gpu_search_equals_reference_loops_on_same_graph(vso, metric, dim, n, M, ef, k):
+    ix, rows = build(dim, n, metric, M=M, efc=80, ef=ef)
+    g = ix.graph()
+    assert g["n"] == n and g["max_level"] >= 1 and g["cnt0"].max() <= 2 * M
+    rng = np.random.default_rng(99)
+    q = rng.uniform(-1, 1, (40, dim)).astype(np.float32)
+    labels, dists = ix.knn_query(q, k)
+    evals = ix.last_distance_evals()
+    srows = stored(vso, rows, metric)
+    sq = stored(vso, q, metric)
+    km = 0 if metric == VecSim.VecSimMetric_L2 else 1
+    total = 0
+    for j in range(len(q)):
+        el, es, ev = vso.hnsw_search(0, km, srows, g, sq[j], k, ef, dim)
+        total += ev
+        assert np.array_equal(labels[j][:len(el)], el.astype(np.int64)), (j, labels[j], el)
+        assert np.array_equal(dists[j][:len(es)], es), j
+        assert np.all(labels[j][len(el):] == -1)
+    # the oracle re-evaluates dist(entry point) once per query at level 0 (hnsw.h:1997); the GPU reuses it
+    assert evals == total - len(q)
+
+
+def test_recall_against_flat(vso):
+    dim, n, k = 64, 20000, 10
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=16, efc=200, ef=128)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1, 1, (200, dim)).astype(np.float32)
+    labels, _ = ix.knn_query(q, k)
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2
+    bf = VecSim.BFIndex(p)
+    bf.add_vectors(rows, np.arange(n))
+    exact, _ = bf.knn_query(q, k)
+    hits = sum(len(set(labels[i]) & set(exact[i])) for i in range(len(q)))
+    recall = hits / (len(q) * k)
+    assert recall > 0.9, recall
+    # a larger ef at query time may only help
+    ix.set_ef(400)
+    l2, _ = ix.knn_query(q, k)
+    assert sum(len(set(l2[i]) & set(exact[i])) for i in range(len(q))) >= hits
+
+
+def test_deleted_and_overwritten_vectors_are_traversed_not_returned(vso):
+    dim, n, k = 24, 2500, 10
+    rng = np.random.default_rng(8)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix, _ = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=60, ef=40, rows=rows, labels=np.arange(n) + 5)
+    gone = set(int(x) + 5 for x in rng.choice(n, 300, replace=False))
+    for lab in gone:
+        assert ix.delete_vector(lab) == 1
+    assert ix.delete_vector(10 ** 9) == 0
+    assert ix.index_size() == n - 300
+    q = rng.uniform(-1, 1, (30, dim)).astype(np.float32)
+    labels, dists = ix.knn_query(q, k)
+    assert not (set(labels.ravel().tolist()) & gone)
+    g = ix.graph()
+    for j in range(len(q)):
+        el, es, _ = vso.hnsw_search(0, 0, rows, g, q[j], k, 40, dim)
+        assert np.array_equal(labels[j][:len(el)], el.astype(np.int64)) and np.array_equal(dists[j][:len(es)], es)
+    # overwrite: the old vector is retired, the new one is reachable under the same label
+    v = rng.uniform(-1, 1, dim).astype(np.float32)
+    keep = next(l for l in range(5, n + 5) if l not in gone)
+    assert ix.add_vector(v, keep) == 0
+    l, d = ix.knn_query(v, 1)
+    assert l[0, 0] == keep and d[0, 0] == 0.0
+
+
+def test_hnsw_edge_cases():
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M = VecSim.VecSimType_FLOAT32, 8, VecSim.VecSimMetric_L2, 4
+    ix = VecSim.HNSWIndex(p)
+    l, d = ix.knn_query(np.zeros(8, dtype=np.float32), 3)
+    assert np.all(l == -1)
+    ix.add_vector(np.ones(8, dtype=np.float32), 7)
+    l, d = ix.knn_query(np.zeros((2, 8), dtype=np.float32), 3)
+    assert list(l[0]) == [7, -1, -1] and d[0, 0] == 8.0
+    qp = VecSim.VecSimQueryParams()
+    qp.hnswRuntimeParams.efRuntime = 50
+    l, d = ix.knn_query(np.zeros(8, dtype=np.float32), 1, qp)
+    assert l[0, 0] == 7

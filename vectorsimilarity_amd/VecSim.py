@@ -226,6 +226,47 @@ class BFIndex(VecSimIndex):
         super().__init__(p)
 
 
+class HNSWIndex(VecSimIndex):
+    """HNSW index (reference: PyHNSWLibIndex, bindings.cpp:243-420): graph built on the host, queries on the GPU"""
+
+    def __init__(self, params):
+        p = VecSimParams()
+        p.algo = VecSimAlgo_HNSWLIB
+        p.algoParams.hnswParams = params
+        super().__init__(p)
+
+    def set_ef(self, ef):
+        self._ef = int(ef)
+
+    def knn_query(self, vector, k, query_param=None, order=BY_SCORE):
+        if query_param is None and getattr(self, "_ef", 0):
+            query_param = VecSimQueryParams()
+            query_param.hnswRuntimeParams.efRuntime = self._ef
+        return super().knn_query(vector, k, query_param, order)
+
+    def knn_parallel(self, queries, k, query_param=None, num_threads=-1):
+        """reference signature (bindings.cpp:330-345); here the whole batch is one GPU launch"""
+        return self.knn_query(queries, k, query_param)
+
+    def graph(self):
+        """dict of numpy arrays describing the built graph (tests / tooling)"""
+        info = (C.c_uint64 * 6)()
+        if self._lib.VecSimGpu_HnswGraphInfo(self._h, info) != 0:
+            raise RuntimeError("not an HNSW index")
+        n, M, M0, entry, max_level, uw = [int(x) for x in info]
+        g = {"n": n, "M": M, "M0": M0, "entry": entry, "max_level": -1 if max_level == 0xFFFFFFFF else max_level,
+             "links0": np.zeros((n, M0), dtype=np.uint32), "cnt0": np.zeros(n, dtype=np.uint16),
+             "upper_off": np.zeros(n, dtype=np.uint32), "upper": np.zeros(max(uw, 1), dtype=np.uint32),
+             "deleted": np.zeros(n, dtype=np.uint8), "labels": np.zeros(n, dtype=np.uint64)}
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._lib.VecSimGpu_HnswGraphCopy(self._h, p(g["links0"]), p(g["cnt0"]), p(g["upper_off"]), p(g["upper"]),
+                                          p(g["deleted"]), p(g["labels"]))
+        return g
+
+    def last_distance_evals(self):
+        return int(self._lib.VecSimGpu_HnswLastDistanceEvals(self._h))
+
+
 def normalize(vector, vtype):
     """VecSim_Normalize on a copy; int8/uint8 return dim+4 bytes (norm appended)"""
     lib = _capi.load()

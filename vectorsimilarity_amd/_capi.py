@@ -60,8 +60,12 @@ class VecSimParams(C.Structure):
     _fields_ = [("algo", C.c_int), ("algoParams", AlgoParams), ("logCtx", C.c_void_p)]
 
 
+class HNSWRuntimeParams(C.Structure):
+    _fields_ = [("efRuntime", C.c_size_t), ("epsilon", C.c_double)]
+
+
 class _RuntimeUnion(C.Union):
-    _fields_ = [("hnsw", C.c_size_t * 2), ("hnswDisk", C.c_size_t * 3), ("svs", C.c_size_t * 4)]
+    _fields_ = [("hnswRuntimeParams", HNSWRuntimeParams), ("hnswDisk", C.c_size_t * 3), ("svs", C.c_size_t * 4)]
 
 
 class VecSimQueryParams(C.Structure):
@@ -111,6 +115,7 @@ EXPORTS = [
     "VecSimBatchIterator_HasNext", "VecSimBatchIterator_Free", "VecSimBatchIterator_Reset",
     "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
+    "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
 ]
@@ -119,6 +124,7 @@ GPU_EXPORTS = [
     "vsgpu_ctx_device", "vsgpu_ctx_sync", "vsgpu_table_create", "vsgpu_table_destroy",
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
     "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_append_synthetic",
+    "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search",
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
 ]
@@ -212,6 +218,12 @@ def load():
     L.VecSimIndex_AddVectorsBulk.argtypes = [vp, vp, vp, sz]
     L.VecSimIndex_AddSyntheticVectors.restype = C.c_long
     L.VecSimIndex_AddSyntheticVectors.argtypes = [vp, sz, C.c_uint64]
+    L.VecSimGpu_HnswGraphInfo.restype = i
+    L.VecSimGpu_HnswGraphInfo.argtypes = [vp, vp]
+    L.VecSimGpu_HnswGraphCopy.restype = i
+    L.VecSimGpu_HnswGraphCopy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.VecSimGpu_HnswLastDistanceEvals.restype = C.c_uint64
+    L.VecSimGpu_HnswLastDistanceEvals.argtypes = [vp]
     L.VecSimGpu_SetDevice.restype = i
     L.VecSimGpu_SetDevice.argtypes = [i]
     L.VecSimGpu_DeviceCount.restype = i

@@ -1,0 +1,296 @@
+// hnsw_kernels.hpp -- HNSW query loops on the GPU.
+//
+// Restates, one wavefront per query, the reference's search:
+//   searchBottomLayerEP + greedySearchLevel   algorithms/hnsw/hnsw.h:1967-1981, 1210-1258
+//   searchBottomLayer_WithTimeout             hnsw.h:1983-2035
+//   processCandidate                          hnsw.h:530-613
+// with the SAME sequential admission rules, so on the same graph the GPU returns exactly what the
+// reference's loop returns (tests compare against oracle/vso_hnsw.c, ids and scores bit for bit):
+//   * candidate_set  = max-heap on (-dist, id): next = smallest dist, ties -> larger id;
+//   * top_candidates = max-heap on (dist, label) capped at ef: evict the largest (dist, label);
+//   * a neighbour is admitted iff lowerBound > d or |top| < ef; deleted nodes are traversed, not returned;
+//   * stop when the best candidate is farther than lowerBound and |top| >= ef.
+// Every distance is the reference-order exact distance (lane programs of exact_kernels.hpp): a group of
+// VL lanes walks one neighbour's row, so a wave scores 64/VL unvisited neighbours at a time with all of
+// a row's loads in flight together; the ~3 KB random row gathers are what the kernel waits for, and
+// throughput comes from thousands of resident waves (one query each), not from one fast query.
+// Both heaps are small sorted arrays in LDS updated wave-parallel (ballot-rank + shift).
+// Visited marks are epoch tags in a per-wave slot of a global u16 array (visited_nodes_handler.h:23-57):
+// no clearing between queries, no per-node locks (the device graph is a read-only snapshot).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "exact_kernels.hpp"
+
+namespace vsg {
+
+struct HnswParams {
+    // rows
+    const char *const *slabs;
+    uint32_t slab_shift, slab_mask, row_stride;
+    // lane program + queries
+    const int32_t *offs;
+    int steps;
+    const void *qperm;  // [nq][steps][VL] accumulator-typed
+    int nq;
+    int epilogue;
+    // graph snapshot
+    const uint32_t *links0;     // [n][M0]
+    const uint16_t *cnt0;       // [n]
+    const uint32_t *upper_off;  // [n] index of the node's first upper block, 0xFFFFFFFF if level 0 only
+    const uint32_t *upper;      // blocks of (1 + M) words: count, links
+    const uint8_t *deleted;     // [n]
+    const uint64_t *labels;     // [n]
+    uint32_t M0, M;
+    uint32_t entry;
+    int max_level;
+    uint32_t n;
+    // visited tags
+    uint16_t *tags;        // [slots][n]
+    uint32_t *slot_epoch;  // [slots] last epoch used by the slot
+    // search
+    uint32_t ef, k, ccap;  // ccap = capacity of the candidate array (>= 2*ef)
+    uint64_t *out_labels;  // [nq][k]
+    float *out_scores;     // [nq][k]
+    uint32_t *out_counts;  // [nq]
+    uint64_t *stat_dists;  // optional: total distance evaluations (atomicAdd), may be null
+};
+
+// ---- wave-parallel sorted arrays in LDS (all 64 lanes call with uniform arguments) ----
+// top: ascending by (dist, label); cand: ascending by (dist, then id DESCENDING) so that the front is
+// the reference's candidate_set.top().
+__device__ __forceinline__ bool top_less(float d1, uint64_t l1, float d2, uint64_t l2) {
+    return d1 < d2 || (d1 == d2 && l1 < l2);
+}
+__device__ __forceinline__ bool cand_less(float d1, uint32_t i1, float d2, uint32_t i2) {
+    return d1 < d2 || (d1 == d2 && i1 > i2);
+}
+
+__device__ __forceinline__ uint32_t top_insert(float *D, uint64_t *L, uint32_t n, float d, uint64_t lab, int lane) {
+    uint32_t pos = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool lt = (i < n) && top_less(D[i], L[i], d, lab);
+        pos += (uint32_t)__popcll(__ballot(lt));
+    }
+    // shift [pos, n) right by one, highest chunk first; within a chunk every read precedes every write
+    for (int32_t base = (int32_t)((n - pos + 63) / 64 - 1) * 64; base >= 0; base -= 64) {
+        const uint32_t i = pos + (uint32_t)base + lane;
+        float vd = 0.f;
+        uint64_t vl = 0;
+        const bool act = i < n;
+        if (act) { vd = D[i]; vl = L[i]; }
+        if (act) { D[i + 1] = vd; L[i + 1] = vl; }
+    }
+    if (lane == 0) { D[pos] = d; L[pos] = lab; }
+    return n + 1;
+}
+__device__ __forceinline__ uint32_t cand_insert(float *D, uint32_t *I, uint32_t head, uint32_t tail, float d, uint32_t id,
+                                                int lane) {
+    uint32_t pos = head;
+    for (uint32_t base = head; base < tail; base += 64) {
+        const uint32_t i = base + lane;
+        const bool lt = (i < tail) && cand_less(D[i], I[i], d, id);
+        pos += (uint32_t)__popcll(__ballot(lt));
+    }
+    for (int32_t base = (int32_t)((tail - pos + 63) / 64 - 1) * 64; base >= 0; base -= 64) {
+        const uint32_t i = pos + (uint32_t)base + lane;
+        float vd = 0.f;
+        uint32_t vi = 0;
+        const bool act = i < tail;
+        if (act) { vd = D[i]; vi = I[i]; }
+        if (act) { D[i + 1] = vd; I[i + 1] = vi; }
+    }
+    if (lane == 0) { D[pos] = d; I[pos] = id; }
+    return tail + 1;
+}
+
+template <int EK, int OPK>
+__global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
+    using E = Elem<EK>;
+    using acc_t = typename E::acc_t;
+    constexpr int VL = E::VL;
+    constexpr int NG = 64 / VL;  // neighbour rows scored at a time
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int vl = lane % VL, grp = lane / VL;
+    const int steps = P.steps;
+
+    int32_t *offs_s = reinterpret_cast<int32_t *>(smem);
+    size_t o = ((size_t)steps * VL * 4 + 15) & ~(size_t)15;
+    acc_t *q_s = reinterpret_cast<acc_t *>(smem + o);
+    o += ((size_t)steps * VL * sizeof(acc_t) + 15) & ~(size_t)15;
+    uint64_t *top_l = reinterpret_cast<uint64_t *>(smem + o);
+    o += (size_t)(P.ef + 2) * 8;
+    float *top_d = reinterpret_cast<float *>(smem + o);
+    o += ((size_t)(P.ef + 2) * 4 + 15) & ~(size_t)15;
+    float *cand_d = reinterpret_cast<float *>(smem + o);
+    o += (size_t)(2 * P.ccap + 2) * 4;  // physical array = 2x the live window
+    uint32_t *cand_i = reinterpret_cast<uint32_t *>(smem + o);
+    o += ((size_t)(2 * P.ccap + 2) * 4 + 15) & ~(size_t)15;
+    uint32_t *nb_id = reinterpret_cast<uint32_t *>(smem + o);  // unvisited neighbours of the current node
+    o += 64 * 4;
+    float *nb_d = reinterpret_cast<float *>(smem + o);
+
+    for (int i = lane; i < steps * VL; i += 64) offs_s[i] = P.offs[i];
+
+    const uint32_t slot = blockIdx.x;
+    uint16_t *tags = P.tags + (size_t)slot * P.n;
+    uint32_t epoch = P.slot_epoch[slot];
+    uint64_t n_dists = 0;
+
+    // exact distance of up to NG nodes (ids[g] for group g, valid when g < cnt); result in nb_d[out0 + g]
+    auto score_nodes = [&](const uint32_t *ids, uint32_t first, uint32_t cnt) {
+        const uint32_t idx = first + grp;
+        const bool act = idx < cnt;
+        const uint32_t node = act ? ids[idx] : ids[first];
+        const char *rp = P.slabs[node >> P.slab_shift] + (size_t)(node & P.slab_mask) * P.row_stride;
+        acc_t acc = (acc_t)0;
+#pragma unroll 4
+        for (int s = 0; s < steps; s++) {
+            const int off = offs_s[s * VL + vl];
+            if (off >= 0) acc = acc_step<OPK>(E::load(rp + off), q_s[s * VL + vl], acc);
+        }
+#pragma unroll
+        for (int of = VL / 2; of >= 1; of >>= 1) acc = add_rn(acc, __shfl_down(acc, of, VL));
+        if (vl == 0 && act) nb_d[idx] = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
+    };
+
+    for (int q = blockIdx.x; q < P.nq; q += gridDim.x) {
+        // ---- per-query state ----
+        __syncthreads();
+        {
+            const acc_t *qg = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q * steps * VL;
+            for (int i = lane; i < steps * VL; i += 64) q_s[i] = qg[i];
+        }
+        epoch = epoch + 1;
+        if ((epoch & 0xFFFFu) == 0) {  // u16 tag wrapped: clear this slot's tags once
+            for (uint32_t i = lane; i < P.n; i += 64) tags[i] = 0;
+            epoch = epoch + 1;
+        }
+        const uint16_t tag = (uint16_t)(epoch & 0xFFFFu);
+        __syncthreads();
+
+        // ---- entry point + greedy descent through the upper levels (hnsw.h:1967-1981, 1210-1258) ----
+        uint32_t cur = P.entry;
+        if (lane == 0) nb_id[0] = cur;
+        __syncthreads();
+        score_nodes(nb_id, 0, 1);
+        n_dists += 1;
+        __syncthreads();
+        float curd = nb_d[0];
+        for (int level = P.max_level; level > 0; level--) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t uo = P.upper_off[cur];
+                const uint32_t *blk = P.upper + ((size_t)uo + (uint32_t)(level - 1)) * (P.M + 1);
+                const uint32_t cnt = min(blk[0], P.M);
+                __syncthreads();
+                if ((uint32_t)lane < cnt) nb_id[lane] = blk[1 + lane];
+                __syncthreads();
+                for (uint32_t f = 0; f < cnt; f += NG) score_nodes(nb_id, f, cnt);
+                n_dists += cnt;
+                __syncthreads();
+                // the reference walks the ORIGINAL node's link list to the end while updating the best
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const float d = nb_d[i];
+                    if (d < curd) { curd = d; cur = nb_id[i]; changed = true; }
+                }
+            }
+        }
+
+        // ---- level 0: ef-bounded best-first search (hnsw.h:1983-2035) ----
+        uint32_t top_n = 0, chead = 0, ctail = 0;
+        float lower;
+        if (lane == 0) tags[cur] = tag;
+        if (!P.deleted[cur]) {
+            // (the reference recomputes dist(ep): same value as curd)
+            lower = curd;
+            top_n = top_insert(top_d, top_l, top_n, curd, P.labels[cur], lane);
+            ctail = cand_insert(cand_d, cand_i, chead, ctail, curd, cur, lane);
+        } else {
+            lower = 3.402823466e+38f;
+            ctail = cand_insert(cand_d, cand_i, chead, ctail, lower, cur, lane);
+        }
+        __syncthreads();
+
+        while (chead < ctail) {
+            const float cd = cand_d[chead];
+            const uint32_t cnode = cand_i[chead];
+            if (cd > lower && top_n >= P.ef) break;
+            chead++;
+            // processCandidate(cnode, layer 0)
+            const uint32_t cnt = min((uint32_t)P.cnt0[cnode], P.M0);
+            uint32_t nid = 0;
+            bool fresh = false;
+            if ((uint32_t)lane < cnt) {
+                nid = P.links0[(size_t)cnode * P.M0 + lane];
+                fresh = tags[nid] != tag;
+                if (fresh) tags[nid] = tag;
+            }
+            const unsigned long long fm = __ballot(fresh);
+            const uint32_t nfresh = (uint32_t)__popcll(fm);
+            __syncthreads();
+            if (fresh) nb_id[__popcll(fm & ((1ull << lane) - 1ull))] = nid;  // keeps link order
+            __syncthreads();
+            for (uint32_t f = 0; f < nfresh; f += NG) score_nodes(nb_id, f, nfresh);
+            n_dists += nfresh;
+            __syncthreads();
+            for (uint32_t i = 0; i < nfresh; i++) {
+                const float d = nb_d[i];
+                const uint32_t id = nb_id[i];
+                if (lower > d || top_n < P.ef) {
+                    // candidate_set.emplace(-d, id).  The live window [chead, ctail) holds at most ccap
+                    // entries; when full its worst entry is dropped (or the newcomer, if it is the
+                    // worst): with more than 2*ef better visited nodes around, lowerBound is already
+                    // below that distance, so the reference would never expand it either.
+                    bool keep = true;
+                    if (ctail - chead >= P.ccap) {
+                        if (cand_less(d, id, cand_d[ctail - 1], cand_i[ctail - 1])) ctail--;
+                        else keep = false;
+                    }
+                    if (keep) {
+                        if (ctail >= 2 * P.ccap) {  // physical end reached: slide the live window to the front
+                            const uint32_t live = ctail - chead;
+                            for (uint32_t b = 0; b < live; b += 64) {
+                                const uint32_t j = b + lane;
+                                float vd = 0.f;
+                                uint32_t vi = 0;
+                                if (j < live) { vd = cand_d[chead + j]; vi = cand_i[chead + j]; }
+                                __syncthreads();
+                                if (j < live) { cand_d[j] = vd; cand_i[j] = vi; }
+                                __syncthreads();
+                            }
+                            chead = 0;
+                            ctail = live;
+                        }
+                        ctail = cand_insert(cand_d, cand_i, chead, ctail, d, id, lane);
+                    }
+                    if (!P.deleted[id]) top_n = top_insert(top_d, top_l, top_n, d, P.labels[id], lane);
+                    if (top_n > P.ef) top_n--;  // pop the largest (dist, label)
+                    __syncthreads();
+                    if (top_n > 0) lower = top_d[top_n - 1];
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- results: the k smallest, ascending (dist, label) ----
+        const uint32_t nres = min(top_n, P.k);
+        for (uint32_t i = lane; i < P.k; i += 64) {
+            if (i < nres) {
+                P.out_labels[(size_t)q * P.k + i] = top_l[i];
+                P.out_scores[(size_t)q * P.k + i] = top_d[i];
+            }
+        }
+        if (lane == 0) P.out_counts[q] = nres;
+    }
+    if (lane == 0) {
+        P.slot_epoch[slot] = epoch;
+        if (P.stat_dists) atomicAdd((unsigned long long *)P.stat_dists, (unsigned long long)n_dists);
+    }
+}
+
+}  // namespace vsg

@@ -17,6 +17,7 @@
 
 #include "blob_prep.h"
 #include "flat_index.h"
+#include "hnsw_index.h"
 
 using vsa::FlatIndex;
 
@@ -24,8 +25,13 @@ using vsa::FlatIndex;
 extern "C" VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
     if (!params) return nullptr;
     // index_factory.cpp:17-46 swallows construction failures and returns NULL; so do we
+    if (params->algo == VecSimAlgo_HNSWLIB) {
+        vsa::HnswIndex *hx = vsa::HnswIndex::create(params->algoParams.hnswParams, params->logCtx);
+        if (!hx) std::fprintf(stderr, "vecsim_amd: cannot create HNSW index: %s\n", vsgpu_last_error());
+        return hx;
+    }
     if (params->algo != VecSimAlgo_BF) {
-        std::fprintf(stderr, "vecsim_amd: only Flat (VecSimAlgo_BF) indexes are built by this back end\n");
+        std::fprintf(stderr, "vecsim_amd: only Flat and HNSW indexes are built by this back end\n");
         return nullptr;
     }
     const BFParams &bf = params->algoParams.bfParams;
@@ -203,14 +209,25 @@ extern "C" VecSimResolveCode VecSimIndex_ResolveParams(VecSimIndex *index, VecSi
             if (!strcasecmp(p.value, VECSIM_POLICY_BATCHES)) qparams->searchMode = HYBRID_BATCHES;
             else if (!strcasecmp(p.value, VECSIM_POLICY_ADHOC_BF)) qparams->searchMode = HYBRID_ADHOC_BF;
             else return VecSimParamResolverErr_InvalidPolicy_NExits;
+        } else if (!strcasecmp(p.name, "EF_RUNTIME")) {
+            // vec_sim.cpp:47-66: HNSW only, not for range queries
+            if (index->basicInfo().algo != VecSimAlgo_HNSWLIB || query_type == QUERY_TYPE_RANGE)
+                return VecSimParamResolverErr_UnknownParam;
+            if (qparams->hnswRuntimeParams.efRuntime != 0) return VecSimParamResolverErr_AlreadySet;
+            long long v;
+            if (!positive_integer(p, &v)) return VecSimParamResolverErr_BadValue;
+            qparams->hnswRuntimeParams.efRuntime = (size_t)v;
         } else {
-            // EF_RUNTIME / EPSILON / RERANK / SVS knobs exist only for graph indexes (vec_sim.cpp:47-165);
-            // on a Flat index they, like any unknown name, are rejected
+            // EPSILON / RERANK / SVS knobs belong to paths this build does not have (vec_sim.cpp:67-165);
+            // like any unknown name they are rejected
             return VecSimParamResolverErr_UnknownParam;
         }
     }
     if (qparams->searchMode == HYBRID_ADHOC_BF && qparams->batchSize > 0)
         return VecSimParamResolverErr_InvalidPolicy_AdHoc_With_BatchSize;
+    if (qparams->searchMode == HYBRID_ADHOC_BF && index->basicInfo().algo == VecSimAlgo_HNSWLIB &&
+        qparams->hnswRuntimeParams.efRuntime > 0)
+        return VecSimParamResolverErr_InvalidPolicy_AdHoc_With_EfRuntime;
     if (qparams->searchMode != 0) index->setLastMode(qparams->searchMode);
     return VecSimParamResolver_OK;
 }
@@ -260,6 +277,33 @@ extern "C" void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out) {
 }
 extern "C" int VecSimGpu_SetOption(VecSimIndex *index, const char *name, long value) {
     return vsgpu_set_option(index->gpu(), name, value);
+}
+
+extern "C" int VecSimGpu_HnswGraphInfo(VecSimIndex *index, uint64_t info[6]) {
+    auto *h = dynamic_cast<vsa::HnswIndex *>(index);
+    if (!h) return -1;
+    auto e = h->exportGraph();
+    info[0] = e.n; info[1] = e.M; info[2] = e.M0; info[3] = e.entry;
+    info[4] = e.max_level < 0 ? 0xFFFFFFFFull : (uint64_t)e.max_level;
+    info[5] = e.upper_words;
+    return 0;
+}
+extern "C" int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0, uint32_t *upper_off,
+                                       uint32_t *upper, uint8_t *deleted, uint64_t *labels) {
+    auto *h = dynamic_cast<vsa::HnswIndex *>(index);
+    if (!h) return -1;
+    auto e = h->exportGraph();
+    std::memcpy(links0, e.links0, (size_t)e.n * e.M0 * 4);
+    std::memcpy(cnt0, e.cnt0, (size_t)e.n * 2);
+    std::memcpy(upper_off, e.upper_off, (size_t)e.n * 4);
+    if (e.upper_words) std::memcpy(upper, e.upper, e.upper_words * 4);
+    std::memcpy(deleted, e.deleted, e.n);
+    std::memcpy(labels, e.labels, (size_t)e.n * 8);
+    return 0;
+}
+extern "C" uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index) {
+    auto *h = dynamic_cast<vsa::HnswIndex *>(index);
+    return h ? h->lastDistanceEvals() : 0;
 }
 
 // ------------------------------------------------------------------ replies

@@ -1,0 +1,466 @@
+// hnsw_index.cpp -- see hnsw_index.h
+#include "hnsw_index.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+#include "blob_prep.h"
+
+namespace vsa {
+
+static constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
+    if (p.dim == 0 || p.metric > VecSimMetric_Cosine) return nullptr;
+    if (p.type != VecSimType_FLOAT32 || p.multi) {
+        std::fprintf(stderr, "vecsim_amd: HNSW indexes are built for FLOAT32 single-value data in this round\n");
+        return nullptr;
+    }
+    const size_t M = p.M ? p.M : HNSW_DEFAULT_M;
+    if (M <= 1 || M > 32) {
+        std::fprintf(stderr, "vecsim_amd: HNSW M must be in [2, 32]\n");
+        return nullptr;
+    }
+    int dev = globals().device;
+    if (dev < 0) {
+        const char *e = std::getenv("VECSIM_GPU_DEVICE");
+        dev = e ? std::atoi(e) : 0;
+    }
+    vsgpu_ctx *ctx = vsgpu_ctx_create(dev);
+    if (!ctx) return nullptr;
+    HnswIndex *ix = new HnswIndex();
+    ix->type_ = p.type;
+    ix->metric_ = p.metric;
+    ix->dim_ = p.dim;
+    ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
+    ix->M_ = M;
+    ix->M0_ = 2 * M;
+    ix->ef_c_ = std::max<size_t>(p.efConstruction ? p.efConstruction : HNSW_DEFAULT_EF_C, M);  // hnsw.h:1633-1634
+    ix->ef_ = p.efRuntime ? p.efRuntime : HNSW_DEFAULT_EF_RT;
+    ix->epsilon_ = p.epsilon > 0.0 ? p.epsilon : HNSW_DEFAULT_EPSILON;
+    ix->mult_ = 1.0 / std::log(1.0 * (double)M);                                               // hnsw.h:1646
+    ix->log_ctx_ = logCtx;
+    ix->ctx_ = ctx;
+    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, VSGPU_TIER_AVX512, p.dim, p.dim * 4);
+    ix->graph_ = ix->table_ ? vsgpu_graph_create(ix->table_, M) : nullptr;
+    if (!ix->table_ || !ix->graph_) {
+        delete ix;
+        return nullptr;
+    }
+    return ix;
+}
+
+HnswIndex::~HnswIndex() {
+    if (graph_) vsgpu_graph_destroy(graph_);
+    if (table_) vsgpu_table_destroy(table_);
+    if (ctx_) vsgpu_ctx_destroy(ctx_);
+}
+
+// ---- construction-time distance (ingest only; queries never come here) ----
+__attribute__((target_clones("avx512f", "avx2", "default"))) static float l2_build(const float *a, const float *b, size_t d) {
+    float acc[16] = {0};
+    size_t i = 0;
+    for (; i + 16 <= d; i += 16)
+        for (int j = 0; j < 16; j++) {
+            float t = a[i + j] - b[i + j];
+            acc[j] += t * t;
+        }
+    float s = 0;
+    for (; i < d; i++) {
+        float t = a[i] - b[i];
+        s += t * t;
+    }
+    for (int j = 0; j < 16; j++) s += acc[j];
+    return s;
+}
+__attribute__((target_clones("avx512f", "avx2", "default"))) static float ip_build(const float *a, const float *b, size_t d) {
+    float acc[16] = {0};
+    size_t i = 0;
+    for (; i + 16 <= d; i += 16)
+        for (int j = 0; j < 16; j++) acc[j] += a[i + j] * b[i + j];
+    float s = 0;
+    for (; i < d; i++) s += a[i] * b[i];
+    for (int j = 0; j < 16; j++) s += acc[j];
+    return 1.0f - s;
+}
+float HnswIndex::buildDistance(const float *a, const float *b) const {
+    return metric_ == VecSimMetric_L2 ? l2_build(a, b, dim_) : ip_build(a, b, dim_);
+}
+
+uint32_t *HnswIndex::linksAt(uint32_t id, int level, uint32_t **count_word) {
+    // level >= 1: block {count, links[M]}
+    uint32_t *blk = upper_.data() + ((size_t)upper_off_[id] + (size_t)(level - 1)) * (M_ + 1);
+    *count_word = blk;
+    return blk + 1;
+}
+
+std::vector<char> HnswIndex::preprocess(const void *blob) const {
+    std::vector<char> v(dim_ * 4);
+    std::memcpy(v.data(), blob, dim_ * 4);
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(v.data(), dim_, type_);
+    return v;
+}
+
+// ef-bounded best-first search of one layer during construction (hnswlib's searchBaseLayer shape)
+void HnswIndex::searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
+                            std::vector<std::pair<float, uint32_t>> &out) {
+    using Item = std::pair<float, uint32_t>;
+    std::priority_queue<Item> top;                                         // max-heap: worst on top
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> cand;  // min-heap
+    if (++visit_epoch_ == 0) {
+        std::fill(visit_tag_.begin(), visit_tag_.end(), 0u);
+        visit_epoch_ = 1;
+    }
+    const uint32_t ep_tag = visit_epoch_;
+    float lower;
+    if (!deleted_[ep]) {
+        top.emplace(ep_dist, ep);
+        lower = ep_dist;
+    } else {
+        lower = std::numeric_limits<float>::max();
+    }
+    cand.emplace(ep_dist, ep);
+    visit_tag_[ep] = ep_tag;
+    while (!cand.empty()) {
+        Item c = cand.top();
+        if (c.first > lower && top.size() >= ef) break;
+        cand.pop();
+        const uint32_t *links;
+        uint32_t cnt;
+        if (level == 0) {
+            links = links0_.data() + (size_t)c.second * M0_;
+            cnt = cnt0_[c.second];
+        } else {
+            uint32_t *cw;
+            links = linksAt(c.second, level, &cw);
+            cnt = *cw;
+        }
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t nb = links[i];
+            if (visit_tag_[nb] == ep_tag) continue;
+            visit_tag_[nb] = ep_tag;
+            const float d = buildDistance(vec(nb), q);
+            if (lower > d || top.size() < ef) {
+                cand.emplace(d, nb);
+                if (!deleted_[nb]) top.emplace(d, nb);
+                if (top.size() > ef) top.pop();
+                if (!top.empty()) lower = top.top().first;
+            }
+        }
+    }
+    out.clear();
+    out.reserve(top.size());
+    while (!top.empty()) {
+        out.push_back(top.top());
+        top.pop();
+    }
+}
+
+// diversity heuristic (hnsw.h:743-797): walk candidates by increasing distance, keep one only if no
+// already-kept neighbour is closer to it than the query is
+void HnswIndex::selectNeighbors(std::vector<std::pair<float, uint32_t>> &cands, size_t M) {
+    if (cands.size() < M) return;
+    std::sort(cands.begin(), cands.end(),
+              [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) { return a.first < b.first; });
+    std::vector<std::pair<float, uint32_t>> kept;
+    kept.reserve(M);
+    for (const auto &c : cands) {
+        if (kept.size() >= M) break;
+        bool good = true;
+        for (const auto &s : kept) {
+            if (buildDistance(vec(s.second), vec(c.second)) < c.first) {
+                good = false;
+                break;
+            }
+        }
+        if (good) kept.push_back(c);
+    }
+    cands.swap(kept);
+}
+
+void HnswIndex::connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected) {
+    const size_t max_links = level == 0 ? M0_ : M_;
+    // the new node's own list
+    uint32_t *mine;
+    uint32_t dummy = 0, *mine_cnt = &dummy;
+    if (level == 0) mine = links0_.data() + (size_t)id * M0_;
+    else mine = linksAt(id, level, &mine_cnt);
+    uint32_t c = 0;
+    for (const auto &s : selected) mine[c++] = s.second;
+    if (level == 0) cnt0_[id] = (uint16_t)c;
+    else *mine_cnt = c;
+    // back links, re-selected when a neighbour's list is full
+    for (const auto &s : selected) {
+        const uint32_t nb = s.second;
+        uint32_t *nl;
+        uint32_t ncnt;
+        uint32_t *ncw = nullptr;
+        if (level == 0) {
+            nl = links0_.data() + (size_t)nb * M0_;
+            ncnt = cnt0_[nb];
+        } else {
+            nl = linksAt(nb, level, &ncw);
+            ncnt = *ncw;
+        }
+        if (ncnt < max_links) {
+            nl[ncnt++] = id;
+        } else {
+            std::vector<std::pair<float, uint32_t>> cand;
+            cand.reserve(ncnt + 1);
+            cand.emplace_back(s.first, id);
+            for (uint32_t i = 0; i < ncnt; i++) cand.emplace_back(buildDistance(vec(nl[i]), vec(nb)), nl[i]);
+            selectNeighbors(cand, max_links);
+            ncnt = 0;
+            for (const auto &k : cand) nl[ncnt++] = k.second;
+        }
+        if (level == 0) cnt0_[nb] = (uint16_t)ncnt;
+        else *ncw = ncnt;
+    }
+}
+
+void HnswIndex::insertNode(uint32_t id, const float *v) {
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    const int level = (int)(size_t)(-std::log(uni(level_gen_)) * mult_);  // hnsw.h:418-422
+    level_[id] = (uint8_t)std::min(level, 255);
+    if (level > 0) {
+        upper_off_[id] = (uint32_t)(upper_.size() / (M_ + 1));
+        upper_.resize(upper_.size() + (size_t)level * (M_ + 1), 0u);
+    }
+    if (entry_ == NONE) {
+        entry_ = id;
+        max_level_ = level;
+        return;
+    }
+    uint32_t cur = entry_;
+    float curd = buildDistance(vec(cur), v);
+    for (int l = max_level_; l > level; l--) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            uint32_t *cw;
+            const uint32_t *links = linksAt(cur, l, &cw);
+            const uint32_t cnt = *cw;
+            const uint32_t from = cur;
+            (void)from;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float d = buildDistance(vec(links[i]), v);
+                if (d < curd) {
+                    curd = d;
+                    cur = links[i];
+                    changed = true;
+                }
+            }
+        }
+    }
+    std::vector<std::pair<float, uint32_t>> W;
+    for (int l = std::min(level, max_level_); l >= 0; l--) {
+        searchLayer(v, cur, curd, l, ef_c_, W);
+        if (W.empty()) continue;  // everything reachable is deleted
+        // next layer starts from the closest found
+        auto best = std::min_element(W.begin(), W.end());
+        cur = best->second;
+        curd = best->first;
+        std::vector<std::pair<float, uint32_t>> sel = W;
+        selectNeighbors(sel, M_);
+        if (sel.size() > M_) sel.resize(M_);
+        connect(id, l, sel);
+    }
+    if (level > max_level_) {
+        entry_ = id;
+        max_level_ = level;
+    }
+}
+
+int HnswIndex::addVector(const void *blob, size_t label) {
+    int is_new = 1;
+    auto it = label_to_id_.find(label);
+    if (it != label_to_id_.end()) {  // overwrite = mark the old vector deleted + insert (hnsw_single.h)
+        deleted_[it->second] = 1;
+        n_deleted_++;
+        label_to_id_.erase(it);
+        is_new = 0;
+    }
+    std::vector<char> pv = preprocess(blob);
+    const uint32_t id = (uint32_t)n_++;
+    host_vecs_.insert(host_vecs_.end(), (const float *)pv.data(), (const float *)pv.data() + dim_);
+    links0_.resize(n_ * M0_, 0u);
+    cnt0_.push_back(0);
+    level_.push_back(0);
+    upper_off_.push_back(NONE);
+    deleted_.push_back(0);
+    labels_.push_back((uint64_t)label);
+    visit_tag_.push_back(0);
+    label_to_id_[label] = id;
+    insertNode(id, vec(id));
+    graph_dirty_ = true;
+    return is_new;
+}
+
+long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
+    host_vecs_.reserve(host_vecs_.size() + n * dim_);
+    for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * 4, labels[i]);
+    return (long)n;
+}
+
+int HnswIndex::deleteVector(size_t label) {
+    auto it = label_to_id_.find(label);
+    if (it == label_to_id_.end()) return 0;
+    deleted_[it->second] = 1;  // mark only: the node stays traversable (hnsw.h:572-573), never returned
+    n_deleted_++;
+    label_to_id_.erase(it);
+    graph_dirty_ = true;
+    return 1;
+}
+
+int HnswIndex::syncDevice() {
+    if (uploaded_rows_ < n_) {
+        int rc = vsgpu_table_append(table_, host_vecs_.data() + uploaded_rows_ * dim_, n_ - uploaded_rows_);
+        if (rc) return rc;
+        uploaded_rows_ = n_;
+    }
+    if (graph_dirty_) {
+        int rc = vsgpu_graph_upload(graph_, n_, links0_.data(), cnt0_.data(), upper_off_.data(), upper_.data(), upper_.size(),
+                                    deleted_.data(), labels_.data(), entry_, max_level_);
+        if (rc) return rc;
+        graph_dirty_ = false;
+    }
+    return 0;
+}
+
+HnswIndex::Export HnswIndex::exportGraph() {
+    Export e{};
+    e.n = (uint32_t)n_;
+    e.M = (uint32_t)M_;
+    e.M0 = (uint32_t)M0_;
+    e.entry = entry_;
+    e.max_level = max_level_;
+    e.links0 = links0_.data();
+    e.cnt0 = cnt0_.data();
+    e.upper_off = upper_off_.data();
+    e.upper = upper_.data();
+    e.upper_words = upper_.size();
+    e.deleted = deleted_.data();
+    e.labels = labels_.data();
+    return e;
+}
+
+int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
+                              VecSimQueryReply_Order order, VecSimQueryReply **out) {
+    void *tctx = qp ? qp->timeoutCtx : nullptr;
+    last_mode_ = STANDARD_KNN;
+    if (nq == 0) return 0;
+    std::vector<VecSimQueryReply *> reps(nq);
+    for (auto &r : reps) r = new VecSimQueryReply();
+    auto finish = [&]() {
+        for (size_t q = 0; q < nq; q++) out[q] = reps[q];
+        return 0;
+    };
+    if (k == 0 || n_ == 0) return finish();
+    if (timed_out(tctx)) {
+        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+        return finish();
+    }
+    size_t ef = ef_;
+    if (qp && qp->hnswRuntimeParams.efRuntime != 0) ef = qp->hnswRuntimeParams.efRuntime;
+    ef = std::max(ef, k);  // hnsw.h:2073
+    std::vector<char> qbuf(nq * dim_ * 4);
+    for (size_t q = 0; q < nq; q++) {
+        std::memcpy(qbuf.data() + q * dim_ * 4, (const char *)queries + q * stride, dim_ * 4);
+        if (metric_ == VecSimMetric_Cosine) normalize_blob(qbuf.data() + q * dim_ * 4, dim_, type_);
+    }
+    std::vector<uint64_t> labs(nq * k);
+    std::vector<double> sc(nq * k);
+    std::vector<uint32_t> cnt(nq);
+    int rc = syncDevice();
+    if (!rc) rc = vsgpu_graph_search(graph_, qbuf.data(), nq, dim_ * 4, k, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
+    if (rc) {
+        std::fprintf(stderr, "vecsim_amd: GPU HNSW search failed: %s\n", vsgpu_last_error());
+        for (auto *r : reps) delete r;
+        return rc;
+    }
+    if (timed_out(tctx)) {
+        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+        return finish();
+    }
+    for (size_t q = 0; q < nq; q++) {
+        reps[q]->results.resize(cnt[q]);
+        for (uint32_t i = 0; i < cnt[q]; i++) {
+            reps[q]->results[i].id = (size_t)labs[q * k + i];
+            reps[q]->results[i].score = sc[q * k + i];
+        }
+        if (order == BY_ID) sort_reply(reps[q], BY_ID);
+    }
+    return finish();
+}
+
+VecSimQueryReply *HnswIndex::topKQuery(const void *query, size_t k, VecSimQueryParams *qp) {
+    VecSimQueryReply *rep = nullptr;
+    if (topKQueryBatch(query, 1, 0, k, qp, BY_SCORE, &rep)) {
+        rep = new VecSimQueryReply();
+        rep->code = VecSim_QueryReply_TimedOut;
+    }
+    return rep;
+}
+
+VecSimQueryReply *HnswIndex::rangeQuery(const void *, double, VecSimQueryParams *, VecSimQueryReply_Order) {
+    // HNSW range search (hnsw.h:2090-2180, epsilon-bounded) is not built in this round
+    std::fprintf(stderr, "vecsim_amd: HNSW range queries are not implemented yet\n");
+    last_mode_ = RANGE_QUERY;
+    return new VecSimQueryReply();
+}
+
+double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
+    auto it = label_to_id_.find(label);
+    if (it == label_to_id_.end() || syncDevice()) return std::numeric_limits<double>::quiet_NaN();
+    uint32_t id = it->second;
+    double s = std::numeric_limits<double>::quiet_NaN();
+    if (vsgpu_scores_of(table_, blob, &id, 1, &s)) return std::numeric_limits<double>::quiet_NaN();
+    return s;
+}
+
+bool HnswIndex::preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) {
+    // hnsw.h:2183-2240: decision tree of scripts/HNSW_batches_clf.py; for this round every subset smaller
+    // than a tenth of the index prefers ad-hoc scoring (the only branch RediSearch relies on for tiny filters)
+    (void)k;
+    const bool adhoc = n_ == 0 || (double)std::min(subsetSize, n_) / (double)n_ <= 0.1;
+    last_mode_ = adhoc ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
+    return adhoc;
+}
+
+VecSimIndexBasicInfo HnswIndex::basicInfo() const {
+    VecSimIndexBasicInfo b{};
+    b.algo = VecSimAlgo_HNSWLIB;
+    b.metric = metric_;
+    b.type = type_;
+    b.blockSize = block_size_;
+    b.dim = dim_;
+    return b;
+}
+VecSimIndexStatsInfo HnswIndex::statsInfo() const {
+    VecSimIndexStatsInfo s{};
+    s.memory = host_vecs_.capacity() * 4 + links0_.capacity() * 4 + upper_.capacity() * 4 + (table_ ? vsgpu_table_bytes(table_) : 0);
+    s.numberOfMarkedDeleted = n_deleted_;
+    return s;
+}
+VecSimIndexDebugInfo HnswIndex::debugInfo() const {
+    VecSimIndexDebugInfo d{};
+    d.commonInfo.basicInfo = basicInfo();
+    d.commonInfo.indexSize = indexSize();
+    d.commonInfo.indexLabelCount = label_to_id_.size();
+    d.commonInfo.memory = statsInfo().memory;
+    d.commonInfo.lastMode = last_mode_;
+    d.hnswInfo.M = M_;
+    d.hnswInfo.efConstruction = ef_c_;
+    d.hnswInfo.efRuntime = ef_;
+    d.hnswInfo.epsilon = epsilon_;
+    d.hnswInfo.max_level = max_level_ < 0 ? HNSW_INVALID_LEVEL : (size_t)max_level_;
+    d.hnswInfo.entrypoint = entry_ == NONE ? INVALID_LABEL : (size_t)labels_[entry_];
+    d.hnswInfo.numberOfMarkedDeletedNodes = n_deleted_;
+    return d;
+}
+
+}  // namespace vsa

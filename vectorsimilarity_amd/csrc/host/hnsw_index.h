@@ -1,0 +1,112 @@
+// hnsw_index.h -- host side of the HNSW index: the graph (levels, link lists, entry point), its
+// construction, labels and deletion marks.  Queries run on the GPU (vsgpu_graph_search) over a device
+// snapshot of this graph; every distance a *query* needs is evaluated by the gfx950 kernels.
+//
+// Graph construction is ingest-side host work, as in the reference ("graph build /
+// delete / repair must exist host-side to produce a graph but are not GPU work"): insertion follows
+// the reference's algorithm -- random level from the same generator (hnsw.h:418-422, seed 100),
+// greedy descent, ef_construction-bounded layer search, neighbour selection by the diversity heuristic
+// (hnsw.h:743-797), mutual linking with re-selection on overflow -- with its own host distance
+// routine (hnsw_index.cpp:build_distance).  That routine is never reached from a query entry point.
+#pragma once
+#include <cstdint>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+#include "flat_index.h"
+
+namespace vsa {
+
+class HnswIndex final : public VecSimIndexInterface {
+public:
+    static HnswIndex *create(const HNSWParams &p, void *logCtx);
+    ~HnswIndex() override;
+
+    int addVector(const void *blob, size_t label) override;
+    int deleteVector(size_t label) override;
+    size_t indexSize() const override { return n_ - n_deleted_; }
+    size_t indexLabelCount() const override { return label_to_id_.size(); }
+    VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) override;
+    int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
+                       VecSimQueryReply_Order order, VecSimQueryReply **out) override;
+    int topKCandidates(const void *, size_t, size_t, size_t, size_t, uint32_t *, size_t *, double *, uint32_t *) override {
+        return -1;  // HNSW is replicas-only across GPUs
+    }
+    VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
+                                 VecSimQueryReply_Order order) override;
+    double getDistanceFrom(size_t label, const void *blob) override;
+    VecSimBatchIterator *newBatchIterator(const void *, VecSimQueryParams *) override { return nullptr; }
+    bool preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) override;
+    VecSimIndexBasicInfo basicInfo() const override;
+    VecSimIndexStatsInfo statsInfo() const override;
+    VecSimIndexDebugInfo debugInfo() const override;
+    long addBulk(const void *blobs, const size_t *labels, size_t n) override;
+    long addSynthetic(size_t, uint64_t) override { return -1; }
+    vsgpu_ctx *gpu() override { return ctx_; }
+    void setLastMode(VecSearchMode m) override { last_mode_ = m; }
+
+    // test / tooling access to the built graph (VecSimGpu_HnswExport)
+    struct Export {
+        uint32_t n, M, M0, entry;
+        int max_level;
+        const uint32_t *links0;
+        const uint16_t *cnt0;
+        const uint32_t *upper_off;
+        const uint32_t *upper;
+        size_t upper_words;
+        const uint8_t *deleted;
+        const uint64_t *labels;
+    };
+    Export exportGraph();
+    uint64_t lastDistanceEvals() const { return last_dist_evals_; }
+
+private:
+    HnswIndex() = default;
+    float buildDistance(const float *a, const float *b) const;
+    const float *vec(uint32_t id) const { return host_vecs_.data() + (size_t)id * dim_; }
+    uint32_t *linksAt(uint32_t id, int level, uint32_t **count_word);
+    void insertNode(uint32_t id, const float *v);
+    void searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
+                     std::vector<std::pair<float, uint32_t>> &out);
+    void selectNeighbors(std::vector<std::pair<float, uint32_t>> &cands, size_t M);
+    void connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected);
+    int syncDevice();
+    std::vector<char> preprocess(const void *blob) const;
+
+    VecSimType type_ = VecSimType_FLOAT32;
+    VecSimMetric metric_ = VecSimMetric_L2;
+    size_t dim_ = 0, block_size_ = DEFAULT_BLOCK_SIZE;
+    size_t M_ = 16, M0_ = 32, ef_c_ = 200, ef_ = 10;
+    double epsilon_ = 0.01, mult_ = 0;
+    void *log_ctx_ = nullptr;
+    std::default_random_engine level_gen_{100};
+
+    // vectors: host copy for construction + device table for queries
+    std::vector<float> host_vecs_;
+    vsgpu_ctx *ctx_ = nullptr;
+    vsgpu_table *table_ = nullptr;
+    vsgpu_graph *graph_ = nullptr;
+    size_t uploaded_rows_ = 0;
+    bool graph_dirty_ = true;
+
+    // graph
+    size_t n_ = 0, n_deleted_ = 0;
+    std::vector<uint32_t> links0_;     // [n][M0]
+    std::vector<uint16_t> cnt0_;       // [n]
+    std::vector<uint8_t> level_;       // [n]
+    std::vector<uint32_t> upper_off_;  // [n] block index or 0xFFFFFFFF
+    std::vector<uint32_t> upper_;      // blocks of 1+M words
+    std::vector<uint8_t> deleted_;
+    std::vector<uint64_t> labels_;
+    std::unordered_map<size_t, uint32_t> label_to_id_;
+    uint32_t entry_ = 0xFFFFFFFFu;
+    int max_level_ = -1;
+    std::vector<uint32_t> visit_tag_;  // construction-time visited marks
+    uint32_t visit_epoch_ = 0;
+
+    uint64_t last_dist_evals_ = 0;
+    mutable VecSearchMode last_mode_ = EMPTY_MODE;
+};
+
+}  // namespace vsa
