@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 shape, scaled to what a single-threaded host build can ingest in minutes:
+HNSW fp32 L2, d=768, M=16, efC=200, efR=128, top-10.  Reports QPS, recall@10 vs the exact Flat answer
+(computed on the GPU), distance evaluations per query and the achieved random-gather bandwidth.
+    python tools/bench_hnsw.py [--rows 200000] [--queries 4096]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vectorsimilarity_amd import VecSim, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=200_000)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--queries", type=int, default=4096)
+ap.add_argument("--M", type=int, default=16)
+ap.add_argument("--efc", type=int, default=200)
+ap.add_argument("--ef", type=int, default=128)
+ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--data", default="uniform", choices=["uniform", "lowrank"],
+                help="uniform: BASELINE's U[-1,1) i.i.d. rows (intrinsic dimension = d, hard for any graph index); "
+                     "lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
+a = ap.parse_args()
+
+rows = synth.rows_f32(47, 0, a.rows, a.dim)
+q = synth.rows_f32(48, 0, a.queries, a.dim)
+if a.data == "lowrank":
+    mix = synth.rows_f32(49, 0, 32, a.dim)
+    rows = (synth.rows_f32(47, 0, a.rows, 32) @ mix + 0.05 * rows).astype(np.float32)
+    q = (synth.rows_f32(48, 0, a.queries, 32) @ mix + 0.05 * q).astype(np.float32)
+p = VecSim.HNSWParams()
+p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2, a.M, a.efc, a.ef
+ix = VecSim.HNSWIndex(p)
+t0 = time.perf_counter()
+ix.add_vectors(rows, np.arange(a.rows))
+build_s = time.perf_counter() - t0
+ix.knn_query(q[:64], a.k)          # uploads rows + graph
+ix.reset_stats()
+best = None
+for _ in range(3):
+    t0 = time.perf_counter()
+    labels, dists = ix.knn_query(q, a.k)
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+evals = ix.last_distance_evals()
+st = ix.stats()
+bp = VecSim.BFParams()
+bp.type, bp.dim, bp.metric = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2
+bf = VecSim.BFIndex(bp)
+bf.add_vectors(rows, np.arange(a.rows))
+exact = np.concatenate([bf.knn_query(q[i:i + 64], a.k)[0] for i in range(0, a.queries, 64)])
+recall = sum(len(set(labels[i]) & set(exact[i])) for i in range(a.queries)) / (a.queries * a.k)
+kms = st["scan_ms"] / max(1, st["scan_launches"])
+print(json.dumps({"config": "HNSW fp32 L2 N=%d d=%d M=%d efC=%d efR=%d k=%d data=%s" % (a.rows, a.dim, a.M, a.efc, a.ef, a.k, a.data),
+                  "host_build_s": build_s, "queries": a.queries, "batch_ms": best * 1e3, "qps": a.queries / best,
+                  "recall_at_%d" % a.k: recall, "dist_evals_per_query": evals / a.queries,
+                  "search_kernel_ms": kms, "gather_GBps": evals * a.dim * 4 / (kms * 1e-3) / 1e9}))
