@@ -103,6 +103,7 @@ struct ScanParams {
     // lane program + queries
     const int32_t *offs;  // [steps][VL]
     int steps;
+    int full_from, full_to;  // every lane is active in steps [full_from, full_to): no predication needed there
     const void *qperm;    // [nq][steps][VL] acc_t, query values already widened & permuted
     int nq;
     // epilogue
@@ -195,8 +196,43 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
 #pragma unroll
             for (int b = 0; b < BT; b++) acc[r][b] = (acc_t)0;
 
-#pragma unroll 4
-        for (int s = 0; s < steps; s++) {
+        // head: steps where some lanes idle (residual handling) -- predicated
+        for (int s = 0; s < P.full_from; s++) {
+            const int off = offs_s[s * VL + lane];
+            if (off >= 0) {
+                acc_t x[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = E::load(rp[r] + off);
+#pragma unroll
+                for (int b = 0; b < BT; b++) {
+                    const acc_t qv = q_s[(b * steps + s) * VL + lane];
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r][b] = acc_step<OPK>(x[r], qv, acc[r][b]);
+                }
+            }
+        }
+        // main: all lanes active; CH steps (R*CH row loads) are issued before their FMAs so the loads of a
+        // chunk overlap instead of paying one memory round trip per step
+        constexpr int CH = 4;
+        int s = P.full_from;
+        for (; s + CH <= P.full_to; s += CH) {
+            acc_t x[CH][R];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const int off = offs_s[(s + j) * VL + lane];
+#pragma unroll
+                for (int r = 0; r < R; r++) x[j][r] = E::load(rp[r] + off);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+                for (int b = 0; b < BT; b++) {
+                    const acc_t qv = q_s[(b * steps + s + j) * VL + lane];
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r][b] = acc_step<OPK>(x[j][r], qv, acc[r][b]);
+                }
+        }
+        for (; s < steps; s++) {  // leftover full steps and any partial tail
             const int off = offs_s[s * VL + lane];
             if (off >= 0) {
                 acc_t x[R];

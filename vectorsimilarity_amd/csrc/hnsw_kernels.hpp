@@ -147,10 +147,24 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         const uint32_t node = act ? ids[idx] : ids[first];
         const char *rp = P.slabs[node >> P.slab_shift] + (size_t)(node & P.slab_mask) * P.row_stride;
         acc_t acc = (acc_t)0;
-#pragma unroll 4
-        for (int s = 0; s < steps; s++) {
-            const int off = offs_s[s * VL + vl];
-            if (off >= 0) acc = acc_step<OPK>(E::load(rp + off), q_s[s * VL + vl], acc);
+        // branch-free, CH steps at a time: all CH row loads of the chunk are issued before the first FMA
+        // (idle table entries load offset 0 and leave the accumulator untouched), so a ~3 KB row costs a
+        // couple of memory round trips instead of one per step
+        constexpr int CH = 12;
+        for (int s0 = 0; s0 < steps; s0 += CH) {
+            int off[CH];
+            acc_t xv[CH], qv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) off[j] = (s0 + j < steps) ? offs_s[(s0 + j) * VL + vl] : -1;
+#pragma unroll
+            for (int j = 0; j < CH; j++) xv[j] = E::load(rp + (off[j] >= 0 ? off[j] : 0));
+#pragma unroll
+            for (int j = 0; j < CH; j++) qv[j] = q_s[min(s0 + j, steps - 1) * VL + vl];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const acc_t t = acc_step<OPK>(xv[j], qv[j], acc);
+                acc = off[j] >= 0 ? t : acc;
+            }
         }
 #pragma unroll
         for (int of = VL / 2; of >= 1; of >>= 1) acc = add_rn(acc, __shfl_down(acc, of, VL));

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <queue>
+#include <thread>
 
 #include "blob_prep.h"
 
@@ -105,17 +106,36 @@ std::vector<char> HnswIndex::preprocess(const void *blob) const {
     return v;
 }
 
+// snapshot of a node's link list (under the node's lock when other threads are linking)
+uint32_t HnswIndex::copyLinks(uint32_t id, int level, uint32_t *dst, bool locked) {
+    if (locked) lockNode(id);
+    const uint32_t *links;
+    uint32_t cnt;
+    if (level == 0) {
+        links = links0_.data() + (size_t)id * M0_;
+        cnt = cnt0_[id];
+    } else {
+        uint32_t *cw;
+        links = linksAt(id, level, &cw);
+        cnt = *cw;
+    }
+    std::memcpy(dst, links, cnt * 4);
+    if (locked) unlockNode(id);
+    return cnt;
+}
+
 // ef-bounded best-first search of one layer during construction (hnswlib's searchBaseLayer shape)
 void HnswIndex::searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
-                            std::vector<std::pair<float, uint32_t>> &out) {
+                            std::vector<std::pair<float, uint32_t>> &out, BuildCtx &bc) {
     using Item = std::pair<float, uint32_t>;
     std::priority_queue<Item> top;                                         // max-heap: worst on top
     std::priority_queue<Item, std::vector<Item>, std::greater<Item>> cand;  // min-heap
-    if (++visit_epoch_ == 0) {
-        std::fill(visit_tag_.begin(), visit_tag_.end(), 0u);
-        visit_epoch_ = 1;
+    if (bc.tag.size() < n_) bc.tag.resize(n_, 0u);
+    if (++bc.epoch == 0) {
+        std::fill(bc.tag.begin(), bc.tag.end(), 0u);
+        bc.epoch = 1;
     }
-    const uint32_t ep_tag = visit_epoch_;
+    const uint32_t ep_tag = bc.epoch;
     float lower;
     if (!deleted_[ep]) {
         top.emplace(ep_dist, ep);
@@ -124,25 +144,17 @@ void HnswIndex::searchLayer(const float *q, uint32_t ep, float ep_dist, int leve
         lower = std::numeric_limits<float>::max();
     }
     cand.emplace(ep_dist, ep);
-    visit_tag_[ep] = ep_tag;
+    bc.tag[ep] = ep_tag;
+    uint32_t links[64];
     while (!cand.empty()) {
         Item c = cand.top();
         if (c.first > lower && top.size() >= ef) break;
         cand.pop();
-        const uint32_t *links;
-        uint32_t cnt;
-        if (level == 0) {
-            links = links0_.data() + (size_t)c.second * M0_;
-            cnt = cnt0_[c.second];
-        } else {
-            uint32_t *cw;
-            links = linksAt(c.second, level, &cw);
-            cnt = *cw;
-        }
+        const uint32_t cnt = copyLinks(c.second, level, links, bc.locked);
         for (uint32_t i = 0; i < cnt; i++) {
             const uint32_t nb = links[i];
-            if (visit_tag_[nb] == ep_tag) continue;
-            visit_tag_[nb] = ep_tag;
+            if (bc.tag[nb] == ep_tag) continue;
+            bc.tag[nb] = ep_tag;
             const float d = buildDistance(vec(nb), q);
             if (lower > d || top.size() < ef) {
                 cand.emplace(d, nb);
@@ -182,20 +194,25 @@ void HnswIndex::selectNeighbors(std::vector<std::pair<float, uint32_t>> &cands, 
     cands.swap(kept);
 }
 
-void HnswIndex::connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected) {
+void HnswIndex::connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected, bool locked) {
     const size_t max_links = level == 0 ? M0_ : M_;
     // the new node's own list
-    uint32_t *mine;
-    uint32_t dummy = 0, *mine_cnt = &dummy;
-    if (level == 0) mine = links0_.data() + (size_t)id * M0_;
-    else mine = linksAt(id, level, &mine_cnt);
-    uint32_t c = 0;
-    for (const auto &s : selected) mine[c++] = s.second;
-    if (level == 0) cnt0_[id] = (uint16_t)c;
-    else *mine_cnt = c;
+    if (locked) lockNode(id);
+    {
+        uint32_t *mine;
+        uint32_t dummy = 0, *mine_cnt = &dummy;
+        if (level == 0) mine = links0_.data() + (size_t)id * M0_;
+        else mine = linksAt(id, level, &mine_cnt);
+        uint32_t c = 0;
+        for (const auto &s : selected) mine[c++] = s.second;
+        if (level == 0) cnt0_[id] = (uint16_t)c;
+        else *mine_cnt = c;
+    }
+    if (locked) unlockNode(id);
     // back links, re-selected when a neighbour's list is full
     for (const auto &s : selected) {
         const uint32_t nb = s.second;
+        if (locked) lockNode(nb);
         uint32_t *nl;
         uint32_t ncnt;
         uint32_t *ncw = nullptr;
@@ -206,46 +223,70 @@ void HnswIndex::connect(uint32_t id, int level, const std::vector<std::pair<floa
             nl = linksAt(nb, level, &ncw);
             ncnt = *ncw;
         }
-        if (ncnt < max_links) {
-            nl[ncnt++] = id;
-        } else {
-            std::vector<std::pair<float, uint32_t>> cand;
-            cand.reserve(ncnt + 1);
-            cand.emplace_back(s.first, id);
-            for (uint32_t i = 0; i < ncnt; i++) cand.emplace_back(buildDistance(vec(nl[i]), vec(nb)), nl[i]);
-            selectNeighbors(cand, max_links);
-            ncnt = 0;
-            for (const auto &k : cand) nl[ncnt++] = k.second;
+        bool present = false;
+        for (uint32_t i = 0; i < ncnt; i++) present |= (nl[i] == id);
+        if (!present) {
+            if (ncnt < max_links) {
+                nl[ncnt++] = id;
+            } else {
+                std::vector<std::pair<float, uint32_t>> cand;
+                cand.reserve(ncnt + 1);
+                cand.emplace_back(s.first, id);
+                for (uint32_t i = 0; i < ncnt; i++) cand.emplace_back(buildDistance(vec(nl[i]), vec(nb)), nl[i]);
+                selectNeighbors(cand, max_links);
+                ncnt = 0;
+                for (const auto &k : cand) nl[ncnt++] = k.second;
+            }
+            if (level == 0) cnt0_[nb] = (uint16_t)ncnt;
+            else *ncw = ncnt;
         }
-        if (level == 0) cnt0_[nb] = (uint16_t)ncnt;
-        else *ncw = ncnt;
+        if (locked) unlockNode(nb);
     }
 }
 
-void HnswIndex::insertNode(uint32_t id, const float *v) {
+int HnswIndex::drawLevel() {
     std::uniform_real_distribution<double> uni(0.0, 1.0);
-    const int level = (int)(size_t)(-std::log(uni(level_gen_)) * mult_);  // hnsw.h:418-422
-    level_[id] = (uint8_t)std::min(level, 255);
+    return std::min((int)(size_t)(-std::log(uni(level_gen_)) * mult_), 255);  // hnsw.h:418-422
+}
+
+// storage for one new node (sequential: vectors may reallocate here, never during linking)
+uint32_t HnswIndex::allocNode(const float *v, size_t label, int level) {
+    const uint32_t id = (uint32_t)n_++;
+    host_vecs_.insert(host_vecs_.end(), v, v + dim_);
+    links0_.resize(n_ * M0_, 0u);
+    cnt0_.push_back(0);
+    level_.push_back((uint8_t)level);
+    upper_off_.push_back(NONE);
+    deleted_.push_back(0);
+    labels_.push_back((uint64_t)label);
+    label_to_id_[label] = id;
     if (level > 0) {
         upper_off_[id] = (uint32_t)(upper_.size() / (M_ + 1));
         upper_.resize(upper_.size() + (size_t)level * (M_ + 1), 0u);
     }
-    if (entry_ == NONE) {
+    return id;
+}
+
+void HnswIndex::insertNode(uint32_t id, const float *v, BuildCtx &bc) {
+    const int level = level_[id];
+    std::unique_lock<std::mutex> entry_lock(entry_mu_, std::defer_lock);
+    if (bc.locked) entry_lock.lock();
+    uint32_t cur = entry_;
+    const int top_level = max_level_;
+    if (cur == NONE) {
         entry_ = id;
         max_level_ = level;
         return;
     }
-    uint32_t cur = entry_;
+    // a node that raises the top level keeps the entry lock for its whole insertion (hnswlib does the same)
+    if (bc.locked && level <= top_level) entry_lock.unlock();
     float curd = buildDistance(vec(cur), v);
-    for (int l = max_level_; l > level; l--) {
+    uint32_t links[64];
+    for (int l = top_level; l > level; l--) {
         bool changed = true;
         while (changed) {
             changed = false;
-            uint32_t *cw;
-            const uint32_t *links = linksAt(cur, l, &cw);
-            const uint32_t cnt = *cw;
-            const uint32_t from = cur;
-            (void)from;
+            const uint32_t cnt = copyLinks(cur, l, links, bc.locked);
             for (uint32_t i = 0; i < cnt; i++) {
                 const float d = buildDistance(vec(links[i]), v);
                 if (d < curd) {
@@ -257,19 +298,21 @@ void HnswIndex::insertNode(uint32_t id, const float *v) {
         }
     }
     std::vector<std::pair<float, uint32_t>> W;
-    for (int l = std::min(level, max_level_); l >= 0; l--) {
-        searchLayer(v, cur, curd, l, ef_c_, W);
+    for (int l = std::min(level, top_level); l >= 0; l--) {
+        searchLayer(v, cur, curd, l, ef_c_, W, bc);
         if (W.empty()) continue;  // everything reachable is deleted
-        // next layer starts from the closest found
         auto best = std::min_element(W.begin(), W.end());
         cur = best->second;
         curd = best->first;
-        std::vector<std::pair<float, uint32_t>> sel = W;
+        std::vector<std::pair<float, uint32_t>> sel;
+        sel.reserve(W.size());
+        for (const auto &w : W)
+            if (w.second != id) sel.push_back(w);  // (a concurrent insert may already have linked to us)
         selectNeighbors(sel, M_);
         if (sel.size() > M_) sel.resize(M_);
-        connect(id, l, sel);
+        connect(id, l, sel, bc.locked);
     }
-    if (level > max_level_) {
+    if (level > top_level) {
         entry_ = id;
         max_level_ = level;
     }
@@ -285,24 +328,57 @@ int HnswIndex::addVector(const void *blob, size_t label) {
         is_new = 0;
     }
     std::vector<char> pv = preprocess(blob);
-    const uint32_t id = (uint32_t)n_++;
-    host_vecs_.insert(host_vecs_.end(), (const float *)pv.data(), (const float *)pv.data() + dim_);
-    links0_.resize(n_ * M0_, 0u);
-    cnt0_.push_back(0);
-    level_.push_back(0);
-    upper_off_.push_back(NONE);
-    deleted_.push_back(0);
-    labels_.push_back((uint64_t)label);
-    visit_tag_.push_back(0);
-    label_to_id_[label] = id;
-    insertNode(id, vec(id));
+    const uint32_t id = allocNode((const float *)pv.data(), label, drawLevel());
+    main_ctx_.locked = false;
+    insertNode(id, vec(id), main_ctx_);
     graph_dirty_ = true;
     return is_new;
 }
 
+// Bulk ingest: storage and levels are laid out sequentially (deterministic ids and levels), then the
+// linking runs on VECSIM_HNSW_BUILD_THREADS host threads (default: all cores, at most 64) with per-node
+// link-list locks, the way the reference's parallel insert path does (hnsw.h:436-445, bindings.cpp:383-426).
 long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if (label_to_id_.count(labels[i])) return -1;
+    size_t threads = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("VECSIM_HNSW_BUILD_THREADS")) threads = (size_t)std::max(1, std::atoi(e));
+    threads = std::max<size_t>(1, std::min<size_t>(threads, 64));
+    if (n < 2048 || threads == 1) {
+        host_vecs_.reserve(host_vecs_.size() + n * dim_);
+        for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * 4, labels[i]);
+        return (long)n;
+    }
+    const uint32_t first = (uint32_t)n_;
     host_vecs_.reserve(host_vecs_.size() + n * dim_);
-    for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * 4, labels[i]);
+    for (size_t i = 0; i < n; i++) {
+        std::vector<char> pv = preprocess((const char *)blobs + i * dim_ * 4);
+        allocNode((const float *)pv.data(), labels[i], drawLevel());
+    }
+    node_lock_.reset(new std::atomic_flag[n_]);
+    for (size_t i = 0; i < n_; i++) node_lock_[i].clear();
+    node_lock_n_ = n_;
+    // the first few nodes go in sequentially so every thread starts from a connected graph
+    size_t seq = std::min<size_t>(n, 256);
+    main_ctx_.locked = false;
+    for (size_t i = 0; i < seq; i++) insertNode(first + (uint32_t)i, vec(first + (uint32_t)i), main_ctx_);
+    std::atomic<size_t> next{seq};
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < threads; t++) {
+        pool.emplace_back([&]() {
+            BuildCtx bc;
+            bc.locked = true;
+            bc.tag.assign(n_, 0u);
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                insertNode(first + (uint32_t)i, vec(first + (uint32_t)i), bc);
+            }
+        });
+    }
+    for (auto &th : pool) th.join();
+    node_lock_.reset();
+    graph_dirty_ = true;
     return (long)n;
 }
 

@@ -9,7 +9,10 @@
 // (hnsw.h:743-797), mutual linking with re-selection on overflow -- with its own host distance
 // routine (hnsw_index.cpp:build_distance).  That routine is never reached from a query entry point.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <unordered_map>
 #include <vector>
@@ -65,12 +68,27 @@ private:
     HnswIndex() = default;
     float buildDistance(const float *a, const float *b) const;
     const float *vec(uint32_t id) const { return host_vecs_.data() + (size_t)id * dim_; }
+    // per-thread construction state (visited marks); `locked` = other threads are inserting too
+    struct BuildCtx {
+        std::vector<uint32_t> tag;
+        uint32_t epoch = 0;
+        bool locked = false;
+        std::vector<uint32_t> scratch;
+    };
     uint32_t *linksAt(uint32_t id, int level, uint32_t **count_word);
-    void insertNode(uint32_t id, const float *v);
+    uint32_t copyLinks(uint32_t id, int level, uint32_t *dst, bool locked);
+    uint32_t allocNode(const float *v, size_t label, int level);
+    int drawLevel();
+    void insertNode(uint32_t id, const float *v, BuildCtx &bc);
     void searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
-                     std::vector<std::pair<float, uint32_t>> &out);
+                     std::vector<std::pair<float, uint32_t>> &out, BuildCtx &bc);
     void selectNeighbors(std::vector<std::pair<float, uint32_t>> &cands, size_t M);
-    void connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected);
+    void connect(uint32_t id, int level, const std::vector<std::pair<float, uint32_t>> &selected, bool locked);
+    void lockNode(uint32_t id) {
+        while (node_lock_[id].test_and_set(std::memory_order_acquire)) {
+        }
+    }
+    void unlockNode(uint32_t id) { node_lock_[id].clear(std::memory_order_release); }
     int syncDevice();
     std::vector<char> preprocess(const void *blob) const;
 
@@ -102,8 +120,10 @@ private:
     std::unordered_map<size_t, uint32_t> label_to_id_;
     uint32_t entry_ = 0xFFFFFFFFu;
     int max_level_ = -1;
-    std::vector<uint32_t> visit_tag_;  // construction-time visited marks
-    uint32_t visit_epoch_ = 0;
+    BuildCtx main_ctx_;                               // single-threaded inserts
+    std::unique_ptr<std::atomic_flag[]> node_lock_;  // per-node link-list locks (parallel bulk build only)
+    size_t node_lock_n_ = 0;
+    std::mutex entry_mu_;
 
     uint64_t last_dist_evals_ = 0;
     mutable VecSearchMode last_mode_ = EMPTY_MODE;

@@ -29,6 +29,23 @@ struct LaneProgram {
     int elem_bytes = 4;
     bool scalar_tier = false;
     std::vector<int32_t> offs;  // steps * vl
+    // [full_from, full_to): the longest run of steps in which every lane is active (residual handling makes
+    // the first step(s) partial for float kernels, the last one partial for the integer striding)
+    bool step_full(int s) const {
+        for (int l = 0; l < vl; l++)
+            if (offs[(size_t)s * vl + l] < 0) return false;
+        return true;
+    }
+    int full_from() const {
+        int s = 0;
+        while (s < steps && !step_full(s)) s++;
+        return s;
+    }
+    int full_to() const {
+        int s = full_from();
+        while (s < steps && step_full(s)) s++;
+        return s;
+    }
 };
 
 inline int elem_bytes_of(int type) {

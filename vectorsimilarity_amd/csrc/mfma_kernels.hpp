@@ -380,9 +380,22 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
         const uint32_t row = rec.x;
         const char *rp = P.slabs[row >> P.slab_shift] + (size_t)(row & P.slab_mask) * P.row_stride;
         acc_t acc = (acc_t)0;
-        for (int st = 0; st < P.steps; st++) {
-            const int off = P.offs[st * VL + lane];
-            if (off >= 0) acc = acc_step<OPK>(E::load(rp + off), qv[st * VL + lane], acc);
+        // branch-free chunks: CH row loads in flight before the first FMA (idle entries keep the accumulator)
+        constexpr int CH = 12;
+        for (int s0 = 0; s0 < P.steps; s0 += CH) {
+            int off[CH];
+            acc_t xv[CH], qq[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) off[j] = (s0 + j < P.steps) ? P.offs[(s0 + j) * VL + lane] : -1;
+#pragma unroll
+            for (int j = 0; j < CH; j++) xv[j] = E::load(rp + (off[j] >= 0 ? off[j] : 0));
+#pragma unroll
+            for (int j = 0; j < CH; j++) qq[j] = qv[min(s0 + j, P.steps - 1) * VL + lane];
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const acc_t t = acc_step<OPK>(xv[j], qq[j], acc);
+                acc = off[j] >= 0 ? t : acc;
+            }
         }
 #pragma unroll
         for (int o = VL / 2; o >= 1; o >>= 1) acc = add_rn(acc, __shfl_down(acc, o, VL));

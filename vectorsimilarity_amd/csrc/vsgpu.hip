@@ -572,6 +572,8 @@ static int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     P.row_stride = (uint32_t)t->row_bytes;
     P.offs = t->d_offs;
     P.steps = t->prog.steps;
+    P.full_from = t->prog.full_from();
+    P.full_to = t->prog.full_to();
     P.qperm = c->qperm.p;
     P.nq = (int)nq;
     P.epilogue = t->epi;
