@@ -84,7 +84,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # launched through torch.distributed.run (RANK set): always bring RCCL up, so a 1-rank run exercises
+    # the same collective path as the 2/4/8-rank runs
+    if world > 1 or "RANK" in os.environ:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -605,6 +605,44 @@ size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, siz
     return cnt;
 }
 
+/* Multi-value Flat top-K: the same scan with the updatable max-heap of utils/updatable_heap.h:20-113
+ * (brute_force_multi.h:108-113): emplace keeps a label's lowest score, pop removes the largest score and,
+ * among equal scores, the largest label.  Kept as a plain array (k is small in tests). */
+size_t vso_topk_replay_multi(const double *scores, const size_t *labels, size_t n, size_t k,
+                             size_t *out_labels, double *out_scores) {
+    if (k == 0 || n == 0) return 0;
+    heap_item *h = malloc((k + 2) * sizeof(heap_item));
+    size_t hs = 0;
+    double upper = -INFINITY;
+    int upper_init = 0;
+    for (size_t i = 0; i < n; i++) {
+        double s = scores[i];
+        if ((upper_init && s < upper) || hs < k) {
+            size_t lab = labels[i], f = hs;
+            for (size_t j = 0; j < hs; j++)
+                if (h[j].label == lab) { f = j; break; }
+            if (f == hs) { h[hs].score = s; h[hs].label = lab; hs++; }
+            else if (h[f].score > s) h[f].score = s;
+            if (hs > k) {
+                size_t m = 0;
+                for (size_t j = 1; j < hs; j++)
+                    if (h[j].score > h[m].score || (h[j].score == h[m].score && h[j].label > h[m].label)) m = j;
+                h[m] = h[--hs];
+            }
+            upper = h[0].score;
+            for (size_t j = 1; j < hs; j++) if (h[j].score > upper) upper = h[j].score;
+            upper_init = 1;
+        }
+    }
+    for (size_t i = 0; i < hs; i++)
+        for (size_t j = i + 1; j < hs; j++)
+            if (h[j].score < h[i].score || (h[j].score == h[i].score && h[j].label < h[i].label)) { heap_item t = h[i]; h[i] = h[j]; h[j] = t; }
+    for (size_t i = 0; i < hs; i++) { out_labels[i] = h[i].label; out_scores[i] = h[i].score; }
+    size_t c = hs;
+    free(h);
+    return c;
+}
+
 size_t vso_range_replay(const double *scores, const size_t *labels, size_t n, double radius,
                         size_t *out_labels, double *out_scores) {
     size_t c = 0;

@@ -69,6 +69,9 @@ float vso_f16_to_f32(uint16_t h);
  * Writes min(k,n) results ascending by (score,label); returns the count. */
 size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, size_t k,
                        size_t *out_labels, double *out_scores);
+/* multi-value variant (labels may repeat; brute_force_multi.h + utils/updatable_heap.h) */
+size_t vso_topk_replay_multi(const double *scores, const size_t *labels, size_t n, size_t k,
+                             size_t *out_labels, double *out_scores);
 /* range scan: score <= radius, in id order (brute_force.h:305-318); returns count */
 size_t vso_range_replay(const double *scores, const size_t *labels, size_t n, double radius,
                         size_t *out_labels, double *out_scores);

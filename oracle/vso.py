@@ -62,6 +62,8 @@ def lib():
         L.vso_f16_to_f32.argtypes = [C.c_uint16]
         L.vso_topk_replay.restype = sz
         L.vso_topk_replay.argtypes = [vp, vp, sz, sz, vp, vp]
+        L.vso_topk_replay_multi.restype = sz
+        L.vso_topk_replay_multi.argtypes = [vp, vp, sz, sz, vp, vp]
         L.vso_range_replay.restype = sz
         L.vso_range_replay.argtypes = [vp, vp, sz, dbl, vp, vp]
         L.vso_flat_topk.restype = sz
@@ -135,6 +137,16 @@ def topk_replay(scores, k, labels=None):
     osc = np.empty(kk, dtype=np.float64)
     c = lib().vso_topk_replay(_ptr(scores), None if lab is None else _ptr(lab), n, k, _ptr(ol),
                               _ptr(osc))
+    return ol[:c].copy(), osc[:c].copy()
+
+
+def topk_replay_multi(scores, k, labels):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    lab = np.ascontiguousarray(labels, dtype=np.uint64)
+    kk = max(1, k)
+    ol = np.empty(kk, dtype=np.uint64)
+    osc = np.empty(kk, dtype=np.float64)
+    c = lib().vso_topk_replay_multi(_ptr(scores), _ptr(lab), scores.size, k, _ptr(ol), _ptr(osc))
     return ol[:c].copy(), osc[:c].copy()
 
 

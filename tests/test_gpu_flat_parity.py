@@ -454,3 +454,71 @@ def test_synthetic_fill_lowp_types_matches_host_twin(vso, typ, metric, dim):
         sc = vso.scan(TYPES[typ], kernel_metric(typ, metric), srows, sq[j], dim)
         el, es = vso.topk_replay(sc, k)
         assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es), (typ, j)
+
+
+# ---------------------------------------------------------------- multi-value Flat (brute_force_multi.h)
+def _multi_index(typ, metric, dim):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric, p.multi = TYPES[typ], dim, METRICS[metric], True
+    return VecSim.BFIndex(p)
+
+
+@pytest.mark.parametrize("typ,metric,dim,n,n_labels", [("f32", "L2", 32, 6000, 500), ("f32", "Cosine", 48, 4000, 90),
+                                                       ("i8", "L2", 32, 5000, 40), ("bf16", "IP", 64, 3000, 700)])
+def test_multi_value_flat_matches_updatable_heap_semantics(vso, typ, metric, dim, n, n_labels):
+    rng = np.random.default_rng(n)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    labels = rng.integers(0, n_labels, n).astype(np.uint64)
+    q = random_vectors(rng, 6, dim, typ, vso)
+    ix = _multi_index(typ, metric, dim)
+    for i in range(n):
+        assert ix.add_vector(rows[i], int(labels[i])) == 1
+    assert ix.index_size() == n
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    for k in (1, 7, 60):
+        got_l, got_d = ix.knn_query(q, k)
+        for j in range(len(q)):
+            sc = vso.scan(TYPES[typ], kernel_metric(typ, metric), srows, sq[j], dim)
+            el, es = vso.topk_replay_multi(sc, k, labels)
+            assert np.array_equal(got_l[j][:len(el)], el.astype(np.int64)), (typ, k, j)
+            assert np.array_equal(got_d[j][:len(es)], es)
+            assert np.all(got_l[j][len(el):] == -1)
+    # getDistanceFrom = lowest distance over the label's vectors
+    lab = int(labels[0])
+    sc = vso.scan(TYPES[typ], kernel_metric(typ, metric), srows, sq[0], dim)
+    assert ix.get_distance_from(lab, sq[0]) == sc[labels == lab].min()
+    # deleting a label removes all of its vectors
+    cnt = int((labels == lab).sum())
+    assert ix.delete_vector(lab) == cnt and ix.index_size() == n - cnt
+    got_l, _ = ix.knn_query(q, 20)
+    assert lab not in set(got_l.ravel().tolist())
+    # range query: one entry per label
+    radius = float(np.sort(sc)[200]) if np.sort(sc)[200] >= 0 else 0.5
+    rl, rs = ix.range_query(q[0], radius, order=VecSim.BY_ID)
+    assert len(set(rl[0].tolist())) == rl.shape[1]
+
+
+def test_multi_value_delete_keeps_remaining_vectors_queryable(vso):
+    rng = np.random.default_rng(4)
+    dim, n = 16, 1200
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    labels = (np.arange(n) % 37).astype(np.uint64)
+    ix = _multi_index("f32", "L2", dim)
+    ix.add_vectors(rows, labels)
+    alive = np.ones(n, dtype=bool)
+    for lab in (3, 17, 36, 0):
+        assert ix.delete_vector(lab) == int((labels[alive] == lab).sum())
+        alive &= labels != lab
+    q = rng.uniform(-1, 1, (4, dim)).astype(np.float32)
+    got_l, got_d = ix.knn_query(q, 10)
+    for j in range(4):
+        sc = vso.scan(0, 0, rows[alive], q[j], dim)
+        # per-label minimum among the surviving vectors (order of internal ids differs after swap-deletes,
+        # and random data has no ties, so compare as sets of (label, score))
+        best = {}
+        for s, l in zip(sc, labels[alive]):
+            best[int(l)] = min(best.get(int(l), np.inf), s)
+        exp = sorted(best.items(), key=lambda kv: kv[1])[:10]
+        assert [int(x) for x in got_l[j]] == [l for l, _ in exp]
+        assert list(got_d[j]) == [s for _, s in exp]

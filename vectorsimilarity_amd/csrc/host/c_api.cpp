@@ -35,10 +35,6 @@ extern "C" VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
         return nullptr;
     }
     const BFParams &bf = params->algoParams.bfParams;
-    if (bf.multi) {
-        std::fprintf(stderr, "vecsim_amd: multi-value Flat indexes are not built yet (SURVEY.md §8f rank 3)\n");
-        return nullptr;
-    }
     FlatIndex *ix = FlatIndex::create(bf, params->logCtx);
     if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create GPU index: %s\n", vsgpu_last_error());
     return ix;
@@ -407,9 +403,24 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
             std::fprintf(stderr, "vecsim_amd: GPU score pass failed: %s\n", vsgpu_last_error());
             return timed_out_reply();
         }
-        it->label_count = s.size();
-        it->scores.resize(s.size());
-        for (size_t i = 0; i < s.size(); i++) it->scores[i] = ScoredLabel(s[i], it->index->labelOf(i));
+        if (it->index->isMulti()) {
+            // bfm_batch_iterator.h:24-53: lowest score per label, emitted in the hash map's iteration order
+            std::unordered_map<size_t, double> best;
+            for (size_t i = 0; i < s.size(); i++) {
+                const size_t label = it->index->labelOf(i);
+                auto f = best.find(label);
+                if (f == best.end()) best.emplace(label, s[i]);
+                else if (f->second > s[i]) f->second = s[i];
+            }
+            it->label_count = best.size();
+            it->scores.clear();
+            it->scores.reserve(best.size());
+            for (auto &p : best) it->scores.emplace_back(p.second, p.first);
+        } else {
+            it->label_count = s.size();
+            it->scores.resize(s.size());
+            for (size_t i = 0; i < s.size(); i++) it->scores[i] = ScoredLabel(s[i], it->index->labelOf(i));
+        }
         it->scored = true;
     }
     if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();

@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <queue>
+#include <unordered_set>
 
 #include "blob_prep.h"
 
@@ -68,6 +70,7 @@ FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
     ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     ix->stored_bytes_ = blob_bytes(p.type, p.dim, p.metric);
     ix->query_bytes_ = ix->stored_bytes_;
+    ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
     ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
@@ -116,7 +119,7 @@ int FlatIndex::flush() {
 }
 
 int FlatIndex::addVector(const void *blob, size_t label) {
-    auto it = label_to_id_.find(label);
+    auto it = multi_ ? label_to_id_.end() : label_to_id_.find(label);  // multi: every call appends (brute_force_multi.h:128-132)
     if (it != label_to_id_.end()) {
         // Overwrite.  The reference copies the caller's blob as-is here, without the storage
         // preprocessing (brute_force_single.h:139-143 -> updateElement).  fp blobs have exactly the
@@ -148,15 +151,17 @@ int FlatIndex::addVector(const void *blob, size_t label) {
         id_to_label_.resize(id_to_label_.size() + block_size_);
     }
     id_to_label_[id] = label;
-    label_to_id_[label] = id;
+    if (multi_) label_to_ids_[label].push_back(id);
+    else label_to_id_[label] = id;
     if (staged_.size() >= ((size_t)8 << 20)) flush();
     return 1;
 }
 
 long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     const size_t in_bytes = dim_ * type_size(type_);
-    for (size_t i = 0; i < n; i++)
-        if (label_to_id_.count(labels[i])) return -1;
+    if (!multi_)
+        for (size_t i = 0; i < n; i++)
+            if (label_to_id_.count(labels[i])) return -1;
     for (size_t i = 0; i < n; i++) addVector(static_cast<const char *>(blobs) + i * in_bytes, labels[i]);
     return flush() ? -1 : (long)n;
 }
@@ -164,7 +169,7 @@ long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
 long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
     // device-generated rows are stored as generated: fp Cosine would need normalisation, so only int8 Cosine
     // (norm appended by the fill kernel) is accepted among the Cosine indexes
-    if (type_ == VecSimType_FLOAT64 || type_ == VecSimType_UINT8) return -1;
+    if (type_ == VecSimType_FLOAT64 || type_ == VecSimType_UINT8 || multi_) return -1;
     if (metric_ == VecSimMetric_Cosine && type_ != VecSimType_INT8) return -1;
     if (flush()) return -1;
     const size_t first = count_;
@@ -182,18 +187,23 @@ long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
     return (long)n;
 }
 
-int FlatIndex::deleteVector(size_t label) {
-    auto it = label_to_id_.find(label);
-    if (it == label_to_id_.end()) return 0;
-    if (flush()) return 0;
-    const uint32_t id = it->second;
-    label_to_id_.erase(it);
-    // removeVector (brute_force.h:196-224): move the last row into the hole, shrink by one
+// removeVector (brute_force.h:196-224): move the last row into the hole, shrink by one
+void FlatIndex::removeRow(uint32_t id) {
     const uint32_t last = (uint32_t)(--count_);
     if (id != last) {
         const size_t last_label = id_to_label_[last];
         id_to_label_[id] = last_label;
-        label_to_id_[last_label] = id;
+        if (multi_) {
+            // replaceIdOfLabel (brute_force_multi.h:241-263): the LAST occurrence of the moved id
+            auto &v = label_to_ids_.at(last_label);
+            for (size_t i = v.size(); i-- > 0;)
+                if (v[i] == last) {
+                    v[i] = id;
+                    break;
+                }
+        } else {
+            label_to_id_[last_label] = id;
+        }
         vsgpu_table_move(table_, id, last);
     }
     vsgpu_table_truncate(table_, count_);
@@ -203,6 +213,28 @@ int FlatIndex::deleteVector(size_t label) {
         else if (id_to_label_.size() >= count_ + 2 * block_size_) id_to_label_.resize(id_to_label_.size() - block_size_);
         id_to_label_.shrink_to_fit();
     }
+}
+
+int FlatIndex::deleteVector(size_t label) {
+    if (multi_) {
+        auto it = label_to_ids_.find(label);
+        if (it == label_to_ids_.end()) return 0;
+        if (flush()) return 0;
+        int removed = 0;
+        // brute_force_multi.h:135-152: walk the label's id list while removals may rewrite its tail
+        for (size_t i = 0; i < it->second.size(); i++) {
+            removeRow(it->second[i]);
+            removed++;
+        }
+        label_to_ids_.erase(label);
+        return removed;
+    }
+    auto it = label_to_id_.find(label);
+    if (it == label_to_id_.end()) return 0;
+    if (flush()) return 0;
+    const uint32_t id = it->second;
+    label_to_id_.erase(it);
+    removeRow(id);
     return 1;
 }
 
@@ -237,6 +269,55 @@ void FlatIndex::replay(const uint32_t *ids, const double *scores, size_t n, size
     }
 }
 
+// Multi-value replay: the same scan with an updatable max-heap keyed by label (utils/updatable_heap.h:
+// 20-113): a label keeps its lowest score; eviction removes the largest score, the largest label among
+// equal scores.
+void FlatIndex::replayMulti(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const {
+    std::multimap<double, size_t, std::greater<double>> by_score;
+    std::unordered_map<size_t, std::multimap<double, size_t, std::greater<double>>::iterator> node_of;
+    auto top_it = [&]() {
+        auto rng = by_score.equal_range(by_score.begin()->first);
+        auto best = rng.first;
+        for (auto i = rng.first; i != rng.second; ++i)
+            if (best->second < i->second) best = i;
+        return best;
+    };
+    double upper = std::numeric_limits<double>::lowest();
+    for (size_t i = 0; i < n; i++) {
+        const double s = scores[i];
+        if (s < upper || node_of.size() < k) {
+            const size_t label = id_to_label_[ids[i]];
+            auto f = node_of.find(label);
+            if (f == node_of.end()) {
+                node_of.emplace(label, by_score.emplace(s, label));
+            } else if (f->second->first > s) {
+                by_score.erase(f->second);
+                f->second = by_score.emplace(s, label);
+            }
+            if (node_of.size() > k) {
+                auto t = top_it();
+                node_of.erase(t->second);
+                by_score.erase(t);
+            }
+            upper = top_it()->first;
+        }
+    }
+    rep->results.resize(node_of.size());
+    for (size_t i = rep->results.size(); i-- > 0;) {
+        auto t = top_it();
+        rep->results[i].score = t->first;
+        rep->results[i].id = t->second;
+        node_of.erase(t->second);
+        by_score.erase(t);
+    }
+}
+
+size_t FlatIndex::distinctLabels(const uint32_t *ids, size_t n) const {
+    std::unordered_set<size_t> seen;
+    for (size_t i = 0; i < n; i++) seen.insert(id_to_label_[ids[i]]);
+    return seen.size();
+}
+
 int FlatIndex::allScores(const void *processed_query, std::vector<double> &scores) {
     if (flush()) return -1;
     scores.resize(count_);
@@ -268,6 +349,51 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     }
     if (count_ == 0) return finish();
     std::vector<char> qbuf = packQueries(queries, nq, stride);
+    if (multi_) {
+        // Rows with score <= the k'-th smallest ROW score, k' grown until they cover k distinct labels (or all
+        // rows): a superset of the rows at or below the k-th smallest per-label minimum, which is what the
+        // label-keyed replay needs.
+        const size_t n_labels = label_to_ids_.size();
+        for (size_t q = 0; q < nq; q++) {
+            size_t kr = std::min(count_, std::max<size_t>(k, 1));
+            std::vector<uint32_t> ids, cnt(1);
+            std::vector<double> sc;
+            for (;;) {
+                const size_t cap = std::max<size_t>(2 * kr, kr + 64);
+                ids.resize(cap);
+                sc.resize(cap);
+                int rc = vsgpu_topk(table_, qbuf.data() + q * query_bytes_, 1, query_bytes_, kr, cap, ids.data(), sc.data(),
+                                    cnt.data());
+                if (rc) {
+                    for (auto *r : reps) delete r;
+                    return rc;
+                }
+                if (cnt[0] == VSGPU_COUNT_OVERFLOW) {  // heavy ties: take every row's score
+                    ids.resize(count_);
+                    sc.resize(count_);
+                    rc = vsgpu_scores(table_, qbuf.data() + q * query_bytes_, 0, count_, sc.data());
+                    if (rc) {
+                        for (auto *r : reps) delete r;
+                        return rc;
+                    }
+                    for (size_t i = 0; i < count_; i++) ids[i] = (uint32_t)i;
+                    cnt[0] = (uint32_t)count_;
+                    break;
+                }
+                if (kr >= count_ || distinctLabels(ids.data(), cnt[0]) >= std::min(k, n_labels)) break;
+                kr = std::min(count_, kr * 4);
+            }
+            replayMulti(ids.data(), sc.data(), cnt[0], k, reps[q]);
+            if (order == BY_ID) sort_reply(reps[q], BY_ID);
+        }
+        if (timed_out(tctx)) {
+            for (auto *r : reps) {
+                r->results.clear();
+                r->code = VecSim_QueryReply_TimedOut;
+            }
+        }
+        return finish();
+    }
     const size_t kk = std::min(k, count_);
     const size_t cap = std::max<size_t>(2 * kk, kk + 64);
     std::vector<uint32_t> ids(nq * cap), counts(nq);
@@ -320,6 +446,7 @@ std::vector<char> FlatIndex::packQueries(const void *queries, size_t nq, size_t 
 int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
                               size_t *labels, double *scores, uint32_t *counts) {
     last_mode_ = STANDARD_KNN;
+    if (multi_) return -1;  // sharded multi-value indexes are not built yet
     if (nq == 0) return 0;
     if (flush()) return -1;
     if (k == 0 || count_ == 0) {
@@ -383,16 +510,43 @@ VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSim
         rep->code = VecSim_QueryReply_TimedOut;
         return rep;
     }
-    rep->results.resize(cnt);
-    for (uint32_t i = 0; i < cnt; i++) {
-        rep->results[i].id = id_to_label_[ids[i]];
-        rep->results[i].score = sc[i];
+    if (multi_) {
+        // unique results container: one entry per label, its lowest score (brute_force_multi.h:100-104)
+        std::unordered_map<size_t, size_t> slot;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const size_t label = id_to_label_[ids[i]];
+            auto f = slot.find(label);
+            if (f == slot.end()) {
+                slot.emplace(label, rep->results.size());
+                rep->results.push_back(VecSimQueryResult{label, sc[i]});
+            } else if (sc[i] < rep->results[f->second].score) {
+                rep->results[f->second].score = sc[i];
+            }
+        }
+    } else {
+        rep->results.resize(cnt);
+        for (uint32_t i = 0; i < cnt; i++) {
+            rep->results[i].id = id_to_label_[ids[i]];
+            rep->results[i].score = sc[i];
+        }
     }
     sort_reply(rep, order);
     return rep;
 }
 
 double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
+    if (multi_) {  // lowest distance over the label's vectors (brute_force_multi.h:224-239)
+        auto f = label_to_ids_.find(label);
+        if (f == label_to_ids_.end() || flush()) return std::numeric_limits<double>::quiet_NaN();
+        std::vector<char> q(query_bytes_);
+        std::memcpy(q.data(), blob, query_bytes_);
+        std::vector<double> s(f->second.size());
+        if (vsgpu_scores_of(table_, q.data(), f->second.data(), f->second.size(), s.data()))
+            return std::numeric_limits<double>::quiet_NaN();
+        double best = std::numeric_limits<double>::infinity();
+        for (double d : s) best = (best < d) ? best : d;
+        return best;
+    }
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end()) return std::numeric_limits<double>::quiet_NaN();
     if (flush()) return std::numeric_limits<double>::quiet_NaN();
@@ -425,7 +579,7 @@ VecSimIndexBasicInfo FlatIndex::basicInfo() const {
     b.algo = VecSimAlgo_BF;
     b.metric = metric_;
     b.type = type_;
-    b.isMulti = false;
+    b.isMulti = multi_;
     b.isTiered = false;
     b.isDisk = false;
     b.blockSize = block_size_;
@@ -441,7 +595,7 @@ VecSimIndexDebugInfo FlatIndex::debugInfo() const {
     VecSimIndexDebugInfo d{};
     d.commonInfo.basicInfo = basicInfo();
     d.commonInfo.indexSize = count_;
-    d.commonInfo.indexLabelCount = count_;
+    d.commonInfo.indexLabelCount = indexLabelCount();
     d.commonInfo.memory = statsInfo().memory;
     d.commonInfo.lastMode = last_mode_;
     return d;
@@ -452,7 +606,7 @@ VecSimBatchIterator *FlatIndex::newBatchIterator(const void *query, VecSimQueryP
     it->index = this;
     it->query = preprocessQuery(query);
     it->timeout_ctx = qp ? qp->timeoutCtx : nullptr;
-    it->label_count = count_;
+    it->label_count = indexLabelCount();
     return it;
 }
 

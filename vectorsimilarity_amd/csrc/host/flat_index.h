@@ -83,7 +83,7 @@ public:
     int addVector(const void *blob, size_t label) override;
     int deleteVector(size_t label) override;
     size_t indexSize() const override { return count_; }
-    size_t indexLabelCount() const override { return count_; }
+    size_t indexLabelCount() const override { return multi_ ? label_to_ids_.size() : count_; }
     VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) override;
     int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                        VecSimQueryReply_Order order, VecSimQueryReply **out) override;
@@ -105,6 +105,7 @@ public:
     // used by the batch iterator
     int allScores(const void *processed_query, std::vector<double> &scores);
     size_t labelOf(size_t id) const { return id_to_label_[id]; }
+    bool isMulti() const { return multi_; }
     size_t queryBytes() const { return query_bytes_; }
     std::vector<char> preprocessQuery(const void *query) const;
 
@@ -115,6 +116,9 @@ private:
     void log(const char *level, const char *fmt, ...) const;
     std::vector<char> packQueries(const void *queries, size_t nq, size_t stride) const;
     void replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const;
+    void replayMulti(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const;
+    size_t distinctLabels(const uint32_t *ids, size_t n) const;
+    void removeRow(uint32_t id);
 
     VecSimType type_ = VecSimType_FLOAT32;
     VecSimMetric metric_ = VecSimMetric_L2;
@@ -126,6 +130,9 @@ private:
     size_t count_ = 0;  // vectors in the index (device rows + staged rows)
     std::vector<size_t> id_to_label_;
     std::unordered_map<size_t, uint32_t> label_to_id_;
+    // multi-value index (brute_force_multi.h): a label owns any number of vectors
+    bool multi_ = false;
+    std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     std::vector<char> staged_;  // rows appended but not yet uploaded
     size_t staged_rows_ = 0;
     mutable VecSearchMode last_mode_ = EMPTY_MODE;

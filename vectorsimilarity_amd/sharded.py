@@ -15,6 +15,7 @@ over the union in gid order (VecSimGpu_MergeTopK), which reproduces the single-i
 ties included.  No other collective touches the data path.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -129,7 +130,7 @@ class ShardedFlatIndex:
         queries = np.ascontiguousarray(queries)
         if queries.ndim == 1:
             queries = queries[None, :]
-        if self.world == 1 or self.dist is None:
+        if self.dist is None or (self.world == 1 and not os.environ.get("VECSIM_FORCE_GATHER")):
             return self.local.knn_query(queries, k)
         nq = queries.shape[0]
         cap = max(2 * k, k + 16)
