@@ -12,10 +12,10 @@ from vectorsimilarity_amd import VecSim, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--scale", type=float, default=0.4)
+ap.add_argument("--scale", type=float, default=0.2)
 a = ap.parse_args()
 CASES = [("i8 cos 1024 B256", VecSim.VecSimType_INT8, VecSim.VecSimMetric_Cosine, 1024, int(50_000_000 * a.scale), 256, 100, synth.rows_i8, 1028),
-         ("bf16 ip 768 B128", VecSim.VecSimType_BFLOAT16, VecSim.VecSimMetric_IP, 768, 12_500_000, 128, 10, synth.rows_bf16, 1536)]
+         ("bf16 ip 768 B128", VecSim.VecSimType_BFLOAT16, VecSim.VecSimMetric_IP, 768, 6_000_000, 128, 10, synth.rows_bf16, 1536)]
 for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = typ, dim, metric
@@ -25,8 +25,12 @@ for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
     base = [ix.knn_query(x, k) for x in q]
     res = {}
     for r in range(a.rounds):
-        for v, w in itertools.product([0, 1, 2], [1, 2, 3]):
-            ix.set_option("lowp_variant", v)
+        combos = list(itertools.product(range(0, 13 if 'i8' in name else 8), [1]))
+        if "i8" in name:
+            combos += [(100, 2)]   # query-split int8: two 128-query workgroups per tile
+        for v, w in combos:
+            ix.set_option("lowp_qsplit", 1 if v == 100 else 0)
+            ix.set_option("lowp_variant", 0 if v == 100 else v)
             ix.set_option("wg_per_cu", w)
             ix.reset_stats()
             for b in range(2):

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mfma_kernels.hpp"
 
 namespace vsg {
@@ -66,22 +68,51 @@ struct LowpParams {
     uint32_t *counts;
     uint2 *cand;
     uint32_t cap;
+    int dbg;                             // diagnosis switches (vsgpu option lowp_dbg), 0 in production
 };
 
-constexpr int lowp_lds_bytes(int nwaves) { return 3 * MF_STAGE_BYTES + nwaves * 512 + MF_EQ_BYTES; }
+// Ring geometry.  NS slots of STAGE bytes (16 KiB unless stated); a slot ("unit") holds RT rows x SEG bytes, a tile is KCH units.  NS-1
+// units are requested ahead of the one being consumed, which reaches TA tiles ahead, so TA+1 per-tile aux
+// buffers (256 B per wave each) are live at once.
+constexpr int lowp_kch(int ksteps, int rt, int stage) { return ksteps / ((stage / rt) / 64); }
+constexpr int lowp_ta(int ksteps, int rt, int ns, int stage) {
+    return (lowp_kch(ksteps, rt, stage) - 1 + (ns - 1)) / lowp_kch(ksteps, rt, stage);
+}
+constexpr int lowp_lds_bytes(int nwaves, int ksteps, int rt, int ns, int stage = MF_STAGE_BYTES) {
+    return ns * stage + nwaves * 256 * (lowp_ta(ksteps, rt, ns, stage) + 1) + MF_EQ_BYTES;
+}
 
-template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1>
+// s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
+__device__ static inline void lowp_wait_vmcnt(int n) {
+    switch (n) {
+#define VSG_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    VSG_W(0) VSG_W(1) VSG_W(2) VSG_W(3) VSG_W(4) VSG_W(5) VSG_W(6) VSG_W(7) VSG_W(8) VSG_W(9) VSG_W(10) VSG_W(11)
+    VSG_W(12) VSG_W(13) VSG_W(14) VSG_W(15) VSG_W(16) VSG_W(17) VSG_W(18) VSG_W(19) VSG_W(20) VSG_W(21) VSG_W(22)
+    VSG_W(23) VSG_W(24) VSG_W(25) VSG_W(26) VSG_W(27) VSG_W(28) VSG_W(29) VSG_W(30) VSG_W(31) VSG_W(32) VSG_W(33)
+    VSG_W(34) VSG_W(35) VSG_W(36) VSG_W(37) VSG_W(38) VSG_W(39) VSG_W(40)
+#undef VSG_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+#ifndef LOWP_PF
+#define LOWP_PF 4
+#endif
+template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
-    constexpr int NS = 3;
+    constexpr int D = NS - 1;                   // units requested ahead
     constexpr int MT = RT / 16;
-    constexpr int SEG = MF_STAGE_BYTES / RT;    // bytes per row per stage: 1024 / 512 / 256
+    constexpr int SEG = STAGE / RT;    // bytes per row per stage: 1024 / 512 / 256
     constexpr int KSUB = SEG / 64;              // k-steps (64 B of row each) per stage
     static_assert(KSTEPS % KSUB == 0, "row bytes must be a multiple of the stage segment");
     constexpr int KCH = KSTEPS / KSUB;
-    static_assert(KCH >= 2, "a tile must span at least two ring slots");
-    constexpr int IPW = 16 / NWAVES;            // DMA instructions per wave per stage
+    constexpr int IPW = (STAGE / 1024) / NWAVES;  // DMA instructions (1 KiB each) per wave per stage
+    static_assert(IPW >= 1 && SEG * RT == STAGE && KSUB >= 1, "stage geometry");
+    constexpr int TA = (KCH - 1 + D) / KCH;     // tiles ahead reached by the prefetch
+    constexpr int NAUX = TA + 1;
+    static_assert((D - 1) * IPW + D <= 40, "vmcnt immediate table");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -115,6 +146,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         for (int s = 0; s < KSTEPS; s++) asm volatile("" : "+v"(qf[nt][s]));
         asm volatile("" : "+v"(qaux[nt]), "+v"(tau[nt]));
     }
+    // int8 Cosine: the exact score needs an IEEE divide per (row, query).  1 - dot/(nx*nq) <= tau  <=>
+    // dot >= (1 - tau) * nq * nx, so a row is first screened with one multiply against cosq = ((1 - tau) - m) * nq,
+    // m covering every rounding on either side (each is below 2^-21 relative to |1 - tau| <= 3); only rows that
+    // pass -- a handful per query -- get the exact score and the exact test.
+    float cosq[NQW];
+#pragma unroll
+    for (int nt = 0; nt < NQW; nt++) {
+        const float omt = 1.0f - tau[nt];
+        cosq[nt] = (omt - 1e-5f * (1.0f + fabsf(omt))) * __uint_as_float(qaux[nt]);
+    }
 
     // staging geometry: instruction g = wave*IPW + t fills LDS bytes [1024 g, 1024 g + 1024)
     uint32_t st_row[IPW], st_off[IPW];
@@ -126,22 +167,38 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * IPW * 1024);
-    char *aux_lds = lds + NS * MF_STAGE_BYTES + wave * 512;
-    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + NWAVES * 512);
-    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + NWAVES * 512 + 16);
-    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
+    char *aux_lds = lds + NS * STAGE + wave * (256 * NAUX);
+    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * STAGE + NWAVES * 256 * NAUX);
+    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * STAGE + NWAVES * 256 * NAUX + 16);
+    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq), aux_lds_off = mf_lds_offset(aux_lds);
     if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
 
     const uint32_t step = gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
-    const char *rp_cur[IPW], *rp_nxt[IPW];
-    const uint32_t *ap_cur, *ap_nxt;
+    // Requests are issued strictly in unit order, so only the frontier tile's addresses are kept
+    const char *rp_f[IPW];
+    const uint32_t *ap_f;
+    // slab base pointers are scalar loads (hundreds of cycles each, and they drain lgkmcnt): reload only when
+    // a tile crosses into another slab
+    uint32_t cur_slab = 0xFFFFFFFFu;
+    uint64_t cur_sbase = 0, cur_abase = 0;
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[IPW], const uint32_t *&ap) {
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;
         const uint32_t r0 = tile_row0(tt);
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
-        const char *sbase = P.slabs[sidx];
-        const uint32_t *abase = P.aux_slabs[sidx];
+        if (sidx != cur_slab) {
+            // asm scalar loads: left to hipcc these become vector loads, and the vmcnt(0) it then needs on the
+            // join path drains the whole DMA ring at every tile
+            cur_slab = sidx;
+            const char *const *sp = P.slabs + sidx;
+            const uint32_t *const *axp = P.aux_slabs + sidx;
+            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(cur_sbase), "=&s"(cur_abase)
+                         : "s"(sp), "s"(axp)
+                         : "memory");
+        }
+        const char *sbase = reinterpret_cast<const char *>(cur_sbase);
+        const uint32_t *abase = reinterpret_cast<const uint32_t *>(cur_abase);
 #pragma unroll
         for (int i = 0; i < IPW; i++) {
             uint32_t row = r0 + st_row[i];
@@ -152,23 +209,35 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         if (arow >= P.n_rows) arow = P.n_rows - 1;
         ap = abase + (arow & P.slab_mask);
     };
-    auto issue = [&](const char *const (&rp)[IPW], const uint32_t *ap, int kc, uint32_t slot, bool with_aux,
-                     uint32_t parity) {
-        const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
+    auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
+                     uint32_t abuf_i) {
+        const uint32_t base = slot * STAGE + lds_stage_wave_off;
+        if (!(P.dbg & 4)) {
 #pragma unroll
-        for (int i = 0; i < IPW; i++) glds16<2>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
-        if (with_aux) glds4(ap, parity * 256, aux_lds);
+            for (int i = 0; i < IPW; i++) glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+        }
+        if (with_aux) glds4(apt, abuf_i * 256, aux_lds);
     };
 
     uint32_t tile = blockIdx.x;
-    make_ptrs(tile, rp_cur, ap_cur);
-    make_ptrs(tile + step, rp_nxt, ap_nxt);
-    uint32_t slot_c = 0, parity = 0;
-    issue(rp_cur, ap_cur, 0, 0, true, 0);
-    issue(rp_cur, ap_cur, 1, 1, false, 0);
+    uint32_t ftile = tile, fbuf = 0;  // frontier: tile and aux buffer of the unit requested next
+    make_ptrs(ftile, rp_f, ap_f);
+    uint32_t slot_c = 0, abuf = 0;   // ring slot / aux buffer of the unit / tile being consumed
+    uint32_t tiles_done = 0;
+    auto advance_frontier = [&]() {
+        ftile += step;
+        make_ptrs(ftile, rp_f, ap_f);
+        fbuf = fbuf + 1 == NAUX ? 0 : fbuf + 1;
+    };
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        if (u > 0 && u % KCH == 0) advance_frontier();
+        issue(rp_f, ap_f, u % KCH, u, (u % KCH) == 0, fbuf);
+    }
 
     for (; tile < P.n_tiles; tile += step) {
         acc_t acc[MT][NQW];
+        u32x4_t auxv[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -176,98 +245,133 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
-            // unit c landed; unit c+1 (IPW loads, +1 aux load if it opens the next tile) may stay in flight
-            if (IPW == 1) {
-                if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            } else if (IPW == 2) {
-                if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                if (c + 1 == KCH) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // unit c landed; units c+1 .. c+D-1 (IPW row loads each, +1 aux load where a unit opens a tile)
+            // may stay in flight
+            {
+                int n_out = (D - 1) * IPW;
+#pragma unroll
+                for (int j = 1; j < D; j++) n_out += ((c + j) % KCH == 0) ? 1 : 0;
+                lowp_wait_vmcnt(n_out);
             }
             __builtin_amdgcn_s_barrier();
-            if (MODE == MF_FILTER && c == 0) {
+            if (MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
+                // (entries past the queue's capacity go straight to global memory, so a late flush is only slower)
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
             }
             {
-                uint32_t slot_p = slot_c + 2;
+                uint32_t slot_p = slot_c + D;
                 if (slot_p >= NS) slot_p -= NS;
-                if (c + 2 < KCH) issue(rp_cur, ap_cur, c + 2, slot_p, false, 0);
-                else issue(rp_nxt, ap_nxt, c + 2 - KCH, slot_p, (c + 2 - KCH) == 0, parity ^ 1u);
+                const int kc = (c + D) % KCH;
+                if (kc == 0) advance_frontier();
+                issue(rp_f, ap_f, kc, slot_p, kc == 0, fbuf);
             }
-            const char *sbase = lds + slot_c * MF_STAGE_BYTES;
-            // LDS reads are issued in groups of PF fragments ahead of the MFMAs that consume them, so the
-            // ds_read latency overlaps the matrix pipe instead of serialising with it (hipcc otherwise
-            // emits read -> wait -> mfma per fragment)
+            const char *sbase = lds + slot_c * STAGE;
+            // The unit's NFRAG A-fragments are read once each and feed NQW MFMAs.  Left alone hipcc emits
+            // ds_read -> s_waitcnt lgkmcnt(0) -> mfma per fragment (measured: 60 % of wave cycles parked, matrix
+            // pipe 25 % busy), so the schedule is pinned: PF reads up front, then one read per NQW MFMAs, which
+            // keeps PF fragments in flight and lets the compiler count lgkmcnt down instead of draining it.
             constexpr int NFRAG = KSUB * MT;
-            constexpr int PF = NFRAG < 8 ? NFRAG : 8;
+            constexpr int PF = NFRAG < LOWP_PF ? NFRAG : LOWP_PF;
+            if (!(P.dbg & 2)) {
+            u32x4_t afr[NFRAG];
 #pragma unroll
-            for (int g = 0; g < NFRAG; g += PF) {
-                u32x4_t afr[PF];
+            for (int f = 0; f < NFRAG; f++) {
+                const int j = f / MT, mt = f % MT;
+                const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
+                const int p = (4 * (j % 4) + kq) ^ m16;
+                afr[f] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
+            }
 #pragma unroll
-                for (int f = 0; f < PF; f++) {
-                    const int j = (g + f) / MT, mt = (g + f) % MT;
-                    const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
-                    const int p = (4 * (j % 4) + kq) ^ m16;
-                    afr[f] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
-                }
+            for (int f = 0; f < NFRAG; f++) {
+                const int j = f / MT, mt = f % MT;
 #pragma unroll
-                for (int f = 0; f < PF; f++) {
-                    const int j = (g + f) / MT, mt = (g + f) % MT;
+                for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(afr[f], qf[nt][c * KSUB + j], acc[mt][nt]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-                    for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(afr[f], qf[nt][c * KSUB + j], acc[mt][nt]);
-                }
+            for (int f = 0; f < NFRAG - PF; f++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NQW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, PF * NQW, 0);
+            }
+            if (c == KCH - 1) {
+                // this tile's aux values (landed with unit 0): plain asm so that hipcc does not tie the read to
+                // the LDS-DMA stream and drain vmcnt in front of it
+                const uint32_t aoff = aux_lds_off + abuf * 256 + kq * 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(auxv[mt]) : "v"(aoff), "n"(mt * 64));
             }
             slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
         }
 
         // ---- epilogue ----
         const uint32_t r0 = tile_row0(tile);
-        const uint32_t *aux = reinterpret_cast<const uint32_t *>(aux_lds + parity * 256);
+        const uint32_t nvalid = P.n_rows - r0;   // rows of this tile that exist (>= RT except in the last tile)
         bool emitted = false;
         float tmin[NQW];
 #pragma unroll
         for (int nt = 0; nt < NQW; nt++) tmin[nt] = INFINITY;
+        // aux values were requested by the asm reads above (invisible to hipcc's own lgkmcnt bookkeeping)
+        if (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]));
+        else if (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]), "+v"(auxv[1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]), "+v"(auxv[1]), "+v"(auxv[2]), "+v"(auxv[3]));
+        auto epilogue = [&](auto epi_tag) {
+            constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const uint4 a4 = *reinterpret_cast<const uint4 *>(aux + mt * 16 + kq * 4);
-            const uint32_t av[4] = {a4.x, a4.y, a4.z, a4.w};
+            for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t row = r0 + mt * 16 + kq * 4 + i;
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lrow = mt * 16 + kq * 4 + i;
+                    const uint32_t av = auxv[mt][i];
 #pragma unroll
-                for (int nt = 0; nt < NQW; nt++) {
-                    float low, up;
-                    if (LK == LP_I8) {
-                        const int dot = (int)acc[mt][nt][i];
-                        float s;
-                        if (P.epi == LE_I8_L2) s = (float)((int)av[i] + (int)qaux[nt] - 2 * dot);
-                        else if (P.epi == LE_I8_IP) s = (float)(1 - dot);
-                        else s = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av[i]), __uint_as_float(qaux[nt]))));
-                        low = up = s;
-                    } else {
-                        const float dot = (float)acc[mt][nt][i];
-                        const float ssum = __uint_as_float(av[i]) + __uint_as_float(qaux[nt]);
-                        const float a = (P.epi == LE_FP_L2) ? (ssum - 2.0f * dot) : (1.0f - dot);
-                        const float E = P.cE * ssum + P.absE;
-                        low = a - E;
-                        up = a + E;
-                    }
-                    if (MODE == MF_PROBE) {
-                        if (row < P.n_rows && up < tmin[nt]) tmin[nt] = up;
-                    } else if (row < P.n_rows && low <= tau[nt]) {
-                        const uint32_t pos = mf_queue_reserve(eq_n_off);
-                        if (pos < MF_EQ_CAP) {
-                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                    for (int nt = 0; nt < NQW; nt++) {
+                        float low, up;
+                        if (LK == LP_I8) {
+                            const int dot = (int)acc[mt][nt][i];
+                            if (MODE == MF_FILTER && EPI == LE_I8_COS) {
+                                // NaN thresholds (zero norms, infinite tau) fall through to the exact test
+                                if ((float)dot < cosq[nt] * __uint_as_float(av)) continue;
+                            }
+                            float sc;
+                            if (EPI == LE_I8_L2) sc = (float)((int)av + (int)qaux[nt] - 2 * dot);
+                            else if (EPI == LE_I8_IP) sc = (float)(1 - dot);
+                            else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qaux[nt]))));
+                            low = up = sc;
                         } else {
-                            uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
-                            if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                            emitted = true;
+                            const float dot = (float)acc[mt][nt][i];
+                            const float ssum = __uint_as_float(av) + __uint_as_float(qaux[nt]);
+                            const float a = (EPI == LE_FP_L2) ? (ssum - 2.0f * dot) : (1.0f - dot);
+                            const float E = P.cE * ssum + P.absE;
+                            low = a - E;
+                            up = a + E;
+                        }
+                        if (MODE == MF_PROBE) {
+                            if (lrow < nvalid && up < tmin[nt]) tmin[nt] = up;
+                        } else if (lrow < nvalid && low <= tau[nt]) {
+                            const uint32_t row = r0 + lrow;
+                            const uint32_t pos = mf_queue_reserve(eq_n_off);
+                            if (pos < MF_EQ_CAP) {
+                                mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                            } else {
+                                uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
+                                if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                                emitted = true;
+                            }
                         }
                     }
                 }
+            }
+        };
+        if (!(P.dbg & 1)) {
+            if (LK == LP_I8) {
+                if (P.epi == LE_I8_COS) epilogue(std::integral_constant<int, LE_I8_COS>{});
+                else if (P.epi == LE_I8_L2) epilogue(std::integral_constant<int, LE_I8_L2>{});
+                else epilogue(std::integral_constant<int, LE_I8_IP>{});
+            } else {
+                if (P.epi == LE_FP_L2) epilogue(std::integral_constant<int, LE_FP_L2>{});
+                else epilogue(std::integral_constant<int, LE_FP_IP>{});
             }
         }
         if (MODE == MF_PROBE) {
@@ -283,11 +387,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int i = 0; i < IPW; i++) rp_cur[i] = rp_nxt[i];
-        ap_cur = ap_nxt;
-        make_ptrs(tile + 2 * step, rp_nxt, ap_nxt);
-        parity ^= 1u;
+        abuf = abuf + 1 == NAUX ? 0 : abuf + 1;
+        tiles_done++;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER) {

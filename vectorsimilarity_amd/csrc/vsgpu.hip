@@ -71,6 +71,8 @@ struct vsgpu_ctx {
     long opt_mfma = 1;
     long opt_mfma_variant = 0;
     long opt_lowp_variant = 0;
+    long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
+    long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;
     long opt_mfma_min_q = 9;          // narrower batches stay on the exact kernel (one BT=8 pass is HBM-bound)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
@@ -164,6 +166,8 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     if (n == "mfma") c->opt_mfma = value;
     else if (n == "mfma_variant") c->opt_mfma_variant = value;
     else if (n == "lowp_variant") c->opt_lowp_variant = value;
+    else if (n == "lowp_dbg") c->opt_lowp_dbg = value;
+    else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = std::max(1L, value);
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
@@ -973,18 +977,25 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
 }
 
 // ------------------------------------------------------------------ low-precision MFMA filter path
+// One launcher for every instantiation: ring depths above 3 slots need more than the default 64 KiB of
+// dynamic LDS, which HIP only grants after the attribute is raised.
+template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES>
+static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto kern = k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+}
 template <int LK, int KS, int RT, int NQW>
 static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE)
-        hipLaunchKernelGGL((k_mfma_filter_lowp<LK, KS, MF_PROBE, RT, 8, NQW>), grid, dim3(512), lowp_lds_bytes(8), s, P);
-    else
-        hipLaunchKernelGGL((k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, 8, NQW>), grid, dim3(512), lowp_lds_bytes(8), s, P);
+    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, KS, MF_FILTER, RT, 8, NQW, 1, 3>(P, grid, s);
 }
 template <int KS, int RT> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE)
-        hipLaunchKernelGGL((k_mfma_filter_lowp<LP_I8, KS, MF_PROBE, RT, 16, 1>), grid, dim3(1024), lowp_lds_bytes(16), s, P);
-    else
-        hipLaunchKernelGGL((k_mfma_filter_lowp<LP_I8, KS, MF_FILTER, RT, 16, 1>), grid, dim3(1024), lowp_lds_bytes(16), s, P);
+    if (mode == MF_PROBE) launch_lowp_k<LP_I8, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LP_I8, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
 }
 template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     switch (ks) {
@@ -994,15 +1005,44 @@ template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams
     default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
     }
 }
-// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024
-static bool launch_lowp_variant(const vsgpu_table *t, int variant, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode != MF_FILTER || variant == 0) return false;
+// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024.  A variant
+// picks its own tile height, so it sizes the tile count and the grid itself.
+static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P, uint32_t max_wgs, unsigned q_tiles,
+                                hipStream_t s) {
+    if (variant == 0) return false;
+    auto go = [&](int rt, auto launcher) {
+        P.tile_first = 0;
+        P.tile_step = 1;
+        P.n_tiles = (uint32_t)((t->n + rt - 1) / rt);
+        launcher(P, dim3(std::min(P.n_tiles, max_wgs), q_tiles), s);
+        return true;
+    };
     if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) {
-        if (variant == 1) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_BF16, 24, MF_FILTER, 32, 8, 1, 4>), grid, dim3(512), lowp_lds_bytes(8), s, P); return true; }
-        if (variant == 2) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_BF16, 24, MF_FILTER, 32, 8, 1, 3>), grid, dim3(512), lowp_lds_bytes(8), s, P); return true; }
+        switch (variant) {
+        case 1: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4>);
+        case 2: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 6>);
+        case 3: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 8>);
+        case 4: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 2, 4>);
+        case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
+        case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
+        case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
+        }
     }
     if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
-        if (variant == 1) { hipLaunchKernelGGL((k_mfma_filter_lowp<LP_I8, 16, MF_FILTER, 32, 8, 2, 1>), grid, dim3(512), lowp_lds_bytes(8), s, P); return true; }
+        switch (variant) {
+        case 1: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4>);
+        case 2: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 6>);
+        case 3: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 8>);
+        case 4: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 4>);           // 16 whole rows
+        case 5: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 6>);
+        case 6: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768>);    // 32 whole rows
+        case 7: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>);
+        case 8: return go(64, launch_lowp_k<LP_I8, 16, MF_FILTER, 64, 16, 1, 1, 4, 32768>);    // 64 rows x 512 B
+        case 9: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3>);            // 8 waves x 32 queries
+        case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
+        case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
+        case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
+        }
     }
     return false;
 }
@@ -1010,12 +1050,32 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
     else {
-        // 16 waves x 16 queries: measured 2.47 TB/s vs 2.0 TB/s for 8 waves x 32 queries (gpurun_out/tune_lowp_3.log)
+        // 16 waves x 16 queries.  d=1024 filter: a ring slot holds 32 whole rows (1 KiB per DMA instruction, one
+        // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
+        // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
         switch (t->lp_ksteps) {
         case 8: launch_lowp_i8<8, 64>(mode, P, grid, s); break;
         case 12: launch_lowp_i8<12, 64>(mode, P, grid, s); break;
-        default: launch_lowp_i8<16, 32>(mode, P, grid, s); break;
+        default:
+            if (mode == MF_FILTER) launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
+            else launch_lowp_i8<16, 32>(mode, P, grid, s);
+            break;
         }
+    }
+}
+
+// int8 with the query batch split over two 8-wave workgroups (blockIdx.y): both stream the same row tiles, the
+// second reader is expected to hit L2 (same XCD when gridDim.x % 8 == 0)
+static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_ksteps == 16 && t->lp_rt == 32) {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 2, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 2, 3>(P, grid, s);
+    } else if (t->lp_ksteps == 12) {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 12, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 12, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
+    } else {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 8, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 8, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
     }
 }
 
@@ -1024,7 +1084,8 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n, dim = t->dim;
     const int KS = t->lp_ksteps, RT = t->lp_rt;
-    const size_t QT = (size_t)t->lp_qtile, NQW = QT / 128;
+    const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
+    const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_int = (t->lp_kind == LP_I8);
     const size_t eb = is_int ? 1 : 2;
@@ -1127,7 +1188,8 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        else launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
                            (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
@@ -1141,11 +1203,19 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
         const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
-        if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream))
+        Q.dbg = (int)c->opt_lowp_dbg;
+        if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
             launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
+        HIPCHK(hipStreamSynchronize(c->stream));
+        account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
+        for (size_t q = 0; q < nq; q++) counts[q] = 0;
+        return VSGPU_OK;
+    }
     if (!is_int) {
         ScanParams S{};
         S.slabs = t->d_slabs;
