@@ -316,12 +316,13 @@ def test_mfma_filter_path_bit_exact(vso, metric, dim, n, nq, k):
     srows = stored_rows(vso, rows, "f32", metric)
     sq = stored_rows(vso, q, "f32", metric)
     el, es = _fast_oracle(vso, "IP" if metric == "Cosine" else metric, srows, sq, k, dim)
-    assert np.array_equal(l1, el)
-    assert np.array_equal(d1, es)
+    bad = np.argwhere(l1 != el)
+    assert bad.size == 0, ("labels differ at (query, rank)", bad[:8].tolist(), l1[bad[0][0]][:12], el[bad[0][0]][:12], st)
+    assert np.array_equal(d1, es), st
     # and the exact (no-MFMA) GPU path agrees too
     ix.set_option("mfma", 0)
     l2, d2 = ix.knn_query(q, k)
-    assert np.array_equal(l1, l2) and np.array_equal(d1, d2)
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2), ix.stats()
 
 
 def test_mfma_filter_adversarial_near_duplicates(vso):

@@ -81,6 +81,21 @@ struct vsgpu_ctx {
     int n_cu = 256;
 };
 
+// VSGPU_POISON=<byte>: fill every fresh device allocation with that byte (test aid: makes any read of memory the
+// library never wrote deterministic instead of depending on what the allocator hands back)
+static int poison_byte() {
+    static const int v = [] {
+        const char *e = getenv("VSGPU_POISON");
+        return e ? (int)(strtol(e, nullptr, 0) & 0xFF) : -1;
+    }();
+    return v;
+}
+static void poison(void *p, size_t bytes) {
+    if (poison_byte() >= 0 && p) {
+        (void)hipMemset(p, poison_byte(), bytes);
+        (void)hipDeviceSynchronize();
+    }
+}
 static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return VSGPU_OK;
     if (b.p) HIPCHK(hipFree(b.p));
@@ -89,6 +104,7 @@ static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     size_t want = std::max(bytes, (size_t)4096);
     want = (want + 0xFFFF) & ~(size_t)0xFFFF;
     HIPCHK(hipMalloc(&b.p, want));
+    poison(b.p, want);
     b.cap = want;
     return VSGPU_OK;
 }
@@ -102,6 +118,7 @@ static int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
     c->pinned_cap = 0;
     size_t want = (std::max(bytes, (size_t)1 << 20) + 0xFFFF) & ~(size_t)0xFFFF;
     HIPCHK(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    if (poison_byte() >= 0) memset(c->pinned, poison_byte(), want);
     c->pinned_cap = want;
     return VSGPU_OK;
 }
@@ -304,10 +321,12 @@ static int grow_to(vsgpu_table *t, size_t rows) {
     while (t->slabs.size() < need) {
         char *p = nullptr;
         HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes));
+        poison(p, slab_rows * t->row_bytes);
         t->slabs.push_back(p);
         if (t->mfma_ok || t->lowp_ok) {
             float *np = nullptr;
             HIPCHK(hipMalloc((void **)&np, slab_rows * sizeof(float)));
+            poison(np, slab_rows * sizeof(float));
             t->norm_slabs.push_back(np);
         }
         changed = true;
