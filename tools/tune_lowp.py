@@ -25,9 +25,7 @@ for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
     base = [ix.knn_query(x, k) for x in q]
     res = {}
     for r in range(a.rounds):
-        combos = list(itertools.product(range(0, 13 if 'i8' in name else 8), [1]))
-        if "i8" in name:
-            combos += [(100, 2)]   # query-split int8: two 128-query workgroups per tile
+        combos = [(v, 1) for v in ([0, 7, 9, 10, 20] if 'i8' in name else [0, 3, 20, 21, 22])]
         for v, w in combos:
             ix.set_option("lowp_qsplit", 1 if v == 100 else 0)
             ix.set_option("lowp_variant", 0 if v == 100 else v)

@@ -78,8 +78,10 @@ constexpr int lowp_kch(int ksteps, int rt, int stage) { return ksteps / ((stage 
 constexpr int lowp_ta(int ksteps, int rt, int ns, int stage) {
     return (lowp_kch(ksteps, rt, stage) - 1 + (ns - 1)) / lowp_kch(ksteps, rt, stage);
 }
-constexpr int lowp_lds_bytes(int nwaves, int ksteps, int rt, int ns, int stage = MF_STAGE_BYTES) {
-    return ns * stage + nwaves * 256 * (lowp_ta(ksteps, rt, ns, stage) + 1) + MF_EQ_BYTES;
+constexpr int LOWP_WQ_CAP = 64;  // SKEW: records per wave-private queue (a 16-byte header holds the fill count)
+constexpr int lowp_lds_bytes(int nwaves, int ksteps, int rt, int ns, int stage = MF_STAGE_BYTES, bool skew = false) {
+    return ns * stage + nwaves * 256 * (lowp_ta(ksteps, rt, ns, stage) + 1) +
+           (skew ? nwaves * (16 + LOWP_WQ_CAP * 16) : MF_EQ_BYTES);
 }
 
 // s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
@@ -98,7 +100,8 @@ __device__ static inline void lowp_wait_vmcnt(int n) {
 #ifndef LOWP_PF
 #define LOWP_PF 4
 #endif
-template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES>
+template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
+          bool SKEW = false>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
@@ -113,11 +116,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     constexpr int TA = (KCH - 1 + D) / KCH;     // tiles ahead reached by the prefetch
     constexpr int NAUX = TA + 1;
     static_assert((D - 1) * IPW + D <= 40, "vmcnt immediate table");
+    static_assert(!SKEW || (MODE == MF_FILTER && D >= 2 && (NWAVES == 8 || NWAVES == 16)), "phase-skewed variant");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = SKEW ? ((wave >> 2) & 1) : 0;  // SKEW: waves w and w+4 share a SIMD, one of each half
     const int m16 = lane & 15;
     const int kq = lane >> 4;
     const int qtile = blockIdx.y;
@@ -171,7 +176,33 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * STAGE + NWAVES * 256 * NAUX);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * STAGE + NWAVES * 256 * NAUX + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq), aux_lds_off = mf_lds_offset(aux_lds);
-    if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
+    // SKEW: wave-private queue [fill count, pad][LOWP_WQ_CAP records] in place of the workgroup queue
+    const uint32_t wq_cnt_off = mf_lds_offset(lds + NS * STAGE + NWAVES * 256 * NAUX) + (uint32_t)wave * (16 + LOWP_WQ_CAP * 16);
+    const uint32_t q_cnt_off = SKEW ? wq_cnt_off : eq_n_off, q_rec_off = SKEW ? wq_cnt_off + 16 : eq_off;
+    constexpr uint32_t Q_CAP = SKEW ? LOWP_WQ_CAP : MF_EQ_CAP;
+    if (SKEW) {
+        const uint32_t zero = 0;
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(wq_cnt_off), "v"(zero) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (MODE == MF_FILTER && tid == 0) {
+        *eq_n = 0;
+    }
+    // SKEW: a wave empties its own queue, no barrier involved
+    auto drain_wave_queue = [&]() {
+        uint32_t n;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(n) : "v"(wq_cnt_off) : "memory");
+        n = min(n, (uint32_t)LOWP_WQ_CAP);
+        if ((uint32_t)lane < n) {
+            u32x4_t r;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(wq_cnt_off + 16u + (uint32_t)lane * 16u) : "memory");
+            const uint32_t s = atomicAdd(&P.counts[r[1]], 1u);
+            if (s < P.cap) P.cand[(size_t)r[1] * P.cap + s] = make_uint2(r[0], r[2]);
+        }
+        const uint32_t zero = 0;
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(wq_cnt_off), "v"(zero) : "memory");
+        // stores/atomics share the VM counter with the staged loads: drain so the counted waits stay exact
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
 
     const uint32_t step = gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
@@ -235,6 +266,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         issue(rp_f, ap_f, u % KCH, u, (u % KCH) == 0, fbuf);
     }
 
+    if (SKEW && half == 1) {
+        // half 1 runs the same program one barrier later; its share of unit 0 must be in LDS before half 0 starts
+        int n_out = (D - 1) * IPW;
+#pragma unroll
+        for (int j = 1; j < D; j++) n_out += (j % KCH == 0) ? 1 : 0;
+        lowp_wait_vmcnt(n_out);
+        __builtin_amdgcn_s_barrier();
+    }
     for (; tile < P.n_tiles; tile += step) {
         acc_t acc[MT][NQW];
         u32x4_t auxv[MT];
@@ -247,31 +286,32 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         for (int c = 0; c < KCH; c++) {
             // unit c landed; units c+1 .. c+D-1 (IPW row loads each, +1 aux load where a unit opens a tile)
             // may stay in flight
-            {
+            if (!SKEW || half == 0) {
                 int n_out = (D - 1) * IPW;
 #pragma unroll
                 for (int j = 1; j < D; j++) n_out += ((c + j) % KCH == 0) ? 1 : 0;
                 lowp_wait_vmcnt(n_out);
             }
             __builtin_amdgcn_s_barrier();
-            if (MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
+            if (!SKEW && MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
                 // (entries past the queue's capacity go straight to global memory, so a late flush is only slower)
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
             }
-            {
+            auto request_ahead = [&]() {  // unit c+D into the slot unit c-1 occupied
                 uint32_t slot_p = slot_c + D;
                 if (slot_p >= NS) slot_p -= NS;
                 const int kc = (c + D) % KCH;
                 if (kc == 0) advance_frontier();
                 issue(rp_f, ap_f, kc, slot_p, kc == 0, fbuf);
-            }
+            };
+            if (!SKEW) request_ahead();
             const char *sbase = lds + slot_c * STAGE;
             // The unit's NFRAG A-fragments are read once each and feed NQW MFMAs.  Left alone hipcc emits
             // ds_read -> s_waitcnt lgkmcnt(0) -> mfma per fragment (measured: 60 % of wave cycles parked, matrix
             // pipe 25 % busy), so the schedule is pinned: PF reads up front, then one read per NQW MFMAs, which
             // keeps PF fragments in flight and lets the compiler count lgkmcnt down instead of draining it.
             constexpr int NFRAG = KSUB * MT;
-            constexpr int PF = NFRAG < LOWP_PF ? NFRAG : LOWP_PF;
+            constexpr int PF = NFRAG < LOWP_PF ? NFRAG : LOWP_PF;  // 8 in flight measured no better (8-wave kernels)
             if (!(P.dbg & 2)) {
             u32x4_t afr[NFRAG];
 #pragma unroll
@@ -303,7 +343,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 for (int mt = 0; mt < MT; mt++)
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(auxv[mt]) : "v"(aoff), "n"(mt * 64));
             }
-            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            if (SKEW) {
+                // second half-step of the unit: the other half is in its MFMA phase now
+                if (half == 1) {  // unit c+1 (half 0 reads it next); this wave has not requested unit c+D yet
+                    int n_out = (D - 2) * IPW;
+#pragma unroll
+                    for (int j = 1; j < D - 1; j++) n_out += ((c + 1 + j) % KCH == 0) ? 1 : 0;
+                    lowp_wait_vmcnt(n_out);
+                }
+                __builtin_amdgcn_s_barrier();
+                if (c < KCH - 1) request_ahead();   // the tile's last unit requests after the epilogue
+            }
+            if (!SKEW || c < KCH - 1) slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
         }
 
         // ---- epilogue ----
@@ -351,9 +402,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                             if (lrow < nvalid && up < tmin[nt]) tmin[nt] = up;
                         } else if (lrow < nvalid && low <= tau[nt]) {
                             const uint32_t row = r0 + lrow;
-                            const uint32_t pos = mf_queue_reserve(eq_n_off);
-                            if (pos < MF_EQ_CAP) {
-                                mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                            const uint32_t pos = mf_queue_reserve(q_cnt_off);
+                            if (SKEW) emitted = true;  // any emission makes the wave drain its queue after the tile
+                            if (pos < Q_CAP) {
+                                mf_queue_write(q_rec_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
                             } else {
                                 uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
                                 if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
@@ -383,6 +435,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 if (kq == 0) P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + tile] = v;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (SKEW) {
+            if (__any(emitted)) drain_wave_queue();
+            {   // the request that the last unit postponed (same arithmetic as request_ahead with c = KCH-1)
+                uint32_t slot_p = slot_c + D;
+                if (slot_p >= NS) slot_p -= NS;
+                constexpr int kc = (KCH - 1 + D) % KCH;
+                if (kc == 0) advance_frontier();
+                issue(rp_f, ap_f, kc, slot_p, kc == 0, fbuf);
+                slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            }
         } else {
             if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -390,8 +452,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         abuf = abuf + 1 == NAUX ? 0 : abuf + 1;
         tiles_done++;
     }
+    if (SKEW && half == 0) __builtin_amdgcn_s_barrier();  // pairs with half 1's leading barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (MODE == MF_FILTER) {
+    if (MODE == MF_FILTER && !SKEW) {
         __builtin_amdgcn_s_barrier();
         mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
     }

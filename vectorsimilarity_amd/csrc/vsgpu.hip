@@ -1007,6 +1007,15 @@ static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
 }
+template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE = MF_STAGE_BYTES>
+static void launch_lowp_skew(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, true);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto kern = k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, NW, NQW, 1, NS, STAGE, true>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+}
 template <int LK, int KS, int RT, int NQW>
 static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
@@ -1045,6 +1054,9 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
         case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
         case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
+        case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
+        case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
+        case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
         }
     }
     if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
@@ -1061,6 +1073,10 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
         case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
         case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
+        case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
+        case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
+        case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
+        case 24: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 6>);
         }
     }
     return false;
