@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct VecSimIndexInterface VecSimIndex;
-typedef struct VecSimDebugInfoIterator VecSimDebugInfoIterator; /* reference: info_iterator.h (debug only) */
+#include "info_iterator.h"
 typedef struct VecSimAdhocBfCtx VecSimAdhocBfCtx;
 
 /* lifetime (vec_sim.cpp:213-215, 369-373) */
@@ -59,7 +59,7 @@ size_t VecSimParams_GetQueryBlobSize(VecSimType type, size_t dim, VecSimMetric m
 VecSimIndexDebugInfo VecSimIndex_DebugInfo(VecSimIndex *index);
 VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index);
 VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index);
-VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index); /* always NULL here */
+VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index);
 
 /* tiered-only entry points: accepted and ignored for Flat indexes */
 void VecSimTieredIndex_GC(VecSimIndex *index);

@@ -523,3 +523,18 @@ def test_multi_value_delete_keeps_remaining_vectors_queryable(vso):
         exp = sorted(best.items(), key=lambda kv: kv[1])[:10]
         assert [int(x) for x in got_l[j]] == [l for l, _ in exp]
         assert list(got_d[j]) == [s for _, s in exp]
+
+
+def test_debug_info_iterator_fields_match_reference_layout():
+    """field names, order and types of BruteForceIndex::debugInfoIterator (brute_force.h:348-365 +
+    vec_sim_index.h:271-310)"""
+    ix = make_index("f32", "Cosine", 24)
+    ix.add_vectors(np.random.default_rng(0).uniform(-1, 1, (37, 24)).astype(np.float32), np.arange(37))
+    ix.knn_query(np.ones((1, 24), dtype=np.float32), 3)
+    f = ix.debug_info_fields()
+    assert [n for n, _ in f] == ["ALGORITHM", "TYPE", "DIMENSION", "METRIC", "IS_MULTI_VALUE", "IS_DISK", "INDEX_SIZE",
+                                 "INDEX_LABEL_COUNT", "MEMORY", "LAST_SEARCH_MODE", "BLOCK_SIZE"]
+    d = dict(f)
+    assert d["ALGORITHM"] == "FLAT" and d["TYPE"] == "FLOAT32" and d["METRIC"] == "COSINE" and d["DIMENSION"] == 24
+    assert d["INDEX_SIZE"] == 37 and d["INDEX_LABEL_COUNT"] == 37 and d["IS_MULTI_VALUE"] == 0
+    assert d["LAST_SEARCH_MODE"] == "STANDARD_KNN" and d["BLOCK_SIZE"] == 1024

@@ -118,3 +118,18 @@ def test_hnsw_edge_cases():
     qp.hnswRuntimeParams.efRuntime = 50
     l, d = ix.knn_query(np.zeros(8, dtype=np.float32), 1, qp)
     assert l[0, 0] == 7
+
+
+def test_hnsw_debug_info_iterator_fields():
+    """HNSWIndex::debugInfoIterator (hnsw.h:2216-2273): common fields, BLOCK_SIZE, then the HNSW block"""
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, 16, VecSim.VecSimMetric_L2, 8, 40, 17
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(np.random.default_rng(1).uniform(-1, 1, (300, 16)).astype(np.float32), np.arange(300))
+    f = ix.debug_info_fields()
+    names = [n for n, _ in f]
+    assert names[0] == "ALGORITHM" and names[10] == "BLOCK_SIZE"
+    assert names[11:] == ["M", "EF_CONSTRUCTION", "EF_RUNTIME", "MAX_LEVEL", "ENTRYPOINT", "EPSILON", "NUMBER_OF_MARKED_DELETED"]
+    d = dict(f)
+    assert d["ALGORITHM"] == "HNSW" and d["M"] == 8 and d["EF_CONSTRUCTION"] == 40 and d["EF_RUNTIME"] == 17
+    assert d["INDEX_SIZE"] == 300 and d["NUMBER_OF_MARKED_DELETED"] == 0

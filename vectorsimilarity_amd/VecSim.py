@@ -185,6 +185,23 @@ class VecSimIndex:
     def index_size(self):
         return self._lib.VecSimIndex_IndexSize(self._h)
 
+    def debug_info_fields(self):
+        """[(name, value)] in the order VecSimIndex_DebugInfoIterator yields them (info_iterator.h)"""
+        it = self._lib.VecSimIndex_DebugInfoIterator(self._h)
+        out = []
+        try:
+            n = self._lib.VecSimDebugInfoIterator_NumberOfFields(it)
+            while self._lib.VecSimDebugInfoIterator_HasNextField(it):
+                f = self._lib.VecSimDebugInfoIterator_NextField(it).contents
+                v = f.fieldValue
+                val = {0: lambda: v.stringValue.decode() if v.stringValue else None, 1: lambda: v.integerValue,
+                       2: lambda: v.uintegerValue, 3: lambda: v.floatingPointValue}[f.fieldType]()
+                out.append((f.fieldName.decode(), val))
+            assert len(out) == n
+        finally:
+            self._lib.VecSimDebugInfoIterator_Free(it)
+        return out
+
     def index_type(self):
         return self._type
 

@@ -94,7 +94,16 @@ class VecSimGpuStats(C.Structure):
 TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p)
 
-# every symbol include/VecSim/{vec_sim,query_results,vec_sim_gpu}.h declares
+class FieldValue(C.Union):
+    _fields_ = [("floatingPointValue", C.c_double), ("integerValue", C.c_int64), ("uintegerValue", C.c_uint64),
+                ("stringValue", C.c_char_p), ("iteratorValue", C.c_void_p)]
+
+
+class VecSim_InfoField(C.Structure):  # include/VecSim/info_iterator.h
+    _fields_ = [("fieldName", C.c_char_p), ("fieldType", C.c_int), ("fieldValue", FieldValue)]
+
+
+# every symbol include/VecSim/{vec_sim,query_results,info_iterator,vec_sim_gpu}.h declares
 EXPORTS = [
     "VecSimIndex_New", "VecSimIndex_Free", "VecSimIndex_EstimateInitialSize",
     "VecSimIndex_EstimateElementSize", "VecSimIndex_AddVector", "VecSimIndex_DeleteVector",
@@ -118,6 +127,8 @@ EXPORTS = [
     "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
+    "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
+    "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
 ]
 GPU_EXPORTS = [
     "vsgpu_device_count", "vsgpu_last_error", "vsgpu_ctx_create", "vsgpu_ctx_destroy",
@@ -171,6 +182,16 @@ def load():
     L.VecSim_Normalize.argtypes = [vp, sz, i]
     L.VecSimParams_GetQueryBlobSize.restype = sz
     L.VecSimParams_GetQueryBlobSize.argtypes = [i, sz, i]
+    L.VecSimIndex_DebugInfoIterator.restype = vp
+    L.VecSimIndex_DebugInfoIterator.argtypes = [vp]
+    L.VecSimDebugInfoIterator_NumberOfFields.restype = C.c_size_t
+    L.VecSimDebugInfoIterator_NumberOfFields.argtypes = [vp]
+    L.VecSimDebugInfoIterator_HasNextField.restype = C.c_bool
+    L.VecSimDebugInfoIterator_HasNextField.argtypes = [vp]
+    L.VecSimDebugInfoIterator_NextField.restype = C.POINTER(VecSim_InfoField)
+    L.VecSimDebugInfoIterator_NextField.argtypes = [vp]
+    L.VecSimDebugInfoIterator_Free.restype = None
+    L.VecSimDebugInfoIterator_Free.argtypes = [vp]
     L.VecSimIndex_BasicInfo.restype = VecSimIndexBasicInfo
     L.VecSimIndex_BasicInfo.argtypes = [vp]
     L.VecSim_SetTimeoutCallbackFunction.restype = None

@@ -238,7 +238,82 @@ extern "C" size_t VecSimParams_GetQueryBlobSize(VecSimType type, size_t dim, Vec
 extern "C" VecSimIndexDebugInfo VecSimIndex_DebugInfo(VecSimIndex *index) { return index->debugInfo(); }
 extern "C" VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index) { return index->basicInfo(); }
 extern "C" VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index) { return index->statsInfo(); }
-extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *) { return nullptr; }
+// Debug-info iterator: the same field names, types and order as the reference's
+// BruteForceIndex::debugInfoIterator (brute_force.h:348-365), HNSWIndex::debugInfoIterator (hnsw.h:2216-2273) and
+// addCommonInfoToIterator (vec_sim_index.h:271-310); strings from utils/vec_utils.cpp:22-75,186-250.
+struct VecSimDebugInfoIterator {
+    std::vector<VecSim_InfoField> fields;
+    size_t pos = 0;
+};
+namespace {
+const char *type_name(VecSimType t) {
+    static const char *n[] = {"FLOAT32", "FLOAT64", "BFLOAT16", "FLOAT16", "INT8", "UINT8", "INT32", "INT64"};
+    return (unsigned)t < 8 ? n[t] : nullptr;
+}
+const char *metric_name(VecSimMetric m) {
+    return m == VecSimMetric_Cosine ? "COSINE" : m == VecSimMetric_IP ? "IP" : m == VecSimMetric_L2 ? "L2" : nullptr;
+}
+const char *mode_name(VecSearchMode m) {
+    static const char *n[] = {"EMPTY_MODE", "STANDARD_KNN", "HYBRID_ADHOC_BF", "HYBRID_BATCHES", "HYBRID_BATCHES_TO_ADHOC_BF",
+                              "RANGE_QUERY"};
+    return (unsigned)m < 6 ? n[m] : nullptr;
+}
+VecSim_InfoField str_field(const char *name, const char *v) {
+    VecSim_InfoField f{};
+    f.fieldName = name;
+    f.fieldType = INFOFIELD_STRING;
+    f.fieldValue.stringValue = v;
+    return f;
+}
+VecSim_InfoField u64_field(const char *name, uint64_t v) {
+    VecSim_InfoField f{};
+    f.fieldName = name;
+    f.fieldType = INFOFIELD_UINT64;
+    f.fieldValue.uintegerValue = v;
+    return f;
+}
+VecSim_InfoField f64_field(const char *name, double v) {
+    VecSim_InfoField f{};
+    f.fieldName = name;
+    f.fieldType = INFOFIELD_FLOAT64;
+    f.fieldValue.floatingPointValue = v;
+    return f;
+}
+}  // namespace
+extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
+    const VecSimIndexDebugInfo info = index->debugInfo();
+    const CommonInfo &ci = info.commonInfo;
+    const bool hnsw = ci.basicInfo.algo == VecSimAlgo_HNSWLIB;
+    auto *it = new VecSimDebugInfoIterator;
+    auto &f = it->fields;
+    f.push_back(str_field("ALGORITHM", hnsw ? "HNSW" : "FLAT"));
+    f.push_back(str_field("TYPE", type_name(ci.basicInfo.type)));
+    f.push_back(u64_field("DIMENSION", ci.basicInfo.dim));
+    f.push_back(str_field("METRIC", metric_name(ci.basicInfo.metric)));
+    f.push_back(u64_field("IS_MULTI_VALUE", ci.basicInfo.isMulti));
+    f.push_back(u64_field("IS_DISK", ci.basicInfo.isDisk));
+    f.push_back(u64_field("INDEX_SIZE", ci.indexSize));
+    f.push_back(u64_field("INDEX_LABEL_COUNT", ci.indexLabelCount));
+    f.push_back(u64_field("MEMORY", ci.memory));
+    f.push_back(str_field("LAST_SEARCH_MODE", mode_name(ci.lastMode)));
+    f.push_back(u64_field("BLOCK_SIZE", ci.basicInfo.blockSize));
+    if (hnsw) {
+        f.push_back(u64_field("M", info.hnswInfo.M));
+        f.push_back(u64_field("EF_CONSTRUCTION", info.hnswInfo.efConstruction));
+        f.push_back(u64_field("EF_RUNTIME", info.hnswInfo.efRuntime));
+        f.push_back(u64_field("MAX_LEVEL", info.hnswInfo.max_level));
+        f.push_back(u64_field("ENTRYPOINT", info.hnswInfo.entrypoint));
+        f.push_back(f64_field("EPSILON", info.hnswInfo.epsilon));
+        f.push_back(u64_field("NUMBER_OF_MARKED_DELETED", info.hnswInfo.numberOfMarkedDeletedNodes));
+    }
+    return it;
+}
+extern "C" size_t VecSimDebugInfoIterator_NumberOfFields(VecSimDebugInfoIterator *it) { return it->fields.size(); }
+extern "C" bool VecSimDebugInfoIterator_HasNextField(VecSimDebugInfoIterator *it) { return it->pos < it->fields.size(); }
+extern "C" VecSim_InfoField *VecSimDebugInfoIterator_NextField(VecSimDebugInfoIterator *it) {
+    return it->pos < it->fields.size() ? &it->fields[it->pos++] : nullptr;
+}
+extern "C" void VecSimDebugInfoIterator_Free(VecSimDebugInfoIterator *it) { delete it; }
 extern "C" void VecSimTieredIndex_GC(VecSimIndex *) {}
 extern "C" void VecSimTieredIndex_AcquireSharedLocks(VecSimIndex *) {}
 extern "C" void VecSimTieredIndex_ReleaseSharedLocks(VecSimIndex *) {}
