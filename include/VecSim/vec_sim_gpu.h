@@ -61,6 +61,12 @@ int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0
                             uint8_t *deleted, uint64_t *labels);
 uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
 
+/* Stored (preprocessed) blobs of a label in internal-id order -- what the reference's Python `get_vector`
+ * reads through getStoredVectorDataByLabel (bindings.cpp:201-214).  *blob_bytes receives the stored blob size;
+ * returns the number of vectors written (0: unknown label, -1: cap_bytes too small / device error); with
+ * out == NULL only *blob_bytes is filled. */
+long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, size_t cap_bytes, size_t *blob_bytes);
+
 /* device selection for indexes created afterwards on this thread/process (default: $VECSIM_GPU_DEVICE or 0) */
 int VecSimGpu_SetDevice(int device);
 int VecSimGpu_DeviceCount(void);

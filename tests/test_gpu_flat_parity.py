@@ -538,3 +538,31 @@ def test_debug_info_iterator_fields_match_reference_layout():
     assert d["ALGORITHM"] == "FLAT" and d["TYPE"] == "FLOAT32" and d["METRIC"] == "COSINE" and d["DIMENSION"] == 24
     assert d["INDEX_SIZE"] == 37 and d["INDEX_LABEL_COUNT"] == 37 and d["IS_MULTI_VALUE"] == 0
     assert d["LAST_SEARCH_MODE"] == "STANDARD_KNN" and d["BLOCK_SIZE"] == 1024
+
+
+@pytest.mark.parametrize("typ", ["f32", "bf16", "i8"])
+def test_get_vector_and_index_memory(vso, typ):
+    """bindings.cpp get_vector / index_memory shapes (tests/flow/test_bruteforce.py uses both)"""
+    rng = np.random.default_rng(11)
+    dim, n = 40, 300
+    rows = random_vectors(rng, n, dim, typ, vso)
+    ix = make_index(typ, "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    got = ix.get_vector(123)
+    assert got.shape == (1, dim) and got.dtype == np.float32
+    if typ == "f32":
+        assert np.array_equal(got[0], rows[123])
+    elif typ == "bf16":
+        assert np.array_equal(got[0], (rows[123].astype(np.uint32) << 16).view(np.float32))
+    else:
+        assert np.array_equal(got[0], rows[123].astype(np.float32))
+    assert ix.get_vector(10_000).shape[0] == 0
+    assert ix.index_memory() > n * dim
+    # multi-value: every vector of the label, in insertion order
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric, p.multi = TYPES["f32"], 8, METRICS["L2"], True
+    mx = VecSim.BFIndex(p)
+    v = rng.uniform(-1, 1, (5, 8)).astype(np.float32)
+    for i in range(5):
+        mx.add_vector(v[i], 7 if i % 2 == 0 else 9)
+    assert np.array_equal(mx.get_vector(7), v[[0, 2, 4]])

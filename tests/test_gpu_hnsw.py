@@ -133,3 +133,16 @@ def test_hnsw_debug_info_iterator_fields():
     d = dict(f)
     assert d["ALGORITHM"] == "HNSW" and d["M"] == 8 and d["EF_CONSTRUCTION"] == 40 and d["EF_RUNTIME"] == 17
     assert d["INDEX_SIZE"] == 300 and d["NUMBER_OF_MARKED_DELETED"] == 0
+
+
+def test_hnsw_python_surface_parity_helpers():
+    """add_vector_parallel / range_parallel / check_integrity / get_vector keep the reference binding's shapes"""
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, 24, VecSim.VecSimMetric_L2, 8, 60, 50
+    ix = VecSim.HNSWIndex(p)
+    rows = np.random.default_rng(5).uniform(-1, 1, (3000, 24)).astype(np.float32)
+    ix.add_vector_parallel(rows, np.arange(3000))
+    assert ix.index_size() == 3000 and ix.check_integrity()
+    assert np.array_equal(ix.get_vector(77)[0], rows[77])
+    l, d = ix.knn_parallel(rows[:5], 3)
+    assert list(l[:, 0]) == [0, 1, 2, 3, 4] and np.all(d[:, 0] == 0)

@@ -185,6 +185,42 @@ class VecSimIndex:
     def index_size(self):
         return self._lib.VecSimIndex_IndexSize(self._h)
 
+    def index_memory(self):
+        """bindings.cpp:205 -- bytes held for the index (host bookkeeping + device table)"""
+        return int(self._lib.VecSimIndex_StatsInfo(self._h).memory)
+
+    def run_gc(self):
+        self._lib.VecSimTieredIndex_GC(self._h)
+
+    def get_vector(self, label):
+        """bindings.cpp:219-235 -- the stored vector(s) of a label as a 2-D array: fp32/fp64 as stored, bf16/fp16
+        widened to float32, int8 as float32 (the reference's NPArrayType), Cosine rows as normalised at ingest"""
+        bb = C.c_size_t(0)
+        self._lib.VecSimGpu_GetStoredVectors(self._h, int(label), None, 0, C.byref(bb))
+        cap = 64
+        while True:
+            buf = np.zeros(cap * bb.value, dtype=np.uint8)
+            n = self._lib.VecSimGpu_GetStoredVectors(self._h, int(label), buf.ctypes.data_as(C.c_void_p), buf.nbytes, C.byref(bb))
+            if n >= 0:
+                break
+            cap *= 8
+            if cap > 1 << 20:
+                raise RuntimeError("get_vector failed")
+        rows = buf[: n * bb.value].reshape(n, bb.value)
+        t, dim = self._type, self._dim
+        if t == VecSimType_FLOAT32:
+            return rows[:, : dim * 4].copy().view(np.float32)
+        if t == VecSimType_FLOAT64:
+            return rows[:, : dim * 8].copy().view(np.float64)
+        if t == VecSimType_BFLOAT16:
+            h = rows[:, : dim * 2].copy().view(np.uint16).astype(np.uint32) << 16
+            return h.view(np.float32)
+        if t == VecSimType_FLOAT16:
+            return rows[:, : dim * 2].copy().view(np.float16).astype(np.float32)
+        if t == VecSimType_INT8:
+            return rows[:, :dim].copy().view(np.int8).astype(np.float32)
+        return rows[:, :dim].copy().astype(np.float32)
+
     def debug_info_fields(self):
         """[(name, value)] in the order VecSimIndex_DebugInfoIterator yields them (info_iterator.h)"""
         it = self._lib.VecSimIndex_DebugInfoIterator(self._h)
@@ -264,6 +300,49 @@ class HNSWIndex(VecSimIndex):
     def knn_parallel(self, queries, k, query_param=None, num_threads=-1):
         """reference signature (bindings.cpp:330-345); here the whole batch is one GPU launch"""
         return self.knn_query(queries, k, query_param)
+
+    def add_vector_parallel(self, vectors, labels, num_threads=-1):
+        """reference signature (bindings.cpp:383-426); the bulk builder links on all host cores"""
+        return self.add_vectors(vectors, labels)
+
+    def range_parallel(self, queries, radius, query_param=None, num_threads=-1):
+        """reference signature (bindings.cpp:347-381): one (labels, distances) pair per query, padded like knn"""
+        res = [self.range_query(q, radius, query_param) for q in np.atleast_2d(queries)]
+        width = max([r[0].shape[1] for r in res] + [1])
+        labels = np.full((len(res), width), -1, dtype=np.int64)
+        dists = np.full((len(res), width), -1.0, dtype=np.float64)
+        for i, (l, d) in enumerate(res):
+            labels[i, : l.shape[1]] = l[0]
+            dists[i, : d.shape[1]] = d[0]
+        return labels, dists
+
+    def check_integrity(self):
+        """structural half of HNSWIndex::checkIntegrity (hnsw_serializer_impl.h:57-140): every link names an existing
+        node other than its owner and no neighbour appears twice in a list"""
+        g = self.graph()
+        n, M0, M = g["n"], g["M0"], g["M"]
+        cnt = g["cnt0"].astype(np.int64)
+        if np.any(cnt > M0):
+            return False
+        links = g["links0"].astype(np.int64)
+        col = np.arange(M0)[None, :]
+        live = col < cnt[:, None]
+        if np.any(links[live] >= n) or np.any((links == np.arange(n)[:, None]) & live):
+            return False
+        srt = np.sort(np.where(live, links, -1 - col), axis=1)
+        if np.any((srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] >= 0)):
+            return False
+        up = g["upper"].astype(np.int64)
+        for b in range(0, len(up) - M, 1 + M):
+            c = up[b]
+            if c == 0:
+                continue
+            if c > M:
+                return False
+            nb = up[b + 1: b + 1 + c]
+            if np.any(nb >= n) or len(set(nb.tolist())) != c:
+                return False
+        return True
 
     def graph(self):
         """dict of numpy arrays describing the built graph (tests / tooling)"""

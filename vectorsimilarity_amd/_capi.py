@@ -94,6 +94,11 @@ class VecSimGpuStats(C.Structure):
 TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p)
 
+class VecSimIndexStatsInfo(C.Structure):  # vec_sim_common.h:276-281
+    _fields_ = [("memory", C.c_size_t), ("numberOfMarkedDeleted", C.c_size_t), ("directHNSWInsertions", C.c_size_t),
+                ("flatBufferSize", C.c_size_t)]
+
+
 class FieldValue(C.Union):
     _fields_ = [("floatingPointValue", C.c_double), ("integerValue", C.c_int64), ("uintegerValue", C.c_uint64),
                 ("stringValue", C.c_char_p), ("iteratorValue", C.c_void_p)]
@@ -124,7 +129,7 @@ EXPORTS = [
     "VecSimBatchIterator_HasNext", "VecSimBatchIterator_Free", "VecSimBatchIterator_Reset",
     "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
-    "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals",
+    "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
@@ -192,6 +197,10 @@ def load():
     L.VecSimDebugInfoIterator_NextField.argtypes = [vp]
     L.VecSimDebugInfoIterator_Free.restype = None
     L.VecSimDebugInfoIterator_Free.argtypes = [vp]
+    L.VecSimGpu_GetStoredVectors.restype = C.c_long
+    L.VecSimGpu_GetStoredVectors.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.VecSimIndex_StatsInfo.restype = VecSimIndexStatsInfo
+    L.VecSimIndex_StatsInfo.argtypes = [vp]
     L.VecSimIndex_BasicInfo.restype = VecSimIndexBasicInfo
     L.VecSimIndex_BasicInfo.argtypes = [vp]
     L.VecSim_SetTimeoutCallbackFunction.restype = None

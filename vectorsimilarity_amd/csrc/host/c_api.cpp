@@ -372,6 +372,10 @@ extern "C" int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uin
     std::memcpy(labels, e.labels, (size_t)e.n * 8);
     return 0;
 }
+extern "C" long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, size_t cap_bytes, size_t *blob_bytes) {
+    if (blob_bytes) *blob_bytes = index->storedBlobBytes();
+    return out ? index->storedVectors(label, out, cap_bytes) : 0;
+}
 extern "C" uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index) {
     auto *h = dynamic_cast<vsa::HnswIndex *>(index);
     return h ? h->lastDistanceEvals() : 0;

@@ -238,6 +238,21 @@ int FlatIndex::deleteVector(size_t label) {
     return 1;
 }
 
+long FlatIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
+    std::vector<uint32_t> ids;
+    if (multi_) {
+        auto f = label_to_ids_.find(label);
+        if (f != label_to_ids_.end()) ids = f->second;
+    } else {
+        auto f = label_to_id_.find(label);
+        if (f != label_to_id_.end()) ids.push_back(f->second);
+    }
+    if (ids.size() * stored_bytes_ > cap_bytes || flush()) return -1;
+    for (size_t i = 0; i < ids.size(); i++)
+        if (vsgpu_table_read(table_, ids[i], (char *)out + i * stored_bytes_)) return -1;
+    return (long)ids.size();
+}
+
 // ---- queries ----
 std::vector<char> FlatIndex::preprocessQuery(const void *query) const {
     std::vector<char> q(query_bytes_);

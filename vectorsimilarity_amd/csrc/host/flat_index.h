@@ -68,6 +68,9 @@ struct VecSimIndexInterface {
     virtual VecSimIndexDebugInfo debugInfo() const = 0;
     virtual long addBulk(const void *blobs, const size_t *labels, size_t n) = 0;
     virtual long addSynthetic(size_t n, uint64_t seed) = 0;
+    // stored blobs of a label, in internal-id order (bindings.cpp get_vector); returns the vector count, -1 on error
+    virtual long storedVectors(size_t label, void *out, size_t cap_bytes) = 0;
+    virtual size_t storedBlobBytes() const = 0;
     virtual vsgpu_ctx *gpu() = 0;
     virtual void setLastMode(VecSearchMode m) = 0;
 };
@@ -99,6 +102,8 @@ public:
     VecSimIndexDebugInfo debugInfo() const override;
     long addBulk(const void *blobs, const size_t *labels, size_t n) override;
     long addSynthetic(size_t n, uint64_t seed) override;
+    long storedVectors(size_t label, void *out, size_t cap_bytes) override;
+    size_t storedBlobBytes() const override { return stored_bytes_; }
     vsgpu_ctx *gpu() override { return ctx_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 

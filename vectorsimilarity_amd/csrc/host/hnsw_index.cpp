@@ -338,6 +338,14 @@ int HnswIndex::addVector(const void *blob, size_t label) {
 // Bulk ingest: storage and levels are laid out sequentially (deterministic ids and levels), then the
 // linking runs on VECSIM_HNSW_BUILD_THREADS host threads (default: all cores, at most 64) with per-node
 // link-list locks, the way the reference's parallel insert path does (hnsw.h:436-445, bindings.cpp:383-426).
+long HnswIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
+    auto f = label_to_id_.find(label);
+    if (f == label_to_id_.end()) return 0;
+    if (cap_bytes < dim_ * sizeof(float)) return -1;
+    std::memcpy(out, vec(f->second), dim_ * sizeof(float));
+    return 1;
+}
+
 long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     for (size_t i = 0; i < n; i++)
         if (label_to_id_.count(labels[i])) return -1;

@@ -46,6 +46,8 @@ public:
     VecSimIndexDebugInfo debugInfo() const override;
     long addBulk(const void *blobs, const size_t *labels, size_t n) override;
     long addSynthetic(size_t, uint64_t) override { return -1; }
+    long storedVectors(size_t label, void *out, size_t cap_bytes) override;
+    size_t storedBlobBytes() const override { return dim_ * sizeof(float); }
     vsgpu_ctx *gpu() override { return ctx_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
