@@ -317,7 +317,18 @@ def test_mfma_filter_path_bit_exact(vso, metric, dim, n, nq, k):
     sq = stored_rows(vso, q, "f32", metric)
     el, es = _fast_oracle(vso, "IP" if metric == "Cosine" else metric, srows, sq, k, dim)
     bad = np.argwhere(l1 != el)
-    assert bad.size == 0, ("labels differ at (query, rank)", bad[:8].tolist(), l1[bad[0][0]][:12], el[bad[0][0]][:12], st)
+    if bad.size:
+        # diagnosis for a rare run-to-run difference: is it the index contents or one query pass?
+        qb = int(bad[0][0])
+        again_l, _ = ix.knn_query(q, k)
+        ix.set_option("mfma", 0)
+        exact_l, _ = ix.knn_query(q, k)
+        ix.set_option("mfma", 1)
+        missing = [int(x) for x in el[qb] if x not in set(l1[qb].tolist())]
+        info = {"query": qb, "got": l1[qb].tolist(), "want": el[qb].tolist(), "missing": missing,
+                "second_pass_ok": bool(np.array_equal(again_l, el)), "exact_path_ok": bool(np.array_equal(exact_l, el)),
+                "bad_queries": sorted(set(int(b[0]) for b in bad)), "stats": st}
+        raise AssertionError(info)
     assert np.array_equal(d1, es), st
     # and the exact (no-MFMA) GPU path agrees too
     ix.set_option("mfma", 0)

@@ -62,6 +62,15 @@ __device__ __forceinline__ void mf_queue_write(uint32_t slot_off, uint32_t row, 
     asm volatile("ds_write_b128 %0, %1" ::"v"(slot_off), "v"(v) : "memory");
 }
 
+// Barrier that licenses overwriting a ring slot.  A raw s_barrier is not enough: hipcc software-pipelines the
+// ds_reads of the unit that just ended across it (their lgkmcnt wait lands after the barrier, next to the MFMAs
+// that consume them), so a wave could arrive with reads of the old slot still queued while another wave's DMA
+// for the new unit -- fast when it hits L2, as the clamped prefetches past the last tile do -- was already
+// rewriting that slot.  Observed as one candidate lost per ~700 query passes (tools/stress_flat.py).
+__device__ __forceinline__ void mf_ring_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // all threads of the workgroup: move the queued records to the per-query candidate lists
 template <int NTHREADS>
 __device__ __forceinline__ void mf_flush_queue(uint32_t *eq_n, uint4 *eq, uint32_t *counts, uint2 *cand, uint32_t cap) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 else if (allowed == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            mf_ring_barrier();
             if (MODE == MF_FILTER && c == 0) {
                 // every wave has finished the previous tile's epilogue: the queue length is final and uniform
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
         for (int j = 1; j < D; j++) n_out += (j % KCH == 0) ? 1 : 0;
         lowp_wait_vmcnt(n_out);
-        __builtin_amdgcn_s_barrier();
+        mf_ring_barrier();
     }
     for (; tile < P.n_tiles; tile += step) {
         acc_t acc[MT][NQW];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 for (int j = 1; j < D; j++) n_out += ((c + j) % KCH == 0) ? 1 : 0;
                 lowp_wait_vmcnt(n_out);
             }
-            __builtin_amdgcn_s_barrier();
+            mf_ring_barrier();  // reads of the slot about to be refilled have returned (see mfma_kernels.hpp)
             if (!SKEW && MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
                 // (entries past the queue's capacity go straight to global memory, so a late flush is only slower)
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     for (int j = 1; j < D - 1; j++) n_out += ((c + 1 + j) % KCH == 0) ? 1 : 0;
                     lowp_wait_vmcnt(n_out);
                 }
-                __builtin_amdgcn_s_barrier();
+                mf_ring_barrier();
                 if (c < KCH - 1) request_ahead();   // the tile's last unit requests after the epilogue
             }
             if (!SKEW || c < KCH - 1) slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         abuf = abuf + 1 == NAUX ? 0 : abuf + 1;
         tiles_done++;
     }
-    if (SKEW && half == 0) __builtin_amdgcn_s_barrier();  // pairs with half 1's leading barrier
+    if (SKEW && half == 0) mf_ring_barrier();  // pairs with half 1's leading barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER && !SKEW) {
         __builtin_amdgcn_s_barrier();

@@ -74,7 +74,8 @@ struct vsgpu_ctx {
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;
-    long opt_mfma_min_q = 9;          // narrower batches stay on the exact kernel (one BT=8 pass is HBM-bound)
+    long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
+                                      // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
     long opt_probe_div = 32;          // probe ~ n / probe_div rows
     long opt_cand_cap = 8192;         // candidate slots per query
@@ -394,11 +395,12 @@ extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t 
     size_t id = t->n, left = n;
     while (left) {
         size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
-        HIPCHK(hipMemcpy(row_ptr(t, id), src, in_slab * t->row_bytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(row_ptr(t, id), src, in_slab * t->row_bytes, hipMemcpyHostToDevice, t->ctx->stream));
         src += in_slab * t->row_bytes;
         id += in_slab;
         left -= in_slab;
     }
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));  // the caller's buffer is borrowed for this call only
     rc = update_norms(t, t->n, n);
     if (rc) return rc;
     t->n += n;
@@ -761,6 +763,46 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
     hsel = hsel_v.data();
     hrec = hrec_v.data();
     const uint32_t *hraw = hsel + nq;
+    if (getenv("VSGPU_VERIFY")) {
+        // Test aid: recompute every query densely and report any row at or below the k-th exact score that the
+        // filter -> re-rank -> select pipeline did not deliver, together with where it was lost.
+        std::vector<uint2> hc(nq * ccap);
+        std::vector<uint32_t> hcnt(nq);
+        std::vector<float> htau(nq);
+        HIPCHK(hipMemcpy(hc.data(), c->cand.p, nq * ccap * sizeof(uint2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hcnt.data(), c->counts.p, nq * 4, hipMemcpyDeviceToHost));
+        if (c->tau.p) HIPCHK(hipMemcpy(htau.data(), c->tau.p, nq * 4, hipMemcpyDeviceToHost));
+        std::vector<double> row(n), tmp;
+        for (size_t q = 0; q < nq; q++) {
+            if (hraw[q] > ccap || hsel[q] == VSGPU_COUNT_OVERFLOW) continue;
+            if (vsgpu_scores(t, (const char *)queries + q * qstride, 0, n, row.data())) break;
+            tmp = row;
+            const size_t kk = std::min(k, n);
+            std::nth_element(tmp.begin(), tmp.begin() + (kk - 1), tmp.end());
+            const double T = tmp[kk - 1];
+            for (size_t i = 0; i < n; i++) {
+                if (!(row[i] <= T)) continue;
+                bool in_sel = false;
+                for (size_t j = 0; j < hsel[q]; j++) in_sel |= (hrec_v[q * ocap + j].x == (uint32_t)i);
+                if (in_sel) continue;
+                long at = -1;
+                const uint32_t cn = std::min<uint32_t>(hcnt[q], (uint32_t)ccap);
+                for (uint32_t j = 0; j < cn; j++)
+                    if (hc[q * ccap + j].x == (uint32_t)i) at = j;
+                float stored = 0;
+                if (at >= 0) memcpy(&stored, &hc[q * ccap + at].y, 4);
+                size_t dup = 0, oob = 0;
+                for (uint32_t j = 0; j < cn; j++) {
+                    oob += hc[q * ccap + j].x >= n;
+                    for (uint32_t j2 = j + 1; j2 < cn && j2 < j + 2; j2++) dup += 0;
+                }
+                fprintf(stderr,
+                        "VSGPU_VERIFY MISS %s q=%zu row=%zu exact=%.9g T_k=%.9g tau=%.9g cand_slot=%ld stored=%.9g count=%u "
+                        "raw=%u sel=%u oob_rows=%zu n=%zu\n",
+                        scan_name, q, i, row[i], T, (double)htau[q], at, (double)stored, hcnt[q], hraw[q], hsel[q], oob, n);
+            }
+        }
+    }
     std::vector<Hit> hits;
     for (size_t q = 0; q < nq; q++) {
         if (hraw[q] > ccap || hraw[q] < std::min(k, n)) {
