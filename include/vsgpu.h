@@ -105,6 +105,11 @@ int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *links0, const u
  * `dist_evals` (may be NULL) receives the number of distance evaluations of the call. */
 int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef,
                        uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals);
+/* Range search (hnsw.h:2087-2187, processCandidate_RangeSearch hnsw.h:616-680): labels/scores are [nq][cap] in
+ * discovery order.  counts[q] bits 0..30 = results found (only min(found, cap) are stored: call again with a
+ * larger cap when it is exceeded); bit 31 = the candidate window (LDS) overflowed, the list may be incomplete. */
+int vsgpu_graph_range(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, double radius, double epsilon,
+                      size_t cap, uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals);
 
 /* ---- measurement hooks (bench.py roofline leg) ----
  * HIP-event time of the dominant scan kernel, accumulated per ctx on the stream it runs on. */

@@ -73,6 +73,9 @@ def lib():
         L.vso_hnsw_search.restype = sz
         L.vso_hnsw_search.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
                                       C.c_uint32, i, vp, sz, sz, vp, vp, vp]
+        L.vso_hnsw_range.restype = sz
+        L.vso_hnsw_range.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
+                                     C.c_uint32, i, vp, dbl, dbl, vp, vp, sz, vp]
         L.vso_has_avx512.restype = i
         L.vso_has_avx512_bf16.restype = i
         L.vso_probe_dpbf16.restype = None
@@ -210,4 +213,20 @@ def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512)
                               _ptr(g["cnt0"]), g["M0"], _ptr(g["upper_off"]), _ptr(g["upper"]), g["M"],
                               _ptr(g["deleted"]), _ptr(g["labels"]), g["entry"], g["max_level"], _ptr(query), k, ef,
                               _ptr(ol), _ptr(osc), C.byref(ev))
+    return ol[:c].copy(), osc[:c].copy(), ev.value
+
+
+def hnsw_range(vtype, metric, rows, graph, query, radius, epsilon, dim, tier=TIER_AVX512):
+    """restated HNSW range search over an exported graph: (labels, scores) in discovery order"""
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    g = graph
+    cap = max(int(g["n"]), 1)
+    ol = np.zeros(cap, dtype=np.uint64)
+    osc = np.zeros(cap, dtype=np.float64)
+    ev = C.c_uint64(0)
+    c = lib().vso_hnsw_range(vtype, metric, tier, dim, _ptr(rows), rows.strides[0], g["n"], _ptr(g["links0"]),
+                             _ptr(g["cnt0"]), g["M0"], _ptr(g["upper_off"]), _ptr(g["upper"]), g["M"],
+                             _ptr(g["deleted"]), _ptr(g["labels"]), g["entry"], g["max_level"], _ptr(query),
+                             float(radius), float(epsilon), _ptr(ol), _ptr(osc), cap, C.byref(ev))
     return ol[:c].copy(), osc[:c].copy(), ev.value

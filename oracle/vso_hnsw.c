@@ -120,3 +120,89 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
     free(visited); free(cand); free(top);
     return nt;
 }
+
+/*
+ * Range search: rangeQuery (hnsw.h:2153-2187) -> searchBottomLayerEP -> searchRangeBottomLayer_WithTimeout
+ * (hnsw.h:2087-2150) with processCandidate_RangeSearch (hnsw.h:616-680).  candidate_set is unbounded; the
+ * dynamic range shrinks towards `radius` as closer candidates are expanded and the search stops when the best
+ * candidate is more than (1 + epsilon) times the dynamic range away.  Results come out in discovery order
+ * (the C API sorts them afterwards).  dyn * (1.0 + epsilon) is evaluated in double and rounded to float, as the
+ * reference's DistType = float assignment does.
+ */
+size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                      const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                      const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                      uint32_t entry, int max_level, const void *query, double radius_d, double epsilon,
+                      uint64_t *out_labels, double *out_scores, size_t out_cap, uint64_t *dist_evals) {
+    if (n == 0 || entry == 0xFFFFFFFFu) return 0;
+    const char *base = rows;
+    const float radius = (float)radius_d;
+    uint64_t evals = 0;
+#define RDIST(node) (evals++, (float)vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query))
+    uint32_t cur = entry;
+    float curd = RDIST(cur);
+    for (int level = max_level; level > 0; level--) {
+        int changed = 1;
+        while (changed) {
+            changed = 0;
+            uint32_t cnt;
+            const uint32_t *lk = links_at(cur, level, links0, cnt0, M0, upper_off, upper, M, &cnt);
+            for (uint32_t i = 0; i < cnt; i++) {
+                float d = RDIST(lk[i]);
+                if (d < curd) { curd = d; cur = lk[i]; changed = 1; }
+            }
+        }
+    }
+    uint8_t *visited = calloc(n, 1);
+    cand_t *cand = malloc(((size_t)n + 1) * sizeof(cand_t));
+    size_t nc = 0, nres = 0;
+    float ep_dist, dyn, bound;
+    if (deleted[cur]) {
+        ep_dist = 3.402823466e+38f;
+        dyn = bound = ep_dist;
+    } else {
+        ep_dist = RDIST(cur);
+        dyn = ep_dist;
+        if (ep_dist <= radius) {
+            if (nres < out_cap) { out_labels[nres] = labels[cur]; out_scores[nres] = ep_dist; }
+            nres++;
+            dyn = radius;
+        }
+        bound = (float)((double)dyn * (1.0 + epsilon));
+    }
+    cand[nc].d = ep_dist; cand[nc].id = cur; nc++;
+    visited[cur] = 1;
+    while (nc) {
+        /* top of a max-heap on (-dist, id): smallest dist, ties -> largest id */
+        size_t b = 0;
+        for (size_t i = 1; i < nc; i++)
+            if (cand[i].d < cand[b].d || (cand[i].d == cand[b].d && cand[i].id > cand[b].id)) b = i;
+        const cand_t c = cand[b];
+        if (c.d > bound) break;
+        cand[b] = cand[--nc];
+        if (c.d < dyn && c.d >= radius) {
+            dyn = c.d;
+            bound = (float)((double)dyn * (1.0 + epsilon));
+        }
+        uint32_t cnt;
+        const uint32_t *lk = links_at(c.id, 0, links0, cnt0, M0, upper_off, upper, M, &cnt);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t id = lk[j];
+            if (visited[id]) continue;
+            visited[id] = 1;
+            const float d = RDIST(id);
+            if (d < bound) {
+                cand[nc].d = d; cand[nc].id = id; nc++;
+                if (d <= radius && !deleted[id]) {
+                    if (nres < out_cap) { out_labels[nres] = labels[id]; out_scores[nres] = d; }
+                    nres++;
+                }
+            }
+        }
+    }
+#undef RDIST
+    free(visited);
+    free(cand);
+    if (dist_evals) *dist_evals = evals;
+    return nres;
+}

@@ -146,3 +146,60 @@ def test_hnsw_python_surface_parity_helpers():
     assert np.array_equal(ix.get_vector(77)[0], rows[77])
     l, d = ix.knn_parallel(rows[:5], 3)
     assert list(l[:, 0]) == [0, 1, 2, 3, 4] and np.all(d[:, 0] == 0)
+
+
+@pytest.mark.parametrize("metric,dim,n,M,eps", [
+    (VecSim.VecSimMetric_L2, 32, 4000, 16, 0.01),
+    (VecSim.VecSimMetric_L2, 64, 3000, 8, 0.1),
+    (VecSim.VecSimMetric_Cosine, 48, 3000, 12, 0.01),
+    (VecSim.VecSimMetric_IP, 40, 2500, 16, 0.05),
+])
+def test_gpu_range_search_equals_reference_loops_on_same_graph(vso, metric, dim, n, M, eps):
+    """searchRangeBottomLayer_WithTimeout + processCandidate_RangeSearch (hnsw.h:616-680, 2087-2187): same
+    results, same scores and the same number of distance evaluations as the restated loops on the same graph"""
+    ix, rows = build(dim, n, metric, M=M, efc=80, ef=50)
+    g = ix.graph()
+    rng = np.random.default_rng(17)
+    q = rng.uniform(-1, 1, (12, dim)).astype(np.float32)
+    srows = stored(vso, rows, metric)
+    sq = stored(vso, q, metric)
+    km = 0 if metric == VecSim.VecSimMetric_L2 else 1
+    qp = VecSim.VecSimQueryParams()
+    qp.hnswRuntimeParams.epsilon = eps
+    for j in range(len(q)):
+        sc = vso.scan(0, km, srows, sq[j], dim)
+        # (VecSimIndex_RangeQuery rejects negative radii, as upstream: IP scores of unnormalised rows can be negative)
+        for radius in sorted({max(float(np.sort(sc)[i]), 0.0) for i in (5, 60, 400)} | {max(float(np.sort(sc)[0]) - 1.0, 0.0)}):
+            el, es, ev = vso.hnsw_range(0, km, srows, g, sq[j], radius, eps, dim)
+            labels, dists = ix.range_query(q[j], radius, qp, order=VecSim.BY_ID)
+            order = np.argsort(el.astype(np.int64), kind="stable")
+            assert labels.shape[1] == len(el), (j, radius, labels.shape, len(el))
+            assert np.array_equal(labels[0], el.astype(np.int64)[order])
+            assert np.array_equal(dists[0], es[order])
+            # the GPU reuses dist(entry point) instead of recomputing it at level 0
+            assert ix.last_distance_evals() == ev - 1
+            # everything returned is inside the radius, and recall against the exact scan is high
+            assert np.all(dists[0] <= np.float32(radius))
+    labels, dists = ix.range_query(q[0], max(float(np.sort(vso.scan(0, km, srows, sq[0], dim))[50]), 0.0), qp)
+    assert np.all(np.diff(dists[0]) >= 0)   # BY_SCORE
+
+
+def test_range_search_with_deleted_nodes_and_wide_radius(vso):
+    dim, n = 24, 3000
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=60, ef=40)
+    for lab in range(0, n, 7):
+        ix.delete_vector(lab)
+    g = ix.graph()
+    q = np.random.default_rng(2).uniform(-1, 1, dim).astype(np.float32)
+    sc = vso.scan(0, 0, rows, q, dim)
+    radius = float(np.sort(sc)[300])
+    el, es, _ = vso.hnsw_range(0, 0, rows, g, q, radius, 0.01, dim)
+    labels, dists = ix.range_query(q, radius, order=VecSim.BY_ID)
+    assert sorted(labels[0].tolist()) == sorted(el.astype(np.int64).tolist())
+    assert not any(l % 7 == 0 for l in labels[0].tolist())
+    # a radius covering the whole index: still the graph walk's answer while its candidate window fits in LDS,
+    # the exact table scan (every live vector) once it does not
+    wide, _ = ix.range_query(q, float(sc.max()) + 1.0, order=VecSim.BY_ID)
+    wl, _, _ = vso.hnsw_range(0, 0, rows, g, q, float(sc.max()) + 1.0, 0.01, dim)
+    alive = [i for i in range(n) if i % 7 != 0]
+    assert wide[0].tolist() in (sorted(wl.astype(np.int64).tolist()), alive)

@@ -140,7 +140,7 @@ GPU_EXPORTS = [
     "vsgpu_ctx_device", "vsgpu_ctx_sync", "vsgpu_table_create", "vsgpu_table_destroy",
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
     "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_append_synthetic",
-    "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search",
+    "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
 ]

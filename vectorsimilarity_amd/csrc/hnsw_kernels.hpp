@@ -55,6 +55,12 @@ struct HnswParams {
     float *out_scores;     // [nq][k]
     uint32_t *out_counts;  // [nq]
     uint64_t *stat_dists;  // optional: total distance evaluations (atomicAdd), may be null
+    // range mode (hnsw.h:616-680, 2087-2150): every result within `radius`, discovery order, up to rcap per query;
+    // out_counts[q] = number found (bit 31: the candidate window overflowed, the caller must not trust the list)
+    int range;
+    float radius;
+    double epsilon;
+    uint32_t rcap;
 };
 
 // ---- wave-parallel sorted arrays in LDS (all 64 lanes call with uniform arguments) ----
@@ -213,6 +219,95 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                     if (d < curd) { curd = d; cur = nb_id[i]; changed = true; }
                 }
             }
+        }
+
+        if (P.range) {
+            // ---- level 0, range search (searchRangeBottomLayer_WithTimeout + processCandidate_RangeSearch) ----
+            uint32_t chead = 0, ctail = 0, nres = 0;
+            bool overflow = false;
+            float dyn, bound, epd;
+            auto emit = [&](uint32_t id, float d) {
+                if (lane == 0 && nres < P.rcap) {
+                    P.out_labels[(size_t)q * P.rcap + nres] = P.labels[id];
+                    P.out_scores[(size_t)q * P.rcap + nres] = d;
+                }
+                nres++;
+            };
+            if (lane == 0) tags[cur] = tag;
+            if (P.deleted[cur]) {
+                epd = 3.402823466e+38f;
+                dyn = bound = epd;
+            } else {
+                epd = curd;
+                dyn = epd;
+                if (epd <= P.radius) {
+                    emit(cur, epd);
+                    dyn = P.radius;
+                }
+                bound = (float)((double)dyn * (1.0 + P.epsilon));
+            }
+            ctail = cand_insert(cand_d, cand_i, chead, ctail, epd, cur, lane);
+            __syncthreads();
+            while (chead < ctail) {
+                const float cd = cand_d[chead];
+                const uint32_t cnode = cand_i[chead];
+                if (cd > bound) break;
+                chead++;
+                if (cd < dyn && cd >= P.radius) {
+                    dyn = cd;
+                    bound = (float)((double)dyn * (1.0 + P.epsilon));
+                }
+                const uint32_t cnt = min((uint32_t)P.cnt0[cnode], P.M0);
+                uint32_t nid = 0;
+                bool fresh = false;
+                if ((uint32_t)lane < cnt) {
+                    nid = P.links0[(size_t)cnode * P.M0 + lane];
+                    fresh = tags[nid] != tag;
+                    if (fresh) tags[nid] = tag;
+                }
+                const unsigned long long fm = __ballot(fresh);
+                const uint32_t nfresh = (uint32_t)__popcll(fm);
+                __syncthreads();
+                if (fresh) nb_id[__popcll(fm & ((1ull << lane) - 1ull))] = nid;
+                __syncthreads();
+                for (uint32_t f = 0; f < nfresh; f += NG) score_nodes(nb_id, f, nfresh);
+                n_dists += nfresh;
+                __syncthreads();
+                for (uint32_t i = 0; i < nfresh; i++) {
+                    const float d = nb_d[i];
+                    const uint32_t id = nb_id[i];
+                    if (d < bound) {
+                        bool keep = true;
+                        if (ctail - chead >= P.ccap) {  // the reference's set is unbounded: report, do not guess
+                            overflow = true;
+                            if (cand_less(d, id, cand_d[ctail - 1], cand_i[ctail - 1])) ctail--;
+                            else keep = false;
+                        }
+                        if (keep) {
+                            if (ctail >= 2 * P.ccap) {
+                                const uint32_t live = ctail - chead;
+                                for (uint32_t b = 0; b < live; b += 64) {
+                                    const uint32_t j = b + lane;
+                                    float vd = 0.f;
+                                    uint32_t vi = 0;
+                                    if (j < live) { vd = cand_d[chead + j]; vi = cand_i[chead + j]; }
+                                    __syncthreads();
+                                    if (j < live) { cand_d[j] = vd; cand_i[j] = vi; }
+                                    __syncthreads();
+                                }
+                                chead = 0;
+                                ctail = live;
+                            }
+                            ctail = cand_insert(cand_d, cand_i, chead, ctail, d, id, lane);
+                        }
+                        if (d <= P.radius && !P.deleted[id]) emit(id, d);
+                        __syncthreads();
+                    }
+                }
+                __syncthreads();
+            }
+            if (lane == 0) P.out_counts[q] = nres | (overflow ? 0x80000000u : 0u);
+            continue;
         }
 
         // ---- level 0: ef-bounded best-first search (hnsw.h:1983-2035) ----

@@ -490,11 +490,63 @@ VecSimQueryReply *HnswIndex::topKQuery(const void *query, size_t k, VecSimQueryP
     return rep;
 }
 
-VecSimQueryReply *HnswIndex::rangeQuery(const void *, double, VecSimQueryParams *, VecSimQueryReply_Order) {
-    // HNSW range search (hnsw.h:2090-2180, epsilon-bounded) is not built in this round
-    std::fprintf(stderr, "vecsim_amd: HNSW range queries are not implemented yet\n");
+// rangeQuery (hnsw.h:2153-2187): greedy descent to the bottom-layer entry point, then the epsilon-bounded
+// range search, both on the GPU (k_hnsw_search in range mode); the reply is then ordered like every range reply.
+VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
+    auto *rep = new VecSimQueryReply();
     last_mode_ = RANGE_QUERY;
-    return new VecSimQueryReply();
+    if (n_ == 0) return rep;
+    void *tctx = qp ? qp->timeoutCtx : nullptr;
+    if (timed_out(tctx)) {
+        rep->code = VecSim_QueryReply_TimedOut;
+        return rep;
+    }
+    double eps = epsilon_;
+    if (qp && qp->hnswRuntimeParams.epsilon != 0.0) eps = qp->hnswRuntimeParams.epsilon;
+    std::vector<char> qbuf(dim_ * 4);
+    std::memcpy(qbuf.data(), query, dim_ * 4);
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(qbuf.data(), dim_, type_);
+    if (syncDevice()) {
+        std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
+        return rep;
+    }
+    size_t cap = 1024;
+    std::vector<uint64_t> labs;
+    std::vector<double> sc;
+    uint32_t cnt = 0;
+    for (;;) {
+        labs.resize(cap);
+        sc.resize(cap);
+        if (vsgpu_graph_range(graph_, qbuf.data(), 1, dim_ * 4, radius, eps, cap, labs.data(), sc.data(), &cnt, &last_dist_evals_)) {
+            std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
+            return rep;
+        }
+        if ((cnt & 0x7FFFFFFFu) <= cap) break;
+        cap = std::max<size_t>(cnt & 0x7FFFFFFFu, 2 * cap);
+    }
+    if (timed_out(tctx)) {
+        rep->code = VecSim_QueryReply_TimedOut;
+        return rep;
+    }
+    if (cnt & 0x80000000u) {
+        // More live candidates than the kernel's LDS window holds (a radius covering a large part of the index):
+        // the graph walk can no longer be replayed exactly, so the query is answered by the exact GPU scan of
+        // the table instead -- every vector within the radius, a superset of what the graph walk would reach.
+        std::vector<uint32_t> ids(n_);
+        std::vector<double> s2(n_);
+        uint32_t c2 = 0;
+        if (vsgpu_range(table_, qbuf.data(), radius, n_, ids.data(), s2.data(), &c2) || c2 == VSGPU_COUNT_OVERFLOW) return rep;
+        for (uint32_t i = 0; i < c2; i++)
+            if (!deleted_[ids[i]]) rep->results.push_back(VecSimQueryResult{(size_t)labels_[ids[i]], s2[i]});
+    } else {
+        rep->results.resize(cnt);
+        for (uint32_t i = 0; i < cnt; i++) {
+            rep->results[i].id = (size_t)labs[i];
+            rep->results[i].score = sc[i];
+        }
+    }
+    sort_reply(rep, order);
+    return rep;
 }
 
 double HnswIndex::getDistanceFrom(size_t label, const void *blob) {

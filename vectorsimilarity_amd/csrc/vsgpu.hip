@@ -1623,8 +1623,9 @@ template <int EK> static void launch_hnsw_ek(int opk, const HnswParams &P, dim3 
     else hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_MULADD>), grid, dim3(64), lds, s, P);
 }
 
-extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef,
-                                  uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
+// top-k search (range == nullptr) or range search (range = {radius, epsilon}; k is then the result capacity per query)
+static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef, const double *range,
+                     uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
     vsgpu_table *t = g->t;
     vsgpu_ctx *c = t->ctx;
     if (dist_evals) *dist_evals = 0;
@@ -1635,12 +1636,18 @@ extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq
     }
     if (t->epi == EPI_INT_COS) return fail(VSGPU_ERR_UNSUPPORTED, "graph search: int8/uint8 Cosine is not supported yet");
     HIPCHK(hipSetDevice(c->device));
-    ef = std::max(ef, k);
+    ef = range ? 1 : std::max(ef, k);
     if (ef > 4096) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu too large for the LDS heaps", ef);
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
-    const size_t ccap = 2 * ef;
     const size_t ab = acc_bytes(t->type);
+    size_t ccap = 2 * ef;
+    if (range) {
+        // the reference's candidate set is unbounded: give the window what LDS allows (overflow is reported)
+        const size_t fixed = 2 * (((size_t)t->prog.steps * t->prog.vl * std::max<size_t>(ab, 4) + 15) & ~(size_t)15) + 1024;
+        ccap = 64;
+        while (ccap < 3072 && fixed + (2 * (2 * ccap) + 2) * 8 + 64 <= 60 * 1024) ccap *= 2;
+    }
     size_t lds = (((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15);
     lds += (((size_t)t->prog.steps * t->prog.vl * ab + 15) & ~(size_t)15);
     lds += (ef + 2) * 8;
@@ -1698,6 +1705,12 @@ extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq
     P.out_scores = (float *)g->out_scores.p;
     P.out_counts = (uint32_t *)g->out_counts.p;
     P.stat_dists = (uint64_t *)g->stat.p;
+    if (range) {
+        P.range = 1;
+        P.radius = (float)range[0];
+        P.epsilon = range[1];
+        P.rcap = (uint32_t)k;
+    }
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     const dim3 grid((unsigned)slots);
     switch (t->ek) {
@@ -1725,8 +1738,19 @@ extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq
             c->stats.scan_launches += 1;
             c->stats.scan_rows += hstat;                    // rows gathered = distance evaluations
             c->stats.scan_bytes += hstat * t->row_bytes;
-            snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, "k_hnsw_search");
+            snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, range ? "k_hnsw_search(range)" : "k_hnsw_search");
         }
     }
     return VSGPU_OK;
+}
+extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef,
+                                  uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
+    return graph_run(g, queries, nq, qstride, k, ef, nullptr, labels, scores, counts, dist_evals);
+}
+extern "C" int vsgpu_graph_range(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, double radius,
+                                 double epsilon, size_t cap, uint64_t *labels, double *scores, uint32_t *counts,
+                                 uint64_t *dist_evals) {
+    if (cap == 0) return fail(VSGPU_ERR_ARG, "range search needs room for results");
+    const double range[2] = {radius, epsilon};
+    return graph_run(g, queries, nq, qstride, cap, 1, range, labels, scores, counts, dist_evals);
 }
