@@ -299,6 +299,11 @@ def _fast_oracle(vso, metric, rows, queries, k, dim):
     ("L2", 384, 50_000, 130, 10),      # three query tiles
     ("L2", 512, 40_000, 64, 1),
     ("L2", 1024, 30_000, 17, 10),
+    ("L2", 192, 60_000, 64, 10),       # the other multiples of 64 with a kernel instance
+    ("IP", 320, 40_000, 33, 5),
+    ("L2", 640, 30_000, 64, 10),
+    ("Cosine", 960, 20_000, 70, 10),
+    ("L2", 896, 20_000, 8, 3),
     ("IP", 768, 60_000, 64, 10),
     ("Cosine", 128, 120_000, 64, 10),
 ])

@@ -263,7 +263,8 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     {
         const size_t ks = dim / 32;
         t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && dim % 64 == 0 && row_bytes == dim * 4 &&
-                      (ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32));
+                      (ks == 4 || ks == 6 || ks == 8 || ks == 10 || ks == 12 || ks == 16 || ks == 20 || ks == 24 || ks == 28 ||
+                       ks == 30 || ks == 32));
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
@@ -893,20 +894,30 @@ static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs
 static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
     switch (ksteps) {
     case 4: launch_filter_ks<4>(P, n, wgs, q_tiles, s); break;
+    case 6: launch_filter_ks<6>(P, n, wgs, q_tiles, s); break;
     case 8: launch_filter_ks<8>(P, n, wgs, q_tiles, s); break;
+    case 10: launch_filter_ks<10>(P, n, wgs, q_tiles, s); break;
     case 12: launch_filter_ks<12>(P, n, wgs, q_tiles, s); break;
     case 16: launch_filter_ks<16>(P, n, wgs, q_tiles, s); break;
+    case 20: launch_filter_ks<20>(P, n, wgs, q_tiles, s); break;
     case 24: launch_filter_ks<24>(P, n, wgs, q_tiles, s); break;
+    case 28: launch_filter_ks<28>(P, n, wgs, q_tiles, s); break;
+    case 30: launch_filter_ks<30>(P, n, wgs, q_tiles, s); break;
     default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
     }
 }
 static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
     switch (ksteps) {
     case 4: launch_probe_ks<4>(P, grid, s); break;
+    case 6: launch_probe_ks<6>(P, grid, s); break;
     case 8: launch_probe_ks<8>(P, grid, s); break;
+    case 10: launch_probe_ks<10>(P, grid, s); break;
     case 12: launch_probe_ks<12>(P, grid, s); break;
     case 16: launch_probe_ks<16>(P, grid, s); break;
+    case 20: launch_probe_ks<20>(P, grid, s); break;
     case 24: launch_probe_ks<24>(P, grid, s); break;
+    case 28: launch_probe_ks<28>(P, grid, s); break;
+    case 30: launch_probe_ks<30>(P, grid, s); break;
     default: launch_probe_ks<32>(P, grid, s); break;
     }
 }
