@@ -203,3 +203,26 @@ def test_range_search_with_deleted_nodes_and_wide_radius(vso):
     wl, _, _ = vso.hnsw_range(0, 0, rows, g, q, float(sc.max()) + 1.0, 0.01, dim)
     alive = [i for i in range(n) if i % 7 != 0]
     assert wide[0].tolist() in (sorted(wl.astype(np.int64).tolist()), alive)
+
+
+def test_hnsw_batch_iterator_hands_out_exact_batches(vso):
+    """VecSimBatchIterator on an HNSW index: every batch is the exact next-best set (same machinery and the same
+    GPU score pass as the Flat iterator), deleted vectors never appear"""
+    dim, n = 32, 2500
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=60, ef=40)
+    for lab in (5, 77, 1200):
+        ix.delete_vector(lab)
+    q = np.random.default_rng(8).uniform(-1, 1, dim).astype(np.float32)
+    sc = vso.scan(0, 0, rows, q, dim)
+    sc[[5, 77, 1200]] = np.inf
+    order = np.lexsort((np.arange(n), sc))
+    it = ix.create_batch_iterator(q)
+    got = []
+    while it.has_next() and len(got) < 300:
+        l, d = it.get_next_results(100, VecSim.BY_SCORE)
+        assert np.all(np.diff(d[0]) >= 0)
+        got += l[0].tolist()
+    assert got == order[:300].tolist()
+    it.reset()
+    l, d = it.get_next_results(10, VecSim.BY_SCORE)
+    assert l[0].tolist() == order[:10].tolist() and np.array_equal(d[0], sc[order[:10]])

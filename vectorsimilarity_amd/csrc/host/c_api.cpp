@@ -477,29 +477,11 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
     };
     if (!it->scored) {
         if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
-        std::vector<double> s;
-        if (it->index->allScores(it->query.data(), s)) {
+        if (it->index->iteratorScores(it->query.data(), it->scores)) {
             std::fprintf(stderr, "vecsim_amd: GPU score pass failed: %s\n", vsgpu_last_error());
             return timed_out_reply();
         }
-        if (it->index->isMulti()) {
-            // bfm_batch_iterator.h:24-53: lowest score per label, emitted in the hash map's iteration order
-            std::unordered_map<size_t, double> best;
-            for (size_t i = 0; i < s.size(); i++) {
-                const size_t label = it->index->labelOf(i);
-                auto f = best.find(label);
-                if (f == best.end()) best.emplace(label, s[i]);
-                else if (f->second > s[i]) f->second = s[i];
-            }
-            it->label_count = best.size();
-            it->scores.clear();
-            it->scores.reserve(best.size());
-            for (auto &p : best) it->scores.emplace_back(p.second, p.first);
-        } else {
-            it->label_count = s.size();
-            it->scores.resize(s.size());
-            for (size_t i = 0; i < s.size(); i++) it->scores[i] = ScoredLabel(s[i], it->index->labelOf(i));
-        }
+        it->label_count = it->scores.size();
         it->scored = true;
     }
     if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();

@@ -340,6 +340,29 @@ int FlatIndex::allScores(const void *processed_query, std::vector<double> &score
     return vsgpu_scores(table_, processed_query, 0, count_, scores.data());
 }
 
+int FlatIndex::iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) {
+    std::vector<double> s;
+    if (allScores(processed_query, s)) return -1;
+    out.clear();
+    if (multi_) {
+        // bfm_batch_iterator.h:24-53: lowest score per label, emitted in the hash map's iteration order
+        std::unordered_map<size_t, double> best;
+        for (size_t i = 0; i < s.size(); i++) {
+            const size_t label = id_to_label_[i];
+            auto f = best.find(label);
+            if (f == best.end()) best.emplace(label, s[i]);
+            else if (f->second > s[i]) f->second = s[i];
+        }
+        out.reserve(best.size());
+        for (auto &p : best) out.emplace_back(p.second, p.first);
+    } else {
+        // bfs_batch_iterator.h:24-41
+        out.resize(s.size());
+        for (size_t i = 0; i < s.size(); i++) out[i] = std::make_pair(s[i], id_to_label_[i]);
+    }
+    return 0;
+}
+
 int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                               VecSimQueryReply_Order order, VecSimQueryReply **out) {
     void *tctx = qp ? qp->timeoutCtx : nullptr;

@@ -71,6 +71,8 @@ struct VecSimIndexInterface {
     // stored blobs of a label, in internal-id order (bindings.cpp get_vector); returns the vector count, -1 on error
     virtual long storedVectors(size_t label, void *out, size_t cap_bytes) = 0;
     virtual size_t storedBlobBytes() const = 0;
+    // batch iterator: (score, label) of every live label against a processed query, one GPU score pass
+    virtual int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) = 0;
     virtual vsgpu_ctx *gpu() = 0;
     virtual void setLastMode(VecSearchMode m) = 0;
 };
@@ -107,7 +109,7 @@ public:
     vsgpu_ctx *gpu() override { return ctx_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
-    // used by the batch iterator
+    int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) override;
     int allScores(const void *processed_query, std::vector<double> &scores);
     size_t labelOf(size_t id) const { return id_to_label_[id]; }
     bool isMulti() const { return multi_; }
@@ -147,7 +149,7 @@ private:
 
 // "next n best" cursor (reference: batch_iterator.h, brute_force/bf_batch_iterator.h:24-199)
 struct VecSimBatchIterator {
-    vsa::FlatIndex *index;
+    VecSimIndexInterface *index;
     std::vector<char> query;  // processed query, owned
     void *timeout_ctx;
     std::vector<std::pair<double, size_t>> scores;  // (score, label) of every vector, lazily filled

@@ -549,6 +549,30 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     return rep;
 }
 
+// Batch iterator.  The reference walks the graph incrementally (hnsw_batch_iterator.h:96-230) and hands out
+// approximate next-best batches; here one exact GPU score pass over the index's vectors feeds the same iterator
+// machinery the Flat index uses, so every batch is the exact next-best set (a deliberate deviation).
+VecSimBatchIterator *HnswIndex::newBatchIterator(const void *query, VecSimQueryParams *qp) {
+    auto *it = new VecSimBatchIterator();
+    it->index = this;
+    it->query.assign((const char *)query, (const char *)query + dim_ * 4);
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(it->query.data(), dim_, type_);
+    it->timeout_ctx = qp ? qp->timeoutCtx : nullptr;
+    it->label_count = indexLabelCount();
+    return it;
+}
+int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) {
+    out.clear();
+    if (n_ == 0) return 0;
+    if (syncDevice()) return -1;
+    std::vector<double> s(n_);
+    if (vsgpu_scores(table_, processed_query, 0, n_, s.data())) return -1;
+    out.reserve(n_ - n_deleted_);
+    for (size_t i = 0; i < n_; i++)
+        if (!deleted_[i]) out.emplace_back(s[i], (size_t)labels_[i]);
+    return 0;
+}
+
 double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end() || syncDevice()) return std::numeric_limits<double>::quiet_NaN();

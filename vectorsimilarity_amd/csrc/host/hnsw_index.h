@@ -39,7 +39,8 @@ public:
     VecSimQueryReply *rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
                                  VecSimQueryReply_Order order) override;
     double getDistanceFrom(size_t label, const void *blob) override;
-    VecSimBatchIterator *newBatchIterator(const void *, VecSimQueryParams *) override { return nullptr; }
+    VecSimBatchIterator *newBatchIterator(const void *query, VecSimQueryParams *qp) override;
+    int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) override;
     bool preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) override;
     VecSimIndexBasicInfo basicInfo() const override;
     VecSimIndexStatsInfo statsInfo() const override;
