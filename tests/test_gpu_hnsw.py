@@ -226,3 +226,19 @@ def test_hnsw_batch_iterator_hands_out_exact_batches(vso):
     it.reset()
     l, d = it.get_next_results(10, VecSim.BY_SCORE)
     assert l[0].tolist() == order[:10].tolist() and np.array_equal(d[0], sc[order[:10]])
+
+
+def test_hnsw_prefer_adhoc_follows_reference_tree():
+    """spot checks of the decision tree (hnsw.h:2275-2408): (index size, subset ratio, k, dim, M) -> ad-hoc?"""
+    def mk(n, dim, M):
+        ix, _ = build(dim, n, VecSim.VecSimMetric_L2, M=M, efc=20, ef=10)
+        return ix
+    small = mk(3000, 16, 8)
+    assert small.prefer_adhoc(3000, 10, True) is True                     # node 1: index_size <= 5500
+    mid_lo = mk(6000, 32, 16)
+    assert mid_lo.prefer_adhoc(600, 10, True) is True                     # r = 0.1 <= 0.17
+    assert mid_lo.prefer_adhoc(3000, 10, True) is False                   # r = 0.5, k <= 12, d <= 55
+    assert mid_lo.prefer_adhoc(3000, 20, True) is True                    # k > 12
+    mid_hi = mk(6000, 64, 16)
+    assert mid_hi.prefer_adhoc(3000, 10, True) is True                    # d > 55, M > 10
+    assert mk(6000, 64, 8).prefer_adhoc(3000, 10, False) is False         # d > 55, M <= 10

@@ -582,11 +582,52 @@ double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
     return s;
 }
 
+// The reference's 20-leaf decision tree (hnsw.h:2275-2408, fitted by scripts/HNSW_batches_clf.py), kept as data:
+// each node tests one feature against a threshold and names the next node for "yes" / "no"; negative entries are
+// the leaves (-1: ad-hoc brute force, -2: batches).
 bool HnswIndex::preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) {
-    // hnsw.h:2183-2240: decision tree of scripts/HNSW_batches_clf.py; for this round every subset smaller
-    // than a tenth of the index prefers ad-hoc scoring (the only branch RediSearch relies on for tiny filters)
-    (void)k;
-    const bool adhoc = n_ == 0 || (double)std::min(subsetSize, n_) / (double)n_ <= 0.1;
+    enum Feature { N, R, K, D, MM };
+    enum { ADHOC = -1, BATCHES = -2 };
+    struct Node { Feature f; double thr; bool strict; int yes, no; };
+    static const Node tree[] = {
+        /* 0*/ {N, 30000, false, 1, 7},
+        /* 1*/ {N, 5500, false, ADHOC, 2},
+        /* 2*/ {R, 0.17, false, ADHOC, 3},
+        /* 3*/ {K, 12, false, 4, ADHOC},
+        /* 4*/ {D, 55, false, BATCHES, 5},
+        /* 5*/ {MM, 10, false, BATCHES, ADHOC},
+        /* 6*/ {N, 0, false, ADHOC, ADHOC},  // unused slot
+        /* 7*/ {R, 0.07, true, 8, 11},
+        /* 8*/ {N, 750000, false, ADHOC, 9},
+        /* 9*/ {K, 7, false, BATCHES, 10},
+        /*10*/ {R, 0.03, false, ADHOC, BATCHES},
+        /*11*/ {D, 75, false, BATCHES, 12},
+        /*12*/ {K, 12, false, 13, 16},
+        /*13*/ {R, 0.21, false, 14, BATCHES},
+        /*14*/ {MM, 57, false, 15, ADHOC},
+        /*15*/ {N, 75000, false, ADHOC, BATCHES},
+        /*16*/ {MM, 10, false, 17, 18},
+        /*17*/ {R, 0.17, false, ADHOC, BATCHES},
+        /*18*/ {N, 300000, false, ADHOC, 19},
+        /*19*/ {R, 0.17, false, ADHOC, BATCHES},
+    };
+    const size_t index_size = indexSize();
+    subsetSize = std::min(subsetSize, index_size);
+    const float r = index_size == 0 ? 0.0f : (float)subsetSize / (float)indexLabelCount();
+    int at = 0;
+    while (at >= 0) {
+        const Node &nd = tree[at];
+        bool yes;
+        switch (nd.f) {
+        case N: yes = (double)index_size <= nd.thr; break;
+        case K: yes = (double)k <= nd.thr; break;
+        case D: yes = (double)dim_ <= nd.thr; break;
+        case MM: yes = (double)M_ <= nd.thr; break;
+        default: yes = nd.strict ? ((double)r < nd.thr) : ((double)r <= nd.thr); break;  // float r against a double literal;
+        }                                                                                // `r < 0.07` is the one strict test
+        at = yes ? nd.yes : nd.no;
+    }
+    const bool adhoc = at == ADHOC;
     last_mode_ = adhoc ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
     return adhoc;
 }
