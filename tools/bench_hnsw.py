@@ -25,6 +25,7 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--data", default="uniform", choices=["uniform", "lowrank"],
                 help="uniform: BASELINE's U[-1,1) i.i.d. rows (intrinsic dimension = d, hard for any graph index); "
                      "lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
+ap.add_argument("--slots", default="", help="comma list of hnsw_slots values to time (waves per CU)")
 a = ap.parse_args()
 
 rows = synth.rows_f32(47, 0, a.rows, a.dim)
@@ -47,6 +48,16 @@ for _ in range(3):
     labels, dists = ix.knn_query(q, a.k)
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
+for sl in [int(x) for x in a.slots.split(",") if x]:
+    ix.set_option("hnsw_slots", sl)
+    ix.knn_query(q, a.k)
+    tb = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ix.knn_query(q, a.k)
+        dt = time.perf_counter() - t0
+        tb = dt if tb is None else min(tb, dt)
+    print("hnsw_slots %d: %.2f ms per %d queries -> %.0f QPS" % (sl, tb * 1e3, a.queries, a.queries / tb), flush=True)
 evals = ix.last_distance_evals()
 st = ix.stats()
 bp = VecSim.BFParams()

@@ -55,6 +55,7 @@ struct HnswParams {
     float *out_scores;     // [nq][k]
     uint32_t *out_counts;  // [nq]
     uint64_t *stat_dists;  // optional: total distance evaluations (atomicAdd), may be null
+    uint32_t *next_query;  // work queue head (zeroed before the launch): waves draw queries one at a time
     // range mode (hnsw.h:616-680, 2087-2150): every result within `radius`, discovery order, up to rcap per query;
     // out_counts[q] = number found (bit 31: the candidate window overflowed, the caller must not trust the list)
     int range;
@@ -177,7 +178,13 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         if (vl == 0 && act) nb_d[idx] = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
     };
 
-    for (int q = blockIdx.x; q < P.nq; q += gridDim.x) {
+    // queries differ a lot in length (evaluations per query vary 2-3x), so they are drawn from a shared counter
+    // instead of being dealt out in advance
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = (int)atomicAdd(P.next_query, 1u);
+        q = __shfl(q, 0);
+        if (q >= P.nq) break;
         // ---- per-query state ----
         __syncthreads();
         {

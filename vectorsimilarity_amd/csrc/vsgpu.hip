@@ -71,6 +71,7 @@ struct vsgpu_ctx {
     long opt_mfma = 1;
     long opt_mfma_variant = 0;
     long opt_lowp_variant = 0;
+    long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;
@@ -185,6 +186,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "mfma_variant") c->opt_mfma_variant = value;
     else if (n == "lowp_variant") c->opt_lowp_variant = value;
     else if (n == "lowp_dbg") c->opt_lowp_dbg = value;
+    else if (n == "hnsw_slots") c->opt_hnsw_slots = std::max(1L, std::min(64L, value));
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = std::max(1L, value);
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
@@ -492,9 +494,16 @@ static int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t 
     if (rc) return rc;
     char *dst = (char *)c->pinned;
     const int32_t *offs = pg.offs.data();
+    bool identity = (t->type == VSGPU_F32 || t->type == VSGPU_F64);
+    for (size_t i = 0; identity && i < per_q; i++) identity = offs[i] == (int32_t)(i * ab);
     for (size_t q = 0; q < nq; q++) {
         const char *src = (const char *)queries + q * qstride;
         char *o = dst + q * per_q * ab;
+        // dims that fill every lane of every step (fp32/fp64, no residual head) make the table the identity
+        if (identity) {
+            memcpy(o, src, per_q * ab);
+            continue;
+        }
         switch (t->type) {
         case VSGPU_F32: {
             float *of = (float *)o;
@@ -1668,7 +1677,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     lds += 64 * 4 + 64 * 4;
     if (lds > 64 * 1024) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu / dim %zu need %zu B of LDS per query", ef, t->dim, lds);
     // resident search waves = tag slots
-    const size_t slots = std::min<size_t>(nq, (size_t)c->n_cu * 8);
+    const size_t slots = std::min<size_t>(nq, (size_t)c->n_cu * (size_t)c->opt_hnsw_slots);
     if (slots > g->tag_slots || g->n > g->tag_n) {
         const size_t ns = std::max(slots, g->tag_slots), nn = std::max(g->n, g->tag_n);
         // grow with headroom on the node axis: the graph usually keeps growing between searches
@@ -1683,8 +1692,8 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     if ((rc = ensure(c, g->out_labels, nq * k * 8))) return rc;
     if ((rc = ensure(c, g->out_scores, nq * k * 4))) return rc;
     if ((rc = ensure(c, g->out_counts, nq * 4))) return rc;
-    if ((rc = ensure(c, g->stat, 8))) return rc;
-    HIPCHK(hipMemsetAsync(g->stat.p, 0, 8, c->stream));
+    if ((rc = ensure(c, g->stat, 16))) return rc;
+    HIPCHK(hipMemsetAsync(g->stat.p, 0, 16, c->stream));
 
     HnswParams P{};
     P.slabs = t->d_slabs;
@@ -1716,6 +1725,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.out_scores = (float *)g->out_scores.p;
     P.out_counts = (uint32_t *)g->out_counts.p;
     P.stat_dists = (uint64_t *)g->stat.p;
+    P.next_query = (uint32_t *)((char *)g->stat.p + 8);
     if (range) {
         P.range = 1;
         P.radius = (float)range[0];
