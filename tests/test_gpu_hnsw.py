@@ -242,3 +242,38 @@ def test_hnsw_prefer_adhoc_follows_reference_tree():
     mid_hi = mk(6000, 64, 16)
     assert mid_hi.prefer_adhoc(3000, 10, True) is True                    # d > 55, M > 10
     assert mk(6000, 64, 8).prefer_adhoc(3000, 10, False) is False         # d > 55, M <= 10
+
+
+@pytest.mark.parametrize("typ,metric,dim", [("bf16", "L2", 64), ("bf16", "Cosine", 96), ("f16", "IP", 48),
+                                            ("i8", "L2", 64), ("u8", "IP", 32)])
+def test_typed_hnsw_search_equals_reference_loops(vso, typ, metric, dim):
+    """HNSW over the other stored types: the graph is built from widened copies (host, ingest side), the GPU
+    search scores the stored blobs with that type's reference-order kernel and equals the restated loops"""
+    from util import METRICS, TYPES, random_vectors, stored_rows
+    n, k, ef = 2500, 8, 40
+    rng = np.random.default_rng(dim)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 25, dim, typ, vso)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = TYPES[typ], dim, METRICS[metric], 12, 80, ef
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(rows, np.arange(n))
+    g = ix.graph()
+    assert g["n"] == n and ix.check_integrity()
+    labels, dists = ix.knn_query(q, k)
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    km = METRICS["IP"] if metric == "Cosine" else METRICS[metric]
+    for j in range(len(q)):
+        el, es, _ = vso.hnsw_search(TYPES[typ], km, srows, g, sq[j], k, ef, dim)
+        assert np.array_equal(labels[j][:len(el)], el.astype(np.int64)), (typ, j)
+        assert np.array_equal(dists[j][:len(es)], es), (typ, j)
+    # exact recall sanity against the Flat index of the same type
+    bp = VecSim.BFParams()
+    bp.type, bp.dim, bp.metric = TYPES[typ], dim, METRICS[metric]
+    bf = VecSim.BFIndex(bp)
+    bf.add_vectors(rows, np.arange(n))
+    exact, _ = bf.knn_query(q, k)
+    hits = sum(len(set(labels[i]) & set(exact[i])) for i in range(len(q)))
+    assert hits / (len(q) * k) > 0.6
+    assert np.array_equal(ix.get_vector(5), bf.get_vector(5))

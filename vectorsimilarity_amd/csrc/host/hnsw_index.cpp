@@ -17,8 +17,13 @@ static constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     if (p.dim == 0 || p.metric > VecSimMetric_Cosine) return nullptr;
-    if (p.type != VecSimType_FLOAT32 || p.multi) {
-        std::fprintf(stderr, "vecsim_amd: HNSW indexes are built for FLOAT32 single-value data in this round\n");
+    if (p.multi) {
+        std::fprintf(stderr, "vecsim_amd: multi-value HNSW indexes are not built yet\n");
+        return nullptr;
+    }
+    if ((unsigned)p.type > (unsigned)VecSimType_UINT8 || p.type == VecSimType_FLOAT64 ||
+        ((p.type == VecSimType_INT8 || p.type == VecSimType_UINT8) && p.metric == VecSimMetric_Cosine)) {
+        std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/bf16/fp16 (L2, IP, Cosine) and int8/uint8 (L2, IP)\n");
         return nullptr;
     }
     const size_t M = p.M ? p.M : HNSW_DEFAULT_M;
@@ -37,6 +42,8 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->type_ = p.type;
     ix->metric_ = p.metric;
     ix->dim_ = p.dim;
+    ix->blob_bytes_ = blob_bytes(p.type, p.dim, p.metric);
+    ix->elem_bytes_ = ix->blob_bytes_ / p.dim;
     ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     ix->M_ = M;
     ix->M0_ = 2 * M;
@@ -46,7 +53,7 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->mult_ = 1.0 / std::log(1.0 * (double)M);                                               // hnsw.h:1646
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, VSGPU_TIER_AVX512, p.dim, p.dim * 4);
+    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, VSGPU_TIER_AVX512, p.dim, ix->blob_bytes_);
     ix->graph_ = ix->table_ ? vsgpu_graph_create(ix->table_, M) : nullptr;
     if (!ix->table_ || !ix->graph_) {
         delete ix;
@@ -100,10 +107,34 @@ uint32_t *HnswIndex::linksAt(uint32_t id, int level, uint32_t **count_word) {
 }
 
 std::vector<char> HnswIndex::preprocess(const void *blob) const {
-    std::vector<char> v(dim_ * 4);
-    std::memcpy(v.data(), blob, dim_ * 4);
+    std::vector<char> v(blob_bytes_);
+    std::memcpy(v.data(), blob, dim_ * elem_bytes_);
     if (metric_ == VecSimMetric_Cosine) normalize_blob(v.data(), dim_, type_);
     return v;
+}
+
+// fp32 image of a stored blob for the builder's own distance routine
+void HnswIndex::widen(const char *b, float *out) const {
+    switch (type_) {
+    case VecSimType_FLOAT32: std::memcpy(out, b, dim_ * 4); break;
+    case VecSimType_FLOAT64:
+        for (size_t i = 0; i < dim_; i++) { double d; std::memcpy(&d, b + 8 * i, 8); out[i] = (float)d; }
+        break;
+    case VecSimType_BFLOAT16:
+    case VecSimType_FLOAT16:
+        for (size_t i = 0; i < dim_; i++) {
+            uint16_t h;
+            std::memcpy(&h, b + 2 * i, 2);
+            out[i] = type_ == VecSimType_BFLOAT16 ? bf16_widen(h) : fp16_widen(h);
+        }
+        break;
+    case VecSimType_INT8:
+        for (size_t i = 0; i < dim_; i++) out[i] = (float)(int)*(const int8_t *)(b + i);
+        break;
+    default:
+        for (size_t i = 0; i < dim_; i++) out[i] = (float)(unsigned)*(const uint8_t *)(b + i);
+        break;
+    }
 }
 
 // snapshot of a node's link list (under the node's lock when other threads are linking)
@@ -250,9 +281,11 @@ int HnswIndex::drawLevel() {
 }
 
 // storage for one new node (sequential: vectors may reallocate here, never during linking)
-uint32_t HnswIndex::allocNode(const float *v, size_t label, int level) {
+uint32_t HnswIndex::allocNode(const char *stored_blob, size_t label, int level) {
     const uint32_t id = (uint32_t)n_++;
-    host_vecs_.insert(host_vecs_.end(), v, v + dim_);
+    raw_.insert(raw_.end(), stored_blob, stored_blob + blob_bytes_);
+    host_vecs_.resize(n_ * dim_);
+    widen(stored_blob, host_vecs_.data() + (size_t)id * dim_);
     links0_.resize(n_ * M0_, 0u);
     cnt0_.push_back(0);
     level_.push_back((uint8_t)level);
@@ -328,7 +361,7 @@ int HnswIndex::addVector(const void *blob, size_t label) {
         is_new = 0;
     }
     std::vector<char> pv = preprocess(blob);
-    const uint32_t id = allocNode((const float *)pv.data(), label, drawLevel());
+    const uint32_t id = allocNode(pv.data(), label, drawLevel());
     main_ctx_.locked = false;
     insertNode(id, vec(id), main_ctx_);
     graph_dirty_ = true;
@@ -341,8 +374,8 @@ int HnswIndex::addVector(const void *blob, size_t label) {
 long HnswIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
     auto f = label_to_id_.find(label);
     if (f == label_to_id_.end()) return 0;
-    if (cap_bytes < dim_ * sizeof(float)) return -1;
-    std::memcpy(out, vec(f->second), dim_ * sizeof(float));
+    if (cap_bytes < blob_bytes_) return -1;
+    std::memcpy(out, raw_.data() + (size_t)f->second * blob_bytes_, blob_bytes_);
     return 1;
 }
 
@@ -354,14 +387,15 @@ long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     threads = std::max<size_t>(1, std::min<size_t>(threads, 64));
     if (n < 2048 || threads == 1) {
         host_vecs_.reserve(host_vecs_.size() + n * dim_);
-        for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * 4, labels[i]);
+        for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * elem_bytes_, labels[i]);
         return (long)n;
     }
     const uint32_t first = (uint32_t)n_;
     host_vecs_.reserve(host_vecs_.size() + n * dim_);
+    raw_.reserve(raw_.size() + n * blob_bytes_);
     for (size_t i = 0; i < n; i++) {
-        std::vector<char> pv = preprocess((const char *)blobs + i * dim_ * 4);
-        allocNode((const float *)pv.data(), labels[i], drawLevel());
+        std::vector<char> pv = preprocess((const char *)blobs + i * dim_ * elem_bytes_);
+        allocNode(pv.data(), labels[i], drawLevel());
     }
     node_lock_.reset(new std::atomic_flag[n_]);
     for (size_t i = 0; i < n_; i++) node_lock_[i].clear();
@@ -402,7 +436,7 @@ int HnswIndex::deleteVector(size_t label) {
 
 int HnswIndex::syncDevice() {
     if (uploaded_rows_ < n_) {
-        int rc = vsgpu_table_append(table_, host_vecs_.data() + uploaded_rows_ * dim_, n_ - uploaded_rows_);
+        int rc = vsgpu_table_append(table_, raw_.data() + uploaded_rows_ * blob_bytes_, n_ - uploaded_rows_);
         if (rc) return rc;
         uploaded_rows_ = n_;
     }
@@ -451,16 +485,24 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     size_t ef = ef_;
     if (qp && qp->hnswRuntimeParams.efRuntime != 0) ef = qp->hnswRuntimeParams.efRuntime;
     ef = std::max(ef, k);  // hnsw.h:2073
-    std::vector<char> qbuf(nq * dim_ * 4);
-    for (size_t q = 0; q < nq; q++) {
-        std::memcpy(qbuf.data() + q * dim_ * 4, (const char *)queries + q * stride, dim_ * 4);
-        if (metric_ == VecSimMetric_Cosine) normalize_blob(qbuf.data() + q * dim_ * 4, dim_, type_);
+    // only Cosine needs a private (normalised) copy of the queries
+    std::vector<char> qbuf;
+    const void *qsrc = queries;
+    size_t qstride = stride;
+    if (metric_ == VecSimMetric_Cosine) {
+        qbuf.resize(nq * blob_bytes_);
+        for (size_t q = 0; q < nq; q++) {
+            std::memcpy(qbuf.data() + q * blob_bytes_, (const char *)queries + q * stride, dim_ * elem_bytes_);
+            normalize_blob(qbuf.data() + q * blob_bytes_, dim_, type_);
+        }
+        qsrc = qbuf.data();
+        qstride = blob_bytes_;
     }
     std::vector<uint64_t> labs(nq * k);
     std::vector<double> sc(nq * k);
     std::vector<uint32_t> cnt(nq);
     int rc = syncDevice();
-    if (!rc) rc = vsgpu_graph_search(graph_, qbuf.data(), nq, dim_ * 4, k, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
+    if (!rc) rc = vsgpu_graph_search(graph_, qsrc, nq, qstride, k, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
     if (rc) {
         std::fprintf(stderr, "vecsim_amd: GPU HNSW search failed: %s\n", vsgpu_last_error());
         for (auto *r : reps) delete r;
@@ -503,9 +545,7 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     }
     double eps = epsilon_;
     if (qp && qp->hnswRuntimeParams.epsilon != 0.0) eps = qp->hnswRuntimeParams.epsilon;
-    std::vector<char> qbuf(dim_ * 4);
-    std::memcpy(qbuf.data(), query, dim_ * 4);
-    if (metric_ == VecSimMetric_Cosine) normalize_blob(qbuf.data(), dim_, type_);
+    std::vector<char> qbuf = preprocess(query);
     if (syncDevice()) {
         std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
         return rep;
@@ -517,7 +557,7 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     for (;;) {
         labs.resize(cap);
         sc.resize(cap);
-        if (vsgpu_graph_range(graph_, qbuf.data(), 1, dim_ * 4, radius, eps, cap, labs.data(), sc.data(), &cnt, &last_dist_evals_)) {
+        if (vsgpu_graph_range(graph_, qbuf.data(), 1, blob_bytes_, radius, eps, cap, labs.data(), sc.data(), &cnt, &last_dist_evals_)) {
             std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
             return rep;
         }
@@ -555,8 +595,7 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
 VecSimBatchIterator *HnswIndex::newBatchIterator(const void *query, VecSimQueryParams *qp) {
     auto *it = new VecSimBatchIterator();
     it->index = this;
-    it->query.assign((const char *)query, (const char *)query + dim_ * 4);
-    if (metric_ == VecSimMetric_Cosine) normalize_blob(it->query.data(), dim_, type_);
+    it->query = preprocess(query);
     it->timeout_ctx = qp ? qp->timeoutCtx : nullptr;
     it->label_count = indexLabelCount();
     return it;
@@ -643,7 +682,7 @@ VecSimIndexBasicInfo HnswIndex::basicInfo() const {
 }
 VecSimIndexStatsInfo HnswIndex::statsInfo() const {
     VecSimIndexStatsInfo s{};
-    s.memory = host_vecs_.capacity() * 4 + links0_.capacity() * 4 + upper_.capacity() * 4 + (table_ ? vsgpu_table_bytes(table_) : 0);
+    s.memory = host_vecs_.capacity() * 4 + raw_.capacity() + links0_.capacity() * 4 + upper_.capacity() * 4 + (table_ ? vsgpu_table_bytes(table_) : 0);
     s.numberOfMarkedDeleted = n_deleted_;
     return s;
 }

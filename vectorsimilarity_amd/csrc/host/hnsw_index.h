@@ -48,7 +48,7 @@ public:
     long addBulk(const void *blobs, const size_t *labels, size_t n) override;
     long addSynthetic(size_t, uint64_t) override { return -1; }
     long storedVectors(size_t label, void *out, size_t cap_bytes) override;
-    size_t storedBlobBytes() const override { return dim_ * sizeof(float); }
+    size_t storedBlobBytes() const override { return blob_bytes_; }
     vsgpu_ctx *gpu() override { return ctx_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
@@ -80,7 +80,8 @@ private:
     };
     uint32_t *linksAt(uint32_t id, int level, uint32_t **count_word);
     uint32_t copyLinks(uint32_t id, int level, uint32_t *dst, bool locked);
-    uint32_t allocNode(const float *v, size_t label, int level);
+    uint32_t allocNode(const char *stored_blob, size_t label, int level);
+    void widen(const char *stored_blob, float *out) const;
     int drawLevel();
     void insertNode(uint32_t id, const float *v, BuildCtx &bc);
     void searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
@@ -104,7 +105,9 @@ private:
     std::default_random_engine level_gen_{100};
 
     // vectors: host copy for construction + device table for queries
-    std::vector<float> host_vecs_;
+    std::vector<float> host_vecs_;  // widened copy of every vector: construction-time distances only
+    std::vector<char> raw_;         // stored (preprocessed) blobs in the index's own type: what goes to HBM
+    size_t blob_bytes_ = 0, elem_bytes_ = 4;
     vsgpu_ctx *ctx_ = nullptr;
     vsgpu_table *table_ = nullptr;
     vsgpu_graph *graph_ = nullptr;
