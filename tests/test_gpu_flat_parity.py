@@ -426,6 +426,9 @@ def test_reply_objects_and_array_entry_points_agree():
     ("i8", "Cosine", 1024, 30_000, 70, 100),    # BASELINE config 3 shape (scaled down), norm-carrying rows
     ("i8", "L2", 512, 40_000, 260, 10),         # two query tiles of 256
     ("i8", "IP", 768, 30_000, 64, 10),
+    ("u8", "L2", 1024, 30_000, 70, 10),         # uint8 rides the int8 MFMA re-centred by 128
+    ("u8", "IP", 512, 40_000, 33, 100),
+    ("u8", "L2", 768, 20_000, 260, 5),
 ])
 def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     rng = np.random.default_rng(dim * 3 + n)
@@ -439,7 +442,7 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     st = ix.stats()
     assert st["scan_kernel"].startswith("k_mfma_filter_lowp"), st
     # ints are heavy on exact ties (integer scores): the candidate lists may legitimately overflow
-    if typ != "i8":
+    if typ not in ("i8", "u8"):
         assert st["fallbacks"] == 0, st
     srows = stored_rows(vso, rows, typ, metric)
     sq = stored_rows(vso, q, typ, metric)

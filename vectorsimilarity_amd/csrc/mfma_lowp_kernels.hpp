@@ -24,8 +24,8 @@
 
 namespace vsg {
 
-enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2 };
-enum LowpEpi { LE_FP_L2 = 0, LE_FP_IP = 1, LE_I8_L2 = 2, LE_I8_IP = 3, LE_I8_COS = 4 };
+enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3 };
+enum LowpEpi { LE_FP_L2 = 0, LE_FP_IP = 1, LE_I8_L2 = 2, LE_I8_IP = 3, LE_I8_COS = 4, LE_U8_IP = 5 };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -42,6 +42,17 @@ template <> struct LowpOps<LP_F16> {
     using acc_t = f32x4_t;
     __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+// uint8 rows ride the signed-int8 MFMA: x ^ 0x80 is x - 128 as int8 (applied to the A fragments after the LDS
+// read and to the query fragments on the host), and
+//   L2:  sum (x-q)^2 = sum x'^2 + sum q'^2 - 2 sum x'q'              (shift invariant; aux = sum x'^2)
+//   IP:  sum x q     = sum x'q' + 128 sum x' + (128 sum q' + 128^2 d)  (aux = sum x', per-query constant)
+// are exact integers, so the reference's epilogues (L2.cpp:164-174, IP.cpp:273-286) apply unchanged.
+template <> struct LowpOps<LP_U8> {
+    using acc_t = i32x4_t;
+    __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
     }
 };
 template <> struct LowpOps<LP_I8> {
@@ -320,6 +331,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
                 const int p = (4 * (j % 4) + kq) ^ m16;
                 afr[f] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
+                if (LK == LP_U8) afr[f] ^= 0x80808080u;
             }
 #pragma unroll
             for (int f = 0; f < NFRAG; f++) {
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
                     for (int nt = 0; nt < NQW; nt++) {
                         float low, up;
-                        if (LK == LP_I8) {
+                        if (LK == LP_I8 || LK == LP_U8) {
                             const int dot = (int)acc[mt][nt][i];
                             if (MODE == MF_FILTER && EPI == LE_I8_COS) {
                                 // NaN thresholds (zero norms, infinite tau) fall through to the exact test
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                             float sc;
                             if (EPI == LE_I8_L2) sc = (float)((int)av + (int)qaux[nt] - 2 * dot);
                             else if (EPI == LE_I8_IP) sc = (float)(1 - dot);
+                            else if (EPI == LE_U8_IP) sc = (float)(1 - (dot + 128 * (int)av + (int)qaux[nt]));
                             else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qaux[nt]))));
                             low = up = sc;
                         } else {
@@ -417,7 +430,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             }
         };
         if (!(P.dbg & 1)) {
-            if (LK == LP_I8) {
+            if (LK == LP_U8) {
+                if (P.epi == LE_U8_IP) epilogue(std::integral_constant<int, LE_U8_IP>{});
+                else epilogue(std::integral_constant<int, LE_I8_L2>{});
+            } else if (LK == LP_I8) {
                 if (P.epi == LE_I8_COS) epilogue(std::integral_constant<int, LE_I8_COS>{});
                 else if (P.epi == LE_I8_L2) epilogue(std::integral_constant<int, LE_I8_L2>{});
                 else epilogue(std::integral_constant<int, LE_I8_IP>{});
@@ -494,8 +510,9 @@ __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t r
     }
     int s = 0;
     for (uint32_t i = lane; i < dim; i += 64) {
-        const int v = (int)*reinterpret_cast<const int8_t *>(p + i);
-        s += v * v;
+        // modes 2/3: uint8 rows re-centred to x - 128 (sum of squares / plain sum)
+        const int v = mode >= 2 ? (int)*reinterpret_cast<const uint8_t *>(p + i) - 128 : (int)*reinterpret_cast<const int8_t *>(p + i);
+        s += mode == 3 ? v : v * v;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);

@@ -277,9 +277,9 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_rt = dim == 256 ? 64 : (dim == 1024 ? 16 : 32);
             t->lp_qtile = 128;
         }
-        if (type == VSGPU_I8 && (dim == 512 || dim == 768 || dim == 1024)) {
+        if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && (dim == 512 || dim == 768 || dim == 1024)) {
             t->lowp_ok = true;
-            t->lp_kind = LP_I8;
+            t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;  // uint8 Cosine would need two aux values per row: exact path
             t->lp_ksteps = (int)(dim / 64);
             t->lp_rt = dim == 1024 ? 32 : 64;
             t->lp_qtile = 256;
@@ -372,9 +372,10 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
         if (t->mfma_ok)
             hipLaunchKernelGGL(k_row_norms_f32, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
-        else if (t->lp_kind == LP_I8)
+        else if (t->lp_kind == LP_I8 || t->lp_kind == LP_U8)
             hipLaunchKernelGGL(k_row_aux_i8, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
-                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, t->metric == VSGPU_COSINE ? 1 : 0,
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
+                               t->lp_kind == LP_U8 ? (t->metric == VSGPU_L2 ? 2 : 3) : (t->metric == VSGPU_COSINE ? 1 : 0),
                                (uint32_t *)np);
         else
             hipLaunchKernelGGL(k_row_norms_h16, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
@@ -1083,9 +1084,9 @@ static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t 
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
     else launch_lowp_k<LK, KS, MF_FILTER, RT, 8, NQW, 1, 3>(P, grid, s);
 }
-template <int KS, int RT> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE) launch_lowp_k<LP_I8, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
-    else launch_lowp_k<LP_I8, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
+template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
 }
 template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     switch (ks) {
@@ -1146,7 +1147,16 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
 static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
-    else {
+    else if (t->lp_kind == LP_U8) {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_i8<8, 64, LP_U8>(mode, P, grid, s); break;
+        case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
+        default:
+            if (mode == MF_FILTER) launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
+            else launch_lowp_i8<16, 32, LP_U8>(mode, P, grid, s);
+            break;
+        }
+    } else {
         // 16 waves x 16 queries.  d=1024 filter: a ring slot holds 32 whole rows (1 KiB per DMA instruction, one
         // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
         // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
@@ -1184,7 +1194,8 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
     const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
-    const bool is_int = (t->lp_kind == LP_I8);
+    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);
+    const bool is_u8 = (t->lp_kind == LP_U8);
     const size_t eb = is_int ? 1 : 2;
     const size_t kelem = is_int ? 64 : 32;        // elements per MFMA k-step
     const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
@@ -1206,8 +1217,19 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
                 const size_t lane = (size_t)kq * 16 + nn;
                 unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
                 memcpy(dst, src + (kelem * s + per_lane * kq) * eb, 16);
+                if (is_u8)
+                    for (int b = 0; b < 16; b++) dst[b] ^= 0x80;  // q - 128 as int8
             }
-        if (is_int) {
+        if (is_u8) {
+            int s1 = 0, s2 = 0;
+            for (size_t i = 0; i < dim; i++) {
+                const int v = (int)src[i] - 128;
+                s1 += v;
+                s2 += v * v;
+            }
+            const int aux = t->epi == EPI_INT_L2 ? s2 : 128 * s1 + 16384 * (int)dim;
+            memcpy(&qaux[q], &aux, 4);
+        } else if (is_int) {
             if (t->epi == EPI_INT_COS) memcpy(&qaux[q], src + dim, 4);
             else if (t->epi == EPI_INT_L2) {
                 int ss = 0;
@@ -1255,7 +1277,7 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     P.qfrag = (const uint4 *)c->qfrag.p;
     P.qaux = (const uint32_t *)c->qn2.p;
     if (is_int) {
-        P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? LE_I8_IP : LE_I8_COS);
+        P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
     } else {
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
         // bf16*bf16 / fp16*fp16 products are exact in fp32: only accumulation order/rounding differs
