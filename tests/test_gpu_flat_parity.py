@@ -585,3 +585,37 @@ def test_get_vector_and_index_memory(vso, typ):
     for i in range(5):
         mx.add_vector(v[i], 7 if i % 2 == 0 else 9)
     assert np.array_equal(mx.get_vector(7), v[[0, 2, 4]])
+
+
+def test_concurrent_readers_on_one_index(vso):
+    """several threads querying the same index at once (RediSearch's read path; bindings.cpp knn_parallel holds
+    only a shared lock): replies equal the serial ones"""
+    import threading
+    rng = np.random.default_rng(21)
+    dim, n = 128, 60_000
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    qs = [rng.uniform(-1, 1, (1 + (i % 5), dim)).astype(np.float32) for i in range(24)]
+    want = [ix.knn_query(q, 10) for q in qs]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for i in range(t, len(qs), 4):
+                    l, d = ix.knn_query(qs[i], 10)
+                    if not (np.array_equal(l, want[i][0]) and np.array_equal(d, want[i][1])):
+                        errors.append((t, i))
+                    r = ix.range_query(qs[i][0], float(want[i][1][0][3]))
+                    if r[0].shape[1] < 4:
+                        errors.append((t, i, "range"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]

@@ -239,6 +239,7 @@ int FlatIndex::deleteVector(size_t label) {
 }
 
 long FlatIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     std::vector<uint32_t> ids;
     if (multi_) {
         auto f = label_to_ids_.find(label);
@@ -334,6 +335,7 @@ size_t FlatIndex::distinctLabels(const uint32_t *ids, size_t n) const {
 }
 
 int FlatIndex::allScores(const void *processed_query, std::vector<double> &scores) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     if (flush()) return -1;
     scores.resize(count_);
     if (count_ == 0) return 0;
@@ -365,6 +367,7 @@ int FlatIndex::iteratorScores(const void *processed_query, std::vector<std::pair
 
 int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                               VecSimQueryReply_Order order, VecSimQueryReply **out) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     void *tctx = qp ? qp->timeoutCtx : nullptr;
     last_mode_ = STANDARD_KNN;
     if (nq == 0) return 0;
@@ -483,6 +486,7 @@ std::vector<char> FlatIndex::packQueries(const void *queries, size_t nq, size_t 
 
 int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
                               size_t *labels, double *scores, uint32_t *counts) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     last_mode_ = STANDARD_KNN;
     if (multi_) return -1;  // sharded multi-value indexes are not built yet
     if (nq == 0) return 0;
@@ -515,6 +519,7 @@ VecSimQueryReply *FlatIndex::topKQuery(const void *query, size_t k, VecSimQueryP
 
 VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
                                         VecSimQueryReply_Order order) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     auto *rep = new VecSimQueryReply();
     void *tctx = qp ? qp->timeoutCtx : nullptr;
     last_mode_ = RANGE_QUERY;
@@ -573,6 +578,7 @@ VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSim
 }
 
 double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     if (multi_) {  // lowest distance over the label's vectors (brute_force_multi.h:224-239)
         auto f = label_to_ids_.find(label);
         if (f == label_to_ids_.end() || flush()) return std::numeric_limits<double>::quiet_NaN();

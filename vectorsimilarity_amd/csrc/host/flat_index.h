@@ -11,6 +11,7 @@
 #include <memory>
 #include <unordered_map>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 #include "VecSim/vec_sim.h"
@@ -138,6 +139,8 @@ private:
     std::vector<size_t> id_to_label_;
     std::unordered_map<size_t, uint32_t> label_to_id_;
     // multi-value index (brute_force_multi.h): a label owns any number of vectors
+    // one GPU context (staging buffers, stream) per index: concurrent readers take turns
+    mutable std::recursive_mutex gpu_mu_;
     bool multi_ = false;
     std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     std::vector<char> staged_;  // rows appended but not yet uploaded

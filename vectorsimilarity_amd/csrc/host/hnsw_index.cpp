@@ -468,6 +468,7 @@ HnswIndex::Export HnswIndex::exportGraph() {
 
 int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                               VecSimQueryReply_Order order, VecSimQueryReply **out) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     void *tctx = qp ? qp->timeoutCtx : nullptr;
     last_mode_ = STANDARD_KNN;
     if (nq == 0) return 0;
@@ -535,6 +536,7 @@ VecSimQueryReply *HnswIndex::topKQuery(const void *query, size_t k, VecSimQueryP
 // rangeQuery (hnsw.h:2153-2187): greedy descent to the bottom-layer entry point, then the epsilon-bounded
 // range search, both on the GPU (k_hnsw_search in range mode); the reply is then ordered like every range reply.
 VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     auto *rep = new VecSimQueryReply();
     last_mode_ = RANGE_QUERY;
     if (n_ == 0) return rep;
@@ -601,6 +603,7 @@ VecSimBatchIterator *HnswIndex::newBatchIterator(const void *query, VecSimQueryP
     return it;
 }
 int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     out.clear();
     if (n_ == 0) return 0;
     if (syncDevice()) return -1;
@@ -613,6 +616,7 @@ int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair
 }
 
 double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end() || syncDevice()) return std::numeric_limits<double>::quiet_NaN();
     uint32_t id = it->second;

@@ -131,6 +131,8 @@ private:
     size_t node_lock_n_ = 0;
     std::mutex entry_mu_;
 
+    // one GPU context (staging buffers, stream) per index: concurrent readers take turns
+    mutable std::recursive_mutex gpu_mu_;
     uint64_t last_dist_evals_ = 0;
     mutable VecSearchMode last_mode_ = EMPTY_MODE;
 };

@@ -1136,6 +1136,8 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
         case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
         case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
+        case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
+        case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
         case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
         case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
         case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
