@@ -8,8 +8,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include <map>
 #include <queue>
+#include <thread>
 #include <unordered_set>
 
 #include "blob_prep.h"
@@ -449,24 +451,39 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
         return finish();
     }
+    // replies are independent: wide batches replay on a few host threads (heap replay + label lookups, ~4 us each)
+    auto replay_range = [&](size_t q0, size_t q1) {
+        for (size_t q = q0; q < q1; q++) {
+            if (counts[q] == VSGPU_COUNT_OVERFLOW) continue;
+            replay(ids.data() + q * cap, sc.data() + q * cap, counts[q], k, reps[q]);
+            if (order == BY_ID) sort_reply(reps[q], BY_ID);
+        }
+    };
+    const size_t workers = nq >= 128 ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency())) : 1;
+    if (workers > 1) {
+        std::vector<std::thread> pool;
+        const size_t per = (nq + workers - 1) / workers;
+        for (size_t w = 0; w < workers; w++)
+            if (w * per < nq) pool.emplace_back(replay_range, w * per, std::min(nq, (w + 1) * per));
+        for (auto &th : pool) th.join();
+    } else {
+        replay_range(0, nq);
+    }
     std::vector<double> all;
     std::vector<uint32_t> all_ids;
     for (size_t q = 0; q < nq; q++) {
-        if (counts[q] == VSGPU_COUNT_OVERFLOW) {
-            // more than `cap` rows tie at the k-th score: replay over every row's GPU score
-            rc = vsgpu_scores(table_, qbuf.data() + q * query_bytes_, 0, count_, (all.resize(count_), all.data()));
-            if (rc) {
-                for (auto *r : reps) delete r;
-                return rc;
-            }
-            if (all_ids.size() != count_) {
-                all_ids.resize(count_);
-                for (size_t i = 0; i < count_; i++) all_ids[i] = (uint32_t)i;
-            }
-            replay(all_ids.data(), all.data(), count_, k, reps[q]);
-        } else {
-            replay(ids.data() + q * cap, sc.data() + q * cap, counts[q], k, reps[q]);
+        if (counts[q] != VSGPU_COUNT_OVERFLOW) continue;
+        // more than `cap` rows tie at the k-th score: replay over every row's GPU score
+        rc = vsgpu_scores(table_, qbuf.data() + q * query_bytes_, 0, count_, (all.resize(count_), all.data()));
+        if (rc) {
+            for (auto *r : reps) delete r;
+            return rc;
         }
+        if (all_ids.size() != count_) {
+            all_ids.resize(count_);
+            for (size_t i = 0; i < count_; i++) all_ids[i] = (uint32_t)i;
+        }
+        replay(all_ids.data(), all.data(), count_, k, reps[q]);
         if (order == BY_ID) sort_reply(reps[q], BY_ID);
     }
     return finish();

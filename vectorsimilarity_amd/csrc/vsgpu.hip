@@ -12,6 +12,8 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <chrono>
+#include <string>
 #include <vector>
 
 #include "vsgpu.h"
@@ -98,6 +100,23 @@ static void poison(void *p, size_t bytes) {
         (void)hipDeviceSynchronize();
     }
 }
+// VSGPU_TIMING=1: host wall-clock marks of a top-k call on stderr (where the non-kernel time goes)
+struct WallMarks {
+    bool on = getenv("VSGPU_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string out;
+    void mark(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char b[96];
+        snprintf(b, sizeof b, " %s=%.3f", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        out += b;
+        t0 = t1;
+    }
+    void flush(const char *tag) {
+        if (on) fprintf(stderr, "VSGPU_TIMING %s:%s\n", tag, out.c_str());
+    }
+};
 static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return VSGPU_OK;
     if (b.p) HIPCHK(hipFree(b.p));
@@ -762,7 +781,9 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
     uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 8);
     HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    WallMarks wm;
     HIPCHK(hipStreamSynchronize(c->stream));
+    wm.mark("wait_gpu");
     {
         account_scan(c, t, n, 1, scan_name);
         float ms = 0;
@@ -838,6 +859,8 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
         std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
         emit(hits, q, cap, ids, scores, counts);
     }
+    wm.mark("host_post");
+    wm.flush("collect");
     return VSGPU_OK;
 }
 
@@ -1455,8 +1478,20 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         return topk_dense_path(t, nq, k, cap, ids, scores, counts, 0, nq, queries, qstride);
     }
 
-    if (t->lowp_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) return topk_lowp(t, queries, nq, qstride, k, cap, ids, scores, counts);
-    if (t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) return topk_mfma(t, queries, nq, qstride, k, cap, ids, scores, counts);
+    if (t->lowp_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) {
+        WallMarks w;
+        int rc = topk_lowp(t, queries, nq, qstride, k, cap, ids, scores, counts);
+        w.mark("vsgpu_topk_total");
+        w.flush("lowp");
+        return rc;
+    }
+    if (t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q) {
+        WallMarks w;
+        int rc = topk_mfma(t, queries, nq, qstride, k, cap, ids, scores, counts);
+        w.mark("vsgpu_topk_total");
+        w.flush("mfma");
+        return rc;
+    }
 
     // ---- probe -> threshold -> filtered scan ----
     int rc = stage_queries(t, queries, nq, qstride);
