@@ -80,6 +80,9 @@ struct LowpParams {
     uint2 *cand;
     uint32_t cap;
     int dbg;                             // diagnosis switches (vsgpu option lowp_dbg), 0 in production
+    // pair_map != 0: 1-D grid of 2*G workgroups; two query tiles walk the same row tiles from the same XCD
+    // (ids 8 apart are dispatched back to back onto one XCD), the second reader is then served by that XCD's L2
+    int pair_map;
 };
 
 // Ring geometry.  NS slots of STAGE bytes (16 KiB unless stated); a slot ("unit") holds RT rows x SEG bytes, a tile is KCH units.  NS-1
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     const int half = SKEW ? ((wave >> 2) & 1) : 0;  // SKEW: waves w and w+4 share a SIMD, one of each half
     const int m16 = lane & 15;
     const int kq = lane >> 4;
-    const int qtile = blockIdx.y;
+    const int qtile = P.pair_map ? (int)((blockIdx.x >> 3) & 1u) : (int)blockIdx.y;
 
     u32x4_t qf[NQW][KSTEPS];
     {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
-    const uint32_t step = gridDim.x;
+    const uint32_t step = P.pair_map ? gridDim.x / 2 : gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
     // Requests are issued strictly in unit order, so only the frontier tile's addresses are kept
     const char *rp_f[IPW];
@@ -256,12 +259,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         const uint32_t base = slot * STAGE + lds_stage_wave_off;
         if (!(P.dbg & 4)) {
 #pragma unroll
-            for (int i = 0; i < IPW; i++) glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+            for (int i = 0; i < IPW; i++) {
+                // paired query tiles want the row to stay in L2 for the partner: default cache policy there
+                if (P.pair_map) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+                else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+            }
         }
         if (with_aux) glds4(apt, abuf_i * 256, aux_lds);
     };
 
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = P.pair_map ? ((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : blockIdx.x;
     uint32_t ftile = tile, fbuf = 0;  // frontier: tile and aux buffer of the unit requested next
     make_ptrs(ftile, rp_f, ap_f);
     uint32_t slot_c = 0, abuf = 0;   // ring slot / aux buffer of the unit / tile being consumed

@@ -1201,7 +1201,12 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
 static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (t->lp_ksteps == 16 && t->lp_rt == 32) {
         if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 2, 3>(P, grid, s);
-        else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 2, 3>(P, grid, s);
+        else if (grid.y == 2 && grid.x % 8 == 0) {
+            // both query tiles resident together: 2 x 8 waves per CU need <= 128 VGPRs (4 waves per SIMD)
+            LowpParams Q = P;
+            Q.pair_map = 1;
+            launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(Q, dim3(grid.x * 2), s);
+        } else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 2, 3>(P, grid, s);
     } else if (t->lp_ksteps == 12) {
         if (mode == MF_PROBE) launch_lowp_k<LP_I8, 12, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
         else launch_lowp_k<LP_I8, 12, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
