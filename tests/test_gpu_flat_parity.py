@@ -304,6 +304,11 @@ def _fast_oracle(vso, metric, rows, queries, k, dim):
     ("L2", 640, 30_000, 64, 10),
     ("Cosine", 960, 20_000, 70, 10),
     ("L2", 896, 20_000, 8, 3),
+    ("L2", 1536, 12_000, 64, 10),      # large dims: query fragments spread over VGPRs + AGPRs
+    ("Cosine", 2048, 8_000, 20, 10),
+    ("IP", 3072, 6_000, 64, 5),
+    ("L2", 1280, 10_000, 30, 10),
+    ("L2", 2560, 6_000, 64, 10),
     ("IP", 768, 60_000, 64, 10),
     ("Cosine", 128, 120_000, 64, 10),
 ])

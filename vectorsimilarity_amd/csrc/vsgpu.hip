@@ -285,7 +285,7 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         const size_t ks = dim / 32;
         t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && dim % 64 == 0 && row_bytes == dim * 4 &&
                       (ks == 4 || ks == 6 || ks == 8 || ks == 10 || ks == 12 || ks == 16 || ks == 20 || ks == 24 || ks == 28 ||
-                       ks == 30 || ks == 32));
+                       ks == 30 || ks == 32 || ks == 40 || ks == 48 || ks == 64 || ks == 80 || ks == 96));
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
@@ -936,6 +936,11 @@ static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wg
     case 24: launch_filter_ks<24>(P, n, wgs, q_tiles, s); break;
     case 28: launch_filter_ks<28>(P, n, wgs, q_tiles, s); break;
     case 30: launch_filter_ks<30>(P, n, wgs, q_tiles, s); break;
+    case 40: launch_filter_ks<40>(P, n, wgs, q_tiles, s); break;
+    case 48: launch_filter_ks<48>(P, n, wgs, q_tiles, s); break;
+    case 80: launch_filter_ks<80>(P, n, wgs, q_tiles, s); break;
+    case 64: launch_filter_ks<64>(P, n, wgs, q_tiles, s); break;
+    case 96: launch_filter_ks<96>(P, n, wgs, q_tiles, s); break;
     default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
     }
 }
@@ -951,6 +956,11 @@ static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t
     case 24: launch_probe_ks<24>(P, grid, s); break;
     case 28: launch_probe_ks<28>(P, grid, s); break;
     case 30: launch_probe_ks<30>(P, grid, s); break;
+    case 40: launch_probe_ks<40>(P, grid, s); break;
+    case 48: launch_probe_ks<48>(P, grid, s); break;
+    case 80: launch_probe_ks<80>(P, grid, s); break;
+    case 64: launch_probe_ks<64>(P, grid, s); break;
+    case 96: launch_probe_ks<96>(P, grid, s); break;
     default: launch_probe_ks<32>(P, grid, s); break;
     }
 }
