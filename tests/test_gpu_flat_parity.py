@@ -426,6 +426,8 @@ def test_reply_objects_and_array_entry_points_agree():
     ("bf16", "Cosine", 512, 20_000, 33, 5),
     ("bf16", "L2", 1024, 12_000, 20, 10),
     ("f16", "L2", 768, 20_000, 40, 10),
+    ("bf16", "IP", 1536, 10_000, 70, 10),
+    ("f16", "Cosine", 1536, 8_000, 16, 5),
     ("f16", "IP", 256, 30_000, 64, 100),
     ("f16", "Cosine", 1024, 12_000, 17, 10),
     ("i8", "Cosine", 1024, 30_000, 70, 100),    # BASELINE config 3 shape (scaled down), norm-carrying rows

@@ -289,11 +289,11 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
-            (dim == 256 || dim == 512 || dim == 768 || dim == 1024) && row_bytes == data_bytes) {
+            (dim == 256 || dim == 512 || dim == 768 || dim == 1024 || dim == 1536) && row_bytes == data_bytes) {
             t->lowp_ok = true;
             t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
             t->lp_ksteps = (int)(dim / 32);
-            t->lp_rt = dim == 256 ? 64 : (dim == 1024 ? 16 : 32);
+            t->lp_rt = dim == 256 ? 64 : (dim >= 1024 ? 16 : 32);
             t->lp_qtile = 128;
         }
         if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && (dim == 512 || dim == 768 || dim == 1024)) {
@@ -1126,6 +1126,7 @@ template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams
     case 8: launch_lowp_t<LK, 8, 64, 1>(mode, P, grid, s); break;
     case 16: launch_lowp_t<LK, 16, 32, 1>(mode, P, grid, s); break;
     case 24: launch_lowp_t<LK, 24, 32, 1>(mode, P, grid, s); break;
+    case 48: launch_lowp_t<LK, 48, 16, 1>(mode, P, grid, s); break;  // d = 1536: 192 VGPRs of query fragments per wave
     default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
     }
 }
