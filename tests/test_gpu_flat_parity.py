@@ -308,6 +308,12 @@ def _fast_oracle(vso, metric, rows, queries, k, dim):
     ("Cosine", 2048, 8_000, 20, 10),
     ("IP", 3072, 6_000, 64, 5),
     ("L2", 1280, 10_000, 30, 10),
+    ("L2", 100, 90_001, 64, 10),       # any dim: padded to the next kernel width inside LDS
+    ("IP", 300, 30_000, 40, 10),
+    ("Cosine", 96, 50_000, 64, 5),
+    ("L2", 1000, 12_345, 64, 10),
+    ("L2", 50, 70_000, 9, 10),
+    ("L2", 33, 40_000, 64, 3),
     ("L2", 2560, 6_000, 64, 10),
     ("IP", 768, 60_000, 64, 10),
     ("Cosine", 128, 120_000, 64, 10),

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                     if (row < P.n_rows && up < tmin) tmin = up;
                 } else {
                     const float low = a - E;
-                    if (row < P.n_rows && low <= tau) {
+                    if (row < P.n_rows && !(low > tau)) {  // NaN bounds (NaN/Inf in the data) go on to the exact re-rank
                         const uint32_t pos = mf_queue_reserve(eq_n_off);
                         if (pos < MF_EQ_CAP) {
                             mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));

@@ -282,10 +282,17 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     t->bt_max = fit >= 8 ? 8 : (fit >= 4 ? 4 : 1);
     if (!t->prog.fused) t->bt_max = 1;  // scalar-tier variants are only instantiated for BT=1
     {
-        const size_t ks = dim / 32;
-        t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && dim % 64 == 0 && row_bytes == dim * 4 &&
-                      (ks == 4 || ks == 6 || ks == 8 || ks == 10 || ks == 12 || ks == 16 || ks == 20 || ks == 24 || ks == 28 ||
-                       ks == 30 || ks == 32 || ks == 40 || ks == 48 || ks == 64 || ks == 80 || ks == 96));
+        // fp32 MFMA filter: any dim up to 3072.  The kernel instance is the next compiled width (k-steps of 32
+        // elements); the columns past `dim` hold the start of the next row in LDS and zeros in the query fragments
+        // (finite x 0 = 0; a NaN there only makes the filter pass the row on to the exact re-rank).
+        static const int kInst[] = {4, 6, 8, 10, 12, 16, 20, 24, 28, 30, 32, 40, 48, 64, 80, 96};
+        size_t ks = 0;
+        for (int v : kInst)
+            if ((size_t)v * 32 >= dim) {
+                ks = (size_t)v;
+                break;
+            }
+        t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && row_bytes == dim * 4 && ks != 0);
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
@@ -343,7 +350,8 @@ static int grow_to(vsgpu_table *t, size_t rows) {
     bool changed = false;
     while (t->slabs.size() < need) {
         char *p = nullptr;
-        HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes));
+        // + slack: the MFMA filter reads a row out to its kernel width (< 128 extra floats past the last row)
+        HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes + 1024));
         poison(p, slab_rows * t->row_bytes);
         t->slabs.push_back(p);
         if (t->mfma_ok || t->lowp_ok) {
@@ -976,7 +984,8 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     // (1) exact-order query images for the re-rank, (2) bf16 B-operand fragments + |q|^2 for the filter
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
-    std::vector<uint16_t> frag(nqp * dim, 0);  // [q_tile][wave][kstep][lane][8]
+    const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
+    std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
     std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
     for (size_t q = 0; q < nq; q++) {
         const float *src = (const float *)((const char *)queries + q * qstride);
@@ -988,7 +997,10 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
             for (int kq = 0; kq < 4; kq++) {
                 const size_t lane = (size_t)kq * 16 + nn;
                 uint16_t *dst = &frag[((((qt * 4 + w) * KS + s) * 64) + lane) * 8];
-                for (int j = 0; j < 8; j++) dst[j] = bf16_rne(src[32 * s + 8 * kq + j]);
+                for (int j = 0; j < 8; j++) {
+                    const size_t e = (size_t)32 * s + 8 * kq + j;
+                    dst[j] = e < dim ? bf16_rne(src[e]) : (uint16_t)0;
+                }
             }
     }
     rc = ensure(c, c->qfrag, frag.size() * 2);
@@ -1012,8 +1024,8 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
     const double u = std::ldexp(1.0, -24);
-    const double cq = std::ldexp(1.0, -8) * (1.0 + std::ldexp(1.0, -10)) + (double)dim * std::ldexp(1.0, -22) * 1.01;
-    const double gref = ((double)dim / 32.0 + 12.0) * u;
+    const double cq = std::ldexp(1.0, -8) * (1.0 + std::ldexp(1.0, -10)) + (double)kdim * std::ldexp(1.0, -22) * 1.01;
+    const double gref = ((double)kdim / 32.0 + 12.0) * u;
     const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
     const float absE = l2 ? 1e-30f : 1e-6f;
 
