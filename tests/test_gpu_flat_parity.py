@@ -442,6 +442,12 @@ def test_reply_objects_and_array_entry_points_agree():
     ("u8", "L2", 1024, 30_000, 70, 10),         # uint8 rides the int8 MFMA re-centred by 128
     ("u8", "IP", 512, 40_000, 33, 100),
     ("u8", "L2", 768, 20_000, 260, 5),
+    ("bf16", "L2", 100, 40_000, 64, 10),        # any dim: next compiled width, zero query columns
+    ("f16", "IP", 300, 30_000, 20, 10),
+    ("bf16", "Cosine", 1000, 10_000, 130, 5),
+    ("i8", "L2", 100, 50_000, 64, 10),
+    ("i8", "Cosine", 600, 20_000, 300, 10),
+    ("u8", "IP", 333, 30_000, 17, 5),
 ])
 def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     rng = np.random.default_rng(dim * 3 + n)

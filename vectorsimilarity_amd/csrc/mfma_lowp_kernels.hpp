@@ -420,7 +420,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                         }
                         if (MODE == MF_PROBE) {
                             if (lrow < nvalid && up < tmin[nt]) tmin[nt] = up;
-                        } else if (lrow < nvalid && low <= tau[nt]) {
+                        } else if (lrow < nvalid && ((LK == LP_I8 || LK == LP_U8) ? (low <= tau[nt]) : !(low > tau[nt]))) {
+                            // (fp kinds: a NaN bound -- NaN/Inf next to the row's padded columns -- goes on to the re-rank)
                             const uint32_t row = r0 + lrow;
                             const uint32_t pos = mf_queue_reserve(q_cnt_off);
                             if (SKEW) emitted = true;  // any emission makes the wave drain its queue after the tile

@@ -295,19 +295,27 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && row_bytes == dim * 4 && ks != 0);
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
+        // low-precision rows: like fp32, any dim runs at the next compiled width (bf16/fp16: 256, 512, 768, 1024,
+        // 1536 elements; int8/uint8: 512, 768, 1024) with zero query columns past `dim`
         if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
-            (dim == 256 || dim == 512 || dim == 768 || dim == 1024 || dim == 1536) && row_bytes == data_bytes) {
-            t->lowp_ok = true;
-            t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
-            t->lp_ksteps = (int)(dim / 32);
-            t->lp_rt = dim == 256 ? 64 : (dim >= 1024 ? 16 : 32);
-            t->lp_qtile = 128;
+            dim <= 1536 && row_bytes == data_bytes) {
+            static const int w16[] = {8, 16, 24, 32, 48};
+            static const int rt16[] = {64, 32, 32, 16, 16};
+            for (int i = 0; i < 5; i++)
+                if ((size_t)w16[i] * 32 >= dim) {
+                    t->lowp_ok = true;
+                    t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
+                    t->lp_ksteps = w16[i];
+                    t->lp_rt = rt16[i];
+                    t->lp_qtile = 128;
+                    break;
+                }
         }
-        if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && (dim == 512 || dim == 768 || dim == 1024)) {
+        if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && dim <= 1024) {
             t->lowp_ok = true;
             t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;  // uint8 Cosine would need two aux values per row: exact path
-            t->lp_ksteps = (int)(dim / 64);
-            t->lp_rt = dim == 1024 ? 32 : 64;
+            t->lp_ksteps = dim <= 512 ? 8 : (dim <= 768 ? 12 : 16);
+            t->lp_rt = t->lp_ksteps == 16 ? 32 : 64;
             t->lp_qtile = 256;
         }
     }
@@ -1259,7 +1267,8 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         if (rc) return rc;
     }
     // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
-    std::vector<unsigned char> frag(nqp * dim * eb, 0);
+    const size_t kdim = (size_t)KS * kelem;  // kernel width >= dim
+    std::vector<unsigned char> frag(nqp * kdim * eb, 0);
     std::vector<uint32_t> qaux(nqp, 0);
     std::vector<float> tau0(nqp, -INFINITY);
     for (size_t q = 0; q < nq; q++) {
@@ -1269,9 +1278,10 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
             for (int kq = 0; kq < 4; kq++) {
                 const size_t lane = (size_t)kq * 16 + nn;
                 unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
-                memcpy(dst, src + (kelem * s + per_lane * kq) * eb, 16);
+                const size_t e0 = (kelem * s + per_lane * kq) * eb, have = e0 < dim * eb ? std::min<size_t>(16, dim * eb - e0) : 0;
+                if (have) memcpy(dst, src + e0, have);
                 if (is_u8)
-                    for (int b = 0; b < 16; b++) dst[b] ^= 0x80;  // q - 128 as int8
+                    for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;  // q - 128 as int8 (columns past dim stay 0)
             }
         if (is_u8) {
             int s1 = 0, s2 = 0;
@@ -1335,8 +1345,8 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
         // bf16*bf16 / fp16*fp16 products are exact in fp32: only accumulation order/rounding differs
         const double u = std::ldexp(1.0, -24);
-        const double cq = (double)dim * std::ldexp(1.0, -22) * 1.01;
-        const double gref = ((double)dim / 16.0 + 12.0) * u;
+        const double cq = (double)kdim * std::ldexp(1.0, -22) * 1.01;
+        const double gref = ((double)kdim / 16.0 + 12.0) * u;
         P.cE = (float)(((cq + 2.0 * gref + 4.0 * u) * 1.001) * (1.0 + 1e-6));
         P.absE = t->metric == VSGPU_L2 ? 1e-30f : 1e-6f;
     }
