@@ -638,3 +638,39 @@ def test_concurrent_readers_on_one_index(vso):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("typ,dim", [("f32", 100), ("bf16", 72)])
+def test_nan_and_inf_rows_do_not_hide_their_neighbours(vso, typ, dim):
+    """dims below the kernel width read the start of the NEXT row into the padded columns: when that row holds
+    NaN/Inf the filter's bound turns NaN and the row must still reach the exact re-rank.  Rows whose own score is
+    NaN are never returned."""
+    rng = np.random.default_rng(5)
+    n, k = 30_000, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    bad = [777, 9000, 20_001]
+    rows[777, 3] = np.nan
+    rows[9000, :] = np.inf
+    rows[20_001, 0] = -np.inf
+    q = rng.uniform(-1, 1, (16, dim)).astype(np.float32)
+    for j, b in enumerate(bad):          # make the rows just before the poisoned ones the true nearest neighbours
+        q[j] = rows[b - 1] + rng.uniform(-1e-3, 1e-3, dim).astype(np.float32)
+    if typ == "bf16":
+        enc = lambda a: (a.view(np.uint32) >> 16).astype(np.uint16)  # truncation keeps NaN/Inf patterns
+        rows_t, q_t = enc(rows), enc(q)
+    else:
+        rows_t, q_t = rows, q
+    ix = make_index(typ, "L2", dim)
+    ix.add_vectors(rows_t, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q_t, k)
+    assert ix.stats()["scan_kernel"].startswith("k_mfma_filter")
+    keep = np.array([i for i in range(n) if i not in bad])
+    for j in range(len(q)):
+        sc = vso.scan(TYPES[typ], 0, rows_t[keep], q_t[j], dim)
+        el, es = vso.topk_replay(sc, k, keep.astype(np.uint64))
+        assert np.array_equal(labels[j], el.astype(np.int64)), (typ, j, labels[j], el)
+        assert np.array_equal(dists[j], es)
+    for j, b in enumerate(bad):
+        assert labels[j][0] == b - 1
