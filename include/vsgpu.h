@@ -82,6 +82,17 @@ int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, s
 /* rows with score <= radius, ascending id (brute_force.h:305-318). Same overflow convention. */
 int vsgpu_range(vsgpu_table *t, const void *query, double radius, size_t cap, uint32_t *ids,
                 double *scores, uint32_t *count);
+/* ---- device-resident score vector: the Flat batch iterator's state (bfs_batch_iterator.h:24-41 materialises
+ * all n scores on the host; here they stay in HBM).  _next returns every not-yet-retired row whose score is at or
+ * below the k-th smallest live score (count = VSGPU_COUNT_OVERFLOW when more than cap rows qualify), _retire
+ * removes rows from later calls, _read copies all n scores (NaN for retired rows) to the host. */
+typedef struct vsgpu_scorebuf vsgpu_scorebuf;
+vsgpu_scorebuf *vsgpu_scorebuf_create(vsgpu_table *t, const void *query); /* NULL: fp64 table, empty table, no memory */
+void vsgpu_scorebuf_destroy(vsgpu_scorebuf *b);
+size_t vsgpu_scorebuf_rows(const vsgpu_scorebuf *b);
+int vsgpu_scorebuf_next(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count);
+int vsgpu_scorebuf_retire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m);
+int vsgpu_scorebuf_read(vsgpu_scorebuf *b, double *all);
 /* dense exact scores of rows [first, first+n) against one query */
 int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, size_t n, double *scores);
 /* exact scores of an explicit list of rows against one query (getDistanceFrom / ad-hoc BF) */

@@ -674,3 +674,43 @@ def test_nan_and_inf_rows_do_not_hide_their_neighbours(vso, typ, dim):
         assert np.array_equal(dists[j], es)
     for j, b in enumerate(bad):
         assert labels[j][0] == b - 1
+
+
+@pytest.mark.parametrize("typ,ties", [("f32", False), ("f32", True), ("i8", True)])
+def test_batch_iterator_device_state_equals_host_array(vso, typ, ties):
+    """sparse mode (scores stay in HBM, GPU picks the rows at or below the batch threshold, host replays the
+    reference's loop and tracks its array compaction) hands out exactly the batches of the all-on-host array,
+    ties included, and switching to the host array mid-way (large batch) continues the same sequence"""
+    import os
+    rng = np.random.default_rng(31)
+    dim, n = 24, 260_000
+    if typ == "i8":
+        rows = rng.integers(-3, 4, (n, dim)).astype(np.int8)          # few distinct scores: ties everywhere
+        q = rng.integers(-3, 4, dim).astype(np.int8)
+    elif ties:
+        rows = rng.integers(-2, 3, (n, dim)).astype(np.float32)
+        q = rng.integers(-2, 3, dim).astype(np.float32)
+    else:
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+    ix = make_index(typ, "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    plan = [10, 50, 7, 100, 100, 1, 33, 64, 100, 20] * 3 + [5000, 40, 100000]   # the 5000 forces the host array
+    def pull(host):
+        if host:
+            os.environ["VECSIM_ITER_HOST"] = "1"
+        try:
+            it = ix.create_batch_iterator(q)
+            out = []
+            for m in plan:
+                l, d = it.get_next_results(m, VecSim.BY_SCORE)
+                out.append((l[0].copy(), d[0].copy()))
+            return out
+        finally:
+            os.environ.pop("VECSIM_ITER_HOST", None)
+    a, b = pull(False), pull(True)
+    for i, ((la, da), (lb, db)) in enumerate(zip(a, b)):
+        assert np.array_equal(la, lb) and np.array_equal(da, db), (typ, ties, i, plan[i])
+    # and the first batch is the exact top-k
+    sc = vso.scan(TYPES[typ], 0, rows, q, dim)
+    assert np.array_equal(a[0][1], np.sort(sc)[:10])

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <queue>
 #include <stdexcept>
 #include <unordered_map>
@@ -467,6 +468,97 @@ static VecSimQueryReply *next_by_select(VecSimBatchIterator *it, size_t n_res) {
     return rep;
 }
 
+// ---- sparse mode: the score vector stays on the GPU --------------------------------------------------------------
+// The reference's array after some batches = original order, minus a dead prefix of `valid_start` slots, with the
+// survivors of each retired prefix moved into the slots vacated by returned entries (next_by_heap above).  Only
+// those moves are tracked; a row's array position is moved_to[row] or the row id itself.
+static bool sparse_next_by_heap(VecSimBatchIterator *it, size_t n_res, VecSimQueryReply **out) {
+    const size_t cap = 2 * n_res + 64;
+    std::vector<uint32_t> ids(cap);
+    std::vector<double> sc(cap);
+    uint32_t cnt = 0;
+    if (it->index->iteratorDeviceNext(it->dev, n_res, cap, ids.data(), sc.data(), &cnt) || cnt == VSGPU_COUNT_OVERFLOW) return false;
+    struct Ent {
+        size_t pos;
+        double score;
+        uint32_t row;
+    };
+    std::vector<Ent> live(cnt);
+    for (uint32_t i = 0; i < cnt; i++) {
+        auto f = it->moved_to.find(ids[i]);
+        live[i] = Ent{f == it->moved_to.end() ? (size_t)ids[i] : f->second, sc[i], ids[i]};
+    }
+    std::sort(live.begin(), live.end(), [](const Ent &a, const Ent &b) { return a.pos < b.pos; });
+    // the reference's loop over the live range, restricted to the entries at or below the n_res-th smallest score
+    using Item = std::pair<ScoredLabel, size_t>;  // ((score, label), index into live)
+    std::priority_queue<Item> best;
+    double upper = std::numeric_limits<double>::lowest();
+    for (size_t i = 0; i < live.size(); i++) {
+        if (best.size() >= n_res) {
+            if (!(live[i].score < upper)) continue;
+            best.pop();
+        }
+        best.emplace(ScoredLabel(live[i].score, it->index->rowLabel(live[i].row)), i);
+        upper = best.top().first.first;
+    }
+    auto *rep = new VecSimQueryReply();
+    const size_t got = best.size();
+    rep->results.resize(got);
+    std::vector<size_t> taken;  // array positions of the returned entries
+    std::vector<uint32_t> rows;
+    taken.reserve(got);
+    rows.reserve(got);
+    for (size_t i = got; i-- > 0;) {
+        rep->results[i].score = best.top().first.first;
+        rep->results[i].id = best.top().first.second;
+        taken.push_back(live[best.top().second].pos);
+        rows.push_back(live[best.top().second].row);
+        best.pop();
+    }
+    std::sort(taken.begin(), taken.end());
+    for (uint32_t r : rows) it->moved_to.erase(r);
+    const size_t next_start = it->valid_start + got;
+    size_t hole = std::lower_bound(taken.begin(), taken.end(), next_start) - taken.begin();
+    size_t t = 0;
+    for (size_t pos = it->valid_start; pos < next_start; pos++) {
+        auto at = it->moved_at.find(pos);
+        const uint32_t row = at == it->moved_at.end() ? (uint32_t)pos : at->second;
+        if (at != it->moved_at.end()) it->moved_at.erase(at);
+        if (t < taken.size() && taken[t] == pos) {
+            t++;  // a returned entry inside the retired prefix: nothing to move
+        } else {
+            const size_t h = taken[hole++];
+            it->moved_to[row] = h;
+            it->moved_at[h] = row;
+        }
+    }
+    it->valid_start = next_start;
+    if (it->index->iteratorDeviceRetire(it->dev, rows.data(), rows.size())) {
+        delete rep;
+        return false;
+    }
+    *out = rep;
+    return true;
+}
+// leave sparse mode: rebuild the reference's array (same order, same dead prefix) on the host
+static bool sparse_materialize(VecSimBatchIterator *it) {
+    const size_t n = it->dev_rows;
+    std::unique_ptr<double[]> all(new double[n]);
+    if (it->index->iteratorDeviceRead(it->dev, all.get())) return false;
+    it->scores.assign(n, ScoredLabel(0.0, 0));
+    for (size_t pos = it->valid_start; pos < n; pos++) {
+        auto at = it->moved_at.find(pos);
+        const uint32_t row = at == it->moved_at.end() ? (uint32_t)pos : at->second;
+        it->scores[pos] = ScoredLabel(all[row], it->index->rowLabel(row));
+    }
+    it->index->iteratorDeviceEnd(it->dev);
+    it->dev = nullptr;
+    it->moved_to.clear();
+    it->moved_at.clear();
+    it->scored = true;
+    return true;
+}
+
 extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, size_t n_results,
                                                       VecSimQueryReply_Order order) {
     assert((order == BY_ID || order == BY_SCORE) && "Possible order values are only 'BY_ID' or 'BY_SCORE'");
@@ -475,6 +567,32 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
         r->code = VecSim_QueryReply_TimedOut;
         return r;
     };
+    if (!it->scored && !it->dev_tried) {
+        if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
+        it->dev_tried = true;
+        // VECSIM_ITER_HOST=1 keeps the reference's host-side array from the first batch on (tests compare the two)
+        it->dev = std::getenv("VECSIM_ITER_HOST") ? nullptr : it->index->iteratorDeviceBegin(it->query.data());
+        if (it->dev) {
+            it->dev_rows = vsgpu_scorebuf_rows(it->dev);
+            it->label_count = it->dev_rows;
+        }
+    }
+    if (it->dev) {
+        if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
+        // small batches out of many live entries: the heap regime of the reference (bf_batch_iterator.h:140-150)
+        if ((it->label_count - it->returned) / 1000 > n_results) {
+            VecSimQueryReply *rep = nullptr;
+            if (sparse_next_by_heap(it, n_results, &rep)) {
+                it->returned += rep->results.size();
+                if (order == BY_ID) vsa::sort_reply(rep, BY_ID);
+                return rep;
+            }
+        }
+        if (!sparse_materialize(it)) {
+            std::fprintf(stderr, "vecsim_amd: GPU score pass failed: %s\n", vsgpu_last_error());
+            return timed_out_reply();
+        }
+    }
     if (!it->scored) {
         if (vsa::timed_out(it->timeout_ctx)) return timed_out_reply();
         if (it->index->iteratorScores(it->query.data(), it->scores)) {
@@ -498,8 +616,16 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
     return rep;
 }
 extern "C" bool VecSimBatchIterator_HasNext(VecSimBatchIterator *it) { return it->returned < it->label_count; }
-extern "C" void VecSimBatchIterator_Free(VecSimBatchIterator *it) { delete it; }
+extern "C" void VecSimBatchIterator_Free(VecSimBatchIterator *it) {
+    if (it->dev) it->index->iteratorDeviceEnd(it->dev);
+    delete it;
+}
 extern "C" void VecSimBatchIterator_Reset(VecSimBatchIterator *it) {
+    if (it->dev) it->index->iteratorDeviceEnd(it->dev);
+    it->dev = nullptr;
+    it->dev_tried = false;
+    it->moved_to.clear();
+    it->moved_at.clear();
     it->scores.clear();
     it->scored = false;
     it->valid_start = 0;

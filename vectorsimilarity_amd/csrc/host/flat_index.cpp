@@ -10,6 +10,7 @@
 #include <limits>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <queue>
 #include <thread>
 #include <unordered_set>
@@ -345,13 +346,16 @@ int FlatIndex::allScores(const void *processed_query, std::vector<double> &score
 }
 
 int FlatIndex::iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) {
-    std::vector<double> s;
-    if (allScores(processed_query, s)) return -1;
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (flush()) return -1;
     out.clear();
+    if (count_ == 0) return 0;
+    std::unique_ptr<double[]> s(new double[count_]);  // (not value-initialised: tens of MB at 10 M rows)
+    if (vsgpu_scores(table_, processed_query, 0, count_, s.get())) return -1;
     if (multi_) {
         // bfm_batch_iterator.h:24-53: lowest score per label, emitted in the hash map's iteration order
         std::unordered_map<size_t, double> best;
-        for (size_t i = 0; i < s.size(); i++) {
+        for (size_t i = 0; i < count_; i++) {
             const size_t label = id_to_label_[i];
             auto f = best.find(label);
             if (f == best.end()) best.emplace(label, s[i]);
@@ -361,10 +365,44 @@ int FlatIndex::iteratorScores(const void *processed_query, std::vector<std::pair
         for (auto &p : best) out.emplace_back(p.second, p.first);
     } else {
         // bfs_batch_iterator.h:24-41
-        out.resize(s.size());
-        for (size_t i = 0; i < s.size(); i++) out[i] = std::make_pair(s[i], id_to_label_[i]);
+        out.resize(count_);
+        const size_t workers = count_ >= ((size_t)1 << 20) ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency())) : 1;
+        auto fill = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) out[i] = std::make_pair(s[i], id_to_label_[i]);
+        };
+        if (workers > 1) {
+            std::vector<std::thread> pool;
+            const size_t per = (count_ + workers - 1) / workers;
+            for (size_t w = 0; w < workers; w++)
+                if (w * per < count_) pool.emplace_back(fill, w * per, std::min(count_, (w + 1) * per));
+            for (auto &th : pool) th.join();
+        } else {
+            fill(0, count_);
+        }
     }
     return 0;
+}
+
+vsgpu_scorebuf *FlatIndex::iteratorDeviceBegin(const void *processed_query) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (multi_ || flush() || count_ == 0) return nullptr;  // multi-value needs the per-label minimum: host path
+    return vsgpu_scorebuf_create(table_, processed_query);
+}
+int FlatIndex::iteratorDeviceNext(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_next(b, k, cap, ids, scores, count);
+}
+int FlatIndex::iteratorDeviceRetire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_retire(b, rows, m);
+}
+int FlatIndex::iteratorDeviceRead(vsgpu_scorebuf *b, double *all) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_read(b, all);
+}
+void FlatIndex::iteratorDeviceEnd(vsgpu_scorebuf *b) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    vsgpu_scorebuf_destroy(b);
 }
 
 int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,

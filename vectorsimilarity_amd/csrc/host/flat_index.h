@@ -74,6 +74,13 @@ struct VecSimIndexInterface {
     virtual size_t storedBlobBytes() const = 0;
     // batch iterator: (score, label) of every live label against a processed query, one GPU score pass
     virtual int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) = 0;
+    // device-resident iterator state (Flat single-value only; others return nullptr and use iteratorScores)
+    virtual vsgpu_scorebuf *iteratorDeviceBegin(const void *) { return nullptr; }
+    virtual int iteratorDeviceNext(vsgpu_scorebuf *, size_t, size_t, uint32_t *, double *, uint32_t *) { return -1; }
+    virtual int iteratorDeviceRetire(vsgpu_scorebuf *, const uint32_t *, size_t) { return -1; }
+    virtual int iteratorDeviceRead(vsgpu_scorebuf *, double *) { return -1; }
+    virtual void iteratorDeviceEnd(vsgpu_scorebuf *) {}
+    virtual size_t rowLabel(size_t) const { return 0; }
     virtual vsgpu_ctx *gpu() = 0;
     virtual void setLastMode(VecSearchMode m) = 0;
 };
@@ -111,6 +118,12 @@ public:
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
     int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) override;
+    vsgpu_scorebuf *iteratorDeviceBegin(const void *processed_query) override;
+    int iteratorDeviceNext(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count) override;
+    int iteratorDeviceRetire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m) override;
+    int iteratorDeviceRead(vsgpu_scorebuf *b, double *all) override;
+    void iteratorDeviceEnd(vsgpu_scorebuf *b) override;
+    size_t rowLabel(size_t id) const override { return id_to_label_[id]; }
     int allScores(const void *processed_query, std::vector<double> &scores);
     size_t labelOf(size_t id) const { return id_to_label_[id]; }
     bool isMulti() const { return multi_; }
@@ -153,6 +166,13 @@ private:
 // "next n best" cursor (reference: batch_iterator.h, brute_force/bf_batch_iterator.h:24-199)
 struct VecSimBatchIterator {
     VecSimIndexInterface *index;
+    // sparse mode: scores stay on the device, the host only tracks where the reference's array compaction
+    // (bf_batch_iterator.h: returned entries are swapped out of the live range) has moved entries
+    vsgpu_scorebuf *dev = nullptr;
+    bool dev_tried = false;
+    size_t dev_rows = 0;
+    std::unordered_map<uint32_t, size_t> moved_to;  // row -> current array position (absent: position == row)
+    std::unordered_map<size_t, uint32_t> moved_at;  // array position -> row sitting there (absent: the row == position)
     std::vector<char> query;  // processed query, owned
     void *timeout_ctx;
     std::vector<std::pair<double, size_t>> scores;  // (score, label) of every vector, lazily filled

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -22,6 +23,7 @@
 #include "mfma_kernels.hpp"
 #include "mfma_lowp_kernels.hpp"
 #include "hnsw_kernels.hpp"
+#include "iter_kernels.hpp"
 
 using namespace vsg;
 
@@ -679,6 +681,20 @@ static void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t p
 
 // ------------------------------------------------------------------ dense scores
 // scores of compact rows (contiguous range or id list) for nq staged queries -> host doubles [nq][n]
+// big host-side loops (widening a few million scores) run on a handful of threads
+template <typename F> static void host_parallel(size_t n, size_t grain, F f) {
+    size_t workers = std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    workers = std::min(workers, std::max<size_t>(1, n / grain));
+    if (workers <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; w++)
+        if (w * per < n) pool.emplace_back(f, w * per, std::min(n, (w + 1) * per));
+    for (auto &th : pool) th.join();
+}
 static int dense_to_host(vsgpu_table *t, size_t nq, const uint32_t *d_ids, size_t first, size_t n,
                          double *out /*[nq][n]*/) {
     vsgpu_ctx *c = t->ctx;
@@ -704,7 +720,9 @@ static int dense_to_host(vsgpu_table *t, size_t nq, const uint32_t *d_ids, size_
     if (f64) memcpy(out, c->pinned, nq * n * 8);
     else {
         const float *src = (const float *)c->pinned;
-        for (size_t i = 0; i < nq * n; i++) out[i] = (double)src[i];
+        host_parallel(nq * n, (size_t)1 << 19, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) out[i] = (double)src[i];
+        });
     }
     return VSGPU_OK;
 }
@@ -722,6 +740,156 @@ extern "C" int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, siz
         rc = dense_to_host(t, 1, nullptr, first + off, m, scores + off);
         if (rc) return rc;
     }
+    return VSGPU_OK;
+}
+
+// ------------------------------------------------------------------ device-resident score vector (batch iterator)
+struct vsgpu_scorebuf {
+    vsgpu_table *t = nullptr;
+    size_t n = 0;
+    uint32_t *scores = nullptr;  // float bits, one per row of the table at creation time
+    uint32_t *work = nullptr;    // [0..2047] histogram, [2048] compact count, then row ids for retire
+    uint2 *out = nullptr;
+    size_t out_cap = 0, work_ids_cap = 0;
+};
+extern "C" void vsgpu_scorebuf_destroy(vsgpu_scorebuf *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->t->ctx->device);
+    if (b->scores) (void)hipFree(b->scores);
+    if (b->work) (void)hipFree(b->work);
+    if (b->out) (void)hipFree(b->out);
+    delete b;
+}
+extern "C" vsgpu_scorebuf *vsgpu_scorebuf_create(vsgpu_table *t, const void *query) {
+    vsgpu_ctx *c = t->ctx;
+    if (t->type == VSGPU_F64 || t->n == 0 || t->n > 0xFFFFFFF0ull) return nullptr;  // fp64 scores are doubles: host path
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (stage_queries(t, query, 1, 0)) return nullptr;
+    auto *b = new vsgpu_scorebuf();
+    b->t = t;
+    b->n = t->n;
+    b->work_ids_cap = 4096;
+    if (hipMalloc((void **)&b->scores, b->n * 4) != hipSuccess || hipMalloc((void **)&b->work, (2064 + b->work_ids_cap) * 4) != hipSuccess) {
+        vsgpu_scorebuf_destroy(b);
+        return nullptr;
+    }
+    const size_t chunk = (size_t)1 << 26;
+    for (size_t off = 0; off < b->n; off += chunk) {
+        const size_t m = std::min(chunk, b->n - off);
+        ScanParams P{};
+        P.row_ids = nullptr;
+        P.row_begin = (uint32_t)off;
+        P.row_end = (uint32_t)t->n;
+        P.n_compact = (uint32_t)m;
+        P.tile_step = (uint32_t)tile_rows_of(t->ek);
+        P.mode = MODE_DENSE;
+        P.out = b->scores + off;
+        P.out_stride = m;
+        if (run_scan(t, P, 1, false)) {
+            vsgpu_scorebuf_destroy(b);
+            return nullptr;
+        }
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        vsgpu_scorebuf_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+extern "C" size_t vsgpu_scorebuf_rows(const vsgpu_scorebuf *b) { return b->n; }
+extern "C" int vsgpu_scorebuf_next(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count) {
+    vsgpu_ctx *c = b->t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    *count = 0;
+    if (k == 0) return VSGPU_OK;
+    if (cap > b->out_cap) {
+        if (b->out) HIPCHK(hipFree(b->out));
+        b->out = nullptr;
+        HIPCHK(hipMalloc((void **)&b->out, cap * sizeof(uint2)));
+        b->out_cap = cap;
+    }
+    const uint32_t n = (uint32_t)b->n;
+    const dim3 grid((unsigned)std::min<size_t>((b->n + 255) / 256, (size_t)c->n_cu * 8));
+    // three histogram passes: bits 31..21, 20..10, 9..0 of the order-preserving key
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t bins[3] = {2048, 2048, 1024};
+    uint32_t mask = 0, prefix = 0;
+    uint64_t need = k;
+    std::vector<uint32_t> h(2048);
+    bool all = false;
+    for (int p = 0; p < 3 && !all; p++) {
+        HIPCHK(hipMemsetAsync(b->work, 0, 2049 * 4, c->stream));
+        hipLaunchKernelGGL(k_iter_hist, grid, dim3(256), 0, c->stream, (const uint32_t *)b->scores, n, mask, prefix, shifts[p], bins[p],
+                           b->work);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h.data(), b->work, bins[p] * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t cum = 0;
+        uint32_t bsel = bins[p];
+        for (uint32_t i = 0; i < bins[p]; i++) {
+            if (cum + h[i] >= need) {
+                bsel = i;
+                break;
+            }
+            cum += h[i];
+        }
+        if (bsel == bins[p]) {  // fewer than k live scores under this prefix: everything qualifies
+            all = true;
+            break;
+        }
+        need -= cum;
+        prefix |= bsel << shifts[p];
+        mask |= (bins[p] - 1) << shifts[p];
+    }
+    const uint32_t tkey = all ? 0xFFFFFFFFu : prefix;
+    HIPCHK(hipMemsetAsync(b->work + 2048, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_iter_compact, grid, dim3(256), 0, c->stream, (const uint32_t *)b->scores, n, tkey, b->out, b->work + 2048,
+                       (uint32_t)cap);
+    HIPCHK(hipGetLastError());
+    uint32_t got = 0;
+    HIPCHK(hipMemcpyAsync(&got, b->work + 2048, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (got > cap) {
+        *count = VSGPU_COUNT_OVERFLOW;
+        return VSGPU_OK;
+    }
+    std::vector<uint2> rec(got);
+    if (got) HIPCHK(hipMemcpy(rec.data(), b->out, got * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < got; i++) {
+        float f;
+        memcpy(&f, &rec[i].y, 4);
+        ids[i] = rec[i].x;
+        scores[i] = (double)f;
+    }
+    *count = got;
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_scorebuf_retire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m) {
+    if (m == 0) return VSGPU_OK;
+    vsgpu_ctx *c = b->t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (m > b->work_ids_cap) {
+        uint32_t *w = nullptr;
+        HIPCHK(hipMalloc((void **)&w, (2064 + m) * 4));
+        HIPCHK(hipFree(b->work));
+        b->work = w;
+        b->work_ids_cap = m;
+    }
+    HIPCHK(hipMemcpyAsync(b->work + 2064, rows, m * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_iter_retire, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, b->scores, (const uint32_t *)(b->work + 2064),
+                       (uint32_t)m);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_scorebuf_read(vsgpu_scorebuf *b, double *all) {
+    vsgpu_ctx *c = b->t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<float> tmp(b->n);
+    HIPCHK(hipMemcpy(tmp.data(), b->scores, b->n * 4, hipMemcpyDeviceToHost));
+    host_parallel(b->n, (size_t)1 << 19, [&](size_t a, size_t e) {
+        for (size_t i = a; i < e; i++) all[i] = (double)tmp[i];
+    });
     return VSGPU_OK;
 }
 
