@@ -277,3 +277,24 @@ def test_typed_hnsw_search_equals_reference_loops(vso, typ, metric, dim):
     hits = sum(len(set(labels[i]) & set(exact[i])) for i in range(len(q)))
     assert hits / (len(q) * k) > 0.6
     assert np.array_equal(ix.get_vector(5), bf.get_vector(5))
+
+
+def test_hnsw_batch_iterator_sparse_mode_with_deleted_nodes(vso):
+    """enough live nodes for the heap regime (device-resident scores): batches still exact, deleted nodes absent"""
+    dim, n = 16, 120_000
+    rng = np.random.default_rng(4)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix, _ = build(dim, n, VecSim.VecSimMetric_L2, M=4, efc=10, ef=10, rows=rows)
+    dead = list(range(0, n, 1001))
+    for lab in dead:
+        ix.delete_vector(lab)
+    q = rng.uniform(-1, 1, dim).astype(np.float32)
+    sc = vso.scan(0, 0, rows, q, dim)
+    sc[dead] = np.inf
+    order = np.lexsort((np.arange(n), sc))
+    it = ix.create_batch_iterator(q)
+    got = []
+    for m in (20, 50, 30, 100):
+        l, d = it.get_next_results(m, VecSim.BY_SCORE)
+        got += l[0].tolist()
+    assert got == order[:200].tolist()

@@ -551,6 +551,13 @@ static bool sparse_materialize(VecSimBatchIterator *it) {
         const uint32_t row = at == it->moved_at.end() ? (uint32_t)pos : at->second;
         it->scores[pos] = ScoredLabel(all[row], it->index->rowLabel(row));
     }
+    if (it->label_count < n) {
+        // rows retired before the first batch (deleted HNSW nodes) carry NaN: they were never part of the array
+        size_t w = it->valid_start;
+        for (size_t pos = it->valid_start; pos < n; pos++)
+            if (!std::isnan(it->scores[pos].first)) it->scores[w++] = it->scores[pos];
+        it->scores.resize(w);
+    }
     it->index->iteratorDeviceEnd(it->dev);
     it->dev = nullptr;
     it->moved_to.clear();
@@ -574,7 +581,7 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
         it->dev = std::getenv("VECSIM_ITER_HOST") ? nullptr : it->index->iteratorDeviceBegin(it->query.data());
         if (it->dev) {
             it->dev_rows = vsgpu_scorebuf_rows(it->dev);
-            it->label_count = it->dev_rows;
+            it->label_count = it->index->indexLabelCount();  // (HNSW: rows minus deleted nodes, retired up front)
         }
     }
     if (it->dev) {

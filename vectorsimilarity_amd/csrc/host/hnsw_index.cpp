@@ -615,6 +615,39 @@ int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair
     return 0;
 }
 
+// device-resident iterator state: the same score buffer as the Flat index, deleted nodes retired up front
+vsgpu_scorebuf *HnswIndex::iteratorDeviceBegin(const void *processed_query) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (n_ == 0 || syncDevice()) return nullptr;
+    vsgpu_scorebuf *b = vsgpu_scorebuf_create(table_, processed_query);
+    if (b && n_deleted_) {
+        std::vector<uint32_t> dead;
+        for (size_t i = 0; i < n_; i++)
+            if (deleted_[i]) dead.push_back((uint32_t)i);
+        if (vsgpu_scorebuf_retire(b, dead.data(), dead.size())) {
+            vsgpu_scorebuf_destroy(b);
+            return nullptr;
+        }
+    }
+    return b;
+}
+int HnswIndex::iteratorDeviceNext(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_next(b, k, cap, ids, scores, count);
+}
+int HnswIndex::iteratorDeviceRetire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_retire(b, rows, m);
+}
+int HnswIndex::iteratorDeviceRead(vsgpu_scorebuf *b, double *all) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    return vsgpu_scorebuf_read(b, all);
+}
+void HnswIndex::iteratorDeviceEnd(vsgpu_scorebuf *b) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    vsgpu_scorebuf_destroy(b);
+}
+
 double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     auto it = label_to_id_.find(label);

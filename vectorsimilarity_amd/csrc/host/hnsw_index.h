@@ -41,6 +41,12 @@ public:
     double getDistanceFrom(size_t label, const void *blob) override;
     VecSimBatchIterator *newBatchIterator(const void *query, VecSimQueryParams *qp) override;
     int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) override;
+    vsgpu_scorebuf *iteratorDeviceBegin(const void *processed_query) override;
+    int iteratorDeviceNext(vsgpu_scorebuf *b, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *count) override;
+    int iteratorDeviceRetire(vsgpu_scorebuf *b, const uint32_t *rows, size_t m) override;
+    int iteratorDeviceRead(vsgpu_scorebuf *b, double *all) override;
+    void iteratorDeviceEnd(vsgpu_scorebuf *b) override;
+    size_t rowLabel(size_t id) const override { return (size_t)labels_[id]; }
     bool preferAdHocSearch(size_t subsetSize, size_t k, bool initial_check) override;
     VecSimIndexBasicInfo basicInfo() const override;
     VecSimIndexStatsInfo statsInfo() const override;
