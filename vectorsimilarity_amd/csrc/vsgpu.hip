@@ -765,6 +765,7 @@ extern "C" vsgpu_scorebuf *vsgpu_scorebuf_create(vsgpu_table *t, const void *que
     if (t->type == VSGPU_F64 || t->n == 0 || t->n > 0xFFFFFFF0ull) return nullptr;  // fp64 scores are doubles: host path
     if (hipSetDevice(c->device) != hipSuccess) return nullptr;
     if (stage_queries(t, query, 1, 0)) return nullptr;
+    WallMarks wm;
     auto *b = new vsgpu_scorebuf();
     b->t = t;
     b->n = t->n;
@@ -790,10 +791,13 @@ extern "C" vsgpu_scorebuf *vsgpu_scorebuf_create(vsgpu_table *t, const void *que
             return nullptr;
         }
     }
+    wm.mark("alloc+launch");
     if (hipStreamSynchronize(c->stream) != hipSuccess) {
         vsgpu_scorebuf_destroy(b);
         return nullptr;
     }
+    wm.mark("dense_scan");
+    wm.flush("scorebuf_create");
     return b;
 }
 extern "C" size_t vsgpu_scorebuf_rows(const vsgpu_scorebuf *b) { return b->n; }
