@@ -510,4 +510,51 @@ __global__ __launch_bounds__(1024) void k_select_dense_upto_kth(const float *den
     if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
 }
 
+// fp64 twin: scores are doubles, keys the order-preserving 64-bit image, records {row, score bits}
+struct SelRec64 {
+    unsigned long long row;
+    unsigned long long bits;
+};
+__device__ __forceinline__ unsigned long long double_sort_key(unsigned long long b) {
+    return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(1024) void k_select_dense_upto_kth_f64(const double *dense, size_t stride, uint32_t n, uint32_t k,
+                                                                    SelRec64 *out, uint32_t *out_counts, uint32_t out_cap) {
+    __shared__ uint32_t red[16];
+    __shared__ uint32_t wpos;
+    const int q = blockIdx.x;
+    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(dense + (size_t)q * stride);
+    unsigned long long T = ~0ull;
+    if (n > k) {
+        T = 0;
+        for (int bit = 63; bit >= 0; bit--) {
+            const unsigned long long trial = T | (1ull << bit);
+            uint32_t cnt = 0;
+#pragma unroll 4
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) cnt += (double_sort_key(c[i]) < trial) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) total += red[w];
+            if (total < k) T = trial;
+        }
+    }
+    if (threadIdx.x == 0) wpos = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const unsigned long long bits = c[i];
+        const bool is_nan = (bits & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull;
+        if (!is_nan && double_sort_key(bits) <= T) {
+            const uint32_t p = atomicAdd(&wpos, 1u);
+            if (p < out_cap) out[(size_t)q * out_cap + p] = SelRec64{i, bits};
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
+}
+
 }  // namespace vsg

@@ -1685,6 +1685,58 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
             }
             return VSGPU_OK;
         }
+        if (f64) {
+            // fp64: dense double scores per group of queries, 64-bit selection on the GPU, survivors to the host
+            const size_t ocap = cap;
+            const size_t group = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 30) / (n * 8)));
+            int rc = ensure(c, c->dense, group * n * 8);
+            if (rc) return rc;
+            rc = ensure(c, c->sel, group * ocap * sizeof(SelRec64));
+            if (rc) return rc;
+            rc = ensure(c, c->selcnt, group * 4);
+            if (rc) return rc;
+            std::vector<uint32_t> hcnt(group);
+            std::vector<SelRec64> hrec(group * ocap);
+            std::vector<Hit> hits;
+            for (size_t q0 = 0; q0 < nq; q0 += group) {
+                const size_t g = std::min(group, nq - q0);
+                rc = stage_queries(t, (const char *)queries + q0 * qstride, g, qstride);
+                if (rc) return rc;
+                ScanParams P{};
+                P.row_ids = nullptr;
+                P.row_begin = 0;
+                P.row_end = (uint32_t)n;
+                P.n_compact = (uint32_t)n;
+                P.tile_step = (uint32_t)tile_rows_of(t->ek);
+                P.mode = MODE_DENSE;
+                P.out = c->dense.p;
+                P.out_stride = n;
+                rc = run_scan(t, P, g, true);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_select_dense_upto_kth_f64, dim3((unsigned)g), dim3(1024), 0, c->stream, (const double *)c->dense.p, n,
+                                   (uint32_t)n, (uint32_t)std::min(k, n), (SelRec64 *)c->sel.p, (uint32_t *)c->selcnt.p, (uint32_t)ocap);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(hcnt.data(), c->selcnt.p, g * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(hrec.data(), c->sel.p, g * ocap * sizeof(SelRec64), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                account_scan(c, t, n, 1, "k_exact_scan(dense f64)");
+                for (size_t j = 0; j < g; j++) {
+                    if (hcnt[j] == VSGPU_COUNT_OVERFLOW) {
+                        counts[q0 + j] = VSGPU_COUNT_OVERFLOW;
+                        continue;
+                    }
+                    hits.resize(hcnt[j]);
+                    for (size_t i = 0; i < hcnt[j]; i++) {
+                        double d;
+                        memcpy(&d, &hrec[j * ocap + i].bits, 8);
+                        hits[i] = Hit{(uint32_t)hrec[j * ocap + i].row, d};
+                    }
+                    std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
+                    emit(hits, q0 + j, cap, ids, scores, counts);
+                }
+            }
+            return VSGPU_OK;
+        }
         return topk_dense_path(t, nq, k, cap, ids, scores, counts, 0, nq, queries, qstride);
     }
 
