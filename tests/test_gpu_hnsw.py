@@ -245,7 +245,7 @@ def test_hnsw_prefer_adhoc_follows_reference_tree():
 
 
 @pytest.mark.parametrize("typ,metric,dim", [("bf16", "L2", 64), ("bf16", "Cosine", 96), ("f16", "IP", 48),
-                                            ("i8", "L2", 64), ("u8", "IP", 32)])
+                                            ("i8", "L2", 64), ("u8", "IP", 32), ("i8", "Cosine", 64), ("u8", "Cosine", 40)])
 def test_typed_hnsw_search_equals_reference_loops(vso, typ, metric, dim):
     """HNSW over the other stored types: the graph is built from widened copies (host, ingest side), the GPU
     search scores the stored blobs with that type's reference-order kernel and equals the restated loops"""
@@ -263,7 +263,7 @@ def test_typed_hnsw_search_equals_reference_loops(vso, typ, metric, dim):
     labels, dists = ix.knn_query(q, k)
     srows = stored_rows(vso, rows, typ, metric)
     sq = stored_rows(vso, q, typ, metric)
-    km = METRICS["IP"] if metric == "Cosine" else METRICS[metric]
+    km = METRICS["IP"] if (metric == "Cosine" and typ not in ("i8", "u8")) else METRICS[metric]
     for j in range(len(q)):
         el, es, _ = vso.hnsw_search(TYPES[typ], km, srows, g, sq[j], k, ef, dim)
         assert np.array_equal(labels[j][:len(el)], el.astype(np.int64)), (typ, j)

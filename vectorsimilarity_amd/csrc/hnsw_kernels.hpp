@@ -35,6 +35,8 @@ struct HnswParams {
     const void *qperm;  // [nq][steps][VL] accumulator-typed
     int nq;
     int epilogue;
+    uint32_t norm_off;     // byte offset of the row's trailing float norm (int8/uint8 Cosine rows)
+    const float *qnorm;    // [nq] query norms (int8/uint8 Cosine)
     // graph snapshot
     const uint32_t *links0;     // [n][M0]
     const uint16_t *cnt0;       // [n]
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
     uint16_t *tags = P.tags + (size_t)slot * P.n;
     uint32_t epoch = P.slot_epoch[slot];
     uint64_t n_dists = 0;
+    float cur_qnorm = 0.f;  // norm of the query being searched (int8/uint8 Cosine)
 
     // exact distance of up to NG nodes (ids[g] for group g, valid when g < cnt); result in nb_d[out0 + g]
     auto score_nodes = [&](const uint32_t *ids, uint32_t first, uint32_t cnt) {
@@ -175,7 +178,14 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         }
 #pragma unroll
         for (int of = VL / 2; of >= 1; of >>= 1) acc = add_rn(acc, __shfl_down(acc, of, VL));
-        if (vl == 0 && act) nb_d[idx] = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
+        if (vl == 0 && act) {
+            float nrow = 0.f;
+            if (P.epilogue == EPI_INT_COS) {
+                const unsigned char *np = reinterpret_cast<const unsigned char *>(rp + P.norm_off);
+                nrow = __uint_as_float((uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24));
+            }
+            nb_d[idx] = epilogue_score<float>(acc, P.epilogue, nrow, cur_qnorm);
+        }
     };
 
     // queries differ a lot in length (evaluations per query vary 2-3x), so they are drawn from a shared counter
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
             const acc_t *qg = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q * steps * VL;
             for (int i = lane; i < steps * VL; i += 64) q_s[i] = qg[i];
         }
+        cur_qnorm = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
         epoch = epoch + 1;
         if ((epoch & 0xFFFFu) == 0) {  // u16 tag wrapped: clear this slot's tags once
             for (uint32_t i = lane; i < P.n; i += 64) tags[i] = 0;

@@ -21,9 +21,8 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
         std::fprintf(stderr, "vecsim_amd: multi-value HNSW indexes are not built yet\n");
         return nullptr;
     }
-    if ((unsigned)p.type > (unsigned)VecSimType_UINT8 || p.type == VecSimType_FLOAT64 ||
-        ((p.type == VecSimType_INT8 || p.type == VecSimType_UINT8) && p.metric == VecSimMetric_Cosine)) {
-        std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/bf16/fp16 (L2, IP, Cosine) and int8/uint8 (L2, IP)\n");
+    if ((unsigned)p.type > (unsigned)VecSimType_UINT8 || p.type == VecSimType_FLOAT64) {
+        std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/bf16/fp16/int8/uint8 (L2, IP, Cosine)\n");
         return nullptr;
     }
     const size_t M = p.M ? p.M : HNSW_DEFAULT_M;
@@ -43,7 +42,7 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->metric_ = p.metric;
     ix->dim_ = p.dim;
     ix->blob_bytes_ = blob_bytes(p.type, p.dim, p.metric);
-    ix->elem_bytes_ = ix->blob_bytes_ / p.dim;
+    ix->elem_bytes_ = type_size(p.type);
     ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     ix->M_ = M;
     ix->M0_ = 2 * M;
@@ -134,6 +133,13 @@ void HnswIndex::widen(const char *b, float *out) const {
     default:
         for (size_t i = 0; i < dim_; i++) out[i] = (float)(unsigned)*(const uint8_t *)(b + i);
         break;
+    }
+    if (metric_ == VecSimMetric_Cosine && (type_ == VecSimType_INT8 || type_ == VecSimType_UINT8)) {
+        // the stored blob carries its norm after the elements: the builder links over unit vectors
+        float nrm;
+        std::memcpy(&nrm, b + dim_, 4);
+        if (nrm > 0)
+            for (size_t i = 0; i < dim_; i++) out[i] /= nrm;
     }
 }
 

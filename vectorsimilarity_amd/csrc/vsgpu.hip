@@ -1975,7 +1975,6 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
         for (size_t q = 0; q < nq; q++) counts[q] = 0;
         return VSGPU_OK;
     }
-    if (t->epi == EPI_INT_COS) return fail(VSGPU_ERR_UNSUPPORTED, "graph search: int8/uint8 Cosine is not supported yet");
     HIPCHK(hipSetDevice(c->device));
     ef = range ? 1 : std::max(ef, k);
     if (ef > 4096) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu too large for the LDS heaps", ef);
@@ -2026,6 +2025,8 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.qperm = c->qperm.p;
     P.nq = (int)nq;
     P.epilogue = t->epi;
+    P.norm_off = (uint32_t)t->dim;
+    P.qnorm = (const float *)c->qnorm.p;
     P.links0 = (const uint32_t *)g->links0.p;
     P.cnt0 = (const uint16_t *)g->cnt0.p;
     P.upper_off = (const uint32_t *)g->upper_off.p;
