@@ -80,3 +80,15 @@ def test_product_never_references_the_oracle():
                 if re.search(r"(import|from)\s+oracle|libvso|vso_[a-z]+\(|#include\s+\"vso", txt):
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_public_headers_compile_as_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: every public header must be usable from a C translation unit"""
+    import subprocess
+    src = tmp_path / "use_headers.c"
+    src.write_text('#include "VecSim/vec_sim.h"\n#include "VecSim/query_results.h"\n#include "VecSim/info_iterator.h"\n'
+                   '#include "VecSim/vec_sim_gpu.h"\n#include "vsgpu.h"\n'
+                   "int main(void) { VecSimParams p; VecSim_InfoField f; (void)p; (void)f; return (int)sizeof(VecSimQueryParams) == 0; }\n")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -28,11 +28,17 @@ ap.add_argument("--data", default="uniform", choices=["uniform", "lowrank"],
 ap.add_argument("--slots", default="", help="comma list of hnsw_slots values to time (waves per CU)")
 a = ap.parse_args()
 
-rows = synth.rows_f32(47, 0, a.rows, a.dim)
+# rows are generated in slices so the generator's temporaries stay small at millions of rows
+rows = np.empty((a.rows, a.dim), dtype=np.float32)
 q = synth.rows_f32(48, 0, a.queries, a.dim)
+mix = synth.rows_f32(49, 0, 32, a.dim)
+for r0 in range(0, a.rows, 200_000):
+    r1 = min(a.rows, r0 + 200_000)
+    part = synth.rows_f32(47, r0, r1 - r0, a.dim)
+    if a.data == "lowrank":
+        part = (synth.rows_f32(47, r0, r1 - r0, 32) @ mix + 0.05 * part).astype(np.float32)
+    rows[r0:r1] = part
 if a.data == "lowrank":
-    mix = synth.rows_f32(49, 0, 32, a.dim)
-    rows = (synth.rows_f32(47, 0, a.rows, 32) @ mix + 0.05 * rows).astype(np.float32)
     q = (synth.rows_f32(48, 0, a.queries, 32) @ mix + 0.05 * q).astype(np.float32)
 p = VecSim.HNSWParams()
 p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2, a.M, a.efc, a.ef
