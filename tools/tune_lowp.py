@@ -25,7 +25,7 @@ for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
     base = [ix.knn_query(x, k) for x in q]
     res = {}
     for r in range(a.rounds):
-        combos = [(v, 1) for v in ([0, 7, 9, 100] if 'i8' in name else [0, 3])]
+        combos = [(v, 1) for v in ([0, 7, 9, 15] if 'i8' in name else [0, 3, 8])]
         for v, w in combos:
             ix.set_option("lowp_qsplit", 1 if v == 100 else 0)
             ix.set_option("lowp_variant", 0 if v == 100 else v)

@@ -115,11 +115,14 @@ __device__ static inline void lowp_wait_vmcnt(int n) {
 #define LOWP_PF 4
 #endif
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
-          bool SKEW = false>
+          bool SKEW = false, int DIST = 0>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
-    constexpr int D = NS - 1;                   // units requested ahead
+    // units requested ahead.  DIST = NS-2 leaves one slot of slack: the slot refilled after a barrier was last read
+    // a whole unit earlier, so the plain s_barrier is enough and hipcc may keep pipelining LDS reads across it
+    constexpr int D = DIST ? DIST : NS - 1;
+    constexpr bool SLACK = (NS - D) >= 2;
     constexpr int MT = RT / 16;
     constexpr int SEG = STAGE / RT;    // bytes per row per stage: 1024 / 512 / 256
     constexpr int KSUB = SEG / 64;              // k-steps (64 B of row each) per stage
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 for (int j = 1; j < D; j++) n_out += ((c + j) % KCH == 0) ? 1 : 0;
                 lowp_wait_vmcnt(n_out);
             }
-            mf_ring_barrier();  // reads of the slot about to be refilled have returned (see mfma_kernels.hpp)
+            // SLACK: only the reads of the unit just finished (KSUB*MT of them) may still be queued; everything
+            // older -- the slot about to be refilled -- has returned once at most 8 are outstanding
+            if (SLACK && KSUB * MT >= 8) asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+            else mf_ring_barrier();  // reads of the slot about to be refilled have returned (see mfma_kernels.hpp)
             if (!SKEW && MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
                 // (entries past the queue's capacity go straight to global memory, so a late flush is only slower)
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);

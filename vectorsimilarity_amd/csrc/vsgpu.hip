@@ -1286,11 +1286,11 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
 // ------------------------------------------------------------------ low-precision MFMA filter path
 // One launcher for every instantiation: ring depths above 3 slots need more than the default 64 KiB of
 // dynamic LDS, which HIP only grants after the attribute is raised.
-template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES>
+template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0>
 static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto kern = k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE>;
+    auto kern = k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
@@ -1343,6 +1343,8 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
         case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
         case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
+        case 8: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 2>);  // 4 slots, 2 ahead: plain barrier
+        case 9: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 5, 16384, 3>);
         case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
         case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
         case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
@@ -1362,6 +1364,8 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
         case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
         case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
+        case 15: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 2>);  // 4 slots, 2 ahead: plain barrier
+        case 16: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 2>);
         case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
         case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
         case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
