@@ -384,11 +384,12 @@ static int grow_to(vsgpu_table *t, size_t rows) {
             if (t->mfma_ok || t->lowp_ok) HIPCHK(hipMalloc((void **)&t->d_norm_slabs, cap * sizeof(float *)));
             t->d_slabs_cap = cap;
         }
-        HIPCHK(hipMemcpy(t->d_slabs, t->slabs.data(), t->slabs.size() * sizeof(char *),
-                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(t->d_slabs, t->slabs.data(), t->slabs.size() * sizeof(char *), hipMemcpyHostToDevice,
+                              t->ctx->stream));
         if (t->mfma_ok || t->lowp_ok)
-            HIPCHK(hipMemcpy(t->d_norm_slabs, t->norm_slabs.data(), t->norm_slabs.size() * sizeof(float *),
-                             hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpyAsync(t->d_norm_slabs, t->norm_slabs.data(), t->norm_slabs.size() * sizeof(float *),
+                                  hipMemcpyHostToDevice, t->ctx->stream));
+        HIPCHK(hipStreamSynchronize(t->ctx->stream));
     }
     return VSGPU_OK;
 }
@@ -450,14 +451,16 @@ extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t 
 extern "C" int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row) {
     if (id >= t->n) return fail(VSGPU_ERR_ARG, "row %zu out of range", id);
     HIPCHK(hipSetDevice(t->ctx->device));
-    HIPCHK(hipMemcpy(row_ptr(t, id), host_row, t->row_bytes, hipMemcpyHostToDevice));
+    // same stream as the norm kernel and the queries (the ctx stream does not synchronise with the legacy stream)
+    HIPCHK(hipMemcpyAsync(row_ptr(t, id), host_row, t->row_bytes, hipMemcpyHostToDevice, t->ctx->stream));
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));
     return update_norms(t, id, 1);
 }
 extern "C" int vsgpu_table_move(vsgpu_table *t, size_t dst, size_t src) {
     if (dst >= t->n || src >= t->n) return fail(VSGPU_ERR_ARG, "move %zu <- %zu out of range", dst, src);
     if (dst == src) return VSGPU_OK;
     HIPCHK(hipSetDevice(t->ctx->device));
-    HIPCHK(hipMemcpy(row_ptr(t, dst), row_ptr(t, src), t->row_bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpyAsync(row_ptr(t, dst), row_ptr(t, src), t->row_bytes, hipMemcpyDeviceToDevice, t->ctx->stream));
     return update_norms(t, dst, 1);
 }
 extern "C" int vsgpu_table_truncate(vsgpu_table *t, size_t new_size) {
@@ -468,7 +471,8 @@ extern "C" int vsgpu_table_truncate(vsgpu_table *t, size_t new_size) {
 extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
     if (id >= t->n) return fail(VSGPU_ERR_ARG, "row %zu out of range", id);
     HIPCHK(hipSetDevice(t->ctx->device));
-    HIPCHK(hipMemcpy(host_row, row_ptr(t, id), t->row_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(host_row, row_ptr(t, id), t->row_bytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));
     return VSGPU_OK;
 }
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
@@ -858,7 +862,10 @@ extern "C" int vsgpu_scorebuf_next(vsgpu_scorebuf *b, size_t k, size_t cap, uint
         return VSGPU_OK;
     }
     std::vector<uint2> rec(got);
-    if (got) HIPCHK(hipMemcpy(rec.data(), b->out, got * sizeof(uint2), hipMemcpyDeviceToHost));
+    if (got) {
+        HIPCHK(hipMemcpyAsync(rec.data(), b->out, got * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     for (uint32_t i = 0; i < got; i++) {
         float f;
         memcpy(&f, &rec[i].y, 4);
@@ -890,7 +897,8 @@ extern "C" int vsgpu_scorebuf_read(vsgpu_scorebuf *b, double *all) {
     vsgpu_ctx *c = b->t->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::vector<float> tmp(b->n);
-    HIPCHK(hipMemcpy(tmp.data(), b->scores, b->n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(tmp.data(), b->scores, b->n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     host_parallel(b->n, (size_t)1 << 19, [&](size_t a, size_t e) {
         for (size_t i = a; i < e; i++) all[i] = (double)tmp[i];
     });
@@ -1875,7 +1883,10 @@ extern "C" int vsgpu_range(vsgpu_table *t, const void *query, double radius, siz
             return VSGPU_OK;
         }
         std::vector<uint2> hc(std::max<uint32_t>(hcount, 1));
-        if (hcount) HIPCHK(hipMemcpy(hc.data(), c->cand.p, hcount * sizeof(uint2), hipMemcpyDeviceToHost));
+        if (hcount) {
+            HIPCHK(hipMemcpyAsync(hc.data(), c->cand.p, hcount * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         hits.resize(hcount);
         for (uint32_t i = 0; i < hcount; i++) {
             float f;
@@ -1948,12 +1959,13 @@ extern "C" int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *link
     if ((rc = ensure(c, g->deleted, n))) return rc;
     if ((rc = ensure(c, g->labels, n * 8))) return rc;
     if (n) {
-        HIPCHK(hipMemcpy(g->links0.p, links0, n * g->M0 * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g->cnt0.p, cnt0, n * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g->upper_off.p, upper_off, n * 4, hipMemcpyHostToDevice));
-        if (upper_words) HIPCHK(hipMemcpy(g->upper.p, upper, upper_words * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g->deleted.p, deleted, n, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(g->labels.p, labels, n * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(g->links0.p, links0, n * g->M0 * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(g->cnt0.p, cnt0, n * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(g->upper_off.p, upper_off, n * 4, hipMemcpyHostToDevice, c->stream));
+        if (upper_words) HIPCHK(hipMemcpyAsync(g->upper.p, upper, upper_words * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(g->deleted.p, deleted, n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(g->labels.p, labels, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // the caller's arrays are borrowed for this call only
     }
     g->n = n;
     g->entry = entry;
