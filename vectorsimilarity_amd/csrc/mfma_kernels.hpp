@@ -196,8 +196,10 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;  // past-the-end prefetches re-read the last tile
         const uint32_t r0 = tile_row0(tt);
-        // a tile never straddles a slab (slab rows are a power of two >= 64), so the slab lookups are
-        // wave-uniform: scalar loads (lgkmcnt), which do not disturb the counted vmcnt waits below
+        // a tile never straddles a slab (slab rows are a power of two >= 64), so the slab lookups are wave-uniform.
+        // hipcc turns them into two vector loads per tile whose vmcnt(0) drains this workgroup's ring once per tile;
+        // replacing them with cached inline-asm scalar loads (as k_mfma_filter_lowp does) was measured SLOWER here
+        // (4.65 vs 4.33 ms on 10 M x 768: with 2-3 workgroups per CU the drain seems to pace them usefully)
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
         const char *sbase = P.slabs[sidx];
         const float *nbase = P.norm_slabs[sidx];
