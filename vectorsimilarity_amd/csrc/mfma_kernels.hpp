@@ -124,7 +124,7 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, c
 
 // RT = rows per workgroup tile: 64 (stage = 64 rows x 256 B, for any dim % 64 == 0) or 16 (stage = 16 rows
 // x 1 KiB, dim % 256 == 0: every DMA instruction moves 1 KiB of ONE row, which HBM likes better).
-template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64>
+template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64, bool SLOAD = false>
 __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     constexpr int MF_NSTAGE = NS;
     static_assert(NS == 3 || NS == 4, "ring depth");
@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
     const char *rp_cur[4], *rp_nxt[4];
     const float *np_cur, *np_nxt;
+    uint32_t cur_slab = 0xFFFFFFFFu;          // SLOAD: slab pointers cached in SGPRs, inline-asm scalar loads
+    uint64_t cur_sbase = 0, cur_nbase = 0;
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;  // past-the-end prefetches re-read the last tile
         const uint32_t r0 = tile_row0(tt);
@@ -201,8 +203,24 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         // replacing them with cached inline-asm scalar loads (as k_mfma_filter_lowp does) was measured SLOWER here
         // (4.65 vs 4.33 ms on 10 M x 768: with 2-3 workgroups per CU the drain seems to pace them usefully)
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
-        const char *sbase = P.slabs[sidx];
-        const float *nbase = P.norm_slabs[sidx];
+        const char *sbase;
+        const float *nbase;
+        if (SLOAD) {
+            if (sidx != cur_slab) {
+                cur_slab = sidx;
+                const char *const *sp = P.slabs + sidx;
+                const float *const *npp = P.norm_slabs + sidx;
+                asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(cur_sbase), "=&s"(cur_nbase)
+                             : "s"(sp), "s"(npp)
+                             : "memory");
+            }
+            sbase = reinterpret_cast<const char *>(cur_sbase);
+            nbase = reinterpret_cast<const float *>(cur_nbase);
+        } else {
+            sbase = P.slabs[sidx];
+            nbase = P.norm_slabs[sidx];
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t row = r0 + st_row[i];
