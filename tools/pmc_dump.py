@@ -11,4 +11,4 @@ for dbf in sorted(glob.glob(sys.argv[1] + "/**/*_results.db", recursive=True)):
          "group by kernel_name, counter_name order by kernel_name, counter_name")
     for k, c, n, v, dur in d.execute(q):
         if pat in k:
-            print("%-60s %-28s n=%-4d mean=%-18.1f dur_us=%.1f" % (k[:60], c, n, v, dur))
+            print("%-75s %-28s n=%-4d mean=%-18.1f dur_us=%.1f" % (k[:75], c, n, v, dur))

@@ -115,7 +115,7 @@ __device__ static inline void lowp_wait_vmcnt(int n) {
 #define LOWP_PF 4
 #endif
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
-          bool SKEW = false, int DIST = 0>
+          bool SKEW = false, int DIST = 0, int DLATE = 0, bool DIAG = false>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
@@ -136,13 +136,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     static_assert(!SKEW || (MODE == MF_FILTER && D >= 2 && (NWAVES == 8 || NWAVES == 16)), "phase-skewed variant");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
+    // the diagnosis switches and the paired mapping are compiled in only where asked for: as run-time flags they
+    // put a branch around every DMA piece of the main loop
+    const int dbg = DIAG ? P.dbg : 0;
+    const int pair_map = DIAG ? P.pair_map : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = SKEW ? ((wave >> 2) & 1) : 0;  // SKEW: waves w and w+4 share a SIMD, one of each half
     const int m16 = lane & 15;
     const int kq = lane >> 4;
-    const int qtile = P.pair_map ? (int)((blockIdx.x >> 3) & 1u) : (int)blockIdx.y;
+    const int qtile = pair_map ? (int)((blockIdx.x >> 3) & 1u) : (int)blockIdx.y;
 
     u32x4_t qf[NQW][KSTEPS];
     {
@@ -165,7 +169,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
     for (int nt = 0; nt < NQW; nt++) {
 #pragma unroll
-        for (int s = 0; s < KSTEPS; s++) asm volatile("" : "+v"(qf[nt][s]));
+        for (int s = 0; s < KSTEPS; s++) {
+            // 256 registers of query fragments (4 column blocks x 16 k-steps): the upper half is parked in AGPRs, which
+            // the MFMA reads directly; left to hipcc they are spilled there and copied back in front of every MFMA
+            if (NQW * KSTEPS * 4 > 192 && nt >= NQW / 2) asm volatile("" : "+a"(qf[nt][s]));
+            else asm volatile("" : "+v"(qf[nt][s]));
+        }
         asm volatile("" : "+v"(qaux[nt]), "+v"(tau[nt]));
     }
     // int8 Cosine: the exact score needs an IEEE divide per (row, query).  1 - dot/(nx*nq) <= tau  <=>
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
-    const uint32_t step = P.pair_map ? gridDim.x / 2 : gridDim.x;
+    const uint32_t step = pair_map ? gridDim.x / 2 : gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
     // Requests are issued strictly in unit order, so only the frontier tile's addresses are kept
     const char *rp_f[IPW];
@@ -260,18 +269,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
                      uint32_t abuf_i) {
         const uint32_t base = slot * STAGE + lds_stage_wave_off;
-        if (!(P.dbg & 4)) {
+        if (!(dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < IPW; i++) {
                 // paired query tiles want the row to stay in L2 for the partner: default cache policy there
-                if (P.pair_map) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+                if (pair_map) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
                 else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
             }
         }
         if (with_aux) glds4(apt, abuf_i * 256, aux_lds);
     };
 
-    uint32_t tile = P.pair_map ? ((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : blockIdx.x;
+    uint32_t tile = pair_map ? ((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : blockIdx.x;
     uint32_t ftile = tile, fbuf = 0;  // frontier: tile and aux buffer of the unit requested next
     make_ptrs(ftile, rp_f, ap_f);
     uint32_t slot_c = 0, abuf = 0;   // ring slot / aux buffer of the unit / tile being consumed
@@ -328,38 +337,52 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 if (kc == 0) advance_frontier();
                 issue(rp_f, ap_f, kc, slot_p, kc == 0, fbuf);
             };
-            if (!SKEW) request_ahead();
+            // DLATE > 0: the refill is requested after the unit's first DLATE fragments instead of right behind the
+            // barrier.  All waves leave the barrier together; with the requests first, every wave queues its DMA
+            // pieces on the CU's one address path before its first LDS read and the matrix pipe idles meanwhile.
+            if (!SKEW && DLATE == 0) request_ahead();
             const char *sbase = lds + slot_c * STAGE;
             // The unit's NFRAG A-fragments are read once each and feed NQW MFMAs.  Left alone hipcc emits
             // ds_read -> s_waitcnt lgkmcnt(0) -> mfma per fragment (measured: 60 % of wave cycles parked, matrix
             // pipe 25 % busy), so the schedule is pinned: PF reads up front, then one read per NQW MFMAs, which
             // keeps PF fragments in flight and lets the compiler count lgkmcnt down instead of draining it.
             constexpr int NFRAG = KSUB * MT;
-            constexpr int PF = NFRAG < LOWP_PF ? NFRAG : LOWP_PF;  // 8 in flight measured no better (8-wave kernels)
-            if (!(P.dbg & 2)) {
-            u32x4_t afr[NFRAG];
+            auto do_frags = [&](auto f0_tag, auto f1_tag) {
+                constexpr int F0 = decltype(f0_tag)::value, F1 = decltype(f1_tag)::value, N = F1 - F0;
+                constexpr int PF = N < LOWP_PF ? N : LOWP_PF;  // 8 in flight measured no better (8-wave kernels)
+                u32x4_t afr[N];
 #pragma unroll
-            for (int f = 0; f < NFRAG; f++) {
-                const int j = f / MT, mt = f % MT;
-                const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
-                const int p = (4 * (j % 4) + kq) ^ m16;
-                afr[f] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
-                if (LK == LP_U8) afr[f] ^= 0x80808080u;
-            }
+                for (int f = F0; f < F1; f++) {
+                    const int j = f / MT, mt = f % MT;
+                    const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
+                    const int p = (4 * (j % 4) + kq) ^ m16;
+                    afr[f - F0] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
+                    if (LK == LP_U8) afr[f - F0] ^= 0x80808080u;
+                }
 #pragma unroll
-            for (int f = 0; f < NFRAG; f++) {
-                const int j = f / MT, mt = f % MT;
+                for (int f = F0; f < F1; f++) {
+                    const int j = f / MT, mt = f % MT;
 #pragma unroll
-                for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(afr[f], qf[nt][c * KSUB + j], acc[mt][nt]);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+                    for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = Ops::mma(afr[f - F0], qf[nt][c * KSUB + j], acc[mt][nt]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-            for (int f = 0; f < NFRAG - PF; f++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, NQW, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, PF * NQW, 0);
-            }
+                for (int f = 0; f < N - PF; f++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, PF * NQW, 0);
+            };
+            if (!(dbg & 2)) {
+                if constexpr (!SKEW && DLATE > 0 && DLATE < NFRAG) {
+                    do_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, DLATE>{});
+                    request_ahead();
+                    do_frags(std::integral_constant<int, DLATE>{}, std::integral_constant<int, NFRAG>{});
+                } else {
+                    do_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, NFRAG>{});
+                    if (!SKEW && DLATE > 0) request_ahead();
+                }
+            } else if (!SKEW && DLATE > 0) request_ahead();
             if (c == KCH - 1) {
                 // this tile's aux values (landed with unit 0): plain asm so that hipcc does not tie the read to
                 // the LDS-DMA stream and drain vmcnt in front of it
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
             }
         };
-        if (!(P.dbg & 1)) {
+        if (!(dbg & 1)) {
             if (LK == LP_U8) {
                 if (P.epi == LE_U8_IP) epilogue(std::integral_constant<int, LE_U8_IP>{});
                 else epilogue(std::integral_constant<int, LE_I8_L2>{});
