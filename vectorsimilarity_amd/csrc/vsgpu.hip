@@ -22,6 +22,7 @@
 #include "exact_kernels.hpp"
 #include "mfma_kernels.hpp"
 #include "mfma_lowp_kernels.hpp"
+#include "mfma_free_kernels.hpp"
 #include "hnsw_kernels.hpp"
 #include "iter_kernels.hpp"
 
@@ -1326,6 +1327,16 @@ static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
     if (P.dbg || P.pair_map) throw std::runtime_error("vsgpu: this kernel variant has no diagnosis build");
     go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false>);
 }
+// barrier-free variant (mfma_free_kernels.hpp): NS slots, D units requested ahead, landed signalled L units early
+template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE, int D, int L>
+static void launch_lowp_free(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = free_lds_bytes(NW, KS, RT, NS, STAGE, D);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto kern = k_mfma_filter_free<LK, KS, RT, NW, NQW, NS, STAGE, D, L>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+}
 template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE = MF_STAGE_BYTES>
 static void launch_lowp_skew(const LowpParams &P, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, true);
@@ -1379,6 +1390,10 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
         case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
         case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
+        case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
+        case 41: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 4, 2>);
+        case 42: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 6, 3>);
+        case 43: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 6, 16384, 4, 2>);
         case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
         case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
         case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
@@ -1401,6 +1416,11 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
         case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
         case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
+        case 40: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 5, 2>);   // barrier-free ring
+        case 41: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 4, 2>);
+        case 42: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 6, 3>);
+        case 43: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 4, 32768, 2, 1>);
+        case 44: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 6, 16384, 4, 2>);
         case 30: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 4>);   // refill requested after 4 / 8 / 16 / all fragments
         case 35: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 2>);
         case 36: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 4>);
