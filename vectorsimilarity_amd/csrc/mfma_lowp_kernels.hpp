@@ -198,7 +198,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * IPW * 1024);
-    char *aux_lds = lds + NS * STAGE + wave * (256 * NAUX);
+    // per-tile aux values: one copy per workgroup, requested by wave 0 (the unit barrier publishes it) -- every LDS-DMA
+    // piece costs its wave hundreds of issue cycles, and 16 waves each fetching the same 256 bytes was a third of all
+    // pieces of the int8 kernel.  (SKEW keeps a private copy per wave: its halves pass different barriers.)
+    const bool aux_loader = SKEW || wave == 0;
+    char *aux_lds = lds + NS * STAGE + (SKEW ? wave : 0) * (256 * NAUX);
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * STAGE + NWAVES * 256 * NAUX);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * STAGE + NWAVES * 256 * NAUX + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq), aux_lds_off = mf_lds_offset(aux_lds);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
             }
         }
-        if (with_aux) glds4(apt, abuf_i * 256, aux_lds);
+        if (with_aux && aux_loader) glds4(apt, abuf_i * 256, aux_lds);
     };
 
     uint32_t tile = pair_map ? ((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : blockIdx.x;
@@ -304,6 +308,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         lowp_wait_vmcnt(n_out);
         mf_ring_barrier();
     }
+    // dbg bit 3 (diagnosis build): s_memtime stamps split each wave's time into vmcnt wait / barrier / refill request /
+    // fragment reads + MFMA issue / epilogue; the sums go to P.tilemin as 8 dwords per wave
+    uint32_t ph[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int i) {
+        if (DIAG && (dbg & 8)) {
+            const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime();
+            if (i >= 0) ph[i] += now - t_prev;
+            t_prev = now;
+        }
+    };
+    stamp(-1);
     for (; tile < P.n_tiles; tile += step) {
         acc_t acc[MT][NQW];
         u32x4_t auxv[MT];
@@ -317,15 +332,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             // unit c landed; units c+1 .. c+D-1 (IPW row loads each, +1 aux load where a unit opens a tile)
             // may stay in flight
             if (!SKEW || half == 0) {
-                int n_out = (D - 1) * IPW;
+                int n_aux = 0;
 #pragma unroll
-                for (int j = 1; j < D; j++) n_out += ((c + j) % KCH == 0) ? 1 : 0;
-                lowp_wait_vmcnt(n_out);
+                for (int j = 1; j < D; j++) n_aux += ((c + j) % KCH == 0) ? 1 : 0;
+                if (aux_loader) lowp_wait_vmcnt((D - 1) * IPW + n_aux);
+                else lowp_wait_vmcnt((D - 1) * IPW);
             }
+            stamp(0);
             // SLACK: only the reads of the unit just finished (KSUB*MT of them) may still be queued; everything
             // older -- the slot about to be refilled -- has returned once at most 8 are outstanding
             if (SLACK && KSUB * MT >= 8) asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
             else mf_ring_barrier();  // reads of the slot about to be refilled have returned (see mfma_kernels.hpp)
+            stamp(1);
             if (!SKEW && MODE == MF_FILTER && c == 0 && (tiles_done & 3u) == 0) {
                 // (entries past the queue's capacity go straight to global memory, so a late flush is only slower)
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<NWAVES * 64>(eq_n, eq, P.counts, P.cand, P.cap);
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             // barrier.  All waves leave the barrier together; with the requests first, every wave queues its DMA
             // pieces on the CU's one address path before its first LDS read and the matrix pipe idles meanwhile.
             if (!SKEW && DLATE == 0) request_ahead();
+            stamp(2);
             const char *sbase = lds + slot_c * STAGE;
             // The unit's NFRAG A-fragments are read once each and feed NQW MFMAs.  Left alone hipcc emits
             // ds_read -> s_waitcnt lgkmcnt(0) -> mfma per fragment (measured: 60 % of wave cycles parked, matrix
@@ -373,7 +392,27 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, PF * NQW, 0);
             };
-            if (!(dbg & 2)) {
+            if constexpr (!SKEW && DLATE < 0) {
+                // staggered refill: the four waves of a SIMD (w, w+4, w+8, w+12) request at different points of
+                // the unit.  Every LDS-DMA piece costs its wave a few hundred cycles of issue (the CU's one
+                // address path serialises the pieces); issued by all waves right behind the barrier that is
+                // 900 cycles during which no wave feeds the matrix pipe (s_memtime phases)
+                constexpr int NG = NWAVES / 4;
+                const int grp = wave >> 2;
+                static_assert(NG == 2 || NG == 4, "staggered refill: 8 or 16 waves");
+                static_assert(NFRAG % NG == 0, "staggered refill: fragments per group");
+                constexpr int Q = NFRAG / NG;
+                if (grp == 0) request_ahead();
+                do_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, Q>{});
+                if (grp == 1) request_ahead();
+                do_frags(std::integral_constant<int, Q>{}, std::integral_constant<int, 2 * Q>{});
+                if constexpr (NG == 4) {
+                    if (grp == 2) request_ahead();
+                    do_frags(std::integral_constant<int, 2 * Q>{}, std::integral_constant<int, 3 * Q>{});
+                    if (grp == 3) request_ahead();
+                    do_frags(std::integral_constant<int, 3 * Q>{}, std::integral_constant<int, 4 * Q>{});
+                }
+            } else if (!(dbg & 2)) {
                 if constexpr (!SKEW && DLATE > 0 && DLATE < NFRAG) {
                     do_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, DLATE>{});
                     request_ahead();
@@ -383,6 +422,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     if (!SKEW && DLATE > 0) request_ahead();
                 }
             } else if (!SKEW && DLATE > 0) request_ahead();
+            stamp(3);
             if (c == KCH - 1) {
                 // this tile's aux values (landed with unit 0): plain asm so that hipcc does not tie the read to
                 // the LDS-DMA stream and drain vmcnt in front of it
@@ -418,6 +458,34 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]), "+v"(auxv[1]), "+v"(auxv[2]), "+v"(auxv[3]));
         auto epilogue = [&](auto epi_tag) {
             constexpr int EPI = decltype(epi_tag)::value;
+            if (MODE == MF_FILTER) {
+                // Survivors are rare (a handful per query in millions of rows): one branch-free pass decides whether
+                // ANY lane of the wave has one (same tests as below, minus the row bound, so a superset); the
+                // per-value branches of the emitting loop are then skipped for almost every tile.
+                bool any = false;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t av = auxv[mt][i];
+#pragma unroll
+                        for (int nt = 0; nt < NQW; nt++) {
+                            if (LK == LP_I8 || LK == LP_U8) {
+                                const int dot = (int)acc[mt][nt][i];
+                                if (EPI == LE_I8_COS) any |= !((float)dot < cosq[nt] * __uint_as_float(av));
+                                else if (EPI == LE_I8_L2) any |= (float)((int)av + (int)qaux[nt] - 2 * dot) <= tau[nt];
+                                else if (EPI == LE_I8_IP) any |= (float)(1 - dot) <= tau[nt];
+                                else any |= (float)(1 - (dot + 128 * (int)av + (int)qaux[nt])) <= tau[nt];
+                            } else {
+                                const float dot = (float)acc[mt][nt][i];
+                                const float ssum = __uint_as_float(av) + __uint_as_float(qaux[nt]);
+                                const float a = (EPI == LE_FP_L2) ? (ssum - 2.0f * dot) : (1.0f - dot);
+                                any |= !(a - (P.cE * ssum + P.absE) > tau[nt]);
+                            }
+                        }
+                    }
+                if (!__any(any)) return;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -504,6 +572,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         }
         abuf = abuf + 1 == NAUX ? 0 : abuf + 1;
         tiles_done++;
+        stamp(4);
+    }
+    if (DIAG && (dbg & 8) && lane == 0) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(P.tilemin) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVES + wave) * 8;
+        for (int i = 0; i < 5; i++) o[i] = ph[i];
+        o[5] = tiles_done;
     }
     if (SKEW && half == 0) mf_ring_barrier();  // pairs with half 1's leading barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -1390,6 +1390,8 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
         case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
         case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
+        case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
+        case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
         case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
         case 41: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 4, 2>);
         case 42: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 6, 3>);
@@ -1416,6 +1418,9 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
         case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
         case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
+        case 50: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, -1>);   // staggered refill
+        case 51: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, -1>);
+        case 52: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 0, -1>);
         case 40: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 5, 2>);   // barrier-free ring
         case 41: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 4, 2>);
         case 42: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 6, 3>);
@@ -1626,10 +1631,33 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
         Q.n_tiles = total_tiles;
         const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
         Q.dbg = (int)c->opt_lowp_dbg;
+        uint32_t *d_ph = nullptr;
+        const size_t ph_words = (size_t)fw * q_tiles * 16 * 8;
+        if (Q.dbg & 8) {
+            HIPCHK(hipMalloc(&d_ph, ph_words * 4));
+            HIPCHK(hipMemsetAsync(d_ph, 0, ph_words * 4, c->stream));
+            Q.tilemin = reinterpret_cast<float *>(d_ph);
+        }
         if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
             launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
+        if (d_ph) {  // phase sums of every wave: mean cycles per tile, printed once per launch
+            std::vector<uint32_t> h(ph_words);
+            HIPCHK(hipMemcpyAsync(h.data(), d_ph, ph_words * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(d_ph));
+            double sum[5] = {0, 0, 0, 0, 0}, tiles = 0;
+            for (size_t w = 0; w < ph_words / 8; w++) {
+                if (!h[w * 8 + 5]) continue;
+                for (int i = 0; i < 5; i++) sum[i] += h[w * 8 + i];
+                tiles += h[w * 8 + 5];
+            }
+            if (tiles > 0)
+                fprintf(stderr, "lowp phases, mean s_memtime ticks per wave and tile: vmcnt-wait %.0f  barrier %.0f  refill-request %.0f  "
+                                "reads+mfma-issue %.0f  epilogue %.0f\n",
+                        sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles);
+        }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
