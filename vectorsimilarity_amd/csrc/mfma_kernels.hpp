@@ -124,9 +124,12 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, c
 
 // RT = rows per workgroup tile: 64 (stage = 64 rows x 256 B, for any dim % 64 == 0) or 16 (stage = 16 rows
 // x 1 KiB, dim % 256 == 0: every DMA instruction moves 1 KiB of ONE row, which HBM likes better).
-template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64, bool SLOAD = false>
+// XOPT (tuning bits): 1 = slab pointers by cached scalar loads, 2 = one norm copy per workgroup (wave 0 requests it),
+// 4 = branch-free "any survivor?" pass in front of the emitting loop
+template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64, int XOPT = 0>
 __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     constexpr int MF_NSTAGE = NS;
+    constexpr bool SLOAD = (XOPT & 1) != 0, SNORM = (XOPT & 2) != 0, PRESCREEN = (XOPT & 4) != 0;
     static_assert(NS == 3 || NS == 4, "ring depth");
     static_assert(RT == 64 || RT == 16, "tile rows");
     constexpr int MT = RT / 16;                      // MFMA M-tiles per tile
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
-    char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + wave * 512;
+    char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + (SNORM ? 0 : wave) * 512;
+    const bool norm_loader = !SNORM || wave == 0;
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
 #pragma unroll
         for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
-        if (with_norm) glds4(np, norm_parity * 256, norm_lds);
+        if (with_norm && norm_loader) glds4(np, norm_parity * 256, norm_lds);
     };
 
     uint32_t tile = my_first;
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
 #pragma unroll
                 for (int a = 1; a <= AHEAD; a++)
                     if ((c + a) % KCH == 0) allowed += 1;
+                if (!norm_loader) allowed = 4 * AHEAD;
                 if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -315,6 +320,22 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * 256);
         bool emitted = false;
         float tmin = INFINITY;
+        bool skip = false;
+        if (PRESCREEN && MODE == MF_FILTER) {
+            bool any = false;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                f32x4_t n4 = *reinterpret_cast<const f32x4_t *>(nrm + mt * 16 + kq * 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float ssum = n4[i] + nq2;
+                    const float a = P.is_l2 ? (ssum - 2.0f * acc[mt][i]) : (1.0f - acc[mt][i]);
+                    any |= !(a - (P.cE * ssum + P.absE) > tau);
+                }
+            }
+            skip = !__any(any);
+        }
+        if (!skip)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             f32x4_t n4 = *reinterpret_cast<const f32x4_t *>(nrm + mt * 16 + kq * 4);

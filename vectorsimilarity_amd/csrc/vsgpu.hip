@@ -1118,21 +1118,24 @@ static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs
     case 7: MF_VARIANT(4, 2, 1, 16)
     case 8: MF_VARIANT(3, 2, 3, 16)
     case 9: MF_VARIANT(3, 0, 1, 16)
-#define MF_VARIANT_S(NS_, AUX_, MINW_, RT_)                                                                           \
+#define MF_VARIANT_X(NS_, AUX_, MINW_, RT_, XOPT_)                                                                         \
     {                                                                                                                 \
         Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                                  \
         dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                                 \
-        auto kern = k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_, true>;                                        \
+        auto kern = k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_, XOPT_>;                                     \
         if (mf_lds_bytes(NS_) > 64 * 1024)                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       mf_lds_bytes(NS_));                                                              \
         hipLaunchKernelGGL(kern, grid, dim3(256), mf_lds_bytes(NS_), s, Q);                                           \
         return RT_;                                                                                                   \
     }
-    case 10: MF_VARIANT_S(3, 2, 1, 16)   // scalar slab loads: no per-tile ring drain
-    case 11: MF_VARIANT_S(4, 2, 1, 16)
-    case 12: MF_VARIANT_S(3, 2, 3, 16)
-    case 13: MF_VARIANT_S(3, 0, 1, 16)
+    case 10: MF_VARIANT_X(3, 2, 1, 16, 1)   // scalar slab loads: no per-tile ring drain
+    case 11: MF_VARIANT_X(4, 2, 1, 16, 1)
+    case 12: MF_VARIANT_X(3, 2, 3, 16, 1)
+    case 13: MF_VARIANT_X(3, 0, 1, 16, 1)
+    case 14: MF_VARIANT_X(3, 2, 1, 16, 2)   // one norm copy per workgroup
+    case 15: MF_VARIANT_X(3, 2, 1, 16, 4)   // survivor pre-screen
+    case 16: MF_VARIANT_X(3, 2, 1, 16, 6)
     default: return 0;
     }
 }
