@@ -476,6 +476,36 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     assert np.array_equal(l1[:8], l2) and np.array_equal(d1[:8], d2)
 
 
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [
+    ("i8", "L2", 64, 600_000, 24, 10),      # 64-row tiles: 9 375 probe tiles
+    ("bf16", "IP", 64, 600_000, 24, 10),
+    ("f32", "L2", 32, 600_000, 70, 10),
+])
+def test_probe_with_more_tiles_than_the_threshold_sort_holds(vso, typ, metric, dim, n, nq, k):
+    """probe_div 1 probes every tile: more per-query tile minima than k_probe_threshold sorts in LDS (8 192), so they
+    are grouped first.  The reply must not change (the threshold only has to keep >= k rows at or below it)."""
+    rng = np.random.default_rng(dim + n)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    l0, d0 = ix.knn_query(q, k)
+    ix.set_option("probe_div", 1)
+    ix.set_option("probe_cap", 1 << 20)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"].startswith("k_mfma_filter"), ix.stats()
+    assert np.array_equal(l0, l1) and np.array_equal(d0, d1)
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    km = kernel_metric(typ, metric)
+    for j in range(0, nq, 5):
+        sc = vso.scan(TYPES[typ], km, srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l1[j], el.astype(np.int64)) and np.array_equal(d1[j], es), (typ, j)
+
+
 @pytest.mark.parametrize("typ,metric,dim", [("bf16", "IP", 256), ("f16", "L2", 256), ("i8", "Cosine", 512), ("i8", "L2", 512)])
 def test_synthetic_fill_lowp_types_matches_host_twin(vso, typ, metric, dim):
     from vectorsimilarity_amd import synth

@@ -84,6 +84,7 @@ struct vsgpu_ctx {
                                       // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
     long opt_probe_div = 32;          // probe ~ n / probe_div rows
+    long opt_probe_cap = 32768;       // ... but at most this many probe tiles
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
 };
@@ -214,6 +215,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
     else if (n == "probe_div") c->opt_probe_div = std::max(1L, value);
+    else if (n == "probe_cap") c->opt_probe_cap = std::min(1L << 20, std::max(64L, value));
     else if (n == "cand_cap") c->opt_cand_cap = std::max(16L, value);
     else return fail(VSGPU_ERR_ARG, "unknown option %s", name);
     return VSGPU_OK;
@@ -1078,7 +1080,7 @@ static inline uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
-// Default shapes: the probe always uses 64-row tiles (its per-tile minima must stay <= 8192 per query);
+// Default shapes: the probe always uses 64-row tiles;
 // the filter uses 16-row x 1-KiB stages with non-temporal DMA when dim % 256 == 0 and the tile is at
 // least as long as the ring (dim >= 512), else 64-row x 256-B stages.  Measured on 10M x 768 (profiles/):
 // 64-row default policy 5.5 ms, 64-row nt 5.16 ms, 16-row nt 4.99 ms.
@@ -1220,7 +1222,7 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     if (rc) return rc;
     const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
@@ -1237,8 +1239,8 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     const float absE = l2 ? 1e-30f : 1e-6f;
 
     const uint32_t tile_step = total_tiles / probe_tiles;
-    uint32_t M = 64;
-    while (M < probe_tiles) M <<= 1;
+    uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
+    while (M < probe_tiles && M < 8192) M <<= 1;
 
     rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
     if (rc) return rc;
@@ -1569,7 +1571,7 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     if (rc) return rc;
     const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), 8192);
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
@@ -1604,8 +1606,10 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     P.cap = (uint32_t)ccap;
 
     const uint32_t tile_step = total_tiles / probe_tiles;
+    // k_probe_threshold sorts M group minima per query in LDS; more probe tiles than that are grouped (the k-th
+    // smallest group minimum still has k distinct rows at or below it, and with k << M grouping costs nothing)
     uint32_t M = 64;
-    while (M < probe_tiles) M <<= 1;
+    while (M < probe_tiles && M < 8192) M <<= 1;
     rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
     if (rc) return rc;
     const uint32_t wgs = (uint32_t)c->n_cu * 2;
