@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-end evidence: the default bench line, rocprofv3 kernel stats of the same command, and the two PMC passes for
+# HBM traffic (separate runs, --kernel-trace only).  Outputs under gpurun_out/prof_$1; profiles/summarize.py turns them
+# into the text files kept in profiles/.
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.db" | head
+python $R/profiles/summarize.py $OUT $OUT/summary || true
+tail -1 $OUT/bench_line.json | cut -c1-1200

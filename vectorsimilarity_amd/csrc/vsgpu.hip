@@ -83,7 +83,7 @@ struct vsgpu_ctx {
     long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
                                       // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
-    long opt_probe_div = 32;          // probe ~ n / probe_div rows
+    long opt_probe_div = 48;          // probe ~ n / probe_div rows (measured optimum on 10 M x 768 fp32: tools/sweep_probe.py)
     long opt_probe_cap = 32768;       // ... but at most this many probe tiles
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
