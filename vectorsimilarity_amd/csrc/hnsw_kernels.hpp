@@ -115,6 +115,12 @@ __device__ __forceinline__ uint32_t cand_insert(float *D, uint32_t *I, uint32_t 
     return tail + 1;
 }
 
+#ifndef HNSW_CH
+#define HNSW_CH 12   // table steps loaded per round trip
+#endif
+#ifndef HNSW_U
+#define HNSW_U 4     // rows per lane group in flight
+#endif
 template <int EK, int OPK>
 __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
     using E = Elem<EK>;
@@ -151,40 +157,58 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
     float cur_qnorm = 0.f;  // norm of the query being searched (int8/uint8 Cosine)
 
     // exact distance of up to NG nodes (ids[g] for group g, valid when g < cnt); result in nb_d[out0 + g]
+    // U * NG nodes per call: node (first + u*NG + grp) for u < U.  All U rows' loads of a chunk are in flight before the
+    // first FMA: the search is latency-bound on random ~3 KB rows, and memory-level parallelism per wave is what buys
+    // throughput (200 K x 768 rows, QPS at CH x U: 12x1 402 K, 24x1 461 K, 24x2 497 K, 12x4 550 K = 6.0 TB/s of gathered
+    // rows; 6x8 and 8x8 the same, 12x6 and 24x4 lose occupancy)
+    constexpr int U = HNSW_U;
     auto score_nodes = [&](const uint32_t *ids, uint32_t first, uint32_t cnt) {
-        const uint32_t idx = first + grp;
-        const bool act = idx < cnt;
-        const uint32_t node = act ? ids[idx] : ids[first];
-        const char *rp = P.slabs[node >> P.slab_shift] + (size_t)(node & P.slab_mask) * P.row_stride;
-        acc_t acc = (acc_t)0;
-        // branch-free, CH steps at a time: all CH row loads of the chunk are issued before the first FMA
-        // (idle table entries load offset 0 and leave the accumulator untouched), so a ~3 KB row costs a
-        // couple of memory round trips instead of one per step
-        constexpr int CH = 12;
+        uint32_t idx[U];
+        bool act[U];
+        const char *rp[U];
+        acc_t acc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            idx[u] = first + (uint32_t)(u * NG) + grp;
+            act[u] = idx[u] < cnt;
+            const uint32_t node = act[u] ? ids[idx[u]] : ids[first];
+            rp[u] = P.slabs[node >> P.slab_shift] + (size_t)(node & P.slab_mask) * P.row_stride;
+            acc[u] = (acc_t)0;
+        }
+        // branch-free, CH steps at a time (idle table entries load offset 0 and leave the accumulator untouched)
+        constexpr int CH = HNSW_CH;
         for (int s0 = 0; s0 < steps; s0 += CH) {
             int off[CH];
-            acc_t xv[CH], qv[CH];
+            acc_t xv[U][CH], qv[CH];
 #pragma unroll
             for (int j = 0; j < CH; j++) off[j] = (s0 + j < steps) ? offs_s[(s0 + j) * VL + vl] : -1;
 #pragma unroll
-            for (int j = 0; j < CH; j++) xv[j] = E::load(rp + (off[j] >= 0 ? off[j] : 0));
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int j = 0; j < CH; j++) xv[u][j] = E::load(rp[u] + (off[j] >= 0 ? off[j] : 0));
 #pragma unroll
             for (int j = 0; j < CH; j++) qv[j] = q_s[min(s0 + j, steps - 1) * VL + vl];
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                const acc_t t = acc_step<OPK>(xv[j], qv[j], acc);
-                acc = off[j] >= 0 ? t : acc;
-            }
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    const acc_t t = acc_step<OPK>(xv[u][j], qv[j], acc[u]);
+                    acc[u] = off[j] >= 0 ? t : acc[u];
+                }
         }
 #pragma unroll
-        for (int of = VL / 2; of >= 1; of >>= 1) acc = add_rn(acc, __shfl_down(acc, of, VL));
-        if (vl == 0 && act) {
-            float nrow = 0.f;
-            if (P.epilogue == EPI_INT_COS) {
-                const unsigned char *np = reinterpret_cast<const unsigned char *>(rp + P.norm_off);
-                nrow = __uint_as_float((uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24));
+        for (int u = 0; u < U; u++) {
+            acc_t a = acc[u];
+#pragma unroll
+            for (int of = VL / 2; of >= 1; of >>= 1) a = add_rn(a, __shfl_down(a, of, VL));
+            if (vl == 0 && act[u]) {
+                float nrow = 0.f;
+                if (P.epilogue == EPI_INT_COS) {
+                    const unsigned char *np = reinterpret_cast<const unsigned char *>(rp[u] + P.norm_off);
+                    nrow = __uint_as_float((uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24));
+                }
+                nb_d[idx[u]] = epilogue_score<float>(a, P.epilogue, nrow, cur_qnorm);
             }
-            nb_d[idx] = epilogue_score<float>(acc, P.epilogue, nrow, cur_qnorm);
         }
     };
 
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                 __syncthreads();
                 if ((uint32_t)lane < cnt) nb_id[lane] = blk[1 + lane];
                 __syncthreads();
-                for (uint32_t f = 0; f < cnt; f += NG) score_nodes(nb_id, f, cnt);
+                for (uint32_t f = 0; f < cnt; f += U * NG) score_nodes(nb_id, f, cnt);
                 n_dists += cnt;
                 __syncthreads();
                 // the reference walks the ORIGINAL node's link list to the end while updating the best
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                 __syncthreads();
                 if (fresh) nb_id[__popcll(fm & ((1ull << lane) - 1ull))] = nid;
                 __syncthreads();
-                for (uint32_t f = 0; f < nfresh; f += NG) score_nodes(nb_id, f, nfresh);
+                for (uint32_t f = 0; f < nfresh; f += U * NG) score_nodes(nb_id, f, nfresh);
                 n_dists += nfresh;
                 __syncthreads();
                 for (uint32_t i = 0; i < nfresh; i++) {
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
             __syncthreads();
             if (fresh) nb_id[__popcll(fm & ((1ull << lane) - 1ull))] = nid;  // keeps link order
             __syncthreads();
-            for (uint32_t f = 0; f < nfresh; f += NG) score_nodes(nb_id, f, nfresh);
+            for (uint32_t f = 0; f < nfresh; f += U * NG) score_nodes(nb_id, f, nfresh);
             n_dists += nfresh;
             __syncthreads();
             for (uint32_t i = 0; i < nfresh; i++) {
