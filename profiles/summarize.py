@@ -8,7 +8,7 @@ import sys
 def main(src, dst):
     out = []
     db = sqlite3.connect(f"{src}/trace/r1_results.db")
-    out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline")
+    out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline")
     out.append("%-78s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         out.append("%-78s %8d %14.1f %12.2f %7.2f" % (name[:78], calls, total, avg, pct))

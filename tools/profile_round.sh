@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.db" | head
