@@ -115,7 +115,7 @@ __device__ static inline void lowp_wait_vmcnt(int n) {
 #define LOWP_PF 4
 #endif
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
-          bool SKEW = false, int DIST = 0, int DLATE = 0, bool DIAG = false>
+          bool SKEW = false, int DIST = 0, int DLATE = 0, bool DIAG = false, int ISS = 0>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
@@ -128,7 +128,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     constexpr int KSUB = SEG / 64;              // k-steps (64 B of row each) per stage
     static_assert(KSTEPS % KSUB == 0, "row bytes must be a multiple of the stage segment");
     constexpr int KCH = KSTEPS / KSUB;
-    constexpr int IPW = (STAGE / 1024) / NWAVES;  // DMA instructions (1 KiB each) per wave per stage
+    // ISS > 0: only waves 0 .. ISS-1 (two per SIMD when ISS = NWAVES/2) request rows, IPW pieces each; the others go
+    // from the barrier straight to their fragment reads, so their MFMAs cover the issuers' LDS-DMA issue time
+    constexpr int NISS = ISS ? ISS : NWAVES;
+    static_assert(!ISS || (!SKEW && ISS < NWAVES), "issuer subset");
+    constexpr int IPW = (STAGE / 1024) / NISS;  // DMA instructions (1 KiB each) per requesting wave per stage
     static_assert(IPW >= 1 && SEG * RT == STAGE && KSUB >= 1, "stage geometry");
     constexpr int TA = (KCH - 1 + D) / KCH;     // tiles ahead reached by the prefetch
     constexpr int NAUX = TA + 1;
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * IPW * 1024);
+    const bool issuer = !ISS || wave < NISS;
     // per-tile aux values: one copy per workgroup, requested by wave 0 (the unit barrier publishes it) -- every LDS-DMA
     // piece costs its wave hundreds of issue cycles, and 16 waves each fetching the same 256 bytes was a third of all
     // pieces of the int8 kernel.  (SKEW keeps a private copy per wave: its halves pass different barriers.)
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     uint32_t cur_slab = 0xFFFFFFFFu;
     uint64_t cur_sbase = 0, cur_abase = 0;
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[IPW], const uint32_t *&ap) {
+        if (!issuer) return;
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;
         const uint32_t r0 = tile_row0(tt);
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     };
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
                      uint32_t abuf_i) {
+        if (!issuer) return;
         const uint32_t base = slot * STAGE + lds_stage_wave_off;
         if (!(dbg & 4)) {
 #pragma unroll
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
                 for (int j = 1; j < D; j++) n_aux += ((c + j) % KCH == 0) ? 1 : 0;
                 if (aux_loader) lowp_wait_vmcnt((D - 1) * IPW + n_aux);
-                else lowp_wait_vmcnt((D - 1) * IPW);
+                else if (issuer) lowp_wait_vmcnt((D - 1) * IPW);
             }
             stamp(0);
             // SLACK: only the reads of the unit just finished (KSUB*MT of them) may still be queued; everything

@@ -1315,7 +1315,7 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
 // ------------------------------------------------------------------ low-precision MFMA filter path
 // One launcher for every instantiation: ring depths above 3 slots need more than the default 64 KiB of
 // dynamic LDS, which HIP only grants after the attribute is raised.
-template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0, int DLATE = 0>
+template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0, int DLATE = 0, int ISS = 0>
 static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
@@ -1325,12 +1325,12 @@ static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
     };
     // the diagnosis build (run-time dbg switches, paired query tiles) exists for the plain 3-slot filter kernels only
-    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16;
+    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16 && ISS == 0;
     if constexpr (has_diag) {
         if (P.dbg || P.pair_map) return go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, true>);
     }
     // (no diagnosis build of this variant: the switches are compiled out, the production kernel runs)
-    go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false>);
+    go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false, ISS>);
 }
 // barrier-free variant (mfma_free_kernels.hpp): NS slots, D units requested ahead, landed signalled L units early
 template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE, int D, int L>
@@ -1395,6 +1395,7 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
         case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
         case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
+        case 60: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
         case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
         case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
         case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
@@ -1423,6 +1424,9 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
         case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
         case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
+        case 60: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 8>);   // 8 of the 16 waves request rows
+        case 61: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 4>);   // one per SIMD
+        case 62: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 0, 8>);
         case 50: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, -1>);   // staggered refill
         case 51: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, -1>);
         case 52: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 0, -1>);
