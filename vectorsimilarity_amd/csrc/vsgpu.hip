@@ -83,7 +83,7 @@ struct vsgpu_ctx {
     long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
                                       // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
-    long opt_probe_div = 48;          // probe ~ n / probe_div rows (measured optimum on 10 M x 768 fp32: tools/sweep_probe.py)
+    long opt_probe_div = 0;           // probe ~ n / probe_div rows; 0 = chosen per call by probe_divisor()
     long opt_probe_cap = 32768;       // ... but at most this many probe tiles
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
@@ -214,7 +214,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "wg_per_cu") c->opt_wg_per_cu = std::max(1L, value);
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
-    else if (n == "probe_div") c->opt_probe_div = std::max(1L, value);
+    else if (n == "probe_div") c->opt_probe_div = std::max(0L, value);
     else if (n == "probe_cap") c->opt_probe_cap = std::min(1L << 20, std::max(64L, value));
     else if (n == "cand_cap") c->opt_cand_cap = std::max(16L, value);
     else return fail(VSGPU_ERR_ARG, "unknown option %s", name);
@@ -1065,6 +1065,17 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
 
 // Candidate slots per query: the threshold comes from a sample of `probe_rows` rows, so about
 // k * n / probe_rows rows pass the filter (more with a loose bound); leave 3x headroom.
+// Probe size.  Probing n/div rows costs (n/div) row reads at streaming speed and leaves ~k*div candidates per query,
+// each re-scored from a randomly placed row at a fraction r ~ 0.15 of that speed: the sum is smallest at
+// div = sqrt(r * n / (nq * k)).  Measured optima (tools/sweep_probe.py, tools/bench_dims.py): 48 at 10 M x 768, batch 64,
+// k 10 (formula: 48); larger probes win on small tables.  Integer kinds have no re-rank and a flat optimum: fixed 48.
+static uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank) {
+    if (c->opt_probe_div > 0) return (uint32_t)c->opt_probe_div;
+    if (!rerank) return 48;
+    const double d = std::sqrt(0.15 * (double)n / (double)(std::max<size_t>(nq, 1) * std::max<size_t>(k, 1)));
+    return (uint32_t)std::min(64.0, std::max(8.0, d));
+}
+
 static size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows) {
     double expect = (double)k * (double)n / (double)std::max<size_t>(probe_rows, 1);
     size_t want = (size_t)std::min(expect * 3.0 + 64.0, 1048576.0);
@@ -1221,7 +1232,7 @@ static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     rc = ensure(c, c->counts, nqp * 4);
     if (rc) return rc;
     const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
@@ -1574,7 +1585,7 @@ static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstr
     rc = ensure(c, c->counts, nqp * 4);
     if (rc) return rc;
     const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / (uint32_t)c->opt_probe_div, (uint32_t)(4 * k));
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, !is_int), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
@@ -1867,7 +1878,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
     if (rc) return rc;
     const int tile_rows = tile_rows_of(t->ek);
     const size_t total_tiles = (n + tile_rows - 1) / tile_rows;
-    size_t probe_tiles = std::max<size_t>(total_tiles / (size_t)c->opt_probe_div, (64 * k + tile_rows - 1) / tile_rows);
+    size_t probe_tiles = std::max<size_t>(total_tiles / (size_t)probe_divisor(c, n, nq, k, false), (64 * k + tile_rows - 1) / tile_rows);
     probe_tiles = std::min(probe_tiles, total_tiles);
     const size_t tile_stride = total_tiles / probe_tiles;  // >= 1
     const size_t n0 = std::min(n, probe_tiles * (size_t)tile_rows);
