@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- Flat fp32 L2 top-10 over N=10M x d=768 synthetic vectors, batch-64 queries
-(BASELINE.json configs[1]); one "step" = one batch of 64 queries answered end to end.
+"""bench.py -- Flat top-K over synthetic vectors resident in HBM; one "step" = one query batch answered end to end.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--dim D] [--batch B] [--topk K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c4] [--rows R] [--dim D] [--batch B] [--topk K]
 
-N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
-(one rank per GPU, RCCL): every rank holds its own 10M-row shard (weak scaling), answers the same
-query batch on it, and the per-shard partial top-K lists are merged through an all-gather
-(vectorsimilarity_amd/sharded.py).  Rank 0 prints ONE JSON line.
+Configs (BASELINE.json `configs`; default c2 = the one `metric` is quoted on):
+    c1  fp32 L2      100 K x 128   1 query    top-10     the reference's own CPU-runnable case
+    c2  fp32 L2       10 M x 768   64 queries top-10     headline
+    c3  int8 Cosine   50 M x 1024  256 queries top-100   int8 MFMA path
+    c4  bf16 IP     12.5 M x 768   128 queries top-10    per GPU: 100 M rows over 8 GPUs, RCCL top-K merge
 
-value      = distances/s = rows(all shards) * batch * steps / wall, wall bracketed by barrier +
-             device sync, max over ranks.  Vectors are resident in HBM before timing; query upload,
-             kernels, candidate download, host replay and reply construction are all inside.
-roofline   = dominant scan kernel: algorithmic bytes (rows * 3072 B per launch) over
-             its mean HIP-event duration, against 8 TB/s.
-cpu_baseline = the oracle's AVX-512 port of the reference kernel + sequential heap (oracle/vso_fast.c)
-             on a bounded sample of the same synthetic rows, all host cores, rank 0, N=1 only.
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (one rank
+per GPU).  Every rank holds its own shard of `rows` vectors (weak scaling), scans it for the same query batch, and the
+per-shard candidate records are exchanged by ONE ncclAllGather per batch -- RCCL over xGMI, issued by the C++ host
+library (csrc/vsgpu_comm.hip behind VecSimGpu_Sharded*, include/VecSim/vec_sim_gpu.h) -- and merged into the exact
+single-index reply on every rank.  torch.distributed is the control plane only (gloo: rank 0's RCCL id, barriers, the
+max-over-ranks of the wall time); it never touches the GPU, so the timed region is bracketed by barrier + the library's
+own device drain (every C-API call returns with its HIP streams synchronised).  Rank 0 prints ONE JSON line.
+
+value        = distances/s = rows(all shards) * batch * steps / wall (max over ranks).  Vectors are resident in HBM
+               before timing; query upload, kernels, candidate download, exchange, host replay and reply construction
+               are all inside.
+roofline     = dominant scan kernel: algorithmic bytes (rows * storedDataSize per launch) over its mean
+               HIP-event duration (measured live on the stream the kernel runs on), against 8 TB/s; for the int8
+               config also the int8 MFMA rate against the 3944 TOP/s ceiling of MI355X_MICROARCH.md.
+cpu_baseline = the oracle's restatement of the reference kernel + sequential heap on a bounded sample of the same
+               synthetic rows: single thread (the reference's actual behaviour, brute_force.h:264-281) and all host
+               cores (independent queries, as bindings.cpp:250-283 knn_parallel does); rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -28,7 +39,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+I8_MFMA_PEAK_TOPS = 3944  # same guide, 16x16x64 int8 ubench ceiling
+
+# name: (type, metric, dim, rows per GPU, batch, k, dtype tag, generator, CPU sample rows)
+CONFIGS = {
+    "c1": ("FLOAT32", "L2", 128, 100_000, 1, 10, "f32", "rows_f32", 100_000),
+    "c2": ("FLOAT32", "L2", 768, 10_000_000, 64, 10, "f32", "rows_f32", 400_000),
+    "c3": ("INT8", "Cosine", 1024, 50_000_000, 256, 100, "i8", "rows_i8", 40_000),
+    "c4": ("BFLOAT16", "IP", 768, 12_500_000, 128, 10, "bf16", "rows_bf16", 40_000),
+}
 
 
 def parse():
@@ -36,46 +56,89 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=10_000_000)
-    ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--topk", type=int, default=0)
     ap.add_argument("--seed", type=int, default=47)
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mfma", type=int, default=1)
-    return ap.parse_args()
+    a = ap.parse_args()
+    typ, metric, dim, rows, batch, k, tag, gen, cpu_rows = CONFIGS[a.config]
+    a.type_name, a.metric_name, a.dtype, a.gen = typ, metric, tag, gen
+    a.dim = a.dim or dim
+    a.rows = a.rows or rows
+    a.batch = a.batch or batch
+    a.topk = a.topk or k
+    a.cpu_sample_rows = a.cpu_sample_rows or cpu_rows
+    return a
 
 
-def cpu_baseline(args, VecSim):
-    """cpu_baseline leg -- the ONLY place bench.py touches oracle/: the reference-order AVX-512 scan +
-    sequential heap (oracle port) timed on a bounded sample of the same synthetic rows, and, as the
-    checker, compared bit for bit with the GPU path on exactly that sample."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(args, VecSim, synth):
+    """cpu_baseline leg -- the ONLY place bench.py touches oracle/: the reference-order scan + sequential heap (oracle
+    port) timed on a bounded sample of the same synthetic rows, and, as the checker, compared bit for bit with the GPU
+    path on exactly that sample."""
     from oracle import vso
     vso.build()
     n = min(args.cpu_sample_rows, args.rows)
-    rows = vso.synth_rows_f32(args.seed, 0, n, args.dim)          # same generator, same seed: rows 0..n-1
-    queries = vso.synth_rows_f32(args.seed + 1, 0, args.batch, args.dim)
-    threads = max(1, min(os.cpu_count() or 1, args.batch))
-    vso.flat_topk_batch_fast(vso.F32, vso.L2, rows[:20000], queries[:threads], args.topk, args.dim, threads)
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        labels, scores, fast = vso.flat_topk_batch_fast(vso.F32, vso.L2, rows, queries, args.topk, args.dim, threads)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+    vt = getattr(vso, {"FLOAT32": "F32", "INT8": "I8", "BFLOAT16": "BF16"}[args.type_name])
+    gen = getattr(synth, args.gen)
+    raw = gen(args.seed, 0, n, args.dim)                    # same generator, same seed: rows 0..n-1
+    qraw = gen(args.seed + 1, 0, args.batch, args.dim)
+    if args.metric_name == "Cosine":                         # int8 Cosine: stored blob = elements + float norm
+        def with_norm(a):
+            out = np.zeros((a.shape[0], args.dim + 4), dtype=np.uint8)
+            out[:, :args.dim] = a.view(np.uint8)
+            for i in range(a.shape[0]):
+                vso.normalize(out[i], args.dim, vt)
+            return out
+        rows, queries, km = with_norm(raw), with_norm(qraw), vso.COSINE
+    else:
+        rows, queries, km = raw, qraw, (vso.L2 if args.metric_name == "L2" else vso.IP)
+    nproc = os.cpu_count() or 1
+    threads = max(1, min(nproc, args.batch))
+    vso.flat_topk_batch_fast(vt, km, rows[:2000], queries[:1], args.topk, args.dim, 1)
+
+    def best_of(nq, th, reps):
+        best, res = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = vso.flat_topk_batch_fast(vt, km, rows, queries[:nq], args.topk, args.dim, th)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, res
+    nq1 = max(1, min(args.batch, 4))
+    t1, _ = best_of(nq1, 1, 3)
+    tall, (labels, scores, fast) = best_of(args.batch, threads, 3)
     # checker: a GPU index over the same n rows must give the same labels, order and scores
     p = VecSim.BFParams()
-    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, args.dim, VecSim.VecSimMetric_L2
+    p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
     small = VecSim.BFIndex(p)
     small.add_synthetic(n, args.seed)
     small.set_option("mfma", args.mfma)
-    gl, gs = small.knn_query(queries, args.topk)
+    gl, gs = small.knn_query(qraw, args.topk)
     same = bool(np.array_equal(gl, labels.astype(np.int64)) and np.array_equal(gs, scores))
-    return {"value": n * args.batch / best, "unit": "distances/s", "cores": threads, "kind": "port",
-            "sample": "first %d of the %d synthetic rows x %d queries, top-%d, best of 3, %s kernel; "
+    return {"value": n * args.batch / tall, "unit": "distances/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": n * nq1 / t1, "unit": "distances/s", "cores": 1,
+                              "note": "the reference scans single-threaded (brute_force.h:264-281)"},
+            "cpu": cpu_model(), "nproc": nproc,
+            "sample": "first %d of the %d synthetic rows x %d queries (single thread: %d), top-%d, best of 3, %s kernel; "
                       "GPU result on the same sample bit-identical: %s" % (
-                          n, args.rows, args.batch, args.topk, "AVX-512 intrinsics" if fast else "portable lanes", same)}
+                          n, args.rows, args.batch, nq1, args.topk,
+                          "AVX-512 intrinsics" if fast else "portable reference-order lanes", same)}
 
 
 def main():
@@ -83,53 +146,55 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ["VECSIM_GPU_DEVICE"] = str(local_rank)
+    # the product's libraries (and with them the ROCm runtime they were built against) come first
+    from vectorsimilarity_amd import VecSim, synth
+    from vectorsimilarity_amd.sharded import ShardedFlatIndex
     dist = None
-    # launched through torch.distributed.run (RANK set): always bring RCCL up, so a 1-rank run exercises
-    # the same collective path as the 2/4/8-rank runs
-    if world > 1 or "RANK" in os.environ:
+    # launched through torch.distributed.run (RANK set): always build the communicator, so a 1-rank run exercises
+    # the same RCCL exchange as the 2/4/8-rank runs
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    os.environ["VECSIM_GPU_DEVICE"] = str(local_rank)
-
-    from vectorsimilarity_amd import VecSim
-    from vectorsimilarity_amd.sharded import ShardedFlatIndex
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     p = VecSim.BFParams()
-    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, args.dim, VecSim.VecSimMetric_L2
-    ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist)
-    # weak scaling: every rank ingests `rows` synthetic vectors (its own seed => its own shard content)
-    ix.add_synthetic_local(args.rows, args.seed + 1000 * rank)
-    ix.local.set_option("mfma", args.mfma)
+    p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
+    if distributed:
+        ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)   # RCCL exchange
+        ix.add_synthetic_local(args.rows, args.seed)     # weak scaling: shard r holds `rows` vectors of seed + 1000 r
+        local = ix.local
+    else:
+        ix = local = VecSim.BFIndex(p)
+        ix.add_synthetic(args.rows, args.seed)
+    local.set_option("mfma", args.mfma)
 
-    from vectorsimilarity_amd import synth
     n_batches = args.warmup + args.steps
-    qall = synth.rows_f32(args.seed + 1, 0, args.batch * n_batches, args.dim)
-    qall = qall.reshape(n_batches, args.batch, args.dim)
+    gen = getattr(synth, args.gen)
+    nb_distinct = min(n_batches, 8)                       # host-side query sets, cycled
+    qsets = [gen(args.seed + 1 + b, 0, args.batch, args.dim) for b in range(nb_distinct)]
 
     def sync():
-        ix.device_sync()
         if dist is not None:
             dist.barrier()
-        ix.device_sync()
 
     for w in range(args.warmup):
-        ix.knn_query(qall[w], args.topk)
-    ix.local.reset_stats()
+        ix.knn_query(qsets[w % nb_distinct], args.topk)
+    local.reset_stats()
     sync()
     t0 = time.perf_counter()
     last = None
     for s in range(args.steps):
-        last = ix.knn_query(qall[args.warmup + s], args.topk)
+        last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    st = ix.local.stats()
+    st = local.stats()
 
     if rank == 0:
         total_rows = args.rows * world
@@ -138,38 +203,47 @@ def main():
         avg_ms = st["scan_ms"] / launches
         bytes_per_launch = st["scan_bytes"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes, committed summary)
+        traffic, traffic_source = None, None
+        try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 passes; committed summary, not this run)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(st["scan_kernel"])
             if t and t["workload"] == {"rows": args.rows, "dim": args.dim, "batch": args.batch}:
                 traffic = t["bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate run; not measured by this run)"
         except (OSError, ValueError, KeyError):
             pass
+        rows_tag = "%dM" % (args.rows // 1_000_000) if args.rows % 1_000_000 == 0 else str(args.rows)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": st["scan_kernel"], "avg_kernel_ms": avg_ms, "launches": int(st["scan_launches"]),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "other_kernels_ms_per_step": st["other_ms"] / max(1, args.steps)}
+        if args.dtype == "i8" and avg_ms > 0:
+            rows_per_launch = st["scan_rows"] / launches
+            tops = 2.0 * rows_per_launch * args.dim * args.batch / (avg_ms * 1e-3) / 1e12
+            roof["mfma"] = {"achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
+                            "note": "balanced config: 256 queries x 1 KiB rows need 4.1 POP/s to stream at 8 TB/s"}
         out = {
-            "metric": "distances/sec, Flat fp32 L2 top-%d, N=%s d=%d, batch-%d" % (
-                args.topk, "%dM" % (args.rows // 1_000_000) if args.rows % 1_000_000 == 0 else str(args.rows),
-                args.dim, args.batch),
+            "metric": "distances/sec, Flat %s %s top-%d, N=%s d=%d, batch-%d" % (
+                args.dtype if args.dtype != "f32" else "fp32", args.metric_name, args.topk, rows_tag, args.dim, args.batch),
             "value": dists / dt,
             "unit": "distances/s",
             "qps": args.batch * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "flat_fp32_l2_top%d" % args.topk, "rows_per_gpu": args.rows, "dim": args.dim,
-                       "batch": args.batch, "k": args.topk, "sharding": "rows x %d, all-gather top-K merge" % world
-                       if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": st["scan_kernel"], "avg_kernel_ms": avg_ms, "launches": int(st["scan_launches"]),
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "other_kernels_ms_per_step":
-                             st["other_ms"] / max(1, args.steps)},
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: flat_%s_%s_top%d" % (args.config, args.dtype, args.metric_name.lower(), args.topk),
+                       "rows_per_gpu": args.rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
+                       "sharding": "rows x %d" % world if world > 1 else "single GPU",
+                       "exchange": "rccl ncclAllGather of per-shard candidate records + exact host merge (C++ host library)"
+                       if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
+            "roofline": roof,
             "candidates_per_query": st["candidates"] / max(1, args.steps * args.batch),
             "fallbacks": int(st["fallbacks"]),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, VecSim)
+            out["cpu_baseline"] = cpu_baseline(args, VecSim, synth)
         # size-independent property at full size: replies are ascending in score
         labels, scores = last
         out["sorted"] = bool(np.all(np.diff(scores, axis=1) >= 0) and np.all(labels >= 0))

@@ -45,6 +45,59 @@ int VecSimGpu_MergeTopK(size_t nq, size_t parts, size_t cap, const uint64_t *gid
                         const double *scores, const uint32_t *counts, size_t k, int64_t *out_labels,
                         double *out_scores);
 
+/* ---- Flat index sharded over the GPUs of a node (BASELINE config 4) ----
+ * The reference is single-process and CPU-only, so nothing upstream maps to these; what they preserve is the reply
+ * of BruteForceIndex::topKQuery (algorithms/brute_force/brute_force.h:242-291) over the union of the shards,
+ * ties included.  Vector number i of the equivalent single index lives in block i / blockSize, block b on shard
+ * b % world.  Ingest and queries are SPMD: every process makes the same calls in the same order; each keeps only
+ * its own shard's rows (ingest moves no data) and every process receives the full reply.
+ *
+ *   one process per GPU   VecSimGpu_ShardedNew: rank 0 draws 128 bytes with VecSimGpu_ShardedGetUniqueId and hands
+ *                         them to the other ranks out of band (env, file, MPI, a torch store); the per-batch
+ *                         exchange is ONE ncclAllGather of fixed-size candidate records over RCCL/xGMI.
+ *   own transport         VecSimGpu_ShardedNewWithTransport: same, the caller moves the bytes (MPI, gloo ...).
+ *   one process, G shards VecSimGpu_ShardedNewLocal: devices[i] is shard i's GPU (may repeat); no communicator,
+ *                         the shards scan concurrently and the partials are merged in-process.
+ *   external shard        VecSimGpu_ShardedNewExternal: the caller also provides this rank's storage and scan
+ *                         (another back end); append-only.
+ */
+typedef struct VecSimShardedIndex VecSimShardedIndex;
+/* recv receives world * bytes in rank order / buf of `root` reaches every rank; return 0 on success */
+typedef int (*VecSimGpu_AllGatherFn)(void *user, const void *send, size_t bytes, void *recv);
+typedef int (*VecSimGpu_BroadcastFn)(void *user, void *buf, size_t bytes, int root);
+/* external shard: add returns 1 (appended) / 0 (overwrote) / -1; candidates has VecSimIndex_TopKCandidatesBatch's contract */
+typedef int (*VecSimGpu_ShardAddFn)(void *user, const void *blob, size_t label);
+typedef int (*VecSimGpu_ShardCandidatesFn)(void *user, const void *queryBlobs, size_t nq, size_t queryStride, size_t k,
+                                           size_t cap, uint32_t *ids, size_t *labels, double *scores, uint32_t *counts);
+int VecSimGpu_ShardedGetUniqueId(void *id128);
+VecSimShardedIndex *VecSimGpu_ShardedNew(const VecSimParams *params, int rank, int world, int device, const void *id128);
+VecSimShardedIndex *VecSimGpu_ShardedNewWithTransport(const VecSimParams *params, int rank, int world, int device,
+                                                      VecSimGpu_AllGatherFn allgather, VecSimGpu_BroadcastFn broadcast,
+                                                      void *user);
+VecSimShardedIndex *VecSimGpu_ShardedNewExternal(const VecSimParams *params, int rank, int world, VecSimGpu_ShardAddFn add,
+                                                 VecSimGpu_ShardCandidatesFn candidates, VecSimGpu_AllGatherFn allgather,
+                                                 void *user);
+VecSimShardedIndex *VecSimGpu_ShardedNewLocal(const VecSimParams *params, int n_shards, const int *devices);
+void VecSimGpu_ShardedFree(VecSimShardedIndex *index);
+/* 1 new / 0 overwrite (the row keeps its place, like brute_force_single.h:139-143) / -1 error */
+int VecSimGpu_ShardedAddVector(VecSimShardedIndex *index, const void *blob, size_t label);
+long VecSimGpu_ShardedAddVectorsBulk(VecSimShardedIndex *index, const void *blobs, const size_t *labels, size_t n);
+/* weak-scaling fill: every shard s appends rows_per_shard device-generated rows (seed_base + 1000 s); the equivalent
+ * single index is the concatenation of the shards in shard order, label = gid.  Append-only afterwards. */
+long VecSimGpu_ShardedAddSyntheticLocal(VecSimShardedIndex *index, size_t rows_per_shard, uint64_t seed_base);
+/* swap-delete of the equivalent single index (brute_force.h:196-224): its last row moves into the hole */
+int VecSimGpu_ShardedDeleteVector(VecSimShardedIndex *index, size_t label);
+size_t VecSimGpu_ShardedIndexSize(VecSimShardedIndex *index);
+int VecSimGpu_ShardedTopKQueryBatch(VecSimShardedIndex *index, const void *queryBlobs, size_t nq, size_t queryStride, size_t k,
+                                    VecSimQueryParams *queryParams, VecSimQueryReply_Order order, VecSimQueryReply **replies);
+int VecSimGpu_ShardedTopKQueryBatchArrays(VecSimShardedIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                          size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                          int64_t *labels, double *scores, int *codes);
+/* the Flat index of a shard held by this process (stats, options); NULL for shards of other processes */
+VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *index, int shard);
+int VecSimGpu_ShardedWorld(VecSimShardedIndex *index);
+int VecSimGpu_ShardedRank(VecSimShardedIndex *index); /* -1: all shards live in this process */
+
 /* n new vectors at once; labels[i] must not exist yet (returns the number added, -1 on error) */
 long VecSimIndex_AddVectorsBulk(VecSimIndex *index, const void *blobs, const size_t *labels, size_t n);
 

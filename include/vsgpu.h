@@ -122,6 +122,22 @@ int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qs
 int vsgpu_graph_range(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, double radius, double epsilon,
                       size_t cap, uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals);
 
+/* ---- shard exchange of a multi-GPU Flat index: RCCL over xGMI, one process per GPU ----
+ * The reference has no counterpart (it is single-process, CPU only); the semantics the exchange must
+ * preserve are those of BruteForceIndex::topKQuery over the union of the shards (brute_force.h:242-291).
+ * Rank 0 draws a 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band; every rank then
+ * creates its communicator.  allgather: every rank contributes `bytes` HOST bytes and receives world*bytes
+ * in rank order; broadcast: `buf` of the root reaches every rank.  Both return when the data is in place. */
+#define VSGPU_COMM_ID_BYTES 128
+typedef struct vsgpu_comm vsgpu_comm;
+int vsgpu_comm_unique_id(void *id128);
+vsgpu_comm *vsgpu_comm_create(vsgpu_ctx *ctx, int rank, int world, const void *id128);
+void vsgpu_comm_destroy(vsgpu_comm *c);
+int vsgpu_comm_rank(const vsgpu_comm *c);
+int vsgpu_comm_world(const vsgpu_comm *c);
+int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t bytes, void *recv);
+int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int root);
+
 /* ---- measurement hooks (bench.py roofline leg) ----
  * HIP-event time of the dominant scan kernel, accumulated per ctx on the stream it runs on. */
 typedef struct {

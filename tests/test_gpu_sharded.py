@@ -1,0 +1,192 @@
+"""GPU: the shard leg of the multi-GPU Flat index on real hardware (BASELINE config 4's defining feature).
+
+One MI355X plays G shards (VecSimGpu_ShardedNewLocal with every shard on device 0): rows are dealt block-round-robin
+into G real GPU Flat indexes, every shard runs VecSimIndex_TopKCandidatesBatch's scan, the records are merged by the
+host library, and the reply must equal BOTH the single-index GPU reply and the oracle -- labels, order and scores,
+0 ulp, ties included.  A world-1 RCCL communicator (ncclCommInitRank + ncclAllGather through librccl inside
+libvsgpu.so) and a torchrun-launched 1-rank bench prove the exchange path and the torch + libvsgpu.so combination
+in one process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import METRICS, TYPES, random_vectors, stored_rows
+from vectorsimilarity_amd import VecSim
+from vectorsimilarity_amd.sharded import ShardedFlatIndex
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def params(typ, metric, dim, block):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric, p.blockSize = TYPES[typ], dim, METRICS[metric], block
+    return p
+
+
+def kernel_metric(typ, metric):
+    return METRICS["IP"] if (metric == "Cosine" and typ not in ("i8", "u8")) else METRICS[metric]
+
+
+def oracle_topk(vso, typ, metric, rows, q, k, labels):
+    st = stored_rows(vso, rows, typ, metric)
+    qq = stored_rows(vso, q[None, :], typ, metric)[0]
+    return vso.flat_topk(TYPES[typ], kernel_metric(typ, metric), st, qq, k, rows.shape[1], labels)
+
+
+def check_equal(vso, sharded, single, typ, metric, rows, labels, queries, k, oracle_queries=None):
+    gl, gs = sharded.knn_query(queries, k)
+    sl, ss = single.knn_query(queries, k)
+    assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
+    for qi in (range(len(queries)) if oracle_queries is None else oracle_queries):
+        el, es = oracle_topk(vso, typ, metric, rows, queries[qi], k, labels.astype(np.uint64))
+        assert np.array_equal(gl[qi], el.astype(np.int64)) and np.array_equal(gs[qi], es), (typ, metric, qi)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_one_gpu_as_G_shards_fp32_ties(vso, G):
+    """fp32 L2 on duplicated small-integer rows: equal scores straddle shard boundaries, so the merge's gid order
+    decides the reply"""
+    rng = np.random.default_rng(100 + G)
+    dim, n, nq, k, block = 32, 6000, 9, 10, 64
+    base = rng.integers(-2, 3, (40, dim)).astype(np.float32)
+    rows = base[rng.integers(0, 40, n)]
+    labels = rng.permutation(n) + 7
+    queries = base[:nq].copy()
+    sx = ShardedFlatIndex(params("f32", "L2", dim, block), shards=G)
+    one = VecSim.BFIndex(params("f32", "L2", dim, block))
+    sx.add_vectors(rows[:4000], labels[:4000])
+    one.add_vectors(rows[:4000], labels[:4000])
+    for i in range(4000, n):
+        assert sx.add_vector(rows[i], labels[i]) == 1
+        one.add_vector(rows[i], labels[i])
+    assert sx.index_size() == n
+    sizes = [sx.local_index(s).index_size() for s in range(G)]
+    assert sum(sizes) == n and max(sizes) - min(sizes) <= block
+    check_equal(vso, sx, one, "f32", "L2", rows, labels, queries, k)
+    # k = 200: far more than cap = 2k rows tie at a shard's k-th score => the wide retry
+    check_equal(vso, sx, one, "f32", "L2", rows, labels, queries[:3], 200)
+
+
+def test_overwrite_and_delete_keep_single_index_order(vso):
+    """overwrite keeps the row's place; delete moves the GLOBAL last row into the hole (brute_force.h:196-224), across
+    shards, so ties keep resolving like the single index"""
+    rng = np.random.default_rng(5)
+    dim, n, G, block = 16, 1500, 3, 32
+    base = rng.integers(-2, 3, (25, dim)).astype(np.float32)
+    rows = base[rng.integers(0, 25, n)].copy()
+    labels = np.arange(n) + 1000
+    sx = ShardedFlatIndex(params("f32", "L2", dim, block), shards=G)
+    one = VecSim.BFIndex(params("f32", "L2", dim, block))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    for i in (5, 700, 1499):
+        v = base[(i * 3) % 25]
+        assert sx.add_vector(v, labels[i]) == 0 and one.add_vector(v, labels[i]) == 0
+    assert sx.index_size() == n
+    for lab in (1000 + 3, 1000 + 1499, 1000 + 64, 1000 + 777, 1000 + 1498, 1000 + 0):
+        assert sx.delete_vector(lab) == 1 and one.delete_vector(lab) == 1
+    assert sx.delete_vector(1000 + 3) == 0
+    assert sx.index_size() == one.index_size() == n - 6
+    # more rows after the deletes land where the single index puts them
+    extra = base[rng.integers(0, 25, 100)]
+    for j in range(100):
+        assert sx.add_vector(extra[j], 50_000 + j) == 1
+        one.add_vector(extra[j], 50_000 + j)
+    q = base[:8].copy()
+    for k in (1, 10, 60):
+        gl, gs = sx.knn_query(q, k)
+        sl, ss = one.knn_query(q, k)
+        assert np.array_equal(gl, sl) and np.array_equal(gs, ss), k
+
+
+def test_config4_shape_bf16_ip_shards(vso):
+    """BASELINE config 4's shape per query batch: bf16 IP, d = 768, 128 queries, top-10 -- on the low-precision MFMA
+    filter path of every shard (dense_pairs = 0 forces it at this test size)"""
+    rng = np.random.default_rng(44)
+    dim, n, nq, k, G = 768, 24_000, 128, 10, 8
+    f = rng.standard_normal((n, dim)).astype(np.float32)
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    rows = vso.f32_to_bf16(f)
+    qf = rng.standard_normal((nq, dim)).astype(np.float32)
+    qf /= np.linalg.norm(qf, axis=1, keepdims=True)
+    queries = vso.f32_to_bf16(qf)
+    labels = np.arange(n) + 1
+    sx = ShardedFlatIndex(params("bf16", "IP", dim, 1024), shards=G)
+    one = VecSim.BFIndex(params("bf16", "IP", dim, 1024))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    for s in range(G):
+        sx.local_index(s).set_option("dense_pairs", 0)
+        sx.local_index(s).reset_stats()
+    one.set_option("dense_pairs", 0)
+    check_equal(vso, sx, one, "bf16", "IP", rows, labels, queries, k, oracle_queries=range(0, nq, 9))
+    for s in range(G):
+        st = sx.local_index(s).stats()
+        assert "lowp" in st["scan_kernel"] and st["fallbacks"] == 0, st
+
+
+@pytest.mark.parametrize("typ,metric,dim", [("i8", "Cosine", 128), ("f32", "Cosine", 100), ("u8", "L2", 64), ("f16", "IP", 96)])
+def test_other_types_shard_identically(vso, typ, metric, dim):
+    rng = np.random.default_rng(dim)
+    n, nq, k, G = 9000, 20, 25, 3
+    rows = random_vectors(rng, n, dim, typ, vso)
+    queries = random_vectors(rng, nq, dim, typ, vso)
+    labels = rng.permutation(n)
+    sx = ShardedFlatIndex(params(typ, metric, dim, 256), shards=G)
+    one = VecSim.BFIndex(params(typ, metric, dim, 256))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    check_equal(vso, sx, one, typ, metric, rows, labels, queries, k, oracle_queries=range(0, nq, 4))
+
+
+def test_rccl_world1_exchange_in_process(vso):
+    """one rank, real communicator: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclBroadcast run through
+    librccl inside libvsgpu.so -- the RCCL + vsgpu combination in one process, no torch involved"""
+    rng = np.random.default_rng(8)
+    dim, n, nq, k = 64, 20_000, 16, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    labels = np.arange(n)
+    sx = ShardedFlatIndex(params("f32", "L2", dim, 1024), rank=0, world=1, device=0)   # transport = rccl
+    one = VecSim.BFIndex(params("f32", "L2", dim, 1024))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    check_equal(vso, sx, one, "f32", "L2", rows, labels, queries, k, oracle_queries=range(0, nq, 5))
+    assert sx.delete_vector(17) == 1 and one.delete_vector(17) == 1
+    gl, gs = sx.knn_query(queries, k)
+    sl, ss = one.knn_query(queries, k)
+    assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
+
+
+def test_synthetic_weak_scaling_fill_matches_concatenation(vso):
+    """bench.py's fill: shard s holds rows generated from seed + 1000 s; the equivalent single index is their
+    concatenation with label = gid"""
+    dim, per, G, nq, k = 128, 5000, 4, 8, 10
+    sx = ShardedFlatIndex(params("f32", "L2", dim, 1024), shards=G)
+    sx.add_synthetic_local(per, 47)
+    assert sx.index_size() == per * G and sx.add_vector(np.zeros(dim, np.float32), 1) == -1   # append-only afterwards
+    rows = np.concatenate([vso.synth_rows_f32(47 + 1000 * s, 0, per, dim) for s in range(G)])
+    queries = vso.synth_rows_f32(48, 0, nq, dim)
+    gl, gs = sx.knn_query(queries, k)
+    for qi in range(nq):
+        el, es = vso.flat_topk(0, 0, rows, queries[qi], k, dim)
+        assert np.array_equal(gl[qi], el.astype(np.int64)) and np.array_equal(gs[qi], es)
+
+
+def test_torchrun_one_rank_bench_uses_rccl():
+    """the driver's launch line with one rank: torch.distributed rendezvous + RCCL communicator inside libvsgpu.so +
+    the scan, in one process; the JSON line must come back and say the replies were sorted"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--rows", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["sorted"] and out["n_gpus"] == 1 and out["config"]["exchange"].startswith("rccl"), out

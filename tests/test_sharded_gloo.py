@@ -1,6 +1,12 @@
-"""CPU, world_size 2 over gloo: the multi-GPU Flat path (row sharding, candidate records, all-gather,
-exact global merge) with an oracle-backed stand-in for the per-rank GPU index.  Checks that the
-merged reply equals the single-index reference reply, ties included."""
+"""CPU, world_size 2 over gloo: the multi-GPU Flat path of the C++ host library (csrc/host/sharded_index.cpp:
+SPMD ingest bookkeeping, block partition, candidate records, exchange, exact global merge) with
+
+  * the exchange done by torch.distributed/gloo through the library's transport callbacks, and
+  * this rank's storage + scan provided through the library's external-shard callbacks by an oracle-backed
+    stand-in (tests only -- the product's shard is the GPU Flat index; there is no GPU in this tier).
+
+Checks that the merged reply equals the single-index reference reply, ties and overwrites included."""
+import ctypes as C
 import os
 import sys
 
@@ -11,31 +17,35 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class OracleLocalIndex:
-    """Test double with the three methods ShardedFlatIndex needs from VecSim.BFIndex; distances come
-    from the CPU oracle (tests only -- the product's local index is the GPU BFIndex)."""
+class OracleShard:
+    """External shard: rows live in numpy, distances come from the CPU oracle"""
 
     def __init__(self, dim):
         from oracle import vso
         self.vso, self.dim = vso, dim
         self.rows, self.labels = [], []
 
-    def add_vector(self, v, label):
-        self.rows.append(np.asarray(v, dtype=np.float32))
+    def add(self, _user, blob, label):
+        v = np.ctypeslib.as_array(C.cast(blob, C.POINTER(C.c_float)), shape=(self.dim,)).copy()
+        if label in self.labels:   # overwrite in place
+            self.rows[self.labels.index(label)] = v
+            return 0
+        self.rows.append(v)
         self.labels.append(int(label))
         return 1
 
-    def add_vectors(self, vs, labels):
-        for v, l in zip(vs, labels):
-            self.add_vector(v, l)
-
-    def topk_candidates(self, queries, k, cap, ids, labels, scores, counts):
+    def candidates(self, _user, queries, nq, stride, k, cap, ids, labels, scores, counts):
+        ids = np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_uint32)), shape=(nq, cap))
+        labels = np.ctypeslib.as_array(C.cast(labels, C.POINTER(C.c_uint64)), shape=(nq, cap))
+        scores = np.ctypeslib.as_array(C.cast(scores, C.POINTER(C.c_double)), shape=(nq, cap))
+        counts = np.ctypeslib.as_array(C.cast(counts, C.POINTER(C.c_uint32)), shape=(nq,))
         rows = np.stack(self.rows) if self.rows else np.zeros((0, self.dim), np.float32)
-        for qi, q in enumerate(queries):
+        for qi in range(nq):
+            q = np.ctypeslib.as_array(C.cast(queries + qi * stride, C.POINTER(C.c_float)), shape=(self.dim,))
             if len(rows) == 0:
                 counts[qi] = 0
                 continue
-            s = self.vso.scan(0, 0, rows, q, self.dim)
+            s = self.vso.scan(0, 0, rows, q.copy(), self.dim)
             kk = min(k, len(s))
             T = np.partition(s, kk - 1)[kk - 1]
             keep = np.nonzero(s <= T)[0]
@@ -46,6 +56,7 @@ class OracleLocalIndex:
             ids[qi, :len(keep)] = keep
             labels[qi, :len(keep)] = np.array(self.labels, dtype=np.uint64)[keep]
             scores[qi, :len(keep)] = s[keep]
+        return 0
 
 
 def _worker(rank, world, port, out):
@@ -67,19 +78,23 @@ def _worker(rank, world, port, out):
     queries = base[:nq].copy()
     p = VecSim.BFParams()
     p.type, p.dim, p.metric, p.blockSize = 0, dim, 0, block
-    ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, local_index=OracleLocalIndex(dim))
+    shard = OracleShard(dim)
+    ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, external=(shard.add, shard.candidates))
     ix.add_vectors(rows[:700], labels[:700])
     for i in range(700, n):
-        ix.add_vector(rows[i], labels[i])
-    got_l, got_s = ix.knn_query(queries, k)
-    # the wide (overflow) path must agree as well
-    wide_l, wide_s = ix._knn_query_wide(queries, k)
+        assert ix.add_vector(rows[i], labels[i]) == 1
+    # overwrites: the label keeps its place in the equivalent single index, the count does not move
+    for i in (3, 250, 777):
+        rows[i] = base[(i * 7) % 30]
+        assert ix.add_vector(rows[i], labels[i]) == 0
+    assert ix.index_size() == n
     ok = True
-    for qi in range(nq):
-        el, es = vso.flat_topk(0, 0, rows, queries[qi], k, dim, labels.astype(np.uint64))
-        ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
-        ok &= np.array_equal(wide_l[qi], el.astype(np.int64)) and np.array_equal(wide_s[qi], es)
-    owned = len(ix.local.rows)
+    for kk in (k, 40):   # k = 40: hundreds of rows tie at the k-th score => the wide (overflow) retry
+        got_l, got_s = ix.knn_query(queries, kk)
+        for qi in range(nq):
+            el, es = vso.flat_topk(0, 0, rows, queries[qi], kk, dim, labels.astype(np.uint64))
+            ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
+    owned = len(shard.rows)
     dist.barrier()
     dist.destroy_process_group()
     out.put((rank, bool(ok), owned))
@@ -94,7 +109,7 @@ def test_sharded_flat_world2_matches_single_index():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=120) for _ in procs]
+    res = [out.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -116,7 +131,6 @@ def test_block_partition_is_a_bijection():
 
 def test_merge_replays_ties_like_the_reference():
     """VecSimGpu_MergeTopK on hand-made partials == sequential heap over the union in gid order"""
-    from oracle import vso
     from vectorsimilarity_amd.sharded import merge_topk
     # the SURVEY tie probe split over two shards: scan order (label,dist) = (5,16),(9,16),(1,4),(2,16),(0,16)
     gids = np.zeros((2, 1, 4), dtype=np.uint64)

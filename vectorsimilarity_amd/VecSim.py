@@ -67,9 +67,14 @@ class BatchIterator:
 
 
 class VecSimIndex:
-    def __init__(self, params):
+    _owned = True
+
+    def __init__(self, params, borrowed_handle=None):
         self._lib = _capi.load()
-        self._h = self._lib.VecSimIndex_New(C.byref(params))
+        if borrowed_handle is not None:   # a shard of a sharded index: the owner frees it
+            self._h, self._owned = borrowed_handle, False
+        else:
+            self._h = self._lib.VecSimIndex_New(C.byref(params))
         if not self._h:
             err = self._lib.VecSimGpu_LastError()
             raise RuntimeError("VecSimIndex_New failed: %s" % (err.decode() if err else "unsupported parameters"))
@@ -267,7 +272,8 @@ class VecSimIndex:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            self._lib.VecSimIndex_Free(self._h)
+            if self._owned:
+                self._lib.VecSimIndex_Free(self._h)
             self._h = None
 
 

@@ -92,6 +92,12 @@ class VecSimGpuStats(C.Structure):
 
 
 TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+# transport / external-shard callbacks of the sharded index (vec_sim_gpu.h)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+SHARD_ADD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+SHARD_CAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p)
 
 class VecSimIndexStatsInfo(C.Structure):  # vec_sim_common.h:276-281
@@ -132,6 +138,11 @@ EXPORTS = [
     "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
+    "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
+    "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
+    "VecSimGpu_ShardedAddVectorsBulk", "VecSimGpu_ShardedAddSyntheticLocal", "VecSimGpu_ShardedDeleteVector",
+    "VecSimGpu_ShardedIndexSize", "VecSimGpu_ShardedTopKQueryBatch", "VecSimGpu_ShardedTopKQueryBatchArrays",
+    "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
 ]
@@ -145,6 +156,8 @@ GPU_EXPORTS = [
     "vsgpu_scorebuf_read",
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
+    "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
+    "vsgpu_comm_allgather", "vsgpu_comm_broadcast",
 ]
 
 _lib = None
@@ -266,5 +279,37 @@ def load():
     L.VecSimGpu_GetStats.argtypes = [vp, C.POINTER(VecSimGpuStats)]
     L.VecSimGpu_SetOption.restype = i
     L.VecSimGpu_SetOption.argtypes = [vp, C.c_char_p, C.c_long]
+    L.VecSimGpu_ShardedGetUniqueId.restype = i
+    L.VecSimGpu_ShardedGetUniqueId.argtypes = [vp]
+    L.VecSimGpu_ShardedNew.restype = vp
+    L.VecSimGpu_ShardedNew.argtypes = [C.POINTER(VecSimParams), i, i, i, vp]
+    L.VecSimGpu_ShardedNewWithTransport.restype = vp
+    L.VecSimGpu_ShardedNewWithTransport.argtypes = [C.POINTER(VecSimParams), i, i, i, ALLGATHER_FN, BROADCAST_FN, vp]
+    L.VecSimGpu_ShardedNewExternal.restype = vp
+    L.VecSimGpu_ShardedNewExternal.argtypes = [C.POINTER(VecSimParams), i, i, SHARD_ADD_FN, SHARD_CAND_FN, ALLGATHER_FN, vp]
+    L.VecSimGpu_ShardedNewLocal.restype = vp
+    L.VecSimGpu_ShardedNewLocal.argtypes = [C.POINTER(VecSimParams), i, vp]
+    L.VecSimGpu_ShardedFree.restype = None
+    L.VecSimGpu_ShardedFree.argtypes = [vp]
+    L.VecSimGpu_ShardedAddVector.restype = i
+    L.VecSimGpu_ShardedAddVector.argtypes = [vp, vp, sz]
+    L.VecSimGpu_ShardedAddVectorsBulk.restype = C.c_long
+    L.VecSimGpu_ShardedAddVectorsBulk.argtypes = [vp, vp, vp, sz]
+    L.VecSimGpu_ShardedAddSyntheticLocal.restype = C.c_long
+    L.VecSimGpu_ShardedAddSyntheticLocal.argtypes = [vp, sz, C.c_uint64]
+    L.VecSimGpu_ShardedDeleteVector.restype = i
+    L.VecSimGpu_ShardedDeleteVector.argtypes = [vp, sz]
+    L.VecSimGpu_ShardedIndexSize.restype = sz
+    L.VecSimGpu_ShardedIndexSize.argtypes = [vp]
+    L.VecSimGpu_ShardedTopKQueryBatch.restype = i
+    L.VecSimGpu_ShardedTopKQueryBatch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, C.POINTER(vp)]
+    L.VecSimGpu_ShardedTopKQueryBatchArrays.restype = i
+    L.VecSimGpu_ShardedTopKQueryBatchArrays.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, vp, vp, vp]
+    L.VecSimGpu_ShardedLocalIndex.restype = vp
+    L.VecSimGpu_ShardedLocalIndex.argtypes = [vp, i]
+    L.VecSimGpu_ShardedWorld.restype = i
+    L.VecSimGpu_ShardedWorld.argtypes = [vp]
+    L.VecSimGpu_ShardedRank.restype = i
+    L.VecSimGpu_ShardedRank.argtypes = [vp]
     _lib = L
     return L

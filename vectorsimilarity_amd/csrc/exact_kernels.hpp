@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
     using score_t = typename E::score_t;
     constexpr int VL = E::VL;
     constexpr int R = ScanShape<EK>::R;
-    constexpr int GROUPS = ScanShape<EK>::GROUPS;
+
     constexpr int TILE_ROWS = ScanShape<EK>::TILE_ROWS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
 // Any k distinct rows bound the k-th smallest score of the whole table from above, and minima of
 // disjoint tiles belong to distinct rows, so tau >= T_q (the exact k-th smallest) always holds.
 // One 1024-thread workgroup per query; M <= 8192 (power of two), bitonic sort in LDS.
-__global__ __launch_bounds__(1024) void k_probe_threshold(const float *dense, size_t stride,
+static __global__ __launch_bounds__(1024) void k_probe_threshold(const float *dense, size_t stride,
                                                           uint32_t n0, uint32_t k, uint32_t M,
                                                           float *tau) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,7 +343,7 @@ __device__ inline uint32_t hash32(uint64_t seed, uint64_t idx) {
     x ^= x >> 31;
     return (uint32_t)(x >> 32);
 }
-__global__ void k_fill_uniform_f32(float *dst, uint64_t first_elem, uint64_t count, uint64_t seed) {
+static __global__ void k_fill_uniform_f32(float *dst, uint64_t first_elem, uint64_t count, uint64_t seed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t strd = (uint64_t)gridDim.x * blockDim.x;
     for (; i < count; i += strd) {
@@ -354,7 +354,7 @@ __global__ void k_fill_uniform_f32(float *dst, uint64_t first_elem, uint64_t cou
 
 // bf16 / fp16 rows: the fp32 synthetic value rounded to nearest-even (bf16) or converted by the
 // hardware RNE cvt (fp16); int8 rows: top byte of the hash.  Twins: vectorsimilarity_amd/synth.py.
-__global__ void k_fill_uniform_h16(uint16_t *dst, uint64_t first_elem, uint64_t count, uint64_t seed, int is_bf16) {
+static __global__ void k_fill_uniform_h16(uint16_t *dst, uint64_t first_elem, uint64_t count, uint64_t seed, int is_bf16) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t strd = (uint64_t)gridDim.x * blockDim.x;
     for (; i < count; i += strd) {
@@ -372,7 +372,7 @@ __global__ void k_fill_uniform_h16(uint16_t *dst, uint64_t first_elem, uint64_t 
 }
 // int8 rows, `row_bytes` apart; when with_norm the float norm sqrt(sum x^2) follows the dim bytes
 // (compute_norm.h:18-31: uint64 sum, sqrt in double, narrowed to float).  One wave per row.
-__global__ __launch_bounds__(256) void k_fill_rows_i8(char *rows, uint32_t row_bytes, uint32_t dim, uint64_t first_row,
+static __global__ __launch_bounds__(256) void k_fill_rows_i8(char *rows, uint32_t row_bytes, uint32_t dim, uint64_t first_row,
                                                       uint32_t n, uint64_t seed, int with_norm) {
     const int lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);

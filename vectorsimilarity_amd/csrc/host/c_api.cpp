@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cerrno>
+#include <cfloat>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include "blob_prep.h"
 #include "flat_index.h"
 #include "hnsw_index.h"
+#include "sharded_index.h"
 
 using vsa::FlatIndex;
 
@@ -104,57 +106,23 @@ extern "C" int VecSimIndex_TopKCandidatesBatch(VecSimIndex *index, const void *q
     return index->topKCandidates(queryBlobs, nq, queryStride, k, cap, ids, labels, scores, counts);
 }
 
-// Global replay over the shards' candidate lists: keep score <= T (k-th smallest of
-// the union), order by the row's id in the equivalent single index, run the sequential heap.
+// Global replay over the shards' candidate lists; the merge itself lives in sharded_index.cpp
 extern "C" int VecSimGpu_MergeTopK(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels,
                                    const double *scores, const uint32_t *counts, size_t k, int64_t *out_labels,
                                    double *out_scores) {
-    struct Cand {
-        uint64_t gid;
-        size_t label;
-        double score;
-    };
+    std::vector<size_t> ol(nq * k);
+    std::vector<double> os(nq * k);
+    std::vector<uint32_t> oc(nq);
     for (size_t i = 0; i < nq * k; i++) {
         out_labels[i] = -1;
         out_scores[i] = -1.0;
     }
-    for (size_t i = 0; i < parts * nq; i++)
-        if (counts[i] == 0xFFFFFFFFu) return -1;
-    if (k == 0) return 0;
-    std::vector<Cand> c;
-    std::vector<double> tmp;
-    for (size_t q = 0; q < nq; q++) {
-        c.clear();
-        for (size_t p = 0; p < parts; p++) {
-            const size_t base = (p * nq + q) * cap;
-            for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
+    if (vsa::merge_topk(nq, parts, cap, gids, labels, scores, counts, k, ol.data(), os.data(), oc.data())) return -1;
+    for (size_t q = 0; q < nq; q++)
+        for (uint32_t j = 0; j < oc[q]; j++) {
+            out_labels[q * k + j] = (int64_t)ol[q * k + j];
+            out_scores[q * k + j] = os[q * k + j];
         }
-        if (c.size() > k) {
-            tmp.resize(c.size());
-            for (size_t i = 0; i < c.size(); i++) tmp[i] = c[i].score;
-            std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(k - 1), tmp.end());
-            const double T = tmp[k - 1];
-            size_t w = 0;
-            for (size_t i = 0; i < c.size(); i++)
-                if (c[i].score <= T) c[w++] = c[i];
-            c.resize(w);
-        }
-        std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
-        std::priority_queue<std::pair<double, size_t>> heap;
-        double upper = std::numeric_limits<double>::lowest();
-        for (const Cand &x : c) {
-            if (x.score < upper || heap.size() < k) {
-                heap.emplace(x.score, x.label);
-                if (heap.size() > k) heap.pop();
-                upper = heap.top().first;
-            }
-        }
-        for (size_t i = heap.size(); i-- > 0;) {
-            out_labels[q * k + i] = (int64_t)heap.top().second;
-            out_scores[q * k + i] = heap.top().first;
-            heap.pop();
-        }
-    }
     return 0;
 }
 
@@ -214,9 +182,19 @@ extern "C" VecSimResolveCode VecSimIndex_ResolveParams(VecSimIndex *index, VecSi
             long long v;
             if (!positive_integer(p, &v)) return VecSimParamResolverErr_BadValue;
             qparams->hnswRuntimeParams.efRuntime = (size_t)v;
+        } else if (!strcasecmp(p.name, "EPSILON")) {
+            // vec_sim.cpp:_ResolveParams_Epsilon: HNSW (or SVS) only, range queries only, a positive double
+            if (index->basicInfo().algo != VecSimAlgo_HNSWLIB) return VecSimParamResolverErr_UnknownParam;
+            if (query_type != QUERY_TYPE_RANGE) return VecSimParamResolverErr_InvalidPolicy_NRange;
+            if (qparams->hnswRuntimeParams.epsilon != 0) return VecSimParamResolverErr_AlreadySet;
+            char *end = nullptr;
+            errno = 0;
+            const double v = std::strtod(p.value, &end);
+            if (v <= 0 || v == DBL_MAX || errno != 0 || end != p.value + p.valLen) return VecSimParamResolverErr_BadValue;
+            qparams->hnswRuntimeParams.epsilon = v;
         } else {
-            // EPSILON / RERANK / SVS knobs belong to paths this build does not have (vec_sim.cpp:67-165);
-            // like any unknown name they are rejected
+            // RERANK / SVS knobs belong to paths this build does not have (vec_sim.cpp:72-165); like any
+            // unknown name they are rejected
             return VecSimParamResolverErr_UnknownParam;
         }
     }
@@ -381,6 +359,129 @@ extern "C" uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index) {
     auto *h = dynamic_cast<vsa::HnswIndex *>(index);
     return h ? h->lastDistanceEvals() : 0;
 }
+
+// ------------------------------------------------------------------ sharded Flat index (vec_sim_gpu.h)
+namespace {
+struct CallbackExchange final : vsa::Exchange {
+    VecSimGpu_AllGatherFn ag;
+    VecSimGpu_BroadcastFn bc;
+    void *user;
+    int allgather(const void *send, size_t bytes, void *recv) override { return ag(user, send, bytes, recv); }
+    int broadcast(void *buf, size_t bytes, int root) override { return bc ? bc(user, buf, bytes, root) : -1; }
+};
+struct CallbackShard final : vsa::ShardOps {
+    VecSimGpu_ShardAddFn add_fn;
+    VecSimGpu_ShardCandidatesFn cand_fn;
+    void *user;
+    size_t rows = 0, stored = 0;
+    int add(const void *blob, size_t label) override {
+        const int rc = add_fn(user, blob, label);
+        if (rc == 1) rows++;
+        return rc;
+    }
+    int candidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids, size_t *labels,
+                   double *scores, uint32_t *counts) override {
+        return cand_fn(user, queries, nq, stride, k, cap, ids, labels, scores, counts);
+    }
+    size_t size() const override { return rows; }
+    size_t storedBytes() const override { return stored; }
+};
+VecSimShardedIndex *wrap(vsa::ShardedIndex *sx) {
+    if (!sx) {
+        std::fprintf(stderr, "vecsim_amd: cannot create sharded index: %s\n", vsgpu_last_error());
+        return nullptr;
+    }
+    auto *w = new VecSimShardedIndex();
+    w->impl.reset(sx);
+    return w;
+}
+}  // namespace
+extern "C" int VecSimGpu_ShardedGetUniqueId(void *id128) { return vsgpu_comm_unique_id(id128); }
+extern "C" VecSimShardedIndex *VecSimGpu_ShardedNew(const VecSimParams *params, int rank, int world, int device,
+                                                    const void *id128) {
+    if (!params || params->algo != VecSimAlgo_BF) return nullptr;
+    // the shard first (it owns the GPU context), then the communicator on that context
+    vsa::ShardedIndex *sx = vsa::ShardedIndex::createDistributed(params->algoParams.bfParams, params->logCtx, rank, world,
+                                                                 device, nullptr);
+    if (!sx) return wrap(nullptr);
+    auto ex = vsa::make_rccl_exchange(sx->localIndex(rank)->gpu(), rank, world, id128);
+    if (!ex) {
+        delete sx;
+        return wrap(nullptr);
+    }
+    sx->setExchange(std::move(ex));
+    return wrap(sx);
+}
+extern "C" VecSimShardedIndex *VecSimGpu_ShardedNewWithTransport(const VecSimParams *params, int rank, int world, int device,
+                                                                 VecSimGpu_AllGatherFn allgather, VecSimGpu_BroadcastFn broadcast,
+                                                                 void *user) {
+    if (!params || params->algo != VecSimAlgo_BF || !allgather) return nullptr;
+    auto ex = std::make_unique<CallbackExchange>();
+    ex->ag = allgather;
+    ex->bc = broadcast;
+    ex->user = user;
+    return wrap(vsa::ShardedIndex::createDistributed(params->algoParams.bfParams, params->logCtx, rank, world, device,
+                                                     std::move(ex)));
+}
+extern "C" VecSimShardedIndex *VecSimGpu_ShardedNewExternal(const VecSimParams *params, int rank, int world,
+                                                            VecSimGpu_ShardAddFn add, VecSimGpu_ShardCandidatesFn candidates,
+                                                            VecSimGpu_AllGatherFn allgather, void *user) {
+    if (!params || params->algo != VecSimAlgo_BF || !add || !candidates || !allgather) return nullptr;
+    const BFParams &bf = params->algoParams.bfParams;
+    auto ex = std::make_unique<CallbackExchange>();
+    ex->ag = allgather;
+    ex->bc = nullptr;
+    ex->user = user;
+    auto sh = std::make_unique<CallbackShard>();
+    sh->add_fn = add;
+    sh->cand_fn = candidates;
+    sh->user = user;
+    sh->stored = vsa::blob_bytes(bf.type, bf.dim, bf.metric);
+    return wrap(vsa::ShardedIndex::createDistributed(bf, params->logCtx, rank, world, -1, std::move(ex), std::move(sh)));
+}
+extern "C" VecSimShardedIndex *VecSimGpu_ShardedNewLocal(const VecSimParams *params, int n_shards, const int *devices) {
+    if (!params || params->algo != VecSimAlgo_BF) return nullptr;
+    return wrap(vsa::ShardedIndex::createLocal(params->algoParams.bfParams, params->logCtx, n_shards, devices));
+}
+extern "C" void VecSimGpu_ShardedFree(VecSimShardedIndex *ix) { delete ix; }
+extern "C" int VecSimGpu_ShardedAddVector(VecSimShardedIndex *ix, const void *blob, size_t label) {
+    return ix->impl->addVector(blob, label);
+}
+extern "C" long VecSimGpu_ShardedAddVectorsBulk(VecSimShardedIndex *ix, const void *blobs, const size_t *labels, size_t n) {
+    return ix->impl->addBulk(blobs, labels, n);
+}
+extern "C" long VecSimGpu_ShardedAddSyntheticLocal(VecSimShardedIndex *ix, size_t rows_per_shard, uint64_t seed_base) {
+    return ix->impl->addSyntheticLocal(rows_per_shard, seed_base);
+}
+extern "C" int VecSimGpu_ShardedDeleteVector(VecSimShardedIndex *ix, size_t label) { return ix->impl->deleteVector(label); }
+extern "C" size_t VecSimGpu_ShardedIndexSize(VecSimShardedIndex *ix) { return ix->impl->indexSize(); }
+extern "C" int VecSimGpu_ShardedTopKQueryBatch(VecSimShardedIndex *ix, const void *queryBlobs, size_t nq, size_t queryStride,
+                                               size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                               VecSimQueryReply **replies) {
+    if (order != BY_ID && order != BY_SCORE) return -1;
+    return ix->impl->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, replies);
+}
+extern "C" int VecSimGpu_ShardedTopKQueryBatchArrays(VecSimShardedIndex *ix, const void *queryBlobs, size_t nq,
+                                                     size_t queryStride, size_t k, VecSimQueryParams *queryParams,
+                                                     VecSimQueryReply_Order order, int64_t *labels, double *scores, int *codes) {
+    if (order != BY_ID && order != BY_SCORE) return -1;
+    std::vector<VecSimQueryReply *> reps(nq, nullptr);
+    int rc = ix->impl->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, reps.data());
+    if (rc) return rc;
+    for (size_t q = 0; q < nq; q++) {
+        const auto &r = reps[q]->results;
+        for (size_t j = 0; j < k; j++) {
+            labels[q * k + j] = j < r.size() ? (int64_t)r[j].id : -1;
+            scores[q * k + j] = j < r.size() ? r[j].score : -1.0;
+        }
+        if (codes) codes[q] = (int)reps[q]->code;
+        delete reps[q];
+    }
+    return 0;
+}
+extern "C" VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *ix, int shard) { return ix->impl->localIndex(shard); }
+extern "C" int VecSimGpu_ShardedWorld(VecSimShardedIndex *ix) { return ix->impl->world(); }
+extern "C" int VecSimGpu_ShardedRank(VecSimShardedIndex *ix) { return ix->impl->rank(); }
 
 // ------------------------------------------------------------------ replies
 extern "C" int64_t VecSimQueryResult_GetId(const VecSimQueryResult *item) { return item ? (int64_t)item->id : (int64_t)INVALID_ID; }

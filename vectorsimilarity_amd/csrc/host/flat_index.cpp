@@ -241,6 +241,28 @@ int FlatIndex::deleteVector(size_t label) {
     return 1;
 }
 
+int FlatIndex::readRow(uint32_t id, void *stored_blob) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (id >= count_ || flush()) return -1;
+    return vsgpu_table_read(table_, id, stored_blob);
+}
+int FlatIndex::overwriteRow(uint32_t id, const void *stored_blob, size_t new_label) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (multi_ || id >= count_ || flush()) return -1;
+    label_to_id_.erase(id_to_label_[id]);
+    id_to_label_[id] = new_label;
+    label_to_id_[new_label] = id;
+    return vsgpu_table_write(table_, id, stored_blob);
+}
+int FlatIndex::dropLastRow() {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (multi_ || count_ == 0 || flush()) return -1;
+    const uint32_t last = (uint32_t)(count_ - 1);
+    auto f = label_to_id_.find(id_to_label_[last]);
+    if (f != label_to_id_.end() && f->second == last) label_to_id_.erase(f);  // (relabelled elsewhere: keep that entry)
+    removeRow(last);
+    return 0;
+}
 long FlatIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     std::vector<uint32_t> ids;
@@ -665,7 +687,8 @@ bool FlatIndex::preferAdHocSearch(size_t subsetSize, size_t k, bool initial_chec
     const size_t n = count_;
     subsetSize = std::min(subsetSize, n);
     const size_t d = dim_;
-    const float r = (n == 0) ? 0.0f : (float)subsetSize / (float)n;
+    // the ratio is taken over LABELS, not vectors (brute_force.h:390): they differ on multi-value indexes
+    const float r = (n == 0) ? 0.0f : (float)subsetSize / (float)indexLabelCount();
     bool adhoc;
     if (n <= 5500) adhoc = true;
     else if (d <= 300) adhoc = (r <= 0.15) || (r <= 0.35 && d > 75 && n <= 550000);

@@ -125,6 +125,11 @@ public:
     void iteratorDeviceEnd(vsgpu_scorebuf *b) override;
     size_t rowLabel(size_t id) const override { return id_to_label_[id]; }
     int allScores(const void *processed_query, std::vector<double> &scores);
+    // row-level operations for the sharded index (sharded_index.cpp), which replays the equivalent single index's
+    // swap-delete (brute_force.h:196-224) across shards: the global last row moves into the hole
+    int readRow(uint32_t id, void *stored_blob);                                   // stored (preprocessed) bytes of a row
+    int overwriteRow(uint32_t id, const void *stored_blob, size_t new_label);     // raw stored bytes, relabelled
+    int dropLastRow();                                                             // forget the shard's last row
     size_t labelOf(size_t id) const { return id_to_label_[id]; }
     bool isMulti() const { return multi_; }
     size_t queryBytes() const { return query_bytes_; }

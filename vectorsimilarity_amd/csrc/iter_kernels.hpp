@@ -20,7 +20,7 @@ constexpr uint32_t ITER_RETIRED = 0x7FC00000u;  // +qNaN
 __device__ __forceinline__ bool iter_is_nan(uint32_t bits) { return (bits & 0x7FFFFFFFu) > 0x7F800000u; }
 
 // hist[(key >> shift) & (bins-1)] over the live scores whose key matches `prefix` under `mask`
-__global__ __launch_bounds__(256) void k_iter_hist(const uint32_t *scores, uint32_t n, uint32_t mask, uint32_t prefix, int shift,
+static __global__ __launch_bounds__(256) void k_iter_hist(const uint32_t *scores, uint32_t n, uint32_t mask, uint32_t prefix, int shift,
                                                    uint32_t bins, uint32_t *hist) {
     __shared__ uint32_t h[2048];
     for (uint32_t i = threadIdx.x; i < bins; i += 256) h[i] = 0;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_iter_hist(const uint32_t *scores, uint3
 }
 
 // every live row with key <= tkey -> out[{row, score bits}]; count keeps counting past cap (overflow signal)
-__global__ __launch_bounds__(256) void k_iter_compact(const uint32_t *scores, uint32_t n, uint32_t tkey, uint2 *out, uint32_t *count,
+static __global__ __launch_bounds__(256) void k_iter_compact(const uint32_t *scores, uint32_t n, uint32_t tkey, uint2 *out, uint32_t *count,
                                                       uint32_t cap) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t b = scores[i];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_iter_compact(const uint32_t *scores, ui
     }
 }
 
-__global__ __launch_bounds__(256) void k_iter_retire(uint32_t *scores, const uint32_t *rows, uint32_t m) {
+static __global__ __launch_bounds__(256) void k_iter_retire(uint32_t *scores, const uint32_t *rows, uint32_t m) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < m) scores[rows[i]] = ITER_RETIRED;
 }

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
 }
 
 // |x|^2 per row in double, rounded once to float (relative error <= 2^-24): feeds the bound E
-__global__ __launch_bounds__(256) void k_row_norms_f32(const char *rows, uint32_t row_stride, uint32_t dim,
+static __global__ __launch_bounds__(256) void k_row_norms_f32(const char *rows, uint32_t row_stride, uint32_t dim,
                                                        uint32_t n, float *out) {
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
 __device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
     return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);  // unsigned order == float order
 }
-__global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
+static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
                                                          uint32_t k, uint2 *out, uint32_t *out_counts,
                                                          uint32_t out_cap) {
     __shared__ uint32_t red[4];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, cons
 
 // Dense variant: the scores of ALL n rows of one query are in `dense` (column = row id); same
 // bitwise k-th search, the survivors (score <= T_k) are compacted as {row, score} records.
-__global__ __launch_bounds__(1024) void k_select_dense_upto_kth(const float *dense, size_t stride, uint32_t n, uint32_t k,
+static __global__ __launch_bounds__(1024) void k_select_dense_upto_kth(const float *dense, size_t stride, uint32_t n, uint32_t k,
                                                                 uint2 *out, uint32_t *out_counts, uint32_t out_cap) {
     __shared__ uint32_t red[16];
     __shared__ uint32_t wpos;
@@ -559,7 +559,7 @@ struct SelRec64 {
 __device__ __forceinline__ unsigned long long double_sort_key(unsigned long long b) {
     return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
 }
-__global__ __launch_bounds__(1024) void k_select_dense_upto_kth_f64(const double *dense, size_t stride, uint32_t n, uint32_t k,
+static __global__ __launch_bounds__(1024) void k_select_dense_upto_kth_f64(const double *dense, size_t stride, uint32_t n, uint32_t k,
                                                                     SelRec64 *out, uint32_t *out_counts, uint32_t out_cap) {
     __shared__ uint32_t red[16];
     __shared__ uint32_t wpos;

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 
 // ---- per-row aux values ----
 // bf16 / fp16: |x|^2 in double -> float.  kind: 2 = bf16, 3 = fp16 (VSGPU type codes)
-__global__ __launch_bounds__(256) void k_row_norms_h16(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
+static __global__ __launch_bounds__(256) void k_row_norms_h16(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
                                                        int kind, uint32_t *out) {
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void k_row_norms_h16(const char *rows, uint32_
     if (lane == 0) out[row] = __float_as_uint((float)s);
 }
 // int8: sum x^2 as int32 (mode 0) or the float norm stored after the elements (mode 1, Cosine rows)
-__global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
+static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
                                                     int mode, uint32_t *out) {
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -2,35 +2,19 @@
 //
 // No CPU fallback lives here: if there is no HIP device every entry point fails with
 // VSGPU_ERR_NO_DEVICE and a message.  Host code in this file only moves bytes, builds lane tables,
-// launches kernels and selects among *GPU-computed* scores.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <string>
-#include <thread>
-#include <chrono>
-#include <string>
-#include <vector>
-
-#include "vsgpu.h"
-#include "lane_program.h"
-#include "exact_kernels.hpp"
+// launches kernels and selects among *GPU-computed* scores.  The MFMA filter paths, the HNSW search and
+// the RCCL exchange live in their own translation units (vsgpu_mfma.hip, vsgpu_lowp.hip, vsgpu_hnsw.hip,
+// vsgpu_comm.hip); vsgpu_internal.hpp is what they share.
+#include "vsgpu_internal.hpp"
 #include "mfma_kernels.hpp"
 #include "mfma_lowp_kernels.hpp"
-#include "mfma_free_kernels.hpp"
-#include "hnsw_kernels.hpp"
 #include "iter_kernels.hpp"
 
 using namespace vsg;
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int vsg_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -39,13 +23,6 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess)                                                                     \
-            return fail(_e == hipErrorOutOfMemory ? VSGPU_ERR_OOM : VSGPU_ERR_HIP, "%s failed: %s (%s:%d)", \
-                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
-    } while (0)
 
 extern "C" const char *vsgpu_last_error(void) { return g_err.c_str(); }
 
@@ -58,70 +35,23 @@ extern "C" int vsgpu_device_count(void) {
     return n;
 }
 
-// ------------------------------------------------------------------ context
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct vsgpu_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt;
-    void *pinned = nullptr;
-    size_t pinned_cap = 0;
-    vsgpu_stats stats{};
-    // options
-    long opt_mfma = 1;
-    long opt_mfma_variant = 0;
-    long opt_lowp_variant = 0;
-    long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
-    long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
-    long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
-    long opt_wg_per_cu = 2;
-    long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
-                                      // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
-    long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
-    long opt_probe_div = 0;           // probe ~ n / probe_div rows; 0 = chosen per call by probe_divisor()
-    long opt_probe_cap = 32768;       // ... but at most this many probe tiles
-    long opt_cand_cap = 8192;         // candidate slots per query
-    int n_cu = 256;
-};
 
 // VSGPU_POISON=<byte>: fill every fresh device allocation with that byte (test aid: makes any read of memory the
 // library never wrote deterministic instead of depending on what the allocator hands back)
-static int poison_byte() {
+int poison_byte() {
     static const int v = [] {
         const char *e = getenv("VSGPU_POISON");
         return e ? (int)(strtol(e, nullptr, 0) & 0xFF) : -1;
     }();
     return v;
 }
-static void poison(void *p, size_t bytes) {
+void poison(void *p, size_t bytes) {
     if (poison_byte() >= 0 && p) {
         (void)hipMemset(p, poison_byte(), bytes);
         (void)hipDeviceSynchronize();
     }
 }
-// VSGPU_TIMING=1: host wall-clock marks of a top-k call on stderr (where the non-kernel time goes)
-struct WallMarks {
-    bool on = getenv("VSGPU_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    std::string out;
-    void mark(const char *what) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        char b[96];
-        snprintf(b, sizeof b, " %s=%.3f", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        out += b;
-        t0 = t1;
-    }
-    void flush(const char *tag) {
-        if (on) fprintf(stderr, "VSGPU_TIMING %s:%s\n", tag, out.c_str());
-    }
-};
-static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
+int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return VSGPU_OK;
     if (b.p) HIPCHK(hipFree(b.p));
     b.p = nullptr;
@@ -133,7 +63,7 @@ static int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     b.cap = want;
     return VSGPU_OK;
 }
-static int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
+int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
     if (bytes <= c->pinned_cap) return VSGPU_OK;
     if (c->pinned) {
         HIPCHK(hipStreamSynchronize(c->stream));  // an async copy may still read the old staging buffer
@@ -222,30 +152,6 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
 }
 
 // ------------------------------------------------------------------ table
-struct vsgpu_table {
-    vsgpu_ctx *ctx = nullptr;
-    int type = 0, metric = 0, tier = 0;
-    size_t dim = 0, row_bytes = 0;
-    LaneProgram prog;
-    int32_t *d_offs = nullptr;
-    std::vector<char *> slabs;
-    char **d_slabs = nullptr;
-    size_t d_slabs_cap = 0;
-    uint32_t slab_shift = 0;
-    size_t n = 0;
-    int ek = 0, opk = 0, epi = 0;
-    int bt_max = 1;  // largest query tile whose LDS image fits
-    // MFMA filter path (fp32, AVX-512-order tier, dim a multiple of 64): |x|^2 per row, slab-parallel
-    bool mfma_ok = false;
-    int ksteps = 0;
-    // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
-    bool lowp_ok = false;
-    int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
-    std::vector<float *> norm_slabs;
-    float **d_norm_slabs = nullptr;
-};
-
-static size_t acc_bytes(int type) { return type == VSGPU_F64 ? 8 : 4; }
 
 extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, int tier, size_t dim,
                                            size_t row_bytes) {
@@ -513,21 +419,9 @@ extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t s
 }
 
 // ------------------------------------------------------------------ query staging
-// widen one stored element to the accumulator type (host side of the LDS query image only)
-static inline float widen_f16(uint16_t h) {
-    _Float16 v;
-    memcpy(&v, &h, 2);
-    return (float)v;
-}
-static inline float widen_bf16(uint16_t h) {
-    uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
 
 // Build [nq][steps][vl] permuted/widened query images in pinned memory and upload them.
-static int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride) {
+int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride) {
     vsgpu_ctx *c = t->ctx;
     const LaneProgram &pg = t->prog;
     const size_t per_q = (size_t)pg.steps * pg.vl;
@@ -633,7 +527,7 @@ static void launch_scan(int ek, int opk, int bt, const ScanParams &P, dim3 grid,
     default: launch_scan_op<EK_U8>(opk, bt, P, grid, lds, s); break;
     }
 }
-static int tile_rows_of(int ek) { return (ek == EK_F64 || ek == EK_BF16) ? (256 / 16) * 4 : (256 / 32) * 4; }
+int tile_rows_of(int ek) { return (ek == EK_F64 || ek == EK_BF16) ? (256 / 16) * 4 : (256 / 32) * 4; }
 
 static int pick_bt(const vsgpu_table *t, size_t nq) {
     int bt = t->bt_max;
@@ -644,7 +538,7 @@ static int pick_bt(const vsgpu_table *t, size_t nq) {
 }
 
 // Fill the table/program part of ScanParams and launch over compact rows.
-static int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
+int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     vsgpu_ctx *c = t->ctx;
     P.slabs = t->d_slabs;
     P.slab_shift = t->slab_shift;
@@ -674,7 +568,7 @@ static int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     return VSGPU_OK;
 }
 
-static void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name) {
+void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) {
         c->stats.scan_ms += ms;
@@ -687,21 +581,6 @@ static void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t p
 }
 
 // ------------------------------------------------------------------ dense scores
-// scores of compact rows (contiguous range or id list) for nq staged queries -> host doubles [nq][n]
-// big host-side loops (widening a few million scores) run on a handful of threads
-template <typename F> static void host_parallel(size_t n, size_t grain, F f) {
-    size_t workers = std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
-    workers = std::min(workers, std::max<size_t>(1, n / grain));
-    if (workers <= 1) {
-        f(0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t per = (n + workers - 1) / workers;
-    for (size_t w = 0; w < workers; w++)
-        if (w * per < n) pool.emplace_back(f, w * per, std::min(n, (w + 1) * per));
-    for (auto &th : pool) th.join();
-}
 static int dense_to_host(vsgpu_table *t, size_t nq, const uint32_t *d_ids, size_t first, size_t n,
                          double *out /*[nq][n]*/) {
     vsgpu_ctx *c = t->ctx;
@@ -958,7 +837,7 @@ static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *i
 // {score <= T_k} in id order; queries whose list overflowed fall back to a dense exact pass.
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride);
-static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                               size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
@@ -1069,652 +948,55 @@ static int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, si
 // each re-scored from a randomly placed row at a fraction r ~ 0.15 of that speed: the sum is smallest at
 // div = sqrt(r * n / (nq * k)).  Measured optima (tools/sweep_probe.py, tools/bench_dims.py): 48 at 10 M x 768, batch 64,
 // k 10 (formula: 48); larger probes win on small tables.  Integer kinds have no re-rank and a flat optimum: fixed 48.
-static uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank) {
+uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank) {
     if (c->opt_probe_div > 0) return (uint32_t)c->opt_probe_div;
     if (!rerank) return 48;
     const double d = std::sqrt(0.15 * (double)n / (double)(std::max<size_t>(nq, 1) * std::max<size_t>(k, 1)));
     return (uint32_t)std::min(64.0, std::max(8.0, d));
 }
 
-static size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows) {
+size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows) {
     double expect = (double)k * (double)n / (double)std::max<size_t>(probe_rows, 1);
     size_t want = (size_t)std::min(expect * 3.0 + 64.0, 1048576.0);
     return std::max<size_t>((size_t)c->opt_cand_cap, want);
 }
 
-// ------------------------------------------------------------------ MFMA filter path (fp32, wide batches)
-static inline uint16_t bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
 
-// Default shapes: the probe always uses 64-row tiles;
-// the filter uses 16-row x 1-KiB stages with non-temporal DMA when dim % 256 == 0 and the tile is at
-// least as long as the ring (dim >= 512), else 64-row x 256-B stages.  Measured on 10M x 768 (profiles/):
-// 64-row default policy 5.5 ms, 64-row nt 5.16 ms, 16-row nt 4.99 ms.
-template <int KS> static uint32_t launch_filter_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
-    if constexpr (KS % 8 == 0 && KS >= 16) {
-        Q.n_tiles = (uint32_t)((n + 15) / 16);
-        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 16>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
-                           mf_lds_bytes(3), s, Q);
-    } else {
-        Q.n_tiles = (uint32_t)((n + 63) / 64);
-        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 64>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
-                           mf_lds_bytes(3), s, Q);
-    }
-    return Q.n_tiles;
-}
-template <int KS> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64>), grid, dim3(256), mf_lds_bytes(3), s, P);
-}
-// tuning variants of the d=768 filter kernel (option "mfma_variant"): ring depth / cache policy /
-// occupancy / tile shape.  Returns the tile height (rows) of the launched variant, 0 if none matched.
-#define MF_VARIANT(NS_, AUX_, MINW_, RT_)                                                                     \
-    {                                                                                                         \
-        Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                          \
-        dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                         \
-        hipLaunchKernelGGL((k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_>), grid, dim3(256), mf_lds_bytes(NS_), \
-                           s, Q);                                                                             \
-        return RT_;                                                                                           \
-    }
-static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
-    switch (variant) {
-    case 1: MF_VARIANT(3, 2, 1, 64)
-    case 2: MF_VARIANT(4, 0, 1, 64)
-    case 3: MF_VARIANT(4, 2, 1, 64)
-    case 4: MF_VARIANT(3, 0, 3, 64)
-    case 5: MF_VARIANT(3, 2, 3, 64)
-    case 6: MF_VARIANT(3, 2, 1, 16)
-    case 7: MF_VARIANT(4, 2, 1, 16)
-    case 8: MF_VARIANT(3, 2, 3, 16)
-    case 9: MF_VARIANT(3, 0, 1, 16)
-#define MF_VARIANT_X(NS_, AUX_, MINW_, RT_, XOPT_)                                                                         \
-    {                                                                                                                 \
-        Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                                  \
-        dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                                 \
-        auto kern = k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_, XOPT_>;                                     \
-        if (mf_lds_bytes(NS_) > 64 * 1024)                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      mf_lds_bytes(NS_));                                                              \
-        hipLaunchKernelGGL(kern, grid, dim3(256), mf_lds_bytes(NS_), s, Q);                                           \
-        return RT_;                                                                                                   \
-    }
-    case 10: MF_VARIANT_X(3, 2, 1, 16, 1)   // scalar slab loads: no per-tile ring drain
-    case 11: MF_VARIANT_X(4, 2, 1, 16, 1)
-    case 12: MF_VARIANT_X(3, 2, 3, 16, 1)
-    case 13: MF_VARIANT_X(3, 0, 1, 16, 1)
-    case 14: MF_VARIANT_X(3, 2, 1, 16, 2)   // one norm copy per workgroup
-    case 15: MF_VARIANT_X(3, 2, 1, 16, 4)   // survivor pre-screen
-    case 16: MF_VARIANT_X(3, 2, 1, 16, 6)
-    default: return 0;
-    }
-}
-static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
-    switch (ksteps) {
-    case 4: launch_filter_ks<4>(P, n, wgs, q_tiles, s); break;
-    case 6: launch_filter_ks<6>(P, n, wgs, q_tiles, s); break;
-    case 8: launch_filter_ks<8>(P, n, wgs, q_tiles, s); break;
-    case 10: launch_filter_ks<10>(P, n, wgs, q_tiles, s); break;
-    case 12: launch_filter_ks<12>(P, n, wgs, q_tiles, s); break;
-    case 16: launch_filter_ks<16>(P, n, wgs, q_tiles, s); break;
-    case 20: launch_filter_ks<20>(P, n, wgs, q_tiles, s); break;
-    case 24: launch_filter_ks<24>(P, n, wgs, q_tiles, s); break;
-    case 28: launch_filter_ks<28>(P, n, wgs, q_tiles, s); break;
-    case 30: launch_filter_ks<30>(P, n, wgs, q_tiles, s); break;
-    case 40: launch_filter_ks<40>(P, n, wgs, q_tiles, s); break;
-    case 48: launch_filter_ks<48>(P, n, wgs, q_tiles, s); break;
-    case 80: launch_filter_ks<80>(P, n, wgs, q_tiles, s); break;
-    case 64: launch_filter_ks<64>(P, n, wgs, q_tiles, s); break;
-    case 96: launch_filter_ks<96>(P, n, wgs, q_tiles, s); break;
-    default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
-    }
-}
-static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
-    switch (ksteps) {
-    case 4: launch_probe_ks<4>(P, grid, s); break;
-    case 6: launch_probe_ks<6>(P, grid, s); break;
-    case 8: launch_probe_ks<8>(P, grid, s); break;
-    case 10: launch_probe_ks<10>(P, grid, s); break;
-    case 12: launch_probe_ks<12>(P, grid, s); break;
-    case 16: launch_probe_ks<16>(P, grid, s); break;
-    case 20: launch_probe_ks<20>(P, grid, s); break;
-    case 24: launch_probe_ks<24>(P, grid, s); break;
-    case 28: launch_probe_ks<28>(P, grid, s); break;
-    case 30: launch_probe_ks<30>(P, grid, s); break;
-    case 40: launch_probe_ks<40>(P, grid, s); break;
-    case 48: launch_probe_ks<48>(P, grid, s); break;
-    case 80: launch_probe_ks<80>(P, grid, s); break;
-    case 64: launch_probe_ks<64>(P, grid, s); break;
-    case 96: launch_probe_ks<96>(P, grid, s); break;
-    default: launch_probe_ks<32>(P, grid, s); break;
-    }
-}
-
-static int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
-                     uint32_t *ids, double *scores, uint32_t *counts) {
+int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     vsgpu_ctx *c = t->ctx;
-    const size_t n = t->n, dim = t->dim;
-    const int KS = t->ksteps;
-    const size_t q_tiles = (nq + MF_QTILE - 1) / MF_QTILE, nqp = q_tiles * MF_QTILE;
-    const bool l2 = (t->metric == VSGPU_L2);
-
-    // (1) exact-order query images for the re-rank, (2) bf16 B-operand fragments + |q|^2 for the filter
-    int rc = stage_queries(t, queries, nq, qstride);
-    if (rc) return rc;
-    const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
-    std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
-    std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
-    for (size_t q = 0; q < nq; q++) {
-        const float *src = (const float *)((const char *)queries + q * qstride);
-        double ss = 0;
-        for (size_t i = 0; i < dim; i++) ss += (double)src[i] * (double)src[i];
-        qn2[q] = (float)ss;
-        const size_t qt = q / MF_QTILE, w = (q % MF_QTILE) / 16, nn = q % 16;
-        for (int s = 0; s < KS; s++)
-            for (int kq = 0; kq < 4; kq++) {
-                const size_t lane = (size_t)kq * 16 + nn;
-                uint16_t *dst = &frag[((((qt * 4 + w) * KS + s) * 64) + lane) * 8];
-                for (int j = 0; j < 8; j++) {
-                    const size_t e = (size_t)32 * s + 8 * kq + j;
-                    dst[j] = e < dim ? bf16_rne(src[e]) : (uint16_t)0;
-                }
-            }
-    }
-    rc = ensure(c, c->qfrag, frag.size() * 2);
-    if (rc) return rc;
-    rc = ensure(c, c->qn2, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->tau, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->counts, nqp * 4);
-    if (rc) return rc;
-    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
-    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
-    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
-
-    // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
-    const double u = std::ldexp(1.0, -24);
-    const double cq = std::ldexp(1.0, -8) * (1.0 + std::ldexp(1.0, -10)) + (double)kdim * std::ldexp(1.0, -22) * 1.01;
-    const double gref = ((double)kdim / 32.0 + 12.0) * u;
-    const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
-    const float absE = l2 ? 1e-30f : 1e-6f;
-
-    const uint32_t tile_step = total_tiles / probe_tiles;
-    uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
-    while (M < probe_tiles && M < 8192) M <<= 1;
-
-    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
-    if (rc) return rc;
-
-    MfmaParams P{};
-    P.slabs = t->d_slabs;
-    P.norm_slabs = t->d_norm_slabs;
-    P.slab_shift = t->slab_shift;
-    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
-    P.row_stride = (uint32_t)t->row_bytes;
-    P.n_rows = (uint32_t)n;
-    P.qfrag = (const uint4 *)c->qfrag.p;
-    P.qn2 = (const float *)c->qn2.p;
-    P.cE = cE;
-    P.absE = absE;
-    P.is_l2 = l2 ? 1 : 0;
-    P.tau = (const float *)c->tau.p;
-    P.counts = (uint32_t *)c->counts.p;
-    P.cand = (uint2 *)c->cand.p;
-    P.cap = (uint32_t)ccap;
-    const uint32_t wg_cap = (uint32_t)c->n_cu * 2;
-
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
-    {   // probe: strided tiles -> per (tile, query) upper bounds
-        MfmaParams Q = P;
-        Q.tile_first = 0;
-        Q.tile_step = tile_step;
-        Q.n_tiles = probe_tiles;
-        Q.tilemin = (float *)c->dense.p;
-        Q.tilemin_stride = probe_tiles;
-        launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
-                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipEventRecord(c->ev_d, c->stream));
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    {   // filter: every tile once
-        MfmaParams Q = P;
-        Q.tile_first = 0;
-        Q.tile_step = 1;
-        Q.n_tiles = total_tiles;
-        const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
-        if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
-            launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    {   // exact re-rank of the survivors, in place
-        ScanParams S{};
-        S.slabs = t->d_slabs;
-        S.slab_shift = t->slab_shift;
-        S.slab_mask = P.slab_mask;
-        S.row_stride = P.row_stride;
-        S.offs = t->d_offs;
-        S.steps = t->prog.steps;
-        S.qperm = c->qperm.p;
-        S.nq = (int)nq;
-        S.epilogue = t->epi;
-        S.counts = (uint32_t *)c->counts.p;
-        S.cand = (uint2 *)c->cand.p;
-        S.cap = (uint32_t)ccap;
-        dim3 grid(64, (unsigned)nq);
-        if (t->opk == OP_L2_FMA) hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+    ScanParams S{};
+    S.slabs = t->d_slabs;
+    S.slab_shift = t->slab_shift;
+    S.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    S.row_stride = (uint32_t)t->row_bytes;
+    S.offs = t->d_offs;
+    S.steps = t->prog.steps;
+    S.qperm = c->qperm.p;
+    S.nq = (int)nq;
+    S.epilogue = t->epi;
+    S.counts = (uint32_t *)c->counts.p;
+    S.cand = (uint2 *)c->cand.p;
+    S.cap = (uint32_t)ccap;
+    dim3 grid(64, (unsigned)nq);
+    const bool l2 = (t->opk == OP_L2_FMA);
+    if (t->type == VSGPU_F32) {
+        if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
         else hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
-        HIPCHK(hipGetLastError());
-    }
-    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
-}
-
-// ------------------------------------------------------------------ low-precision MFMA filter path
-// One launcher for every instantiation: ring depths above 3 slots need more than the default 64 KiB of
-// dynamic LDS, which HIP only grants after the attribute is raised.
-template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0, int DLATE = 0, int ISS = 0>
-static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto go = [&](auto kern) {
-        if (lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
-    };
-    // the diagnosis build (run-time dbg switches, paired query tiles) exists for the plain 3-slot filter kernels only
-    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16 && ISS == 0;
-    if constexpr (has_diag) {
-        if (P.dbg || P.pair_map) return go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, true>);
-    }
-    // (no diagnosis build of this variant: the switches are compiled out, the production kernel runs)
-    go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false, ISS>);
-}
-// barrier-free variant (mfma_free_kernels.hpp): NS slots, D units requested ahead, landed signalled L units early
-template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE, int D, int L>
-static void launch_lowp_free(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = free_lds_bytes(NW, KS, RT, NS, STAGE, D);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto kern = k_mfma_filter_free<LK, KS, RT, NW, NQW, NS, STAGE, D, L>;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
-}
-template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE = MF_STAGE_BYTES>
-static void launch_lowp_skew(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, true);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto kern = k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, NW, NQW, 1, NS, STAGE, true>;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
-}
-template <int LK, int KS, int RT, int NQW>
-static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
-    else launch_lowp_k<LK, KS, MF_FILTER, RT, 8, NQW, 1, 3>(P, grid, s);
-}
-template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
-    else launch_lowp_k<LK, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
-}
-template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    switch (ks) {
-    case 8: launch_lowp_t<LK, 8, 64, 1>(mode, P, grid, s); break;
-    case 16: launch_lowp_t<LK, 16, 32, 1>(mode, P, grid, s); break;
-    case 24: launch_lowp_t<LK, 24, 32, 1>(mode, P, grid, s); break;
-    case 48: launch_lowp_t<LK, 48, 16, 1>(mode, P, grid, s); break;  // d = 1536: 192 VGPRs of query fragments per wave
-    default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
-    }
-}
-// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024.  A variant
-// picks its own tile height, so it sizes the tile count and the grid itself.
-static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P, uint32_t max_wgs, unsigned q_tiles,
-                                hipStream_t s) {
-    if (variant == 0) return false;
-    auto go = [&](int rt, auto launcher) {
-        P.tile_first = 0;
-        P.tile_step = 1;
-        P.n_tiles = (uint32_t)((t->n + rt - 1) / rt);
-        launcher(P, dim3(std::min(P.n_tiles, max_wgs), q_tiles), s);
-        return true;
-    };
-    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) {
-        switch (variant) {
-        case 1: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4>);
-        case 2: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 6>);
-        case 3: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 8>);
-        case 4: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 2, 4>);
-        case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
-        case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
-        case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
-        case 8: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 2>);  // 4 slots, 2 ahead: plain barrier
-        case 9: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 5, 16384, 3>);
-        case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
-        case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
-        case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
-        case 60: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
-        case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
-        case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
-        case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
-        case 41: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 4, 2>);
-        case 42: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 6, 3>);
-        case 43: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 6, 16384, 4, 2>);
-        case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
-        case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
-        case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
-        }
-    }
-    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
-        switch (variant) {
-        case 1: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4>);
-        case 2: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 6>);
-        case 3: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 8>);
-        case 4: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 4>);           // 16 whole rows
-        case 5: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 6>);
-        case 6: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768>);    // 32 whole rows
-        case 7: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>);
-        case 8: return go(64, launch_lowp_k<LP_I8, 16, MF_FILTER, 64, 16, 1, 1, 4, 32768>);    // 64 rows x 512 B
-        case 9: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3>);            // 8 waves x 32 queries
-        case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
-        case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
-        case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
-        case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
-        case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
-        case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
-        case 60: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 8>);   // 8 of the 16 waves request rows
-        case 61: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 4>);   // one per SIMD
-        case 62: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 0, 8>);
-        case 50: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, -1>);   // staggered refill
-        case 51: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, -1>);
-        case 52: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 0, -1>);
-        case 40: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 5, 2>);   // barrier-free ring
-        case 41: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 4, 2>);
-        case 42: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 6, 3>);
-        case 43: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 4, 32768, 2, 1>);
-        case 44: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 6, 16384, 4, 2>);
-        case 30: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 4>);   // refill requested after 4 / 8 / 16 / all fragments
-        case 35: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 2>);
-        case 36: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 4>);
-        case 31: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 8>);
-        case 32: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 16>);
-        case 33: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 8>);
-        case 34: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 32>);
-        case 15: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 2>);  // 4 slots, 2 ahead: plain barrier
-        case 16: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 2>);
-        case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
-        case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
-        case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
-        case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
-        case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
-        case 24: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 6>);
-        }
-    }
-    return false;
-}
-static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
-    else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
-    else if (t->lp_kind == LP_U8) {
-        switch (t->lp_ksteps) {
-        case 8: launch_lowp_i8<8, 64, LP_U8>(mode, P, grid, s); break;
-        case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
-        default:
-            if (mode == MF_FILTER) launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
-            else launch_lowp_i8<16, 32, LP_U8>(mode, P, grid, s);
-            break;
-        }
+    } else if (t->type == VSGPU_BF16) {
+        if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+        else hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else {
-        // 16 waves x 16 queries.  d=1024 filter: a ring slot holds 32 whole rows (1 KiB per DMA instruction, one
-        // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
-        // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
-        switch (t->lp_ksteps) {
-        case 8: launch_lowp_i8<8, 64>(mode, P, grid, s); break;
-        case 12: launch_lowp_i8<12, 64>(mode, P, grid, s); break;
-        default:
-            if (mode == MF_FILTER) launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
-            else launch_lowp_i8<16, 32>(mode, P, grid, s);
-            break;
-        }
+        if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+        else hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     }
+    HIPCHK(hipGetLastError());
+    return VSGPU_OK;
 }
-
-// int8 with the query batch split over two 8-wave workgroups (blockIdx.y): both stream the same row tiles, the
-// second reader is expected to hit L2 (same XCD when gridDim.x % 8 == 0)
-static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (t->lp_ksteps == 16 && t->lp_rt == 32) {
-        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 2, 3>(P, grid, s);
-        else if (grid.y == 2 && grid.x % 8 == 0) {
-            // both query tiles resident together: 2 x 8 waves per CU need <= 128 VGPRs (4 waves per SIMD)
-            LowpParams Q = P;
-            Q.pair_map = 1;
-            launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(Q, dim3(grid.x * 2), s);
-        } else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 2, 3>(P, grid, s);
-    } else if (t->lp_ksteps == 12) {
-        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 12, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
-        else launch_lowp_k<LP_I8, 12, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
-    } else {
-        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 8, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
-        else launch_lowp_k<LP_I8, 8, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
-    }
-}
-
-static int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
-                     uint32_t *ids, double *scores, uint32_t *counts) {
-    vsgpu_ctx *c = t->ctx;
-    const size_t n = t->n, dim = t->dim;
-    const int KS = t->lp_ksteps, RT = t->lp_rt;
-    const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
-    const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
-    const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
-    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);
-    const bool is_u8 = (t->lp_kind == LP_U8);
-    const size_t eb = is_int ? 1 : 2;
-    const size_t kelem = is_int ? 64 : 32;        // elements per MFMA k-step
-    const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
-
-    int rc = VSGPU_OK;
-    if (!is_int) {
-        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
-        if (rc) return rc;
-    }
-    // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
-    const size_t kdim = (size_t)KS * kelem;  // kernel width >= dim
-    std::vector<unsigned char> frag(nqp * kdim * eb, 0);
-    std::vector<uint32_t> qaux(nqp, 0);
-    std::vector<float> tau0(nqp, -INFINITY);
-    for (size_t q = 0; q < nq; q++) {
-        const unsigned char *src = (const unsigned char *)queries + q * qstride;
-        const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
-        for (int s = 0; s < KS; s++)
-            for (int kq = 0; kq < 4; kq++) {
-                const size_t lane = (size_t)kq * 16 + nn;
-                unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
-                const size_t e0 = (kelem * s + per_lane * kq) * eb, have = e0 < dim * eb ? std::min<size_t>(16, dim * eb - e0) : 0;
-                if (have) memcpy(dst, src + e0, have);
-                if (is_u8)
-                    for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;  // q - 128 as int8 (columns past dim stay 0)
-            }
-        if (is_u8) {
-            int s1 = 0, s2 = 0;
-            for (size_t i = 0; i < dim; i++) {
-                const int v = (int)src[i] - 128;
-                s1 += v;
-                s2 += v * v;
-            }
-            const int aux = t->epi == EPI_INT_L2 ? s2 : 128 * s1 + 16384 * (int)dim;
-            memcpy(&qaux[q], &aux, 4);
-        } else if (is_int) {
-            if (t->epi == EPI_INT_COS) memcpy(&qaux[q], src + dim, 4);
-            else if (t->epi == EPI_INT_L2) {
-                int ss = 0;
-                for (size_t i = 0; i < dim; i++) ss += (int)(int8_t)src[i] * (int)(int8_t)src[i];
-                memcpy(&qaux[q], &ss, 4);
-            }
-        } else {
-            double ss = 0;
-            for (size_t i = 0; i < dim; i++) {
-                uint16_t h;
-                memcpy(&h, src + 2 * i, 2);
-                double v = t->type == VSGPU_BF16 ? (double)widen_bf16(h) : (double)widen_f16(h);
-                ss += v * v;
-            }
-            float f = (float)ss;
-            memcpy(&qaux[q], &f, 4);
-        }
-    }
-    rc = ensure(c, c->qfrag, frag.size());
-    if (rc) return rc;
-    rc = ensure(c, c->qn2, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->tau, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->counts, nqp * 4);
-    if (rc) return rc;
-    const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, !is_int), (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
-    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
-    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
-
-    LowpParams P{};
-    P.slabs = t->d_slabs;
-    P.aux_slabs = (const uint32_t *const *)t->d_norm_slabs;
-    P.slab_shift = t->slab_shift;
-    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
-    P.row_stride = (uint32_t)t->row_bytes;
-    P.n_rows = (uint32_t)n;
-    P.qfrag = (const uint4 *)c->qfrag.p;
-    P.qaux = (const uint32_t *)c->qn2.p;
-    if (is_int) {
-        P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
-    } else {
-        P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
-        // bf16*bf16 / fp16*fp16 products are exact in fp32: only accumulation order/rounding differs
-        const double u = std::ldexp(1.0, -24);
-        const double cq = (double)kdim * std::ldexp(1.0, -22) * 1.01;
-        const double gref = ((double)kdim / 16.0 + 12.0) * u;
-        P.cE = (float)(((cq + 2.0 * gref + 4.0 * u) * 1.001) * (1.0 + 1e-6));
-        P.absE = t->metric == VSGPU_L2 ? 1e-30f : 1e-6f;
-    }
-    P.tau = (const float *)c->tau.p;
-    P.counts = (uint32_t *)c->counts.p;
-    P.cand = (uint2 *)c->cand.p;
-    P.cap = (uint32_t)ccap;
-
-    const uint32_t tile_step = total_tiles / probe_tiles;
-    // k_probe_threshold sorts M group minima per query in LDS; more probe tiles than that are grouped (the k-th
-    // smallest group minimum still has k distinct rows at or below it, and with k << M grouping costs nothing)
-    uint32_t M = 64;
-    while (M < probe_tiles && M < 8192) M <<= 1;
-    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
-    if (rc) return rc;
-    const uint32_t wgs = (uint32_t)c->n_cu * 2;
-
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
-    {
-        LowpParams Q = P;
-        Q.tile_first = 0;
-        Q.tile_step = tile_step;
-        Q.n_tiles = probe_tiles;
-        Q.tilemin = (float *)c->dense.p;
-        Q.tilemin_stride = probe_tiles;
-        if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
-        else launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
-                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipEventRecord(c->ev_d, c->stream));
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    {
-        LowpParams Q = P;
-        Q.tile_first = 0;
-        Q.tile_step = 1;
-        Q.n_tiles = total_tiles;
-        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
-        Q.dbg = (int)c->opt_lowp_dbg;
-        uint32_t *d_ph = nullptr;
-        const size_t ph_words = (size_t)fw * q_tiles * 16 * 8;
-        if (Q.dbg & 8) {
-            HIPCHK(hipMalloc(&d_ph, ph_words * 4));
-            HIPCHK(hipMemsetAsync(d_ph, 0, ph_words * 4, c->stream));
-            Q.tilemin = reinterpret_cast<float *>(d_ph);
-        }
-        if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
-        else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
-            launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
-        HIPCHK(hipGetLastError());
-        if (d_ph) {  // phase sums of every wave: mean cycles per tile, printed once per launch
-            std::vector<uint32_t> h(ph_words);
-            HIPCHK(hipMemcpyAsync(h.data(), d_ph, ph_words * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipFree(d_ph));
-            double sum[5] = {0, 0, 0, 0, 0}, tiles = 0;
-            for (size_t w = 0; w < ph_words / 8; w++) {
-                if (!h[w * 8 + 5]) continue;
-                for (int i = 0; i < 5; i++) sum[i] += h[w * 8 + i];
-                tiles += h[w * 8 + 5];
-            }
-            if (tiles > 0)
-                fprintf(stderr, "lowp phases, mean s_memtime ticks per wave and tile: vmcnt-wait %.0f  barrier %.0f  refill-request %.0f  "
-                                "reads+mfma-issue %.0f  epilogue %.0f\n",
-                        sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles);
-        }
-    }
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
-        HIPCHK(hipStreamSynchronize(c->stream));
-        account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
-        for (size_t q = 0; q < nq; q++) counts[q] = 0;
-        return VSGPU_OK;
-    }
-    if (!is_int) {
-        ScanParams S{};
-        S.slabs = t->d_slabs;
-        S.slab_shift = t->slab_shift;
-        S.slab_mask = P.slab_mask;
-        S.row_stride = P.row_stride;
-        S.offs = t->d_offs;
-        S.steps = t->prog.steps;
-        S.qperm = c->qperm.p;
-        S.nq = (int)nq;
-        S.epilogue = t->epi;
-        S.counts = (uint32_t *)c->counts.p;
-        S.cand = (uint2 *)c->cand.p;
-        S.cap = (uint32_t)ccap;
-        dim3 grid(64, (unsigned)nq);
-        const bool l2 = (t->opk == OP_L2_FMA);
-        if (t->type == VSGPU_BF16) {
-            if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
-            else hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
-        } else {
-            if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
-            else hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
-        }
-        HIPCHK(hipGetLastError());
-    }
-    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
-                              is_int ? "k_mfma_filter_lowp(i8)" : "k_mfma_filter_lowp(h16)");
+int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M) {
+    hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                       (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+    HIPCHK(hipGetLastError());
+    return VSGPU_OK;
 }
 
 // ------------------------------------------------------------------ top-K
@@ -2011,211 +1293,4 @@ extern "C" int vsgpu_range(vsgpu_table *t, const void *query, double radius, siz
         scores[i] = hits[i].score;
     }
     return VSGPU_OK;
-}
-
-// ------------------------------------------------------------------ HNSW graph snapshot + search
-struct vsgpu_graph {
-    vsgpu_table *t = nullptr;
-    uint32_t M = 16, M0 = 32;
-    size_t n = 0;
-    DevBuf links0, cnt0, upper_off, upper, deleted, labels;
-    uint32_t entry = 0xFFFFFFFFu;
-    int max_level = -1;
-    // visited tags: one u16 per node per resident search wave
-    DevBuf tags, slot_epoch;
-    size_t tag_slots = 0, tag_n = 0;
-    DevBuf out_labels, out_scores, out_counts, stat;
-};
-
-extern "C" vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M) {
-    if (!t || M < 2 || M > 32) {
-        fail(VSGPU_ERR_ARG, "graph: M must be in [2, 32] (2M neighbours are scored by one wavefront)");
-        return nullptr;
-    }
-    if (t->type == VSGPU_F64) {
-        fail(VSGPU_ERR_UNSUPPORTED, "graph search: fp64 tables are not supported yet");
-        return nullptr;
-    }
-    vsgpu_graph *g = new vsgpu_graph();
-    g->t = t;
-    g->M = (uint32_t)M;
-    g->M0 = (uint32_t)(2 * M);
-    return g;
-}
-extern "C" void vsgpu_graph_destroy(vsgpu_graph *g) {
-    if (!g) return;
-    (void)hipSetDevice(g->t->ctx->device);
-    (void)hipStreamSynchronize(g->t->ctx->stream);
-    for (DevBuf *b : {&g->links0, &g->cnt0, &g->upper_off, &g->upper, &g->deleted, &g->labels, &g->tags, &g->slot_epoch,
-                      &g->out_labels, &g->out_scores, &g->out_counts, &g->stat})
-        if (b->p) (void)hipFree(b->p);
-    delete g;
-}
-extern "C" int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *links0, const uint16_t *cnt0,
-                                  const uint32_t *upper_off, const uint32_t *upper, size_t upper_words,
-                                  const uint8_t *deleted, const uint64_t *labels, uint32_t entry, int max_level) {
-    vsgpu_ctx *c = g->t->ctx;
-    HIPCHK(hipSetDevice(c->device));
-    if (n > g->t->n) return fail(VSGPU_ERR_ARG, "graph has %zu nodes but the table holds %zu rows", n, g->t->n);
-    int rc;
-    if ((rc = ensure(c, g->links0, n * g->M0 * 4))) return rc;
-    if ((rc = ensure(c, g->cnt0, n * 2))) return rc;
-    if ((rc = ensure(c, g->upper_off, n * 4))) return rc;
-    if ((rc = ensure(c, g->upper, std::max<size_t>(upper_words, 1) * 4))) return rc;
-    if ((rc = ensure(c, g->deleted, n))) return rc;
-    if ((rc = ensure(c, g->labels, n * 8))) return rc;
-    if (n) {
-        HIPCHK(hipMemcpyAsync(g->links0.p, links0, n * g->M0 * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(g->cnt0.p, cnt0, n * 2, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(g->upper_off.p, upper_off, n * 4, hipMemcpyHostToDevice, c->stream));
-        if (upper_words) HIPCHK(hipMemcpyAsync(g->upper.p, upper, upper_words * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(g->deleted.p, deleted, n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(g->labels.p, labels, n * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));  // the caller's arrays are borrowed for this call only
-    }
-    g->n = n;
-    g->entry = entry;
-    g->max_level = max_level;
-    return VSGPU_OK;
-}
-
-template <int EK> static void launch_hnsw_ek(int opk, const HnswParams &P, dim3 grid, size_t lds, hipStream_t s) {
-    if (opk == OP_L2_FMA) hipLaunchKernelGGL((k_hnsw_search<EK, OP_L2_FMA>), grid, dim3(64), lds, s, P);
-    else if (opk == OP_IP_FMA) hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_FMA>), grid, dim3(64), lds, s, P);
-    else if (opk == OP_L2_MULADD) hipLaunchKernelGGL((k_hnsw_search<EK, OP_L2_MULADD>), grid, dim3(64), lds, s, P);
-    else hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_MULADD>), grid, dim3(64), lds, s, P);
-}
-
-// top-k search (range == nullptr) or range search (range = {radius, epsilon}; k is then the result capacity per query)
-static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef, const double *range,
-                     uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
-    vsgpu_table *t = g->t;
-    vsgpu_ctx *c = t->ctx;
-    if (dist_evals) *dist_evals = 0;
-    if (nq == 0) return VSGPU_OK;
-    if (k == 0 || g->n == 0 || g->entry == 0xFFFFFFFFu) {
-        for (size_t q = 0; q < nq; q++) counts[q] = 0;
-        return VSGPU_OK;
-    }
-    HIPCHK(hipSetDevice(c->device));
-    ef = range ? 1 : std::max(ef, k);
-    if (ef > 4096) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu too large for the LDS heaps", ef);
-    int rc = stage_queries(t, queries, nq, qstride);
-    if (rc) return rc;
-    const size_t ab = acc_bytes(t->type);
-    size_t ccap = 2 * ef;
-    if (range) {
-        // the reference's candidate set is unbounded: give the window what LDS allows (overflow is reported)
-        const size_t fixed = 2 * (((size_t)t->prog.steps * t->prog.vl * std::max<size_t>(ab, 4) + 15) & ~(size_t)15) + 1024;
-        ccap = 64;
-        while (ccap < 3072 && fixed + (2 * (2 * ccap) + 2) * 8 + 64 <= 60 * 1024) ccap *= 2;
-    }
-    size_t lds = (((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15);
-    lds += (((size_t)t->prog.steps * t->prog.vl * ab + 15) & ~(size_t)15);
-    lds += (ef + 2) * 8;
-    lds += (((ef + 2) * 4 + 15) & ~(size_t)15);
-    lds += (2 * ccap + 2) * 4;
-    lds += (((2 * ccap + 2) * 4 + 15) & ~(size_t)15);
-    lds += 64 * 4 + 64 * 4;
-    if (lds > 64 * 1024) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu / dim %zu need %zu B of LDS per query", ef, t->dim, lds);
-    // resident search waves = tag slots
-    const size_t slots = std::min<size_t>(nq, (size_t)c->n_cu * (size_t)c->opt_hnsw_slots);
-    if (slots > g->tag_slots || g->n > g->tag_n) {
-        const size_t ns = std::max(slots, g->tag_slots), nn = std::max(g->n, g->tag_n);
-        // grow with headroom on the node axis: the graph usually keeps growing between searches
-        const size_t nn2 = std::max(nn, g->tag_n + g->tag_n / 2);
-        if ((rc = ensure(c, g->tags, ns * nn2 * 2))) return rc;
-        if ((rc = ensure(c, g->slot_epoch, ns * 4))) return rc;
-        HIPCHK(hipMemsetAsync(g->tags.p, 0, ns * nn2 * 2, c->stream));
-        HIPCHK(hipMemsetAsync(g->slot_epoch.p, 0, ns * 4, c->stream));
-        g->tag_slots = ns;
-        g->tag_n = nn2;
-    }
-    if ((rc = ensure(c, g->out_labels, nq * k * 8))) return rc;
-    if ((rc = ensure(c, g->out_scores, nq * k * 4))) return rc;
-    if ((rc = ensure(c, g->out_counts, nq * 4))) return rc;
-    if ((rc = ensure(c, g->stat, 16))) return rc;
-    HIPCHK(hipMemsetAsync(g->stat.p, 0, 16, c->stream));
-
-    HnswParams P{};
-    P.slabs = t->d_slabs;
-    P.slab_shift = t->slab_shift;
-    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
-    P.row_stride = (uint32_t)t->row_bytes;
-    P.offs = t->d_offs;
-    P.steps = t->prog.steps;
-    P.qperm = c->qperm.p;
-    P.nq = (int)nq;
-    P.epilogue = t->epi;
-    P.norm_off = (uint32_t)t->dim;
-    P.qnorm = (const float *)c->qnorm.p;
-    P.links0 = (const uint32_t *)g->links0.p;
-    P.cnt0 = (const uint16_t *)g->cnt0.p;
-    P.upper_off = (const uint32_t *)g->upper_off.p;
-    P.upper = (const uint32_t *)g->upper.p;
-    P.deleted = (const uint8_t *)g->deleted.p;
-    P.labels = (const uint64_t *)g->labels.p;
-    P.M0 = g->M0;
-    P.M = g->M;
-    P.entry = g->entry;
-    P.max_level = g->max_level;
-    P.n = (uint32_t)g->tag_n;  // tag row pitch
-    P.tags = (uint16_t *)g->tags.p;
-    P.slot_epoch = (uint32_t *)g->slot_epoch.p;
-    P.ef = (uint32_t)ef;
-    P.k = (uint32_t)k;
-    P.ccap = (uint32_t)ccap;
-    P.out_labels = (uint64_t *)g->out_labels.p;
-    P.out_scores = (float *)g->out_scores.p;
-    P.out_counts = (uint32_t *)g->out_counts.p;
-    P.stat_dists = (uint64_t *)g->stat.p;
-    P.next_query = (uint32_t *)((char *)g->stat.p + 8);
-    if (range) {
-        P.range = 1;
-        P.radius = (float)range[0];
-        P.epsilon = range[1];
-        P.rcap = (uint32_t)k;
-    }
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    const dim3 grid((unsigned)slots);
-    switch (t->ek) {
-    case EK_F32: launch_hnsw_ek<EK_F32>(t->opk, P, grid, lds, c->stream); break;
-    case EK_BF16: launch_hnsw_ek<EK_BF16>(t->opk, P, grid, lds, c->stream); break;
-    case EK_F16: launch_hnsw_ek<EK_F16>(t->opk, P, grid, lds, c->stream); break;
-    case EK_I8: launch_hnsw_ek<EK_I8>(t->opk, P, grid, lds, c->stream); break;
-    default: launch_hnsw_ek<EK_U8>(t->opk, P, grid, lds, c->stream); break;
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    std::vector<float> hs(nq * k);
-    uint64_t hstat = 0;
-    HIPCHK(hipMemcpyAsync(labels, g->out_labels.p, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hs.data(), g->out_scores.p, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(counts, g->out_counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&hstat, g->stat.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < nq * k; i++) scores[i] = (double)hs[i];
-    if (dist_evals) *dist_evals = hstat;
-    {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) {
-            c->stats.scan_ms += ms;
-            c->stats.scan_launches += 1;
-            c->stats.scan_rows += hstat;                    // rows gathered = distance evaluations
-            c->stats.scan_bytes += hstat * t->row_bytes;
-            snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, range ? "k_hnsw_search(range)" : "k_hnsw_search");
-        }
-    }
-    return VSGPU_OK;
-}
-extern "C" int vsgpu_graph_search(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, size_t k, size_t ef,
-                                  uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
-    return graph_run(g, queries, nq, qstride, k, ef, nullptr, labels, scores, counts, dist_evals);
-}
-extern "C" int vsgpu_graph_range(vsgpu_graph *g, const void *queries, size_t nq, size_t qstride, double radius,
-                                 double epsilon, size_t cap, uint64_t *labels, double *scores, uint32_t *counts,
-                                 uint64_t *dist_evals) {
-    if (cap == 0) return fail(VSGPU_ERR_ARG, "range search needs room for results");
-    const double range[2] = {radius, epsilon};
-    return graph_run(g, queries, nq, qstride, cap, 1, range, labels, scores, counts, dist_evals);
 }

@@ -1,0 +1,158 @@
+// vsgpu_internal.hpp -- shared by the translation units of libvsgpu.so (vsgpu.hip, vsgpu_mfma.hip,
+// vsgpu_lowp.hip, vsgpu_hnsw.hip, vsgpu_comm.hip): context / table objects and the host helpers around
+// the kernels.  Not part of any ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vsgpu.h"
+#include "lane_program.h"
+#include "exact_kernels.hpp"
+
+int vsg_fail(int code, const char *fmt, ...);
+#define fail vsg_fail
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(_e == hipErrorOutOfMemory ? VSGPU_ERR_OOM : VSGPU_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct vsgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    vsgpu_stats stats{};
+    // options
+    long opt_mfma = 1;
+    long opt_mfma_variant = 0;
+    long opt_lowp_variant = 0;
+    long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
+    long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
+    long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
+    long opt_wg_per_cu = 2;
+    long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
+                                      // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
+    long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
+    long opt_probe_div = 0;           // probe ~ n / probe_div rows; 0 = chosen per call by probe_divisor()
+    long opt_probe_cap = 32768;       // ... but at most this many probe tiles
+    long opt_cand_cap = 8192;         // candidate slots per query
+    int n_cu = 256;
+};
+
+int poison_byte();
+void poison(void *p, size_t bytes);
+// VSGPU_TIMING=1: host wall-clock marks of a top-k call on stderr (where the non-kernel time goes)
+struct WallMarks {
+    bool on = getenv("VSGPU_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string out;
+    void mark(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char b[96];
+        snprintf(b, sizeof b, " %s=%.3f", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        out += b;
+        t0 = t1;
+    }
+    void flush(const char *tag) {
+        if (on) fprintf(stderr, "VSGPU_TIMING %s:%s\n", tag, out.c_str());
+    }
+};
+int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes);
+int ensure_pinned(vsgpu_ctx *c, size_t bytes);
+
+struct vsgpu_table {
+    vsgpu_ctx *ctx = nullptr;
+    int type = 0, metric = 0, tier = 0;
+    size_t dim = 0, row_bytes = 0;
+    vsg::LaneProgram prog;
+    int32_t *d_offs = nullptr;
+    std::vector<char *> slabs;
+    char **d_slabs = nullptr;
+    size_t d_slabs_cap = 0;
+    uint32_t slab_shift = 0;
+    size_t n = 0;
+    int ek = 0, opk = 0, epi = 0;
+    int bt_max = 1;  // largest query tile whose LDS image fits
+    // MFMA filter path (fp32, AVX-512-order tier, dim a multiple of 64): |x|^2 per row, slab-parallel
+    bool mfma_ok = false;
+    int ksteps = 0;
+    // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
+    bool lowp_ok = false;
+    int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
+    std::vector<float *> norm_slabs;
+    float **d_norm_slabs = nullptr;
+};
+
+static inline size_t acc_bytes(int type) { return type == VSGPU_F64 ? 8 : 4; }
+
+// widen one stored element to the accumulator type (host side of the LDS query image only)
+static inline float widen_f16(uint16_t h) {
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (float)v;
+}
+static inline float widen_bf16(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride);
+int tile_rows_of(int ek);
+int run_scan(vsgpu_table *t, vsg::ScanParams &P, size_t nq, bool timed);
+void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name);
+// scores of compact rows (contiguous range or id list) for nq staged queries -> host doubles [nq][n]
+// big host-side loops (widening a few million scores) run on a handful of threads
+template <typename F> static void host_parallel(size_t n, size_t grain, F f) {
+    size_t workers = std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    workers = std::min(workers, std::max<size_t>(1, n / grain));
+    if (workers <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; w++)
+        if (w * per < n) pool.emplace_back(f, w * per, std::min(n, (w + 1) * per));
+    for (auto &th : pool) th.join();
+}
+int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                       size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name);
+uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank);
+size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows);
+// stage 2 of the filter paths: reference-order exact re-score of the candidate lists in ctx->cand (in place)
+int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap);
+// threshold of every query from the probe's per-tile minima (ctx->dense -> ctx->tau)
+int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M);
+int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
+              double *scores, uint32_t *counts);
+int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
+              double *scores, uint32_t *counts);

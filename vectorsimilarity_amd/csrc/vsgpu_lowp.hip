@@ -1,0 +1,386 @@
+// vsgpu_lowp.hip -- bf16 / fp16 / int8 / uint8 MFMA filter path of vsgpu_topk (kernels: mfma_lowp_kernels.hpp)
+#include "vsgpu_internal.hpp"
+#include "mfma_lowp_kernels.hpp"
+#ifdef VSGPU_TUNING
+#include "mfma_free_kernels.hpp"
+#endif
+
+using namespace vsg;
+
+// ------------------------------------------------------------------ low-precision MFMA filter path
+// One launcher for every instantiation: ring depths above 3 slots need more than the default 64 KiB of
+// dynamic LDS, which HIP only grants after the attribute is raised.
+template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0, int DLATE = 0, int ISS = 0>
+static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto go = [&](auto kern) {
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+    };
+    // the diagnosis build (run-time dbg switches, paired query tiles) exists for the plain 3-slot filter kernels only
+    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16 && ISS == 0;
+    if constexpr (has_diag) {
+        if (P.dbg || P.pair_map) return go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, true>);
+    }
+    // (no diagnosis build of this variant: the switches are compiled out, the production kernel runs)
+    go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false, ISS>);
+}
+#ifdef VSGPU_TUNING
+// barrier-free variant (mfma_free_kernels.hpp): NS slots, D units requested ahead, landed signalled L units early
+template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE, int D, int L>
+static void launch_lowp_free(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = free_lds_bytes(NW, KS, RT, NS, STAGE, D);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto kern = k_mfma_filter_free<LK, KS, RT, NW, NQW, NS, STAGE, D, L>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+}
+template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE = MF_STAGE_BYTES>
+static void launch_lowp_skew(const LowpParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, true);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
+    auto kern = k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, NW, NQW, 1, NS, STAGE, true>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
+}
+#endif
+template <int LK, int KS, int RT, int NQW>
+static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, KS, MF_FILTER, RT, 8, NQW, 1, 3>(P, grid, s);
+}
+template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
+}
+template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    switch (ks) {
+    case 8: launch_lowp_t<LK, 8, 64, 1>(mode, P, grid, s); break;
+    case 16: launch_lowp_t<LK, 16, 32, 1>(mode, P, grid, s); break;
+    case 24: launch_lowp_t<LK, 24, 32, 1>(mode, P, grid, s); break;
+    case 48: launch_lowp_t<LK, 48, 16, 1>(mode, P, grid, s); break;  // d = 1536: 192 VGPRs of query fragments per wave
+    default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
+    }
+}
+#ifdef VSGPU_TUNING
+// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024.  A variant
+// picks its own tile height, so it sizes the tile count and the grid itself.
+static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P, uint32_t max_wgs, unsigned q_tiles,
+                                hipStream_t s) {
+    if (variant == 0) return false;
+    auto go = [&](int rt, auto launcher) {
+        P.tile_first = 0;
+        P.tile_step = 1;
+        P.n_tiles = (uint32_t)((t->n + rt - 1) / rt);
+        launcher(P, dim3(std::min(P.n_tiles, max_wgs), q_tiles), s);
+        return true;
+    };
+    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) {
+        switch (variant) {
+        case 1: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4>);
+        case 2: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 6>);
+        case 3: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 8>);
+        case 4: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 2, 4>);
+        case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
+        case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
+        case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
+        case 8: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 2>);  // 4 slots, 2 ahead: plain barrier
+        case 9: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 5, 16384, 3>);
+        case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
+        case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
+        case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
+        case 60: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
+        case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
+        case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
+        case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
+        case 41: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 4, 2>);
+        case 42: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 6, 3>);
+        case 43: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 6, 16384, 4, 2>);
+        case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
+        case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
+        case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
+        }
+    }
+    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
+        switch (variant) {
+        case 1: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4>);
+        case 2: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 6>);
+        case 3: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 8>);
+        case 4: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 4>);           // 16 whole rows
+        case 5: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 6>);
+        case 6: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768>);    // 32 whole rows
+        case 7: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>);
+        case 8: return go(64, launch_lowp_k<LP_I8, 16, MF_FILTER, 64, 16, 1, 1, 4, 32768>);    // 64 rows x 512 B
+        case 9: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3>);            // 8 waves x 32 queries
+        case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
+        case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
+        case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
+        case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
+        case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
+        case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
+        case 60: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 8>);   // 8 of the 16 waves request rows
+        case 61: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 4>);   // one per SIMD
+        case 62: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 0, 8>);
+        case 50: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, -1>);   // staggered refill
+        case 51: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, -1>);
+        case 52: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 0, -1>);
+        case 40: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 5, 2>);   // barrier-free ring
+        case 41: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 4, 2>);
+        case 42: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 6, 3>);
+        case 43: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 4, 32768, 2, 1>);
+        case 44: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 6, 16384, 4, 2>);
+        case 30: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 4>);   // refill requested after 4 / 8 / 16 / all fragments
+        case 35: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 2>);
+        case 36: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 4>);
+        case 31: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 8>);
+        case 32: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 16>);
+        case 33: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 8>);
+        case 34: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 32>);
+        case 15: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 2>);  // 4 slots, 2 ahead: plain barrier
+        case 16: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 2>);
+        case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
+        case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
+        case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
+        case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
+        case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
+        case 24: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 6>);
+        }
+    }
+    return false;
+}
+#else
+static bool launch_lowp_variant(const vsgpu_table *, int, LowpParams, uint32_t, unsigned, hipStream_t) { return false; }
+#endif
+static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
+    else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
+    else if (t->lp_kind == LP_U8) {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_i8<8, 64, LP_U8>(mode, P, grid, s); break;
+        case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
+        default:
+            if (mode == MF_FILTER) launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
+            else launch_lowp_i8<16, 32, LP_U8>(mode, P, grid, s);
+            break;
+        }
+    } else {
+        // 16 waves x 16 queries.  d=1024 filter: a ring slot holds 32 whole rows (1 KiB per DMA instruction, one
+        // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
+        // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_i8<8, 64>(mode, P, grid, s); break;
+        case 12: launch_lowp_i8<12, 64>(mode, P, grid, s); break;
+        default:
+            if (mode == MF_FILTER) launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
+            else launch_lowp_i8<16, 32>(mode, P, grid, s);
+            break;
+        }
+    }
+}
+
+// int8 with the query batch split over two 8-wave workgroups (blockIdx.y): both stream the same row tiles, the
+// second reader is expected to hit L2 (same XCD when gridDim.x % 8 == 0)
+static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_ksteps == 16 && t->lp_rt == 32) {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 2, 3>(P, grid, s);
+        else if (grid.y == 2 && grid.x % 8 == 0) {
+            // both query tiles resident together: 2 x 8 waves per CU need <= 128 VGPRs (4 waves per SIMD)
+            LowpParams Q = P;
+            Q.pair_map = 1;
+            launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(Q, dim3(grid.x * 2), s);
+        } else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 2, 3>(P, grid, s);
+    } else if (t->lp_ksteps == 12) {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 12, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 12, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
+    } else {
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 8, MF_PROBE, 64, 8, 1, 2, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 8, MF_FILTER, 64, 8, 1, 2, 3>(P, grid, s);
+    }
+}
+
+int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                     uint32_t *ids, double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, dim = t->dim;
+    const int KS = t->lp_ksteps, RT = t->lp_rt;
+    const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
+    const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
+    const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
+    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);
+    const bool is_u8 = (t->lp_kind == LP_U8);
+    const size_t eb = is_int ? 1 : 2;
+    const size_t kelem = is_int ? 64 : 32;        // elements per MFMA k-step
+    const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
+
+    int rc = VSGPU_OK;
+    if (!is_int) {
+        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
+        if (rc) return rc;
+    }
+    // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
+    const size_t kdim = (size_t)KS * kelem;  // kernel width >= dim
+    std::vector<unsigned char> frag(nqp * kdim * eb, 0);
+    std::vector<uint32_t> qaux(nqp, 0);
+    std::vector<float> tau0(nqp, -INFINITY);
+    for (size_t q = 0; q < nq; q++) {
+        const unsigned char *src = (const unsigned char *)queries + q * qstride;
+        const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
+        for (int s = 0; s < KS; s++)
+            for (int kq = 0; kq < 4; kq++) {
+                const size_t lane = (size_t)kq * 16 + nn;
+                unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
+                const size_t e0 = (kelem * s + per_lane * kq) * eb, have = e0 < dim * eb ? std::min<size_t>(16, dim * eb - e0) : 0;
+                if (have) memcpy(dst, src + e0, have);
+                if (is_u8)
+                    for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;  // q - 128 as int8 (columns past dim stay 0)
+            }
+        if (is_u8) {
+            int s1 = 0, s2 = 0;
+            for (size_t i = 0; i < dim; i++) {
+                const int v = (int)src[i] - 128;
+                s1 += v;
+                s2 += v * v;
+            }
+            const int aux = t->epi == EPI_INT_L2 ? s2 : 128 * s1 + 16384 * (int)dim;
+            memcpy(&qaux[q], &aux, 4);
+        } else if (is_int) {
+            if (t->epi == EPI_INT_COS) memcpy(&qaux[q], src + dim, 4);
+            else if (t->epi == EPI_INT_L2) {
+                int ss = 0;
+                for (size_t i = 0; i < dim; i++) ss += (int)(int8_t)src[i] * (int)(int8_t)src[i];
+                memcpy(&qaux[q], &ss, 4);
+            }
+        } else {
+            double ss = 0;
+            for (size_t i = 0; i < dim; i++) {
+                uint16_t h;
+                memcpy(&h, src + 2 * i, 2);
+                double v = t->type == VSGPU_BF16 ? (double)widen_bf16(h) : (double)widen_f16(h);
+                ss += v * v;
+            }
+            float f = (float)ss;
+            memcpy(&qaux[q], &f, 4);
+        }
+    }
+    rc = ensure(c, c->qfrag, frag.size());
+    if (rc) return rc;
+    rc = ensure(c, c->qn2, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->tau, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->counts, nqp * 4);
+    if (rc) return rc;
+    const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, !is_int), (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
+    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+
+    LowpParams P{};
+    P.slabs = t->d_slabs;
+    P.aux_slabs = (const uint32_t *const *)t->d_norm_slabs;
+    P.slab_shift = t->slab_shift;
+    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    P.row_stride = (uint32_t)t->row_bytes;
+    P.n_rows = (uint32_t)n;
+    P.qfrag = (const uint4 *)c->qfrag.p;
+    P.qaux = (const uint32_t *)c->qn2.p;
+    if (is_int) {
+        P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
+    } else {
+        P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
+        // bf16*bf16 / fp16*fp16 products are exact in fp32: only accumulation order/rounding differs
+        const double u = std::ldexp(1.0, -24);
+        const double cq = (double)kdim * std::ldexp(1.0, -22) * 1.01;
+        const double gref = ((double)kdim / 16.0 + 12.0) * u;
+        P.cE = (float)(((cq + 2.0 * gref + 4.0 * u) * 1.001) * (1.0 + 1e-6));
+        P.absE = t->metric == VSGPU_L2 ? 1e-30f : 1e-6f;
+    }
+    P.tau = (const float *)c->tau.p;
+    P.counts = (uint32_t *)c->counts.p;
+    P.cand = (uint2 *)c->cand.p;
+    P.cap = (uint32_t)ccap;
+
+    const uint32_t tile_step = total_tiles / probe_tiles;
+    // k_probe_threshold sorts M group minima per query in LDS; more probe tiles than that are grouped (the k-th
+    // smallest group minimum still has k distinct rows at or below it, and with k << M grouping costs nothing)
+    uint32_t M = 64;
+    while (M < probe_tiles && M < 8192) M <<= 1;
+    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
+    if (rc) return rc;
+    const uint32_t wgs = (uint32_t)c->n_cu * 2;
+
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    {
+        LowpParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = tile_step;
+        Q.n_tiles = probe_tiles;
+        Q.tilemin = (float *)c->dense.p;
+        Q.tilemin_stride = probe_tiles;
+        if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        else launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+        rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    {
+        LowpParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = 1;
+        Q.n_tiles = total_tiles;
+        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
+        Q.dbg = (int)c->opt_lowp_dbg;
+        uint32_t *d_ph = nullptr;
+        const size_t ph_words = (size_t)fw * q_tiles * 16 * 8;
+        if (Q.dbg & 8) {
+            HIPCHK(hipMalloc(&d_ph, ph_words * 4));
+            HIPCHK(hipMemsetAsync(d_ph, 0, ph_words * 4, c->stream));
+            Q.tilemin = reinterpret_cast<float *>(d_ph);
+        }
+        if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
+            launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+        if (d_ph) {  // phase sums of every wave: mean cycles per tile, printed once per launch
+            std::vector<uint32_t> h(ph_words);
+            HIPCHK(hipMemcpyAsync(h.data(), d_ph, ph_words * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(d_ph));
+            double sum[5] = {0, 0, 0, 0, 0}, tiles = 0;
+            for (size_t w = 0; w < ph_words / 8; w++) {
+                if (!h[w * 8 + 5]) continue;
+                for (int i = 0; i < 5; i++) sum[i] += h[w * 8 + i];
+                tiles += h[w * 8 + 5];
+            }
+            if (tiles > 0)
+                fprintf(stderr, "lowp phases, mean s_memtime ticks per wave and tile: vmcnt-wait %.0f  barrier %.0f  refill-request %.0f  "
+                                "reads+mfma-issue %.0f  epilogue %.0f\n",
+                        sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles);
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
+        HIPCHK(hipStreamSynchronize(c->stream));
+        account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
+        for (size_t q = 0; q < nq; q++) counts[q] = 0;
+        return VSGPU_OK;
+    }
+    if (!is_int) {
+        rc = launch_exact_pairs(t, nq, ccap);
+        if (rc) return rc;
+    }
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
+                              is_int ? "k_mfma_filter_lowp(i8)" : "k_mfma_filter_lowp(h16)");
+}

@@ -1,0 +1,223 @@
+// vsgpu_mfma.hip -- fp32 MFMA filter path of vsgpu_topk (kernels: mfma_kernels.hpp)
+#include "vsgpu_internal.hpp"
+#include "mfma_kernels.hpp"
+
+using namespace vsg;
+
+// Default shapes: the probe always uses 64-row tiles;
+// the filter uses 16-row x 1-KiB stages with non-temporal DMA when dim % 256 == 0 and the tile is at
+// least as long as the ring (dim >= 512), else 64-row x 256-B stages.  Measured on 10M x 768 (profiles/):
+// 64-row default policy 5.5 ms, 64-row nt 5.16 ms, 16-row nt 4.99 ms.
+template <int KS> static uint32_t launch_filter_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    if constexpr (KS % 8 == 0 && KS >= 16) {
+        Q.n_tiles = (uint32_t)((n + 15) / 16);
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 16>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+                           mf_lds_bytes(3), s, Q);
+    } else {
+        Q.n_tiles = (uint32_t)((n + 63) / 64);
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 64>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+                           mf_lds_bytes(3), s, Q);
+    }
+    return Q.n_tiles;
+}
+template <int KS> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64>), grid, dim3(256), mf_lds_bytes(3), s, P);
+}
+#ifdef VSGPU_TUNING
+// tuning variants of the d=768 filter kernel (option "mfma_variant"): ring depth / cache policy /
+// occupancy / tile shape.  Returns the tile height (rows) of the launched variant, 0 if none matched.
+#define MF_VARIANT(NS_, AUX_, MINW_, RT_)                                                                     \
+    {                                                                                                         \
+        Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                          \
+        dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                         \
+        hipLaunchKernelGGL((k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_>), grid, dim3(256), mf_lds_bytes(NS_), \
+                           s, Q);                                                                             \
+        return RT_;                                                                                           \
+    }
+static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    switch (variant) {
+    case 1: MF_VARIANT(3, 2, 1, 64)
+    case 2: MF_VARIANT(4, 0, 1, 64)
+    case 3: MF_VARIANT(4, 2, 1, 64)
+    case 4: MF_VARIANT(3, 0, 3, 64)
+    case 5: MF_VARIANT(3, 2, 3, 64)
+    case 6: MF_VARIANT(3, 2, 1, 16)
+    case 7: MF_VARIANT(4, 2, 1, 16)
+    case 8: MF_VARIANT(3, 2, 3, 16)
+    case 9: MF_VARIANT(3, 0, 1, 16)
+#define MF_VARIANT_X(NS_, AUX_, MINW_, RT_, XOPT_)                                                                         \
+    {                                                                                                                 \
+        Q.n_tiles = (uint32_t)((n + RT_ - 1) / RT_);                                                                  \
+        dim3 grid(std::min(Q.n_tiles, wgs), q_tiles);                                                                 \
+        auto kern = k_mfma_filter<24, MF_FILTER, NS_, AUX_, MINW_, RT_, XOPT_>;                                     \
+        if (mf_lds_bytes(NS_) > 64 * 1024)                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      mf_lds_bytes(NS_));                                                              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), mf_lds_bytes(NS_), s, Q);                                           \
+        return RT_;                                                                                                   \
+    }
+    case 10: MF_VARIANT_X(3, 2, 1, 16, 1)   // scalar slab loads: no per-tile ring drain
+    case 11: MF_VARIANT_X(4, 2, 1, 16, 1)
+    case 12: MF_VARIANT_X(3, 2, 3, 16, 1)
+    case 13: MF_VARIANT_X(3, 0, 1, 16, 1)
+    case 14: MF_VARIANT_X(3, 2, 1, 16, 2)   // one norm copy per workgroup
+    case 15: MF_VARIANT_X(3, 2, 1, 16, 4)   // survivor pre-screen
+    case 16: MF_VARIANT_X(3, 2, 1, 16, 6)
+    default: return 0;
+    }
+}
+#else
+static int launch_mfma_variant(int, MfmaParams, size_t, uint32_t, unsigned, hipStream_t) { return 0; }
+#endif
+static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_filter_ks<4>(P, n, wgs, q_tiles, s); break;
+    case 6: launch_filter_ks<6>(P, n, wgs, q_tiles, s); break;
+    case 8: launch_filter_ks<8>(P, n, wgs, q_tiles, s); break;
+    case 10: launch_filter_ks<10>(P, n, wgs, q_tiles, s); break;
+    case 12: launch_filter_ks<12>(P, n, wgs, q_tiles, s); break;
+    case 16: launch_filter_ks<16>(P, n, wgs, q_tiles, s); break;
+    case 20: launch_filter_ks<20>(P, n, wgs, q_tiles, s); break;
+    case 24: launch_filter_ks<24>(P, n, wgs, q_tiles, s); break;
+    case 28: launch_filter_ks<28>(P, n, wgs, q_tiles, s); break;
+    case 30: launch_filter_ks<30>(P, n, wgs, q_tiles, s); break;
+    case 40: launch_filter_ks<40>(P, n, wgs, q_tiles, s); break;
+    case 48: launch_filter_ks<48>(P, n, wgs, q_tiles, s); break;
+    case 80: launch_filter_ks<80>(P, n, wgs, q_tiles, s); break;
+    case 64: launch_filter_ks<64>(P, n, wgs, q_tiles, s); break;
+    case 96: launch_filter_ks<96>(P, n, wgs, q_tiles, s); break;
+    default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
+    }
+}
+static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_probe_ks<4>(P, grid, s); break;
+    case 6: launch_probe_ks<6>(P, grid, s); break;
+    case 8: launch_probe_ks<8>(P, grid, s); break;
+    case 10: launch_probe_ks<10>(P, grid, s); break;
+    case 12: launch_probe_ks<12>(P, grid, s); break;
+    case 16: launch_probe_ks<16>(P, grid, s); break;
+    case 20: launch_probe_ks<20>(P, grid, s); break;
+    case 24: launch_probe_ks<24>(P, grid, s); break;
+    case 28: launch_probe_ks<28>(P, grid, s); break;
+    case 30: launch_probe_ks<30>(P, grid, s); break;
+    case 40: launch_probe_ks<40>(P, grid, s); break;
+    case 48: launch_probe_ks<48>(P, grid, s); break;
+    case 80: launch_probe_ks<80>(P, grid, s); break;
+    case 64: launch_probe_ks<64>(P, grid, s); break;
+    case 96: launch_probe_ks<96>(P, grid, s); break;
+    default: launch_probe_ks<32>(P, grid, s); break;
+    }
+}
+
+int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                     uint32_t *ids, double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, dim = t->dim;
+    const int KS = t->ksteps;
+    const size_t q_tiles = (nq + MF_QTILE - 1) / MF_QTILE, nqp = q_tiles * MF_QTILE;
+    const bool l2 = (t->metric == VSGPU_L2);
+
+    // (1) exact-order query images for the re-rank, (2) bf16 B-operand fragments + |q|^2 for the filter
+    int rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
+    const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
+    std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
+    std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
+    for (size_t q = 0; q < nq; q++) {
+        const float *src = (const float *)((const char *)queries + q * qstride);
+        double ss = 0;
+        for (size_t i = 0; i < dim; i++) ss += (double)src[i] * (double)src[i];
+        qn2[q] = (float)ss;
+        const size_t qt = q / MF_QTILE, w = (q % MF_QTILE) / 16, nn = q % 16;
+        for (int s = 0; s < KS; s++)
+            for (int kq = 0; kq < 4; kq++) {
+                const size_t lane = (size_t)kq * 16 + nn;
+                uint16_t *dst = &frag[((((qt * 4 + w) * KS + s) * 64) + lane) * 8];
+                for (int j = 0; j < 8; j++) {
+                    const size_t e = (size_t)32 * s + 8 * kq + j;
+                    dst[j] = e < dim ? bf16_rne(src[e]) : (uint16_t)0;
+                }
+            }
+    }
+    rc = ensure(c, c->qfrag, frag.size() * 2);
+    if (rc) return rc;
+    rc = ensure(c, c->qn2, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->tau, nqp * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->counts, nqp * 4);
+    if (rc) return rc;
+    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
+    rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+
+    // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
+    const double u = std::ldexp(1.0, -24);
+    const double cq = std::ldexp(1.0, -8) * (1.0 + std::ldexp(1.0, -10)) + (double)kdim * std::ldexp(1.0, -22) * 1.01;
+    const double gref = ((double)kdim / 32.0 + 12.0) * u;
+    const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
+    const float absE = l2 ? 1e-30f : 1e-6f;
+
+    const uint32_t tile_step = total_tiles / probe_tiles;
+    uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
+    while (M < probe_tiles && M < 8192) M <<= 1;
+
+    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
+    if (rc) return rc;
+
+    MfmaParams P{};
+    P.slabs = t->d_slabs;
+    P.norm_slabs = t->d_norm_slabs;
+    P.slab_shift = t->slab_shift;
+    P.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);
+    P.row_stride = (uint32_t)t->row_bytes;
+    P.n_rows = (uint32_t)n;
+    P.qfrag = (const uint4 *)c->qfrag.p;
+    P.qn2 = (const float *)c->qn2.p;
+    P.cE = cE;
+    P.absE = absE;
+    P.is_l2 = l2 ? 1 : 0;
+    P.tau = (const float *)c->tau.p;
+    P.counts = (uint32_t *)c->counts.p;
+    P.cand = (uint2 *)c->cand.p;
+    P.cap = (uint32_t)ccap;
+    const uint32_t wg_cap = (uint32_t)c->n_cu * 2;
+
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    {   // probe: strided tiles -> per (tile, query) upper bounds
+        MfmaParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = tile_step;
+        Q.n_tiles = probe_tiles;
+        Q.tilemin = (float *)c->dense.p;
+        Q.tilemin_stride = probe_tiles;
+        launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        HIPCHK(hipGetLastError());
+        rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    {   // filter: every tile once
+        MfmaParams Q = P;
+        Q.tile_first = 0;
+        Q.tile_step = 1;
+        Q.n_tiles = total_tiles;
+        const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
+        if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
+            launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
+    if (rc) return rc;
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
+}

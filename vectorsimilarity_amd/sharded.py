@@ -1,18 +1,14 @@
-"""Multi-GPU Flat index: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in CPU tests), vector blocks dealt round-robin to the ranks, one exchange step
-per query batch.
+"""Multi-GPU Flat index: a binding over the C ABI's VecSimGpu_Sharded* entry points (include/VecSim/
+vec_sim_gpu.h; host code csrc/host/sharded_index.cpp, exchange csrc/vsgpu_comm.hip).
 
-Partition: vector number i of the equivalent single index (its internal id, `gid`)
-lives in block b = i // blockSize; block b belongs to rank b % G; its local id is
-(b // G) * blockSize + i % blockSize.  Every rank sees every add call (SPMD) and keeps only its own
-blocks, so ingest needs no communication.
+Partition, candidate records, the RCCL all-gather over xGMI and the exact global merge all live in the C++
+host library; Python only carries arrays across and -- when the ranks are `torch.distributed` processes --
+hands rank 0's 128-byte RCCL id to the others (`broadcast_object_list`, the one thing the library leaves to
+its caller).  torch never touches the data path.
 
-Query: every rank computes, on its own GPU, every local row with score <= T_local (the k-th
-smallest local score) -- VecSimIndex_TopKCandidatesBatch -- packs them into a fixed-size int64
-record [nq, 1 + 3*cap] and ONE all_gather_into_tensor moves the G records to every rank (tens of
-KB: latency-bound, no bandwidth tuning needed).  The merge replays the reference's sequential heap
-over the union in gid order (VecSimGpu_MergeTopK), which reproduces the single-index reply exactly,
-ties included.  No other collective touches the data path.
+    ShardedFlatIndex(params, rank, world, dist)           one process per GPU, RCCL exchange
+    ShardedFlatIndex(params, shards=G, devices=[...])      one process drives G shards (may share a GPU)
+    ShardedFlatIndex(params, rank, world, dist, transport="dist")   exchange through `dist` itself (gloo in CPU tests)
 """
 import ctypes as C
 import os
@@ -37,126 +33,160 @@ def gid_to_local(gid, block, world):
     return (b // world) * block + gid % block
 
 
+def _dist_transport(dist):
+    """(allgather, broadcast) callbacks that move the library's byte records with torch.distributed"""
+    import torch
+
+    def allgather(_user, send, nbytes, recv):
+        try:
+            world = dist.get_world_size()
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            out = torch.empty((world * nbytes,), dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, torch.from_numpy(src.copy()))
+            C.memmove(recv, out.numpy().ctypes.data, world * nbytes)
+            return 0
+        except Exception:  # a Python exception must not unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    def broadcast(_user, buf, nbytes, root):
+        try:
+            arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            t = torch.from_numpy(arr.copy())
+            dist.broadcast(t, src=root)
+            C.memmove(buf, t.numpy().ctypes.data, nbytes)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    return _capi.ALLGATHER_FN(allgather), _capi.BROADCAST_FN(broadcast)
+
+
 class ShardedFlatIndex:
-    def __init__(self, params, rank=0, world=1, dist=None, local_index=None, gather_device=None):
-        self.rank, self.world, self.dist = rank, world, dist
+    def __init__(self, params, rank=0, world=1, dist=None, shards=None, devices=None, device=None, transport="rccl",
+                 external=None):
+        self._lib = lib = _capi.load()
+        p = _capi.VecSimParams()
+        p.algo = _capi.VecSimAlgo_BF
+        p.algoParams.bfParams = params
         self.block = params.blockSize or 1024
         self.dim, self.type, self.metric = params.dim, params.type, params.metric
-        self.local = local_index if local_index is not None else VecSim.BFIndex(params)
-        self.n_global = 0            # vectors added so far across all ranks (same on every rank)
-        self._label_gid = {}         # label -> gid of vectors this rank owns (for locate/delete)
-        self._synthetic = None       # (rows_per_rank,) when filled by add_synthetic_local
-        self._gather_device = gather_device
-        self._lib = None
+        self._keep = []
+        if shards is not None:
+            devs = list(devices) if devices is not None else [0] * shards
+            arr = (C.c_int * shards)(*devs)
+            self._h = lib.VecSimGpu_ShardedNewLocal(C.byref(p), shards, arr)
+            self.rank, self.world = -1, shards
+        elif external is not None:
+            add_fn, cand_fn = external
+            ag, _bc = _dist_transport(dist)
+            a, c = _capi.SHARD_ADD_FN(add_fn), _capi.SHARD_CAND_FN(cand_fn)
+            self._keep += [ag, a, c]
+            self._h = lib.VecSimGpu_ShardedNewExternal(C.byref(p), rank, world, a, c, ag, None)
+            self.rank, self.world = rank, world
+        else:
+            if device is None:
+                device = int(os.environ.get("VECSIM_GPU_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if transport == "dist":
+                ag, bc = _dist_transport(dist)
+                self._keep += [ag, bc]
+                self._h = lib.VecSimGpu_ShardedNewWithTransport(C.byref(p), rank, world, device, ag, bc, None)
+            else:
+                uid = [None]
+                if rank == 0:
+                    buf = (C.c_char * 128)()
+                    if lib.VecSimGpu_ShardedGetUniqueId(buf) != 0:
+                        raise RuntimeError("RCCL id: %s" % lib.VecSimGpu_LastError().decode())
+                    uid[0] = bytes(buf)
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                self._h = lib.VecSimGpu_ShardedNew(C.byref(p), rank, world, device, uid[0])
+            self.rank, self.world = rank, world
+        if not self._h:
+            err = lib.VecSimGpu_LastError()
+            raise RuntimeError("sharded index: %s" % (err.decode() if err else "bad parameters"))
+        self._qbytes = lib.VecSimParams_GetQueryBlobSize(self.type, self.dim, self.metric)
+
+    # ---- shards held by this process ----
+    def local_index(self, shard=None):
+        """the shard's own Flat index (stats, options) as a non-owning VecSim.BFIndex"""
+        s = self.rank if shard is None else shard
+        h = self._lib.VecSimGpu_ShardedLocalIndex(self._h, max(s, 0))
+        if not h:
+            return None
+        ix = VecSim.VecSimIndex.__new__(VecSim.BFIndex)
+        VecSim.VecSimIndex.__init__(ix, None, borrowed_handle=h)
+        ix._parent = self
+        return ix
+
+    @property
+    def local(self):
+        return self.local_index()
 
     # ---- ingest (SPMD: call on every rank with the same arguments) ----
+    def _blob(self, a):
+        want = VecSim._NP[self.type]
+        a = np.asarray(a)
+        if a.dtype != want:
+            a = a.view(np.uint16) if (a.dtype.itemsize == 2 and want == np.uint16) else a.astype(want)
+        return np.ascontiguousarray(a)
+
     def add_vector(self, vector, label):
-        gid = self.n_global
-        self.n_global += 1
-        if block_owner(gid, self.block, self.world) == self.rank:
-            self._label_gid[int(label)] = gid
-            return self.local.add_vector(vector, label)
-        return 1
+        v = self._blob(vector)
+        return self._lib.VecSimGpu_ShardedAddVector(self._h, v.ctypes.data_as(C.c_void_p), int(label))
 
     def add_vectors(self, vectors, labels):
-        vectors = np.asarray(vectors)
-        labels = np.asarray(labels)
-        gids = np.arange(self.n_global, self.n_global + len(labels))
-        mine = ((gids // self.block) % self.world) == self.rank
-        self.n_global += len(labels)
-        if mine.any():
-            self.local.add_vectors(np.ascontiguousarray(vectors[mine]), labels[mine])
-            for lab, g in zip(labels[mine], gids[mine]):
-                self._label_gid[int(lab)] = int(g)
-        return len(labels)
+        v = self._blob(vectors)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        n = self._lib.VecSimGpu_ShardedAddVectorsBulk(self._h, v.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p),
+                                                      lab.size)
+        if n < 0:
+            raise RuntimeError("sharded bulk add failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return n
 
-    def add_synthetic_local(self, rows_per_rank, seed):
-        """weak-scaling fill: THIS rank appends rows_per_rank device-generated rows.  The equivalent
-        single index is the concatenation of the shards in rank order: gid = rank*rows_per_rank + local
-        id, label = gid."""
-        assert self.n_global == 0
-        self.local.add_synthetic(rows_per_rank, seed)
-        self._synthetic = rows_per_rank
-        self.n_global = rows_per_rank * self.world
+    def add_synthetic_local(self, rows_per_shard, seed):
+        """weak-scaling fill: every shard s appends rows_per_shard device-generated rows (seed + 1000 s); the
+        equivalent single index is the concatenation of the shards, label = gid.  Append-only afterwards."""
+        n = self._lib.VecSimGpu_ShardedAddSyntheticLocal(self._h, rows_per_shard, seed)
+        if n < 0:
+            raise RuntimeError("synthetic fill failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return n
 
-    def locate(self, label):
-        """(owner rank, local row) of a label; synthetic fills use label == gid"""
-        if self._synthetic is not None:
-            return label // self._synthetic, label % self._synthetic
-        gid = self._label_gid[label]
-        return block_owner(gid, self.block, self.world), gid_to_local(gid, self.block, self.world)
+    def delete_vector(self, label):
+        return self._lib.VecSimGpu_ShardedDeleteVector(self._h, int(label))
 
     def index_size(self):
-        return self.n_global
+        return self._lib.VecSimGpu_ShardedIndexSize(self._h)
 
     def device_sync(self):
-        pass  # every C-API call returns with its stream drained
+        pass  # every C-API call returns with its streams drained
 
     # ---- query ----
-    def _candidates(self, queries, k, cap):
-        """local candidate record: int64 [nq, 1 + 3*cap] = count | gids | labels | score bits"""
-        q = np.ascontiguousarray(queries)
+    def knn_query(self, queries, k, order=VecSim.BY_SCORE):
+        q = self._blob(queries)
+        q = q.reshape(-1, q.shape[-1])
+        stride = q.strides[0]
+        if stride < self._qbytes:  # int8/uint8 Cosine: room for the appended norm
+            buf = np.zeros((q.shape[0], self._qbytes), dtype=np.uint8)
+            buf[:, :stride] = q.view(np.uint8).reshape(q.shape[0], stride)
+            q, stride = buf, self._qbytes
         nq = q.shape[0]
-        ids = np.zeros((nq, cap), dtype=np.uint32)
-        labels = np.zeros((nq, cap), dtype=np.uint64)
-        scores = np.zeros((nq, cap), dtype=np.float64)
-        counts = np.zeros(nq, dtype=np.uint32)
-        self.local.topk_candidates(q, k, cap, ids, labels, scores, counts)
-        rec = np.zeros((nq, 1 + 3 * cap), dtype=np.int64)
-        rec[:, 0] = counts
-        lid = ids.astype(np.int64)
-        if self._synthetic is not None:
-            gids = self.rank * self._synthetic + lid    # contiguous shards
-            rec[:, 1 + cap:1 + 2 * cap] = gids          # label := gid (globally unique)
-        else:
-            gids = ((lid // self.block) * self.world + self.rank) * self.block + lid % self.block
-            rec[:, 1 + cap:1 + 2 * cap] = labels.view(np.int64)
-        rec[:, 1:1 + cap] = gids
-        rec[:, 1 + 2 * cap:] = scores.view(np.int64)
-        return rec
+        labels = np.empty((nq, k), dtype=np.int64)
+        dists = np.empty((nq, k), dtype=np.float64)
+        rc = self._lib.VecSimGpu_ShardedTopKQueryBatchArrays(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k, None,
+                                                            order, labels.ctypes.data_as(C.c_void_p),
+                                                            dists.ctypes.data_as(C.c_void_p), None)
+        if rc != 0:
+            raise RuntimeError("sharded top-k failed: %s" % self._lib.VecSimGpu_LastError().decode())
+        return labels, dists
 
-    def _all_gather(self, rec):
-        import torch
-        dev = self._gather_device
-        if dev is None:
-            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(rec).to(dev)
-        # concatenated form (world*nq, W): accepted by both RCCL and gloo
-        out = torch.empty((self.world * rec.shape[0], rec.shape[1]), dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().reshape((self.world,) + tuple(rec.shape))
-
-    def knn_query(self, queries, k):
-        queries = np.ascontiguousarray(queries)
-        if queries.ndim == 1:
-            queries = queries[None, :]
-        if self.dist is None or (self.world == 1 and not os.environ.get("VECSIM_FORCE_GATHER")):
-            return self.local.knn_query(queries, k)
-        nq = queries.shape[0]
-        cap = max(2 * k, k + 16)
-        rec = self._candidates(queries, k, cap)
-        allrec = self._all_gather(rec)                      # [G, nq, 1+3cap]
-        counts = np.ascontiguousarray(allrec[:, :, 0]).astype(np.uint32)
-        gids = np.ascontiguousarray(allrec[:, :, 1:1 + cap]).view(np.uint64)
-        labels = np.ascontiguousarray(allrec[:, :, 1 + cap:1 + 2 * cap]).view(np.uint64)
-        scores = np.ascontiguousarray(allrec[:, :, 1 + 2 * cap:]).view(np.float64)
-        if (counts == OVERFLOW).any():
-            # more than `cap` rows tie at some shard's k-th score: redo with room for every tie
-            return self._knn_query_wide(queries, k)
-        return merge_topk(counts, gids, labels, scores, k)
-
-    def _knn_query_wide(self, queries, k):
-        cap = 4 * max(2 * k, k + 16)
-        while True:
-            rec = self._candidates(queries, k, cap)
-            allrec = self._all_gather(rec)
-            counts = np.ascontiguousarray(allrec[:, :, 0]).astype(np.uint32)
-            if not (counts == OVERFLOW).any():
-                gids = np.ascontiguousarray(allrec[:, :, 1:1 + cap]).view(np.uint64)
-                labels = np.ascontiguousarray(allrec[:, :, 1 + cap:1 + 2 * cap]).view(np.uint64)
-                scores = np.ascontiguousarray(allrec[:, :, 1 + 2 * cap:]).view(np.float64)
-                return merge_topk(counts, gids, labels, scores, k)
-            cap *= 8
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.VecSimGpu_ShardedFree(self._h)
+            self._h = None
 
 
 def merge_topk(counts, gids, labels, scores, k):
