@@ -260,6 +260,62 @@ DEFINE_TWO_ACC_F32(f32_ip_lanes, float, WIDEN_ID, 0)
 DEFINE_TWO_ACC_F32(f16_l2_lanes, uint16_t, vso_f16_to_f32, 1)
 DEFINE_TWO_ACC_F32(f16_ip_lanes, uint16_t, vso_f16_to_f32, 0)
 
+/* fp16 F16C tier (spaces/L2/L2_F16C_FP16.h:28-83, spaces/IP/IP_F16C_FP16.h:27-81; chooser L2_space.cpp:404-409,
+ * IP_space.cpp:664-669: dim >= 8 once the AVX512F tier (dim >= 16) has declined, i.e. dims 8..15 on an AVX-512 host).
+ * Four 8-lane fp32 accumulators.  Head: the first residual%8 elements into sum0 through a zero blend (L2: fmadd on a
+ * zero accumulator, IP: a plain multiply); then residual/8 whole 8-blocks into sum1, sum2, sum3; then 32 elements per
+ * iteration into sum0..sum3.  Lane-wise (sum0+sum1)+(sum2+sum3), then my_mm256_reduce_add_ps (AVX_utils.h:32-37): the
+ * eight lanes added left to right. */
+static float f16_f16c(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+    float s[4][8];
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 8; j++) s[k][j] = 0.0f;
+    const size_t residual = d % 32, r8 = residual % 8;
+    size_t pos = 0;
+    if (r8) {
+        for (int j = 0; j < 8; j++) {
+            float x = (size_t)j < r8 ? vso_f16_to_f32(a[j]) : 0.0f, y = (size_t)j < r8 ? vso_f16_to_f32(b[j]) : 0.0f;
+            if (l2) {
+                float c = x - y;
+                s[0][j] = fmaf(c, c, s[0][j]);
+            } else {
+                s[0][j] = x * y;
+            }
+        }
+        pos = r8;
+    }
+    for (size_t blk = 1; blk <= residual / 8; blk++) {
+        for (int j = 0; j < 8; j++) {
+            float x = vso_f16_to_f32(a[pos + j]), y = vso_f16_to_f32(b[pos + j]);
+            if (l2) {
+                float c = x - y;
+                s[blk][j] = fmaf(c, c, s[blk][j]);
+            } else {
+                s[blk][j] = fmaf(x, y, s[blk][j]);
+            }
+        }
+        pos += 8;
+    }
+    while (pos < d) {
+        for (int k = 0; k < 4; k++) {
+            for (int j = 0; j < 8; j++) {
+                float x = vso_f16_to_f32(a[pos + j]), y = vso_f16_to_f32(b[pos + j]);
+                if (l2) {
+                    float c = x - y;
+                    s[k][j] = fmaf(c, c, s[k][j]);
+                } else {
+                    s[k][j] = fmaf(x, y, s[k][j]);
+                }
+            }
+            pos += 8;
+        }
+    }
+    float t[8];
+    for (int j = 0; j < 8; j++) t[j] = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+    float r = t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7];
+    return l2 ? r : 1.0f - r;
+}
+
 /* L2_AVX512F_FP64.h:21-59 and IP twin: residual = dim % 16, 8-lane accumulators */
 #define DEFINE_TWO_ACC_F64(NAME, IS_L2)                                                            \
     static double NAME(const double *a, const double *b, size_t d) {                               \
@@ -411,11 +467,16 @@ static float bf16_ip_dpbf16(const uint16_t *a, const uint16_t *b, size_t d) {
     return 1.0f - reduce16_f32(s);
 }
 
+/* the F16C restatement at any dim >= 8 (the chooser only sends dims 8..15 there on an AVX-512 host) */
+double vso_f16c_distance(int metric, size_t dim, const void *a, const void *b) {
+    return dim < 8 ? NAN : f16_f16c(a, b, dim, metric == VSO_L2);
+}
+
 /* ------------------------------------------------------------------ tier choosers */
 
 /* Mirrors the x86 branch of L2_space.cpp / IP_space.cpp for a gcc-11 build (no AVX512FP16 tier):
  *   fp32: dim < 8  -> scalar (L2_space.cpp:215-217)     fp64: dim < 4  (:274-276)
- *   bf16: dim < 32 -> scalar (:329-331)                 fp16: dim < 16 -> not the AVX512F tier (:397)
+ *   bf16: dim < 32 -> scalar (:329-331)                 fp16: dim < 8 -> scalar, 8..15 -> F16C (:404-409), 16+ -> AVX512F (:397)
  *   int8/uint8: exact integers in every tier. */
 int vso_uses_scalar(int type, int metric, int tier, size_t dim) {
     (void)metric;
@@ -424,7 +485,7 @@ int vso_uses_scalar(int type, int metric, int tier, size_t dim) {
     case VSO_F32: return dim < 8;
     case VSO_F64: return dim < 4;
     case VSO_BF16: return dim < 32;
-    case VSO_F16: return dim < 16; /* 8..15 would be the F16C tier on a real host: not restated */
+    case VSO_F16: return dim < 8;  /* 8..15: the F16C tier, 16+: the AVX512F tier */
     default: return 1;
     }
 }
@@ -443,6 +504,7 @@ double vso_distance(int type, int metric, int tier, size_t dim, const void *a, c
         if (scalar)
             return l2 ? h16_l2_scalar(a, b, dim, vso_f16_to_f32)
                       : h16_ip_scalar(a, b, dim, vso_f16_to_f32);
+        if (dim < 16) return f16_f16c(a, b, dim, l2);
         return l2 ? f16_l2_lanes(a, b, dim) : f16_ip_lanes(a, b, dim);
     case VSO_BF16:
         if (scalar)

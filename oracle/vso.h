@@ -105,6 +105,11 @@ int vso_flat_topk_batch_fast(int type, int metric, size_t dim, const void *rows,
                              size_t stride, const void *queries, size_t nq, size_t qstride,
                              size_t k, int threads, size_t *out_labels, double *out_scores);
 int vso_has_avx512(void);
+/* fp16 F16C tier (L2_F16C_FP16.h / IP_F16C_FP16.h): the portable restatement at any dim >= 8, and the same
+ * algorithm on the host's F16C/FMA units (NaN when absent) -- the tests compare them bit for bit */
+double vso_f16c_distance(int metric, size_t dim, const void *a, const void *b);
+double vso_f16c_distance_hw(int metric, size_t dim, const void *a, const void *b);
+int vso_has_f16c(void);
 
 /* deterministic synthetic data shared with the device generator (vsgpu_fill_uniform):
  * value(seed, idx) is a pure function, so any row can be re-created on the host. */

@@ -77,6 +77,11 @@ def lib():
         L.vso_hnsw_range.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
                                      C.c_uint32, i, vp, dbl, dbl, vp, vp, sz, vp]
         L.vso_has_avx512.restype = i
+        L.vso_has_f16c.restype = i
+        L.vso_f16c_distance.restype = dbl
+        L.vso_f16c_distance.argtypes = [i, sz, vp, vp]
+        L.vso_f16c_distance_hw.restype = dbl
+        L.vso_f16c_distance_hw.argtypes = [i, sz, vp, vp]
         L.vso_has_avx512_bf16.restype = i
         L.vso_probe_dpbf16.restype = None
         L.vso_probe_dpbf16.argtypes = [vp, vp, vp]

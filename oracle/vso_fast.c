@@ -88,6 +88,53 @@ TGT static float f32_ip_avx512(const float *a, const float *b, size_t d) {
     return 1.0f - hsum16(_mm512_add_ps(acc0, acc1));
 }
 
+/* fp16, F16C tier, as the published algorithm runs on real hardware (vcvtph2ps + 256-bit fmadd): four 8-lane
+ * accumulators, zero-blended head, whole 8-blocks of the residual into accumulators 1..3, 32 elements per turn of the
+ * main loop, lane-wise (0+1)+(2+3), the eight lanes added left to right.  Cross-check for vso.c:f16_f16c. */
+__attribute__((target("avx,avx2,fma,f16c"))) static float f16_f16c_hw(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+    __m256 acc[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+    const size_t residual = d & 31, head = residual & 7;
+    size_t pos = 0;
+    if (head) {
+        float keep[8];
+        for (int j = 0; j < 8; j++) keep[j] = (size_t)j < head ? 1.0f : 0.0f;
+        const __m256 m = _mm256_cmp_ps(_mm256_loadu_ps(keep), _mm256_setzero_ps(), _CMP_NEQ_OQ);
+        __m256 x = _mm256_and_ps(m, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)a)));
+        __m256 y = _mm256_and_ps(m, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)b)));
+        if (l2) {
+            __m256 c = _mm256_sub_ps(x, y);
+            acc[0] = _mm256_fmadd_ps(c, c, acc[0]);
+        } else {
+            acc[0] = _mm256_mul_ps(x, y);
+        }
+        pos = head;
+    }
+    for (size_t blk = 1; blk <= residual / 8; blk++, pos += 8) {
+        __m256 x = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(a + pos)));
+        __m256 y = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(b + pos)));
+        if (l2) x = _mm256_sub_ps(x, y), y = x;
+        acc[blk] = _mm256_fmadd_ps(x, y, acc[blk]);
+    }
+    while (pos < d)
+        for (int k = 0; k < 4; k++, pos += 8) {
+            __m256 x = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(a + pos)));
+            __m256 y = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(b + pos)));
+            if (l2) x = _mm256_sub_ps(x, y), y = x;
+            acc[k] = _mm256_fmadd_ps(x, y, acc[k]);
+        }
+    float t[8];
+    _mm256_storeu_ps(t, _mm256_add_ps(_mm256_add_ps(acc[0], acc[1]), _mm256_add_ps(acc[2], acc[3])));
+    volatile float r = t[0];  /* (volatile: the eight adds stay scalar and in this order) */
+    for (int j = 1; j < 8; j++) r = r + t[j];
+    return l2 ? r : 1.0f - r;
+}
+int vso_has_f16c(void) { return (__builtin_cpu_supports("f16c") && __builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2")) ? 1 : 0; }
+/* the F16C-tier kernel on this host's vector unit at any dim >= 8; NaN when the host lacks F16C */
+double vso_f16c_distance_hw(int metric, size_t dim, const void *a, const void *b) {
+    if (!vso_has_f16c() || dim < 8) return NAN;
+    return f16_f16c_hw(a, b, dim, metric == VSO_L2);
+}
+
 /* one vdpbf16ps on 16 lanes, exposed so the tests can characterise the instruction on hosts
  * that have it (acc, x, y: 16 floats / 32 + 32 bf16) */
 __attribute__((target("avx512f,avx512bw,avx512vl,avx512bf16"))) void
@@ -101,6 +148,8 @@ int vso_has_avx512_bf16(void) { return __builtin_cpu_supports("avx512bf16") ? 1 
 #else
 void vso_probe_dpbf16(float *acc, const uint16_t *x, const uint16_t *y) { (void)acc; (void)x; (void)y; }
 int vso_has_avx512_bf16(void) { return 0; }
+int vso_has_f16c(void) { return 0; }
+double vso_f16c_distance_hw(int metric, size_t dim, const void *a, const void *b) { (void)metric; (void)dim; (void)a; (void)b; return NAN; }
 #endif
 
 /* single distance through the intrinsics path (fp32, dim >= 8 only); NaN when unavailable */

@@ -116,7 +116,41 @@ def flat():
     return dict(cases=cases)
 
 
+def flat_multi():
+    """closed forms of tests/unit/test_bruteforce_multi.cpp: every vector is [value]*4, fp32 L2, query = 0; a case lists
+    (label, value) per vector in insertion order, k, and the (label, score) reply the reference test asserts"""
+    dim = 4
+    cases = []
+    # :251-288 5 vectors under 2 labels, k=3 -> only 2 results (unique labels), label i at rank i
+    vec = [[i // 3, float(i)] for i in range(5)]
+    cases.append(dict(name="search_more_than_there_is", dim=dim, vectors=vec, k=3, expect_labels=[0, 1],
+                      expect_scores=[0.0, 4.0 * 9.0], src="test_bruteforce_multi.cpp:251-288"))
+    # :290-324 100 vectors, 10 per label, value i: label i at rank i (its best vector is 10 i)
+    vec = [[i // 10, float(i)] for i in range(100)]
+    cases.append(dict(name="indexing_same_vector", dim=dim, vectors=vec, k=10, expect_labels=list(range(10)),
+                      expect_scores=[4.0 * (10 * i) ** 2 for i in range(10)], src="test_bruteforce_multi.cpp:290-324"))
+    # :326-371 each label gets ever better vectors, neighbours share scores; rank r -> label k-r-1, score el^2*dim
+    n, nl, k = 100, 10, 10
+    vec, best = [], {}
+    for i in range(n):
+        el = ((n - i - 1) % nl) + ((n - i - 1) // nl)
+        vec.append([i // nl, float(el)])
+        if i % nl == nl - 1:
+            best[i // nl] = float(el * el * dim)
+    cases.append(dict(name="find_better_score", dim=dim, vectors=vec, k=k, expect_labels=[k - r - 1 for r in range(k)],
+                      expect_scores=[best[k - r - 1] for r in range(k)], src="test_bruteforce_multi.cpp:326-371"))
+    # :373-403 12 vectors over 3 labels, each better than the previous: rank r -> label n_labels-r-1, for k = 2 and k = 3
+    n, nl = 12, 3
+    vec = [[i % nl, float(n - i)] for i in range(n)]
+    for k in (nl - 1, nl):
+        cases.append(dict(name="find_better_score_after_pop_k%d" % k, dim=dim, vectors=vec, k=k,
+                          expect_labels=[nl - r - 1 for r in range(k)], src="test_bruteforce_multi.cpp:373-403"))
+    return dict(cases=cases)
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "kat_flat_multi.json"), "w") as f:
+        json.dump(flat_multi(), f, indent=1)
     with open(os.path.join(HERE, "kat_spaces.json"), "w") as f:
         json.dump(spaces(), f, indent=0)
     with open(os.path.join(HERE, "kat_flat.json"), "w") as f:

@@ -38,6 +38,15 @@ template <typename T> static T tree(std::vector<T> v, int vl) {
     return v[0];
 }
 
+// the F16C kernel's horizontal add (LaneProgram::reduce == 1)
+static float reduce_f16c(const std::vector<float> &v) {
+    float t[8];
+    for (int j = 0; j < 8; j++) t[j] = (v[j] + v[j + 8]) + 0.0f;
+    float r = t[0];
+    for (int j = 1; j < 8; j++) r = r + t[j];
+    return r;
+}
+
 extern "C" int lane_emul_steps(int type, int metric, int tier, size_t dim) {
     return vsg::build_lane_program(type, metric, tier, dim).steps;
 }
@@ -92,7 +101,16 @@ extern "C" double lane_emul(int type, int metric, int tier, size_t dim, const vo
                 x = widen16(type, hx);
                 q = widen16(type, hq);
             }
-            if (p.is_l2) {
+            if (p.dpbf16) {
+                auto ftz = [](float v) {
+                    uint32_t u;
+                    std::memcpy(&u, &v, 4);
+                    if ((u & 0x7f800000u) == 0) u &= 0x80000000u;
+                    std::memcpy(&v, &u, 4);
+                    return v;
+                };
+                acc[l] = ftz(std::fma(ftz(x), ftz(q), ftz(acc[l])));
+            } else if (p.is_l2) {
                 float t = x - q;
                 if (p.fused) acc[l] = std::fma(t, t, acc[l]);
                 else { float m = t * t; acc[l] = acc[l] + m; }
@@ -101,5 +119,6 @@ extern "C" double lane_emul(int type, int metric, int tier, size_t dim, const vo
                 else { float m = x * q; acc[l] = acc[l] + m; }
             }
         }
+    if (p.reduce == 1) return (double)reduce_f16c(acc);
     return (double)tree(acc, p.vl);
 }

@@ -34,6 +34,7 @@ def oracle_topk(vso, typ, metric, rows, q, k, labels=None):
 
 CASES = [(t, m, d) for t in ("f32", "f16", "bf16", "f64", "i8", "u8") for m in ("L2", "IP", "Cosine")
          for d in (4, 17, 33, 64, 100, 128)]
+CASES += [("f16", m, d) for m in ("L2", "IP", "Cosine") for d in (8, 12, 15, 16)]   # F16C tier (dims 8..15) and its upper edge
 
 
 @pytest.mark.parametrize("typ,metric,dim", CASES)
@@ -52,6 +53,71 @@ def test_all_scores_bit_exact(vso, typ, metric, dim):
         el, es = oracle_topk(vso, typ, metric, rows, q[j], n)
         assert np.array_equal(labels[j], el.astype(np.int64)), (typ, metric, dim, j)
         assert np.array_equal(dists[j], es), (typ, metric, dim, j)
+
+
+TIER_CASES = [("scalar", t, m, d) for t in ("f32", "f16", "bf16", "f64", "i8") for m in ("L2", "IP") for d in (17, 64, 100)]
+TIER_CASES += [("avx512_bf16", "bf16", m, d) for m in ("IP", "Cosine", "L2") for d in (32, 33, 47, 64, 100, 768)]
+
+
+@pytest.mark.parametrize("tier,typ,metric,dim", TIER_CASES)
+def test_all_scores_bit_exact_other_tiers(vso, monkeypatch, tier, typ, metric, dim):
+    """VECSIM_GPU_TIER selects which reference ISA tier's summation order the kernels reproduce: `scalar` (hosts without
+    SIMD, L2.cpp:76-133 / IP.cpp:185-238) and `avx512_bf16` (vdpbf16ps, what IP_space.cpp:586-590 picks first on any
+    avx512_bf16 host -- bf16 IP/Cosine only, L2 stays on the VBMI2 kernel).  0 ulp against the oracle's model of that tier."""
+    from util import TIERS
+    monkeypatch.setenv("VECSIM_GPU_TIER", tier)
+    rng = np.random.default_rng(dim * 3 + len(typ) + len(tier))
+    n = 300
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 3, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    labels, dists = ix.knn_query(q, n)
+    st = stored_rows(vso, rows, typ, metric)
+    for j in range(3):
+        qq = stored_rows(vso, q[j][None, :], typ, metric)[0]
+        el, es = vso.flat_topk(TYPES[typ], kernel_metric(typ, metric), st, qq, n, dim, tier=TIERS[tier])
+        assert np.array_equal(labels[j], el.astype(np.int64)), (tier, typ, metric, dim, j)
+        assert np.array_equal(dists[j], es), (tier, typ, metric, dim, j)
+
+
+def test_avx512_bf16_tier_on_the_mfma_filter_and_flushes_subnormals(vso, monkeypatch):
+    """the vdpbf16ps tier as a first-class path: (1) config 4's shape runs on the low-precision MFMA filter with the
+    survivors re-scored in the vdpbf16ps order; (2) subnormal bf16 inputs count as zero (DAZ) exactly as the
+    instruction does -- 0x0040 x 0x7F00 would contribute ~1.0 to a dot without the flush"""
+    from util import TIERS
+    monkeypatch.setenv("VECSIM_GPU_TIER", "avx512_bf16")
+    rng = np.random.default_rng(2024)
+    dim, n, nq, k = 768, 30_000, 128, 10
+    rows = random_vectors(rng, n, dim, "bf16", vso)
+    q = random_vectors(rng, nq, dim, "bf16", vso)
+    ix = make_index("bf16", "IP", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    stt = ix.stats()
+    assert "lowp" in stt["scan_kernel"] and stt["fallbacks"] == 0, stt
+    for j in range(0, nq, 7):
+        el, es = vso.flat_topk(TYPES["bf16"], METRICS["IP"], rows, q[j], k, dim, tier=TIERS["avx512_bf16"])
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), j
+    # (2) subnormals
+    dim, n = 64, 200
+    rows = random_vectors(rng, n, dim, "bf16", vso)
+    rows[:, ::5] = np.uint16(0x0040)          # subnormal bf16 (5.9e-39)
+    rows[1::2, 1::5] = np.uint16(0x8033)      # negative subnormal
+    qq = random_vectors(rng, 2, dim, "bf16", vso)
+    qq[:, ::5] = np.uint16(0x7F00)            # 1.7e38: the product would be a perfectly normal ~1.0
+    ix = make_index("bf16", "IP", dim)
+    ix.add_vectors(rows, np.arange(n))
+    labels, dists = ix.knn_query(qq, n)
+    differs = 0
+    for j in range(2):
+        el, es = vso.flat_topk(TYPES["bf16"], METRICS["IP"], rows, qq[j], n, dim, tier=TIERS["avx512_bf16"])
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), j
+        _, es0 = vso.flat_topk(TYPES["bf16"], METRICS["IP"], rows, qq[j], n, dim, tier=TIERS["avx512"])
+        differs += int(not np.array_equal(np.sort(es), np.sort(es0)))
+    assert differs == 2   # the flush is observable: the VBMI2 order (no DAZ) scores these rows differently
 
 
 @pytest.mark.parametrize("typ,metric,dim,n,nq,k", [
@@ -581,6 +647,31 @@ def test_multi_value_flat_matches_updatable_heap_semantics(vso, typ, metric, dim
     radius = float(np.sort(sc)[200]) if np.sort(sc)[200] >= 0 else 0.5
     rl, rs = ix.range_query(q[0], radius, order=VecSim.BY_ID)
     assert len(set(rl[0].tolist())) == rl.shape[1]
+
+
+def test_multi_value_reference_kats_and_prefer_adhoc(vso):
+    """(1) the closed forms of tests/unit/test_bruteforce_multi.cpp through the C API; (2) preferAdHocSearch takes its
+    ratio over LABELS (brute_force.h:390): 6000 vectors under 3000 labels, d = 400, subset 2000 -> r = 0.67 > 0.55 ->
+    batches (a ratio over vectors, 0.33, would have said ad-hoc)"""
+    with open(os.path.join(GOLD, "kat_flat_multi.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        ix = _multi_index("f32", "L2", c["dim"])
+        for label, value in c["vectors"]:
+            ix.add_vector(np.full(c["dim"], value, np.float32), label)
+        labels, dists = ix.knn_query(np.zeros(c["dim"], np.float32), c["k"])
+        exp = c["expect_labels"] + [-1] * (c["k"] - len(c["expect_labels"]))
+        assert list(labels[0]) == exp, c["name"]
+        if "expect_scores" in c:
+            assert list(dists[0][: len(c["expect_scores"])]) == c["expect_scores"], c["name"]
+    rng = np.random.default_rng(1)
+    ix = _multi_index("f32", "L2", 400)
+    ix.add_vectors(rng.uniform(-1, 1, (6000, 400)).astype(np.float32), np.arange(6000) // 2)
+    assert ix.prefer_adhoc(2000, 10, True) is False
+    assert ix.prefer_adhoc(1500, 10, True) is True      # r = 0.5 <= 0.55
+    single = make_index("f32", "L2", 400)
+    single.add_vectors(rng.uniform(-1, 1, (6000, 400)).astype(np.float32), np.arange(6000))
+    assert single.prefer_adhoc(2000, 10, True) is True  # same sizes, one vector per label: r = 0.33
 
 
 def test_multi_value_delete_keeps_remaining_vectors_queryable(vso):

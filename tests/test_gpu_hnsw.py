@@ -298,3 +298,29 @@ def test_hnsw_batch_iterator_sparse_mode_with_deleted_nodes(vso):
         l, d = it.get_next_results(m, VecSim.BY_SCORE)
         got += l[0].tolist()
     assert got == order[:200].tolist()
+
+
+def test_topk_beyond_the_lds_heaps_and_beyond_the_index(vso):
+    """the reference answers any k (hnsw.h:2037-2084).  (1) k larger than the index: every live node comes back, like
+    ef = live; (2) ef past what the kernel's per-query LDS heaps hold (about 1.3 K at dim 768): the batch is answered by
+    the exact GPU scan -- the true k best live vectors -- and the reply is OK, not TimedOut; deleted nodes never appear"""
+    dim, n = 768, 6000
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=40, ef=20)
+    for lab in (5, 77, 4000):
+        ix.delete_vector(lab)
+    q = np.random.default_rng(4).uniform(-1, 1, (3, dim)).astype(np.float32)
+    k = 3000
+    labels, dists, code = None, None, None
+    l1, d1, code = ix.knn_query_code(q[0], k)
+    assert code == VecSim._capi.VecSim_QueryReply_OK
+    keep = np.ones(n, bool)
+    keep[[5, 77, 4000]] = False
+    for j in range(3):
+        labels, dists = ix.knn_query(q[j], k)
+        el, es = vso.flat_topk(0, 0, rows[keep], q[j], k, dim, np.nonzero(keep)[0].astype(np.uint64))
+        assert np.array_equal(labels[0], el.astype(np.int64)) and np.array_equal(dists[0], es), j
+    small, rows2 = build(16, 50, VecSim.VecSimMetric_L2, M=4, efc=20, ef=10)
+    small.delete_vector(7)
+    labels, dists = small.knn_query(rows2[0], 200)
+    got = labels[0][labels[0] >= 0]
+    assert len(got) == 49 and 7 not in got and np.all(np.diff(dists[0][:49]) >= 0) and np.all(labels[0][49:] == -1)

@@ -1,0 +1,79 @@
+"""GPU: bounded slices (<= ~30 s in all) of tools/stress_flat.py and tools/stress_updates.py, so that the ring-slot
+race fixed in round 1 (one candidate lost per ~700 first query passes, always in a workgroup's last tile: the barrier
+that frees a ring slot must wait for the slot's LDS reads, mfma_kernels.hpp:mf_ring_barrier) cannot come back
+unnoticed.  Fresh index over alternating data (the allocator hands back the same device addresses), FIRST query pass on
+the MFMA filter path vs the exact path of the same data."""
+import time
+
+import numpy as np
+import pytest
+
+from vectorsimilarity_amd import VecSim
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {"f32": (VecSim.VecSimType_FLOAT32, 128, 150_000, 64), "f32odd": (VecSim.VecSimType_FLOAT32, 100, 150_000, 64),
+          "bf16": (VecSim.VecSimType_BFLOAT16, 256, 120_000, 100), "i8": (VecSim.VecSimType_INT8, 512, 100_000, 200)}
+
+
+def fresh(vt, dim, rows):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = vt, dim, VecSim.VecSimMetric_L2
+    ix = VecSim.BFIndex(p)
+    ix.add_vectors(rows, np.arange(len(rows)))
+    return ix
+
+
+@pytest.mark.parametrize("kind", list(SHAPES))
+def test_first_pass_on_a_fresh_index_never_loses_a_candidate(kind):
+    vt, dim, n, nq = SHAPES[kind]
+    rng = np.random.default_rng(1)
+    sets = []
+    for _ in range(2):
+        if kind == "i8":
+            rows = rng.integers(-128, 128, (n, dim)).astype(np.int8)
+            q = rng.integers(-128, 128, (nq, dim)).astype(np.int8)
+        else:
+            rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+            q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+            if kind == "bf16":
+                rows = (rows.view(np.uint32) >> 16).astype(np.uint16)
+                q = (q.view(np.uint32) >> 16).astype(np.uint16)
+        ix = fresh(vt, dim, rows)
+        ix.set_option("mfma", 0)
+        sets.append((rows, q, ix.knn_query(q, 10)))
+        del ix
+    t0, reps, bad = time.perf_counter(), 0, []
+    while reps < 60 and time.perf_counter() - t0 < 7.0:
+        rows, q, ref = sets[reps % 2]
+        ix = fresh(vt, dim, rows)
+        ix.set_option("dense_pairs", 0)
+        labels, dists = ix.knn_query(q, 10)
+        if not (np.array_equal(labels, ref[0]) and np.array_equal(dists, ref[1])):
+            bad.append(reps)
+        del ix
+        reps += 1
+    assert reps >= 10 and not bad, (kind, reps, bad)
+
+
+def test_updates_followed_at_once_by_a_filter_query():
+    """deletes (device row move + norm update) and overwrites, then straight into an MFMA-path query"""
+    rng = np.random.default_rng(3)
+    dim, n = 128, 40_000
+    t0, reps = time.perf_counter(), 0
+    while reps < 25 and time.perf_counter() - t0 < 6.0:
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32) * np.float32(1 + (reps % 5))
+        ix = fresh(VecSim.VecSimType_FLOAT32, dim, rows)
+        q = rng.uniform(-1, 1, (32, dim)).astype(np.float32)
+        for lab in rng.choice(n, 200, replace=False):
+            ix.delete_vector(int(lab))
+        for lab in rng.choice(n, 50, replace=False):
+            ix.add_vector(rng.uniform(-3, 3, dim).astype(np.float32), int(lab))
+        ix.set_option("dense_pairs", 0)
+        l1, d1 = ix.knn_query(q, 10)
+        ix.set_option("mfma", 0)
+        l2, d2 = ix.knn_query(q, 10)
+        assert np.array_equal(l1, l2) and np.array_equal(d1, d2), reps
+        del ix
+        reps += 1
+    assert reps >= 5

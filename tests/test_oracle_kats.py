@@ -95,6 +95,20 @@ def test_flat_kats(vso):
                 assert sorted(int(x) for x in got_l) == c["expect_id_set"], (c["name"], typ)
 
 
+def test_multi_value_replay_kats(vso):
+    """the label-keyed replay (vso_topk_replay_multi, restating utils/updatable_heap.h:20-113 +
+    brute_force_multi.h:108-277) against the closed forms of tests/unit/test_bruteforce_multi.cpp"""
+    for c in _load("kat_flat_multi.json")["cases"]:
+        dim = c["dim"]
+        labels = np.array([v[0] for v in c["vectors"]], dtype=np.uint64)
+        rows = np.array([[v[1]] * dim for v in c["vectors"]], dtype=np.float32)
+        scores = vso.scan(0, 0, rows, np.zeros(dim, np.float32), dim)
+        got_l, got_s = vso.topk_replay_multi(scores, c["k"], labels)
+        assert [int(x) for x in got_l] == c["expect_labels"], c["name"]
+        if "expect_scores" in c:
+            assert list(got_s) == c["expect_scores"], c["name"]
+
+
 def test_lanes_match_avx512_intrinsics(vso):
     """portable 32-lane emulation == hand-written AVX-512 intrinsics (vso_fast.c), bit for bit"""
     if not vso.lib().vso_has_avx512():
@@ -105,6 +119,33 @@ def test_lanes_match_avx512_intrinsics(vso):
         b = rng.uniform(-1, 1, d).astype(np.float32)
         for m in (0, 1):
             assert vso.distance(0, m, a, b) == vso.distance_fast(0, m, a, b), (d, m)
+
+
+def test_f16c_restatement_matches_the_hosts_f16c_unit(vso):
+    """fp16 F16C tier (the reference's kernel for dims 8..15 on an AVX-512 host, L2_space.cpp:404-409): the portable
+    restatement equals the same published algorithm run on this host's vcvtph2ps/fmadd units, bit for bit, at every
+    residual class; and the chooser sends dims 8..15 there, 16+ to the AVX512F order, < 8 to the scalar order"""
+    L = vso.lib()
+    if not L.vso_has_f16c():
+        pytest.skip("host CPU has no F16C/FMA/AVX2")
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for d in list(range(8, 140)) + [768]:
+        for rep in range(3):
+            a = rng.uniform(-1, 1, d).astype(np.float16).view(np.uint16)
+            b = rng.uniform(-1, 1, d).astype(np.float16).view(np.uint16)
+            for m in (0, 1):
+                sw, hw = L.vso_f16c_distance(m, d, p(a), p(b)), L.vso_f16c_distance_hw(m, d, p(a), p(b))
+                assert sw == hw, (d, m, sw, hw)
+                if d < 16:
+                    assert vso.distance(3, m, a, b) == hw, (d, m)
+    differs = 0
+    for _ in range(200):   # ... and that order is NOT the scalar one the previous round used there
+        a = rng.uniform(-1, 1, 15).astype(np.float16).view(np.uint16)
+        b = rng.uniform(-1, 1, 15).astype(np.float16).view(np.uint16)
+        differs += vso.distance(3, 1, a, b, tier=0) != vso.distance(3, 1, a, b, tier=1)
+    assert differs > 0
 
 
 def test_scalar_and_lane_orders_differ_in_last_bits(vso):

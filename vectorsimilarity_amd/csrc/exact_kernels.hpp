@@ -18,7 +18,7 @@
 namespace vsg {
 
 enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5 };
-enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3 };
+enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3, OP_IP_DPBF16 = 4 };
 enum ScanMode { MODE_DENSE = 0, MODE_FILTER = 1 };
 // how the reduced accumulator becomes a score
 enum Epilogue {
@@ -65,8 +65,15 @@ template <> struct Elem<EK_U8> {
     __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const uint8_t *>(p)); }
 };
 
+// vdpbf16ps treats subnormal inputs as zero and flushes subnormal results (IP_AVX512_BF16_VL_BF16.h:14-47; the
+// instruction ignores MXCSR: DAZ/FTZ always on)
+__device__ inline float ftz_f32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x7f800000u) ? v : __uint_as_float(u & 0x80000000u);
+}
 // one accumulation step; explicit rounding intrinsics so no contraction flag can change it
 template <int OPK> __device__ inline float acc_step(float x, float q, float acc) {
+    if (OPK == OP_IP_DPBF16) { return ftz_f32(__fmaf_rn(ftz_f32(x), ftz_f32(q), ftz_f32(acc))); }
     if (OPK == OP_L2_FMA) { float t = __fsub_rn(x, q); return __fmaf_rn(t, t, acc); }
     if (OPK == OP_IP_FMA) { return __fmaf_rn(x, q, acc); }
     if (OPK == OP_L2_MULADD) { float t = __fsub_rn(x, q); return __fadd_rn(acc, __fmul_rn(t, t)); }
@@ -79,6 +86,7 @@ template <int OPK> __device__ inline double acc_step(double x, double q, double 
     return __dadd_rn(acc, __dmul_rn(x, q));
 }
 template <int OPK> __device__ inline int acc_step(int x, int q, int acc) {
+    static_assert(OPK != OP_IP_DPBF16, "vdpbf16ps order is a bf16 matter");
     if (OPK == OP_L2_FMA || OPK == OP_L2_MULADD) { int t = x - q; return acc + t * t; }
     return acc + x * q;
 }
@@ -86,6 +94,23 @@ template <int OPK> __device__ inline int acc_step(int x, int q, int acc) {
 __device__ inline float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ inline double add_rn(double a, double b) { return __dadd_rn(a, b); }
 __device__ inline int add_rn(int a, int b) { return a + b; }
+
+// Horizontal add of a VL-lane accumulator group; the result is valid in the group's lane 0.
+//   kind 0: halving tree, offsets VL/2 .. 1 (sum0 + sum1, then gcc 11's _mm512_reduce_add order)
+//   kind 1: the fp16 F16C kernel (dims 8..15): (lane j + lane j+8) + 0 for j < 8, then the eight sums left to right
+//           (L2_F16C_FP16.h:81-82, AVX_utils.h:32-37)
+template <int VL, typename T> __device__ inline T lane_reduce(T v, int kind) {
+    if (kind == 0) {
+#pragma unroll
+        for (int o = VL / 2; o >= 1; o >>= 1) v = add_rn(v, __shfl_down(v, o, VL));
+        return v;
+    }
+    v = add_rn(add_rn(v, __shfl_down(v, 8, VL)), (T)0);
+    T t = __shfl(v, 0, VL);
+#pragma unroll
+    for (int j = 1; j < 8; j++) t = add_rn(t, __shfl(v, j, VL));
+    return t;
+}
 
 struct ScanParams {
     // table view: row i lives at slabs[i >> slab_shift] + (i & slab_mask) * row_stride
@@ -103,6 +128,7 @@ struct ScanParams {
     // lane program + queries
     const int32_t *offs;  // [steps][VL]
     int steps;
+    int reduce;           // LaneProgram::reduce
     int full_from, full_to;  // every lane is active in steps [full_from, full_to): no predication needed there
     const void *qperm;    // [nq][steps][VL] acc_t, query values already widened & permuted
     int nq;
@@ -252,10 +278,7 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int b = 0; b < BT; b++) {
-                acc_t v = acc[r][b];
-#pragma unroll
-                for (int o = VL / 2; o >= 1; o >>= 1) v = add_rn(v, __shfl_down(v, o, VL));
-                acc[r][b] = v;
+                acc[r][b] = lane_reduce<VL>(acc[r][b], P.reduce);
             }
 
         if (lane == 0) {

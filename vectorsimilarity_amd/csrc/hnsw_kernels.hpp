@@ -32,6 +32,7 @@ struct HnswParams {
     // lane program + queries
     const int32_t *offs;
     int steps;
+    int reduce;            // LaneProgram::reduce
     const void *qperm;  // [nq][steps][VL] accumulator-typed
     int nq;
     int epilogue;
@@ -198,9 +199,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            acc_t a = acc[u];
-#pragma unroll
-            for (int of = VL / 2; of >= 1; of >>= 1) a = add_rn(a, __shfl_down(a, of, VL));
+            const acc_t a = lane_reduce<VL>(acc[u], P.reduce);
             if (vl == 0 && act[u]) {
                 float nrow = 0.f;
                 if (P.epilogue == EPI_INT_COS) {

@@ -495,6 +495,12 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     size_t ef = ef_;
     if (qp && qp->hnswRuntimeParams.efRuntime != 0) ef = qp->hnswRuntimeParams.efRuntime;
     ef = std::max(ef, k);  // hnsw.h:2073
+    // top_candidates never holds more than the live nodes, so an ef (and k) beyond that behaves exactly like ef = live
+    // (the admission test `size < ef` then never fails): clamp before sizing the kernel's LDS heaps
+    const size_t live = n_ - n_deleted_;
+    if (live == 0) return finish();
+    const size_t k_eff = std::min(k, live);
+    ef = std::min(ef, live);
     // only Cosine needs a private (normalised) copy of the queries
     std::vector<char> qbuf;
     const void *qsrc = queries;
@@ -508,11 +514,51 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         qsrc = qbuf.data();
         qstride = blob_bytes_;
     }
-    std::vector<uint64_t> labs(nq * k);
-    std::vector<double> sc(nq * k);
+    std::vector<uint64_t> labs(nq * k_eff);
+    std::vector<double> sc(nq * k_eff);
     std::vector<uint32_t> cnt(nq);
     int rc = syncDevice();
-    if (!rc) rc = vsgpu_graph_search(graph_, qsrc, nq, qstride, k, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
+    if (!rc) rc = vsgpu_graph_search(graph_, qsrc, nq, qstride, k_eff, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
+    if (rc == VSGPU_ERR_UNSUPPORTED) {
+        // ef beyond what the per-query LDS heaps hold (about 1.3 K at dim 768): the graph walk cannot be replayed, so
+        // the batch is answered by the exact GPU scan of the table -- the k best live vectors, a reply at least as good
+        // as any graph walk's.  Deleted nodes still sit in the table: ask for that many more rows and drop them.
+        const size_t kk = std::min(n_, k_eff + n_deleted_);
+        const size_t cap = std::max<size_t>(2 * kk, kk + 64);
+        std::vector<uint32_t> ids(cap), c1(1);
+        std::vector<double> s1(cap);
+        using Item = std::pair<double, size_t>;
+        for (size_t q = 0; q < nq; q++) {
+            const char *qp1 = (const char *)qsrc + q * qstride;
+            rc = vsgpu_topk(table_, qp1, 1, qstride, kk, cap, ids.data(), s1.data(), c1.data());
+            std::vector<double> all;
+            if (!rc && c1[0] == VSGPU_COUNT_OVERFLOW) {  // massive ties at the kk-th score: every row's score
+                all.resize(n_);
+                rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
+            }
+            if (rc) break;
+            std::priority_queue<Item> heap;
+            double upper = std::numeric_limits<double>::lowest();
+            const size_t m = all.empty() ? c1[0] : n_;
+            for (size_t i = 0; i < m; i++) {
+                const uint32_t id = all.empty() ? ids[i] : (uint32_t)i;
+                const double sco = all.empty() ? s1[i] : all[i];
+                if (deleted_[id]) continue;
+                if (sco < upper || heap.size() < k_eff) {
+                    heap.emplace(sco, (size_t)labels_[id]);
+                    if (heap.size() > k_eff) heap.pop();
+                    upper = heap.top().first;
+                }
+            }
+            cnt[q] = (uint32_t)heap.size();
+            for (size_t i = heap.size(); i-- > 0;) {
+                labs[q * k_eff + i] = heap.top().second;
+                sc[q * k_eff + i] = heap.top().first;
+                heap.pop();
+            }
+        }
+        last_dist_evals_ = (uint64_t)nq * n_;
+    }
     if (rc) {
         std::fprintf(stderr, "vecsim_amd: GPU HNSW search failed: %s\n", vsgpu_last_error());
         for (auto *r : reps) delete r;
@@ -525,8 +571,8 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     for (size_t q = 0; q < nq; q++) {
         reps[q]->results.resize(cnt[q]);
         for (uint32_t i = 0; i < cnt[q]; i++) {
-            reps[q]->results[i].id = (size_t)labs[q * k + i];
-            reps[q]->results[i].score = sc[q * k + i];
+            reps[q]->results[i].id = (size_t)labs[q * k_eff + i];
+            reps[q]->results[i].score = sc[q * k_eff + i];
         }
         if (order == BY_ID) sort_reply(reps[q], BY_ID);
     }

@@ -28,6 +28,11 @@ struct LaneProgram {
     bool is_l2 = true;  // L2: (x-q)^2 terms; otherwise x*q terms
     int elem_bytes = 4;
     bool scalar_tier = false;
+    // how the vl accumulator lanes become one number: 0 = halving tree (offsets vl/2 .. 1), 1 = the F16C kernel's
+    // (lane j + lane j+8) + 0, j < 8, then the eight sums added left to right (AVX_utils.h:32-37)
+    int reduce = 0;
+    // vdpbf16ps step (avx512_bf16 tier, bf16 IP): inputs and result of every fma flushed to zero when subnormal
+    bool dpbf16 = false;
     std::vector<int32_t> offs;  // steps * vl
     // [full_from, full_to): the longest run of steps in which every lane is active (residual handling makes
     // the first step(s) partial for float kernels, the last one partial for the integer striding)
@@ -60,15 +65,14 @@ inline int elem_bytes_of(int type) {
 
 // Minimum dims below which the x86 choosers keep the scalar kernel:
 // fp32 <8 (L2_space.cpp:215-217, IP_space.cpp twin), fp64 <4 (:274-276), bf16 <32 (:329-331),
-// fp16 <16 for the AVX512F tier (:397-402; dims 8..15 would be the F16C tier, not restated: we
-// use the scalar order there and say so in DESIGN.md).
+// fp16 <8; fp16 dims 8..15 are the F16C tier (:404-409), 16 and up the AVX512F tier (:397-402).
 inline bool uses_scalar_tier(int type, int tier, size_t dim) {
     if (tier == VSGPU_TIER_SCALAR) return true;
     switch (type) {
     case VSGPU_F32: return dim < 8;
     case VSGPU_F64: return dim < 4;
     case VSGPU_BF16: return dim < 32;
-    case VSGPU_F16: return dim < 16;
+    case VSGPU_F16: return dim < 8;
     default: return false;  // integer kernels are exact in any order
     }
 }
@@ -107,6 +111,18 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         return p;
     }
 
+    if (type == VSGPU_F16 && dim < 16) {
+        // F16C tier at dims 8..15 (L2_F16C_FP16.h:28-83, IP_F16C_FP16.h:27-81): the first dim-8 elements go through a
+        // zero blend into sum0 (lanes 0..7), the remaining 8-block into sum1 (lanes 8..15); sum2 and sum3 stay zero.
+        // A multiply and an fma onto a zero accumulator round alike, so one fused step covers both heads.
+        p.reduce = 1;
+        const size_t r8 = dim - 8;
+        int s = new_step();
+        for (size_t j = 0; j < r8; j++) put(s, (int)j, j);
+        for (size_t j = 0; j < 8; j++) put(s, (int)(8 + j), r8 + j);
+        return p;
+    }
+
     if (type == VSGPU_F32 || type == VSGPU_F16 || type == VSGPU_F64) {
         // two accumulators of h lanes each (h = 16 for 32-bit math, 8 for fp64):
         // L2_AVX512F_FP32.h:21-59, L2_AVX512F_FP16.h, L2_AVX512F_FP64.h:21-59 and the IP twins.
@@ -136,6 +152,7 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         // vdpbf16ps (IP_AVX512_BF16_VL_BF16.h:14-47): lane j takes the pair (2j, 2j+1), the odd
         // element first, each accumulated with its own rounding (characterised on hardware, see
         // oracle/vso.c).
+        p.dpbf16 = true;
         if (residual) {
             int s1 = new_step(), s0 = new_step();
             for (int j = 0; j < 16; j++) {

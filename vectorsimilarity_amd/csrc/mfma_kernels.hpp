@@ -447,8 +447,7 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
                 acc = off[j] >= 0 ? t : acc;
             }
         }
-#pragma unroll
-        for (int o = VL / 2; o >= 1; o >>= 1) acc = add_rn(acc, __shfl_down(acc, o, VL));
+        acc = lane_reduce<VL>(acc, P.reduce);
         if (lane == 0) {
             float sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
             rec.y = __float_as_uint(sc);

@@ -178,6 +178,8 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     t->ek = type;  // ElemKind values equal the type codes
     bool l2 = (metric == VSGPU_L2);
     t->opk = t->prog.fused ? (l2 ? OP_L2_FMA : OP_IP_FMA) : (l2 ? OP_L2_MULADD : OP_IP_MULADD);
+    // bf16 IP on the avx512_bf16 tier: the vdpbf16ps step (odd element, then even, each with FTZ)
+    if (t->prog.dpbf16) t->opk = OP_IP_DPBF16;
     if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
     else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
     // LDS budget 64 KiB: offs + BT query images
@@ -191,7 +193,7 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     }
     size_t fit = (budget - offs_b) / q_b;
     t->bt_max = fit >= 8 ? 8 : (fit >= 4 ? 4 : 1);
-    if (!t->prog.fused) t->bt_max = 1;  // scalar-tier variants are only instantiated for BT=1
+    if (!t->prog.fused || t->opk == OP_IP_DPBF16) t->bt_max = 1;  // these orders are only instantiated for BT=1
     {
         // fp32 MFMA filter: any dim up to 3072.  The kernel instance is the next compiled width (k-steps of 32
         // elements); the columns past `dim` hold the start of the next row in LDS and zeros in the query fragments
@@ -208,8 +210,10 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         // low-precision rows: like fp32, any dim runs at the next compiled width (bf16/fp16: 256, 512, 768, 1024,
         // 1536 elements; int8/uint8: 512, 768, 1024) with zero query columns past `dim`
-        if (!t->prog.scalar_tier && (type == VSGPU_BF16 || type == VSGPU_F16) && tier != VSGPU_TIER_AVX512_BF16 &&
-            dim <= 1536 && row_bytes == data_bytes) {
+        // (the avx512_bf16 tier rides the same filter: E covers any accumulation order of the exact bf16 products, its
+        // absolute term the flushed subnormals; survivors are re-scored in the vdpbf16ps order)
+        if (!t->prog.scalar_tier && t->prog.reduce == 0 && (type == VSGPU_BF16 || type == VSGPU_F16) && dim <= 1536 &&
+            row_bytes == data_bytes) {
             static const int w16[] = {8, 16, 24, 32, 48};
             static const int rt16[] = {64, 32, 32, 16, 16};
             for (int i = 0; i < 5; i++)
@@ -514,6 +518,9 @@ template <int EK> static void launch_scan_op(int opk, int bt, const ScanParams &
     case OP_L2_FMA: launch_scan_bt<EK, OP_L2_FMA>(bt, P, grid, lds, s); break;
     case OP_IP_FMA: launch_scan_bt<EK, OP_IP_FMA>(bt, P, grid, lds, s); break;
     case OP_L2_MULADD: launch_scan_t<EK, OP_L2_MULADD, 1>(P, grid, lds, s); break;
+    case OP_IP_DPBF16:
+        if constexpr (EK == EK_BF16) launch_scan_t<EK, OP_IP_DPBF16, 1>(P, grid, lds, s);
+        break;
     default: launch_scan_t<EK, OP_IP_MULADD, 1>(P, grid, lds, s); break;
     }
 }
@@ -546,6 +553,7 @@ int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     P.row_stride = (uint32_t)t->row_bytes;
     P.offs = t->d_offs;
     P.steps = t->prog.steps;
+    P.reduce = t->prog.reduce;
     P.full_from = t->prog.full_from();
     P.full_to = t->prog.full_to();
     P.qperm = c->qperm.p;
@@ -971,6 +979,7 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     S.row_stride = (uint32_t)t->row_bytes;
     S.offs = t->d_offs;
     S.steps = t->prog.steps;
+    S.reduce = t->prog.reduce;
     S.qperm = c->qperm.p;
     S.nq = (int)nq;
     S.epilogue = t->epi;
@@ -984,6 +993,7 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
         else hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else if (t->type == VSGPU_BF16) {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+        else if (t->opk == OP_IP_DPBF16) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_DPBF16>), grid, dim3(256), 0, c->stream, S);
         else hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);

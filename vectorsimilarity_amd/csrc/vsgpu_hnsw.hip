@@ -74,6 +74,9 @@ template <int EK> static void launch_hnsw_ek(int opk, const HnswParams &P, dim3 
     if (opk == OP_L2_FMA) hipLaunchKernelGGL((k_hnsw_search<EK, OP_L2_FMA>), grid, dim3(64), lds, s, P);
     else if (opk == OP_IP_FMA) hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_FMA>), grid, dim3(64), lds, s, P);
     else if (opk == OP_L2_MULADD) hipLaunchKernelGGL((k_hnsw_search<EK, OP_L2_MULADD>), grid, dim3(64), lds, s, P);
+    else if (opk == OP_IP_DPBF16) {
+        if constexpr (EK == EK_BF16) hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_DPBF16>), grid, dim3(64), lds, s, P);
+    }
     else hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_MULADD>), grid, dim3(64), lds, s, P);
 }
 
@@ -135,6 +138,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.row_stride = (uint32_t)t->row_bytes;
     P.offs = t->d_offs;
     P.steps = t->prog.steps;
+    P.reduce = t->prog.reduce;
     P.qperm = c->qperm.p;
     P.nq = (int)nq;
     P.epilogue = t->epi;
