@@ -3,6 +3,7 @@
 #include "mfma_lowp_kernels.hpp"
 #ifdef VSGPU_TUNING
 #include "mfma_free_kernels.hpp"
+#include "mfma_i8ks_kernels.hpp"
 #endif
 
 using namespace vsg;
@@ -155,7 +156,32 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
 #else
 static bool launch_lowp_variant(const vsgpu_table *, int, LowpParams, uint32_t, unsigned, hipStream_t) { return false; }
 #endif
+#ifdef VSGPU_TUNING
+// K-split filter for 1 KiB int8 / uint8 rows (mfma_i8ks_kernels.hpp); option lowp_ksplit: 1 = on, 2 = + s_setprio
+template <int LK> static void launch_i8_ksplit(int flavour, const LowpParams &P, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS_BYTES);
+        hipLaunchKernelGGL(kern, grid, dim3(KS_NW * 64), KS_LDS_BYTES, s, P);
+    };
+    // flavour - 1 = MODE bits of the kernel (setprio, refill placement); P.dbg selects the diagnosis build
+    if (P.dbg) return flavour == 3 ? go(k_i8_filter_ksplit<LK, 10>) : go(k_i8_filter_ksplit<LK, 8>);
+    switch (flavour - 1) {
+    case 1: go(k_i8_filter_ksplit<LK, 1>); break;
+    case 2: go(k_i8_filter_ksplit<LK, 2>); break;
+    default: go(k_i8_filter_ksplit<LK, 0>); break;
+    }
+}
+#endif
 static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+#ifdef VSGPU_TUNING
+    // measured, not faster than the 16 x 16 kernel (profiles/r02_i8_ksplit.txt): tuning build only
+    const long ksplit = t->ctx->opt_lowp_ksplit;
+    if (ksplit && mode == MF_FILTER && t->lp_ksteps == 16 && t->lp_rt == 32 && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8)) {
+        if (t->lp_kind == LP_I8) launch_i8_ksplit<LP_I8>((int)ksplit, P, grid, s);
+        else launch_i8_ksplit<LP_U8>((int)ksplit, P, grid, s);
+        return;
+    }
+#endif
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_U8) {
@@ -382,5 +408,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
-                              is_int ? "k_mfma_filter_lowp(i8)" : "k_mfma_filter_lowp(h16)");
+                              !is_int ? "k_mfma_filter_lowp(h16)"
+#ifdef VSGPU_TUNING
+                              : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
+#endif
+                              : "k_mfma_filter_lowp(i8)");
 }
