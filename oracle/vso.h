@@ -76,6 +76,19 @@ size_t vso_topk_replay_multi(const double *scores, const size_t *labels, size_t 
 size_t vso_range_replay(const double *scores, const size_t *labels, size_t n, double radius,
                         size_t *out_labels, double *out_scores);
 
+/* ---- SQ8: uint8 codes + FP32 metadata (vso_sq8.c; types/sq8.h:19-62, preprocessors.h:259-649, IP.cpp:34-183,
+ * L2.cpp:30-45,185-201 and their AVX-512 twins).  `metric` is the index metric; Cosine blobs are normalised before. ---- */
+size_t vso_sq8_storage_size(int metric, size_t dim); /* dim + 12 (IP/Cosine) or 16 (L2) bytes */
+size_t vso_sq8_query_size(int metric, size_t dim);   /* (dim + 1 or 2) floats */
+void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out);
+void vso_sq8_query_blob(const float *y, size_t dim, int metric, float *out);
+int vso_sq8_fp32_uses_scalar(int tier, size_t dim);
+int vso_sq8_sq8_uses_scalar(int tier, size_t dim);
+double vso_sq8_fp32_distance(int metric, int tier, size_t dim, const void *storage, const void *query);
+double vso_sq8_sq8_distance(int metric, int tier, size_t dim, const void *a, const void *b);
+void vso_sq8_fp32_scan(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                       double *out);
+
 /* whole Flat query on host rows (scan + replay) */
 size_t vso_flat_topk(int type, int metric, int tier, size_t dim, const void *rows, size_t n,
                      size_t stride, const size_t *labels, const void *query, size_t k,

@@ -22,7 +22,7 @@ NP_DTYPE = {F32: np.float32, F64: np.float64, BF16: np.uint16, F16: np.uint16, I
 
 def build(force=False):
     """Compile oracle/libvso.so from the C restatement (gcc + make)."""
-    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso_hnsw.c", "vso.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso_hnsw.c", "vso_sq8.c", "vso.h", "Makefile")]
     if (not force and os.path.exists(_LIB)
             and os.path.getmtime(_LIB) >= max(os.path.getmtime(s) for s in srcs)):
         return _LIB
@@ -76,6 +76,20 @@ def lib():
         L.vso_hnsw_range.restype = sz
         L.vso_hnsw_range.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
                                      C.c_uint32, i, vp, dbl, dbl, vp, vp, sz, vp]
+        L.vso_sq8_storage_size.restype = sz
+        L.vso_sq8_storage_size.argtypes = [i, sz]
+        L.vso_sq8_query_size.restype = sz
+        L.vso_sq8_query_size.argtypes = [i, sz]
+        L.vso_sq8_quantize.restype = None
+        L.vso_sq8_quantize.argtypes = [vp, sz, i, vp]
+        L.vso_sq8_query_blob.restype = None
+        L.vso_sq8_query_blob.argtypes = [vp, sz, i, vp]
+        L.vso_sq8_fp32_distance.restype = dbl
+        L.vso_sq8_fp32_distance.argtypes = [i, i, sz, vp, vp]
+        L.vso_sq8_sq8_distance.restype = dbl
+        L.vso_sq8_sq8_distance.argtypes = [i, i, sz, vp, vp]
+        L.vso_sq8_fp32_scan.restype = None
+        L.vso_sq8_fp32_scan.argtypes = [i, i, sz, vp, sz, sz, vp, vp]
         L.vso_has_avx512.restype = i
         L.vso_has_f16c.restype = i
         L.vso_f16c_distance.restype = dbl
@@ -126,6 +140,43 @@ def scan(vtype, metric, rows, query, dim, tier=TIER_AVX512):
     n = rows.shape[0]
     out = np.empty(n, dtype=np.float64)
     lib().vso_scan(vtype, metric, tier, dim, _ptr(rows), n, rows.strides[0], _ptr(query), _ptr(out))
+    return out
+
+
+# ---- SQ8 (vso_sq8.c): uint8 codes + FP32 metadata; metric is the index metric (Cosine blobs are normalised first) ----
+def sq8_quantize(x, metric):
+    """Storage blob of one fp32 vector (QuantPreprocessor<float, metric>): uint8 array of dim + 12 (16 for L2) bytes."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(lib().vso_sq8_storage_size(metric, x.size), dtype=np.uint8)
+    lib().vso_sq8_quantize(_ptr(x), x.size, metric, _ptr(out))
+    return out
+
+
+def sq8_query_blob(y, metric):
+    """Query blob: the fp32 values followed by y_sum (and y_sum_squares for L2)."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    out = np.zeros(lib().vso_sq8_query_size(metric, y.size) // 4, dtype=np.float32)
+    lib().vso_sq8_query_blob(_ptr(y), y.size, metric, _ptr(out))
+    return out
+
+
+def sq8_fp32_distance(metric, storage, query, dim, tier=TIER_AVX512):
+    storage = np.ascontiguousarray(storage)
+    query = np.ascontiguousarray(query)
+    return lib().vso_sq8_fp32_distance(metric, tier, dim, _ptr(storage), _ptr(query))
+
+
+def sq8_sq8_distance(metric, a, b, dim, tier=TIER_AVX512):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return lib().vso_sq8_sq8_distance(metric, tier, dim, _ptr(a), _ptr(b))
+
+
+def sq8_fp32_scan(metric, rows, query, dim, tier=TIER_AVX512):
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    out = np.empty(rows.shape[0], dtype=np.float64)
+    lib().vso_sq8_fp32_scan(metric, tier, dim, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(query), _ptr(out))
     return out
 
 

@@ -148,7 +148,59 @@ def flat_multi():
     return dict(cases=cases)
 
 
+def sq8():
+    """SQ8 known answers the reference's tests hold (tests/unit/test_components.cpp, test_spaces.cpp).  Expected bytes of the
+    quantiser tests follow the test helper the reference compares with (unit_test_utils.h:240-277: round((x - min) / delta));
+    metadata expectations are the values the tests assert (FLOAT_EQ = 4 ulp), distances the closed forms they state."""
+    import math
+    import struct
+
+    def f32(x):
+        return struct.unpack("f", struct.pack("f", x))[0]
+
+    def helper_bytes(v):   # ComputeSQ8Quantization, in fp32 like the helper
+        mn, mx = min(v), max(v)
+        diff = f32(mx - mn)
+        delta = 1.0 if diff == 0.0 else f32(diff / 255.0)
+        return [int(math.floor(f32(f32(x - mn) / delta) + 0.5)) & 0xFF for x in v], mn, delta
+
+    q = []
+    for name, v, metric, src in (("quantization_test", [1, 2, 3, 4, 5, 6], "L2", "test_components.cpp:1047-1100"),
+                                 ("metric_l2", [1, 2, 3, 4, 5], "L2", "test_components.cpp:1446-1596"),
+                                 ("metric_ip", [1, 2, 3, 4, 5], "IP", "test_components.cpp:1446-1596"),
+                                 ("metric_cosine", [1, 2, 3, 4, 5], "Cosine", "test_components.cpp:1446-1596")):
+        b, mn, delta = helper_bytes([float(x) for x in v])
+        qs, qq = sum(b), sum(x * x for x in b)
+        sm = f32(len(v) * mn + delta * qs)
+        sq = f32(len(v) * mn * mn + 2.0 * mn * delta * qs + delta * delta * qq)
+        q.append(dict(name=name, input=[float(x) for x in v], metric=metric, bytes=b, min=mn, delta=delta, sum=sm,
+                      sum_squares=sq if metric == "L2" else None, exact_meta=True,
+                      query_sum=float(sum(v)), query_sum_squares=float(sum(x * x for x in v)) if metric == "L2" else None, src=src))
+    q.append(dict(name="all_entries_equal", input=[3.5] * 5, metric="L2", bytes=[0] * 5, min=3.5, delta=1.0, sum=17.5,
+                  sum_squares=61.25, exact_meta=False, src="test_components.cpp:1395-1443"))
+    huge = 3.4028234663852886e38
+    q.append(dict(name="non_representable_range", input=[-huge, 0.0, huge, 1.0], metric="L2", bytes=[0, 0, 0, 0],
+                  src="test_components.cpp:1208-1239"))
+    q.append(dict(name="delta_underflows", input=[0.0, 1e-44], metric="L2", bytes=[0, 255], src="test_components.cpp:1250-1270"))
+    for name, v, b in (("all_equal_positive", [3.5] * 3, [0] * 3), ("all_equal_negative", [-2.5] * 3, [0] * 3),
+                       ("all_zero", [0.0] * 3, [0] * 3), ("subnormal_delta_survives", [0.0, 7e-37], [0, 255]),
+                       ("single_element", [7.5], [0])):
+        q.append(dict(name=name, input=v, metric="L2", bytes=b, finite_positive_delta=True, src="test_components.cpp:1356-1393"))
+    d = []
+    # test_spaces.cpp:485-530 states this closed form for the FP16-query kernel; the same blobs through the FP32-query
+    # kernel have the same exact answer (every term is a small integer): L2 = 55 + 90 - 2*70 = 5, IP = 1 - 70
+    d.append(dict(name="l2_closed_form", dim=5, codes=[1, 2, 3, 4, 5], meta=[0.0, 1.0, 15.0, 55.0],
+                  query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="L2", expect=5.0, src="test_spaces.cpp:485-530"))
+    d.append(dict(name="ip_closed_form", dim=5, codes=[1, 2, 3, 4, 5], meta=[0.0, 1.0, 15.0, 55.0],
+                  query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="IP", expect=-69.0, src="test_spaces.cpp:485-530"))
+    return dict(quantize=q, distance=d,
+                tolerance_property=dict(abs=0.01, src="test_spaces.cpp:326-410, 2330-2700: every tier within 0.01 of the "
+                                        "reconstruct-then-dot baseline (tests/utils/tests_utils.h:76-170, 244-270)"))
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "kat_sq8.json"), "w") as f:
+        json.dump(sq8(), f, indent=1)
     with open(os.path.join(HERE, "kat_flat_multi.json"), "w") as f:
         json.dump(flat_multi(), f, indent=1)
     with open(os.path.join(HERE, "kat_spaces.json"), "w") as f:

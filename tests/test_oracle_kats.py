@@ -195,3 +195,84 @@ def test_synthetic_generator_is_uniform_and_exact(vso):
     assert abs(rows.mean()) < 0.01 and abs(rows.var() - 1 / 3) < 0.01
     again = vso.synth_rows_f32(47, 10, 2, 768)
     assert np.array_equal(again, rows[10:12])
+
+
+# ---------------------------------------------------------------- SQ8 (oracle/vso_sq8.c)
+SQ8_METRIC = {"L2": 0, "IP": 1, "Cosine": 2}
+
+
+def _ulps(a, b):
+    ia = np.array([a], dtype=np.float32).view(np.int32)[0]
+    ib = np.array([b], dtype=np.float32).view(np.int32)[0]
+    return abs(int(ia) - int(ib))
+
+
+def test_sq8_quantizer_kats(vso):
+    """QuantPreprocessor known answers (test_components.cpp:1047-1596): code bytes, metadata, query metadata."""
+    kats = _load("kat_sq8.json")["quantize"]
+    assert len(kats) >= 12
+    for c in kats:
+        m = SQ8_METRIC[c["metric"]]
+        x = np.array(c["input"], dtype=np.float32)
+        blob = vso.sq8_quantize(x, m)
+        dim = x.size
+        assert blob.size == dim + (16 if c["metric"] == "L2" else 12), c["name"]
+        assert blob[:dim].tolist() == c["bytes"], (c["name"], blob[:dim].tolist())
+        meta = blob[dim:].view(np.float32)
+        if c.get("finite_positive_delta"):
+            assert np.isfinite(meta[0]) and np.isfinite(meta[1]) and meta[1] > 0, c["name"]
+        if "min" in c:
+            names = ["min", "delta", "sum"] + (["sum_squares"] if c["metric"] == "L2" else [])
+            for i, n in enumerate(names):
+                exp = np.float32(c[n])
+                if c["exact_meta"]:   # the reference compares the whole blob bytewise with its helper
+                    assert meta[i] == exp, (c["name"], n, meta[i], exp)
+                else:                 # ASSERT_FLOAT_EQ
+                    assert _ulps(meta[i], exp) <= 4, (c["name"], n, meta[i], exp)
+        if "query_sum" in c:
+            qb = vso.sq8_query_blob(x, m)
+            assert qb.size == dim + (2 if c["metric"] == "L2" else 1)
+            assert np.array_equal(qb[:dim], x)
+            assert _ulps(qb[dim], np.float32(c["query_sum"])) <= 4
+            if c["metric"] == "L2":
+                assert _ulps(qb[dim + 1], np.float32(c["query_sum_squares"])) <= 4
+
+
+def test_sq8_distance_kats(vso):
+    for c in _load("kat_sq8.json")["distance"]:
+        dim = c["dim"]
+        st = np.zeros(dim + 16, dtype=np.uint8)
+        st[:dim] = c["codes"]
+        st[dim:].view(np.float32)[:] = c["meta"]
+        q = np.array(c["query"] + c["qmeta"], dtype=np.float32)
+        for tier in (vso.TIER_AVX512, vso.TIER_SCALAR):
+            got = vso.sq8_fp32_distance(SQ8_METRIC[c["metric"]], st, q, dim, tier=tier)
+            assert got == c["expect"], (c["name"], tier, got)
+
+
+@pytest.mark.parametrize("dim", [1, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 777])
+def test_sq8_tiers_within_the_reference_tolerance(vso, dim):
+    """The reference's SQ8 tests (test_spaces.cpp:326-410, 2330-4111) demand every tier within 0.01 of the
+    reconstruct-then-dot baseline on random data; the restated scalar and AVX-512 orders must satisfy the same."""
+    tol = _load("kat_sq8.json")["tolerance_property"]["abs"]
+    rng = np.random.default_rng(dim)
+    for metric in (0, 1, 2):
+        x = rng.uniform(-1, 1, dim).astype(np.float32)
+        y = rng.uniform(-1, 1, dim).astype(np.float32)
+        z = rng.uniform(-1, 1, dim).astype(np.float32)
+        if metric == 2:
+            x /= np.linalg.norm(x)
+            y /= np.linalg.norm(y)
+            z /= np.linalg.norm(z)
+        st, st2 = vso.sq8_quantize(x, metric), vso.sq8_quantize(z, metric)
+        qb = vso.sq8_query_blob(y, metric)
+        meta, meta2 = st[dim:].view(np.float32), st2[dim:].view(np.float32)
+        xr = meta[0] + meta[1] * st[:dim].astype(np.float64)
+        zr = meta2[0] + meta2[1] * st2[:dim].astype(np.float64)
+        base = float(np.sum((xr - y) ** 2)) if metric == 0 else 1.0 - float(np.dot(xr, y))
+        base2 = float(np.sum((xr - zr) ** 2)) if metric == 0 else 1.0 - float(np.dot(xr, zr))
+        for tier in (vso.TIER_AVX512, vso.TIER_SCALAR):
+            assert abs(vso.sq8_fp32_distance(metric, st, qb, dim, tier=tier) - base) < tol, (metric, tier)
+            assert abs(vso.sq8_sq8_distance(metric, st, st2, dim, tier=tier) - base2) < tol, (metric, tier)
+        # the stored sums describe the reconstruction (preprocessors.h:369-381)
+        assert abs(meta[2] - xr.sum()) <= 1e-4 * max(1.0, abs(xr.sum()))
