@@ -114,6 +114,25 @@ int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0
                             uint8_t *deleted, uint64_t *labels);
 uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
 
+/* ---- SQ8 storage: scalar-quantised 8-bit rows (uint8 codes + FP32 metadata) scored against FP32 queries.
+ * The reference defines the layouts (src/VecSim/types/sq8.h:19-62), the quantising preprocessor
+ * (spaces/computer/preprocessors.h:259-649) and the distance kernels (spaces/IP/IP.cpp:34-183, spaces/L2/L2.cpp:30-45,
+ * 185-201 and the AVX-512 twins chosen by L2_space.cpp:41-107, 518-571 / IP_space.cpp:41-176), but none of its RAM index
+ * factories selects them, so the constructor is an extension.  A FlatSQ8 index takes fp32 vectors (params->type must be
+ * VecSimType_FLOAT32) through the ordinary VecSimIndex_AddVector / _TopKQuery / _RangeQuery / batch-iterator calls:
+ * rows are stored as SQ8 blobs (Cosine: normalised first), queries get y_sum / y_sum_squares appended, every score is the
+ * reference's asymmetric SQ8_FP32 distance in its AVX-512 tier order (scalar tier below dim 8), evaluated on the GPU.
+ * VecSimIndex_GetDistanceFrom_Unsafe takes the fp32 vector as given (caller-normalised for Cosine).
+ * Quarter-size rows: four times the distances per byte of HBM traffic of an fp32 index. */
+VecSimIndex *VecSimGpu_NewFlatSQ8(const BFParams *params, void *logCtx);
+/* symmetric SQ8_SQ8 distance (IP.cpp:146-183, L2.cpp:185-201) between the stored vectors of two labels; NaN if unknown */
+double VecSimGpu_SQ8_StoredDistance(VecSimIndex *index, size_t label_a, size_t label_b);
+/* the preprocessor on its own (host, no GPU): storage blob = dim + 12 bytes (16 for L2), query blob = dim + 1 (2) floats */
+size_t VecSimGpu_SQ8_StorageBlobSize(size_t dim, VecSimMetric metric);
+size_t VecSimGpu_SQ8_QueryBlobSize(size_t dim, VecSimMetric metric);
+void VecSimGpu_SQ8_Quantize(const float *vector, size_t dim, VecSimMetric metric, void *storage_blob);
+void VecSimGpu_SQ8_QueryBlob(const float *vector, size_t dim, VecSimMetric metric, float *query_blob);
+
 /* Stored (preprocessed) blobs of a label in internal-id order -- what the reference's Python `get_vector`
  * reads through getStoredVectorDataByLabel (bindings.cpp:201-214).  *blob_bytes receives the stored blob size;
  * returns the number of vectors written (0: unknown label, -1: cap_bytes too small / device error); with

@@ -25,7 +25,11 @@ extern "C" {
 #endif
 
 /* element types / metrics: numeric values equal VecSimType / VecSimMetric (vec_sim_common.h:60-69,87) */
-enum { VSGPU_F32 = 0, VSGPU_F64 = 1, VSGPU_BF16 = 2, VSGPU_F16 = 3, VSGPU_I8 = 4, VSGPU_U8 = 5 };
+enum { VSGPU_F32 = 0, VSGPU_F64 = 1, VSGPU_BF16 = 2, VSGPU_F16 = 3, VSGPU_I8 = 4, VSGPU_U8 = 5,
+       /* SQ8 storage rows (types/sq8.h:19-62): dim uint8 codes + FP32 {min, delta, sum[, sum_squares for L2]}, scored
+        * against FP32 query blobs {y[dim], y_sum[, y_sum_squares]} by the asymmetric kernels of IP.cpp:34-80,
+        * L2.cpp:30-45 and their AVX-512 twins.  Not a VecSimType: reached through VecSimGpu_NewFlatSQ8. */
+       VSGPU_SQ8 = 6 };
 enum { VSGPU_L2 = 0, VSGPU_IP = 1, VSGPU_COSINE = 2 };
 /* which reference ISA tier's summation order the kernels reproduce */
 enum { VSGPU_TIER_AVX512 = 0, VSGPU_TIER_SCALAR = 1, VSGPU_TIER_AVX512_BF16 = 2 };
@@ -98,6 +102,10 @@ int vsgpu_scores(vsgpu_table *t, const void *query, size_t first, size_t n, doub
 /* exact scores of an explicit list of rows against one query (getDistanceFrom / ad-hoc BF) */
 int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t *ids, size_t n,
                     double *scores);
+
+/* SQ8 tables only: symmetric distances (SQ8_SQ8_InnerProduct / _Cosine / _L2Sqr, IP.cpp:146-183, L2.cpp:185-201 and the
+ * AVX-512 VNNI twins) between stored rows ids_a[i] and ids_b[i]. */
+int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t *ids_b, size_t n, double *scores);
 
 /* ---- HNSW query loops (algorithms/hnsw/hnsw.h:530-613, 1210-1258, 1967-2084) ----
  * A device snapshot of the graph the host index built (vectors stay in the vsgpu_table): level-0

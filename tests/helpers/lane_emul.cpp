@@ -122,3 +122,34 @@ extern "C" double lane_emul(int type, int metric, int tier, size_t dim, const vo
     if (p.reduce == 1) return (double)reduce_f16c(acc);
     return (double)tree(acc, p.vl);
 }
+
+// SQ8 storage x FP32 query (VSGPU_SQ8): walks the table like k_exact_scan<EK_SQ8> (float(code) * y, fp32 accumulators, the
+// halving tree) and applies the epilogue the way exact_kernels.hpp:sq8_score does.  metric: 0 L2, 1 IP / Cosine.
+extern "C" double lane_emul_sq8(int metric, int tier, size_t dim, const void *storage, const void *query_blob) {
+    vsg::LaneProgram p = vsg::build_lane_program(VSGPU_SQ8, VSGPU_IP, tier, dim);
+    const unsigned char *c = (const unsigned char *)storage;
+    const char *y = (const char *)query_blob;
+    std::vector<float> acc(p.vl, 0.0f);
+    for (int s = 0; s < p.steps; s++)
+        for (int l = 0; l < p.vl; l++) {
+            int off = p.offs[(size_t)s * p.vl + l];
+            if (off < 0) continue;
+            const float x = (float)c[off];
+            float q;
+            std::memcpy(&q, y + 4 * (size_t)off, 4);
+            if (p.fused) acc[l] = std::fma(x, q, acc[l]);
+            else { float m = x * q; acc[l] = acc[l] + m; }
+        }
+    const float qdot = tree(acc, p.vl);
+    float meta[4] = {0, 0, 0, 0}, qm[2] = {0, 0};
+    std::memcpy(meta, c + dim, metric == 0 ? 16 : 12);
+    std::memcpy(qm, y + 4 * dim, metric == 0 ? 8 : 4);
+    const float dq = meta[1] * qdot;
+    float ip;
+    if (p.fused) ip = std::fma(meta[0], qm[0], dq);
+    else { float a = meta[0] * qm[0]; ip = a + dq; }
+    if (metric != 0) return (double)(1.0f - ip);
+    const float t = meta[3] + qm[1];
+    const float two_ip = 2.0f * ip;
+    return (double)(t - two_ip);
+}

@@ -1,0 +1,165 @@
+"""GPU: the SQ8 index (VecSimGpu_NewFlatSQ8: uint8 codes + FP32 metadata in HBM, fp32 queries) against oracle/vso_sq8.c,
+through the C API.  Labels, order and scores bit-exact (0 ulp): the kernels reproduce the reference's asymmetric SQ8 x FP32
+distance in its AVX-512 tier order (IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104; scalar tier IP.cpp:34-70 below dim 8) and the
+symmetric SQ8 x SQ8 distance (IP.cpp:146-183, ..._SQ8_SQ8.h:38-65); the stored bytes are the QuantPreprocessor's."""
+import numpy as np
+import pytest
+
+from vectorsimilarity_amd import VecSim
+
+pytestmark = pytest.mark.gpu
+MET = {"L2": 0, "IP": 1, "Cosine": 2}
+
+
+def make(metric, dim):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, dim, MET[metric]
+    return VecSim.SQ8Index(p)
+
+
+def oracle_blobs(vso, rows, queries, metric):
+    """what the index stores / what its kernels are handed: Cosine vectors are normalised first"""
+    m = MET[metric]
+    rows = np.array(rows, dtype=np.float32, copy=True)
+    queries = np.array(queries, dtype=np.float32, copy=True)
+    if metric == "Cosine":
+        for v in rows:
+            vso.normalize(v, v.size, vso.F32)
+        for v in queries:
+            vso.normalize(v, v.size, vso.F32)
+    st = np.stack([vso.sq8_quantize(v, m) for v in rows])
+    qb = np.stack([vso.sq8_query_blob(v, m) for v in queries])
+    return st, qb
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+@pytest.mark.parametrize("dim", [1, 4, 7, 8, 17, 33, 64, 100, 128])
+def test_sq8_all_scores_bit_exact(vso, metric, dim):
+    """k = n returns every row: every distance and the full (score, label) order"""
+    rng = np.random.default_rng(dim * 5 + len(metric))
+    n = 300
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (3, dim)).astype(np.float32)
+    ix = make(metric, dim)
+    for i in range(n):
+        ix.add_vector(rows[i], i)
+    assert ix.index_size() == n
+    labels, dists = ix.knn_query(q, n)
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(3):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, n)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, dim, j)
+        assert np.array_equal(dists[j], es), (metric, dim, j)
+
+
+@pytest.mark.parametrize("metric,dim", [("L2", 17), ("IP", 64), ("Cosine", 100)])
+def test_sq8_scalar_tier(vso, monkeypatch, metric, dim):
+    monkeypatch.setenv("VECSIM_GPU_TIER", "scalar")
+    rng = np.random.default_rng(dim)
+    n = 200
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (2, dim)).astype(np.float32)
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    labels, dists = ix.knn_query(q, n)
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(2):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim, tier=vso.TIER_SCALAR)
+        el, es = vso.topk_replay(sc, n)
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (metric, dim, j)
+
+
+@pytest.mark.parametrize("metric,dim,n,nq,k", [
+    ("L2", 768, 30_000, 40, 10),
+    ("IP", 128, 50_000, 9, 10),
+    ("Cosine", 1000, 12_000, 70, 5),
+    ("L2", 96, 40_000, 1, 100),
+])
+def test_sq8_topk_filtered_path(vso, metric, dim, n, nq, k):
+    """large enough for the probe -> threshold -> filter route; bulk add"""
+    rng = np.random.default_rng(dim + n)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    labels, dists = ix.knn_query(q, k)
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(0, nq, 3):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, dim, j)
+        assert np.array_equal(dists[j], es), (metric, dim, j)
+
+
+def test_sq8_range_iterator_distance_delete_overwrite(vso):
+    rng = np.random.default_rng(9)
+    metric, dim, n = "L2", 48, 4000
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (1, dim)).astype(np.float32)
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    sc = vso.sq8_fp32_scan(MET[metric], st, qb[0], dim)
+    # range query: score <= radius, ascending score
+    radius = float(np.sort(sc)[57])
+    l, d = ix.range_query(q[0], radius)
+    el, es = vso.range_replay(sc, radius)
+    order = np.lexsort((el, es))
+    assert np.array_equal(l[0][:len(el)], el[order].astype(np.int64)) and np.array_equal(d[0][:len(el)], es[order])
+    # batch iterator: successive batches are the next-best rows
+    it = ix.create_batch_iterator(q[0])
+    got_l, got_d = [], []
+    for _ in range(3):
+        bl, bd = it.get_next_results(25, VecSim.BY_SCORE)
+        got_l += list(bl[0])
+        got_d += list(bd[0])
+    el, es = vso.topk_replay(sc, 75)
+    assert got_l == list(el.astype(np.int64)) and got_d == list(es)
+    # distance to one stored vector
+    assert ix.get_distance_from(123, q[0]) == sc[123]
+    # delete (swap with the last row) and overwrite, then everything again
+    ix.delete_vector(10)
+    new = rng.uniform(-1, 1, dim).astype(np.float32)
+    ix.add_vector(new, 20)
+    rows2 = rows.copy()
+    rows2[20] = new
+    st2, _ = oracle_blobs(vso, rows2, q, metric)
+    sc2 = vso.sq8_fp32_scan(MET[metric], st2, qb[0], dim)
+    labels_ids = list(range(n))
+    labels_ids[10] = n - 1          # the last row moved into the hole
+    labels_ids = labels_ids[:n - 1]
+    sc_by_id = np.array([sc2[lab] for lab in labels_ids])
+    el, es = vso.topk_replay(sc_by_id, 30, np.array(labels_ids, dtype=np.uint64))
+    l, d = ix.knn_query(q, 30)
+    assert np.array_equal(l[0], el.astype(np.int64)) and np.array_equal(d[0], es)
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+@pytest.mark.parametrize("dim", [5, 63, 64, 100, 768])
+def test_sq8_symmetric_stored_distance(vso, metric, dim):
+    """SQ8 x SQ8 between stored rows: scalar tier below dim 64, the VNNI tier (exact int32 dot, fused epilogue) from 64"""
+    rng = np.random.default_rng(dim + len(metric))
+    n = 40
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    st, _ = oracle_blobs(vso, rows, rows[:1], metric)
+    for a, b in [(0, 1), (3, 3), (7, 39), (20, 5)]:
+        want = vso.sq8_sq8_distance(MET[metric], st[a], st[b], dim)
+        assert ix.stored_distance(a, b) == want, (metric, dim, a, b)
+    assert np.isnan(ix.stored_distance(0, 10_000))
+
+
+def test_sq8_stored_blob_is_the_preprocessors(vso):
+    rng = np.random.default_rng(2)
+    dim = 33
+    rows = rng.uniform(-3, 3, (5, dim)).astype(np.float32)
+    for metric in ("L2", "IP", "Cosine"):
+        ix = make(metric, dim)
+        ix.add_vectors(rows, np.arange(5))
+        st, _ = oracle_blobs(vso, rows, rows[:1], metric)
+        for i in range(5):
+            got = ix.get_vector(i)
+            assert got.shape == (1, st.shape[1]) and np.array_equal(got[0], st[i]), (metric, i)

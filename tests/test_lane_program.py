@@ -25,6 +25,8 @@ def emul():
     L = C.CDLL(so)
     L.lane_emul.restype = C.c_double
     L.lane_emul.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.lane_emul_sq8.restype = C.c_double
+    L.lane_emul_sq8.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -56,3 +58,22 @@ def test_lane_tables_reproduce_oracle(emul, vso, typ):
                 else:
                     got = acc if metric == 0 else float(np.float32(1.0) - np.float32(acc))
                 assert got == want, (typ, d, metric, tier, got, want)
+
+
+def test_sq8_lane_tables_reproduce_oracle(emul, vso):
+    """SQ8 storage x FP32 query: the table + epilogue the GPU kernel runs (k_exact_scan<EK_SQ8>, sq8_score) against
+    oracle/vso_sq8.c, scalar and AVX-512 tier, every residual class of dim, all three metrics."""
+    rng = np.random.default_rng(11)
+    for d in list(range(1, 140)) + [768, 1000, 1024]:
+        for metric in (0, 1, 2):
+            x = rng.uniform(-1, 1, d).astype(np.float32)
+            y = rng.uniform(-1, 1, d).astype(np.float32)
+            if metric == 2:
+                x /= max(np.linalg.norm(x), 1e-6)
+                y /= max(np.linalg.norm(y), 1e-6)
+            st = vso.sq8_quantize(x, metric)
+            qb = vso.sq8_query_blob(y, metric)
+            for tier in (0, 1):
+                got = emul.lane_emul_sq8(0 if metric == 0 else 1, tier, d, st.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p))
+                want = vso.sq8_fp32_distance(metric, st, qb, d, tier=tier)
+                assert got == want, (d, metric, tier, got, want)

@@ -69,10 +69,12 @@ class BatchIterator:
 class VecSimIndex:
     _owned = True
 
-    def __init__(self, params, borrowed_handle=None):
+    def __init__(self, params, borrowed_handle=None, sq8=False):
         self._lib = _capi.load()
         if borrowed_handle is not None:   # a shard of a sharded index: the owner frees it
             self._h, self._owned = borrowed_handle, False
+        elif sq8:                         # params is a BFParams here
+            self._h = self._lib.VecSimGpu_NewFlatSQ8(C.byref(params), None)
         else:
             self._h = self._lib.VecSimIndex_New(C.byref(params))
         if not self._h:
@@ -283,6 +285,46 @@ class BFIndex(VecSimIndex):
         p.algo = VecSimAlgo_BF
         p.algoParams.bfParams = params
         super().__init__(p)
+
+
+class SQ8Index(VecSimIndex):
+    """Flat index over SQ8 storage (include/VecSim/vec_sim_gpu.h: VecSimGpu_NewFlatSQ8): fp32 vectors in, uint8 codes + FP32
+    metadata in HBM, the reference's asymmetric SQ8 x FP32 distances (types/sq8.h, IP.cpp:34-80, L2.cpp:30-45) out."""
+
+    def __init__(self, params):
+        super().__init__(params, sq8=True)
+
+    def stored_distance(self, label_a, label_b):
+        """symmetric SQ8 x SQ8 distance between two stored vectors (IP.cpp:146-183, L2.cpp:185-201)"""
+        return self._lib.VecSimGpu_SQ8_StoredDistance(self._h, int(label_a), int(label_b))
+
+    def get_vector(self, label):
+        """the stored SQ8 blob(s) of a label as a 2-D uint8 array: dim codes + FP32 {min, delta, sum[, sum_squares]}"""
+        bb = C.c_size_t(0)
+        self._lib.VecSimGpu_GetStoredVectors(self._h, int(label), None, 0, C.byref(bb))
+        buf = np.zeros(64 * bb.value, dtype=np.uint8)
+        n = self._lib.VecSimGpu_GetStoredVectors(self._h, int(label), buf.ctypes.data_as(C.c_void_p), buf.nbytes, C.byref(bb))
+        if n < 0:
+            raise RuntimeError("get_vector failed")
+        return buf[: n * bb.value].reshape(n, bb.value).copy()
+
+
+def sq8_quantize(vector, metric):
+    """QuantPreprocessor storage blob of one fp32 vector (host only): uint8 array, dim + 12 bytes (16 for L2)."""
+    lib = _capi.load()
+    v = np.ascontiguousarray(vector, dtype=np.float32)
+    out = np.zeros(lib.VecSimGpu_SQ8_StorageBlobSize(v.size, int(metric)), dtype=np.uint8)
+    lib.VecSimGpu_SQ8_Quantize(v.ctypes.data_as(C.c_void_p), v.size, int(metric), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def sq8_query_blob(vector, metric):
+    """Query blob of one fp32 vector (host only): the values followed by y_sum (and y_sum_squares for L2)."""
+    lib = _capi.load()
+    v = np.ascontiguousarray(vector, dtype=np.float32)
+    out = np.zeros(lib.VecSimGpu_SQ8_QueryBlobSize(v.size, int(metric)) // 4, dtype=np.float32)
+    lib.VecSimGpu_SQ8_QueryBlob(v.ctypes.data_as(C.c_void_p), v.size, int(metric), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 class HNSWIndex(VecSimIndex):

@@ -136,6 +136,8 @@ EXPORTS = [
     "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
     "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors",
+    "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
+    "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
@@ -154,7 +156,7 @@ GPU_EXPORTS = [
     "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",
-    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_stats_reset",
+    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
     "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
     "vsgpu_comm_allgather", "vsgpu_comm_broadcast",
@@ -212,6 +214,18 @@ def load():
     L.VecSimDebugInfoIterator_NextField.argtypes = [vp]
     L.VecSimDebugInfoIterator_Free.restype = None
     L.VecSimDebugInfoIterator_Free.argtypes = [vp]
+    L.VecSimGpu_NewFlatSQ8.restype = vp
+    L.VecSimGpu_NewFlatSQ8.argtypes = [vp, vp]
+    L.VecSimGpu_SQ8_StoredDistance.restype = C.c_double
+    L.VecSimGpu_SQ8_StoredDistance.argtypes = [vp, C.c_size_t, C.c_size_t]
+    L.VecSimGpu_SQ8_StorageBlobSize.restype = C.c_size_t
+    L.VecSimGpu_SQ8_StorageBlobSize.argtypes = [C.c_size_t, C.c_int]
+    L.VecSimGpu_SQ8_QueryBlobSize.restype = C.c_size_t
+    L.VecSimGpu_SQ8_QueryBlobSize.argtypes = [C.c_size_t, C.c_int]
+    L.VecSimGpu_SQ8_Quantize.restype = None
+    L.VecSimGpu_SQ8_Quantize.argtypes = [vp, C.c_size_t, C.c_int, vp]
+    L.VecSimGpu_SQ8_QueryBlob.restype = None
+    L.VecSimGpu_SQ8_QueryBlob.argtypes = [vp, C.c_size_t, C.c_int, vp]
     L.VecSimGpu_GetStoredVectors.restype = C.c_long
     L.VecSimGpu_GetStoredVectors.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.VecSimIndex_StatsInfo.restype = VecSimIndexStatsInfo

@@ -17,7 +17,7 @@
 
 namespace vsg {
 
-enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5 };
+enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5, EK_SQ8 = 6 };
 enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3, OP_IP_DPBF16 = 4 };
 enum ScanMode { MODE_DENSE = 0, MODE_FILTER = 1 };
 // how the reduced accumulator becomes a score
@@ -26,7 +26,11 @@ enum Epilogue {
     EPI_ONE_MINUS = 1,  // score = 1 - acc            (IP / fp Cosine: IP.cpp:185-238)
     EPI_INT_L2 = 2,     // score = float(acc)         (L2.cpp:164-174)
     EPI_INT_IP = 3,     // score = float(1 - acc)     (IP.cpp:258-262, 273-277)
-    EPI_INT_COS = 4     // score = 1.0f - float(acc) / (norm_row * norm_q)   (IP.cpp:264-271)
+    EPI_INT_COS = 4,    // score = 1.0f - float(acc) / (norm_row * norm_q)   (IP.cpp:264-271)
+    // SQ8 storage x FP32 query: acc = sum(code_i * y_i);  ip = min * y_sum + delta * acc  (IP.cpp:60-70; fused into
+    // fma(min, y_sum, delta * acc) by gcc in the AVX-512 translation unit, see oracle/vso_sq8.c)
+    EPI_SQ8_IP = 5,     // score = 1 - ip                                    (IP.cpp:72-80)
+    EPI_SQ8_L2 = 6      // score = (x_sum_sq + y_sum_sq) - 2 ip               (L2.cpp:30-45)
 };
 
 template <int EK> struct Elem;
@@ -63,6 +67,11 @@ template <> struct Elem<EK_U8> {
     using acc_t = int; using score_t = float;
     static constexpr int VL = 32;
     __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const uint8_t *>(p)); }
+};
+template <> struct Elem<EK_SQ8> {   // uint8 code widened exactly to float; the query side is fp32
+    using acc_t = float; using score_t = float;
+    static constexpr int VL = 32;
+    __device__ static inline float load(const char *p) { return (float)(*reinterpret_cast<const uint8_t *>(p)); }
 };
 
 // vdpbf16ps treats subnormal inputs as zero and flushes subnormal results (IP_AVX512_BF16_VL_BF16.h:14-47; the
@@ -135,8 +144,9 @@ struct ScanParams {
     // epilogue
     int mode;
     int epilogue;
-    uint32_t norm_off;     // byte offset of the row's trailing float norm (EPI_INT_COS)
-    const float *qnorm;    // [nq] query norms (EPI_INT_COS)
+    uint32_t norm_off;     // byte offset of the row's trailing float norm (EPI_INT_COS) / SQ8 metadata (EPI_SQ8_*)
+    const float *qnorm;    // [nq] query norms (EPI_INT_COS); [nq][2] {y_sum, y_sum_squares} (EPI_SQ8_*)
+    int sq8_fused;         // EPI_SQ8_*: 1 = the AVX-512 tier's fma(min, y_sum, delta * acc), 0 = the scalar tier's two products
     void *out;             // MODE_DENSE: score_t [nq][out_stride], column = compact row
     size_t out_stride;
     const void *tau;       // MODE_FILTER: score_t [nq]
@@ -153,6 +163,19 @@ template <typename S> __device__ inline S epilogue_score(int acc, int epi, float
 }
 template <typename S> __device__ inline S epilogue_score(float acc, int epi, float, float) {
     return (epi == EPI_ONE_MINUS) ? (S)__fsub_rn(1.0f, acc) : (S)acc;
+}
+__device__ inline float load_f32_unaligned(const char *p) {
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
+    return __uint_as_float((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
+}
+// SQ8 x FP32 score from the reduced code dot product; `meta` = the row's {min, delta, sum, sum_squares} (unaligned)
+__device__ inline float sq8_score(float qdot, int epi, int fused, const char *meta, float y_sum, float y_sum_sq) {
+    const float min_val = load_f32_unaligned(meta), delta = load_f32_unaligned(meta + 4);
+    const float dq = __fmul_rn(delta, qdot);
+    const float ip = fused ? __fmaf_rn(min_val, y_sum, dq) : __fadd_rn(__fmul_rn(min_val, y_sum), dq);
+    if (epi == EPI_SQ8_IP) return __fsub_rn(1.0f, ip);
+    const float x_sq = load_f32_unaligned(meta + 12);
+    return __fsub_rn(__fadd_rn(x_sq, y_sum_sq), __fmul_rn(2.0f, ip));
 }
 template <typename S> __device__ inline S epilogue_score(double acc, int epi, float, float) {
     return (epi == EPI_ONE_MINUS) ? (S)__dsub_rn(1.0, acc) : (S)acc;
@@ -297,7 +320,12 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
                     if (b >= nqt) break;
                     const int q = q0 + b;
                     const float nq = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
-                    const score_t sc = epilogue_score<score_t>(acc[r][b], P.epilogue, nrow, nq);
+                    score_t sc;
+                    if constexpr (EK == EK_SQ8) {
+                        sc = sq8_score(acc[r][b], P.epilogue, P.sq8_fused, rp[r] + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
+                    } else {
+                        sc = epilogue_score<score_t>(acc[r][b], P.epilogue, nrow, nq);
+                    }
                     if (P.mode == MODE_DENSE) {
                         reinterpret_cast<score_t *>(P.out)[(size_t)q * P.out_stride + comp[r]] = sc;
                     } else {

@@ -19,6 +19,7 @@
 
 #include "blob_prep.h"
 #include "flat_index.h"
+#include "sq8_prep.h"
 #include "hnsw_index.h"
 #include "sharded_index.h"
 
@@ -43,6 +44,27 @@ extern "C" VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
     return ix;
 }
 extern "C" void VecSimIndex_Free(VecSimIndex *index) { delete index; }
+
+// ---- SQ8 storage (vec_sim_gpu.h): the reference has the spaces and the preprocessor (types/sq8.h, preprocessors.h:259-649,
+// IP.cpp:34-183, L2.cpp:30-45,185-201) but no RAM index factory that selects them, so the constructor is an extension
+extern "C" VecSimIndex *VecSimGpu_NewFlatSQ8(const BFParams *params, void *logCtx) {
+    if (!params) return nullptr;
+    FlatIndex *ix = FlatIndex::createSQ8(*params, logCtx);
+    if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create SQ8 GPU index: %s\n", vsgpu_last_error());
+    return ix;
+}
+extern "C" double VecSimGpu_SQ8_StoredDistance(VecSimIndex *index, size_t label_a, size_t label_b) {
+    auto *f = dynamic_cast<FlatIndex *>(index);
+    return f ? f->storedDistance(label_a, label_b) : std::numeric_limits<double>::quiet_NaN();
+}
+extern "C" size_t VecSimGpu_SQ8_StorageBlobSize(size_t dim, VecSimMetric metric) { return vsa::sq8_storage_bytes(dim, metric); }
+extern "C" size_t VecSimGpu_SQ8_QueryBlobSize(size_t dim, VecSimMetric metric) { return vsa::sq8_query_bytes(dim, metric); }
+extern "C" void VecSimGpu_SQ8_Quantize(const float *vector, size_t dim, VecSimMetric metric, void *storage_blob) {
+    vsa::sq8_quantize(vector, dim, metric, static_cast<uint8_t *>(storage_blob));
+}
+extern "C" void VecSimGpu_SQ8_QueryBlob(const float *vector, size_t dim, VecSimMetric metric, float *query_blob) {
+    vsa::sq8_query_blob(vector, dim, metric, query_blob);
+}
 
 extern "C" size_t VecSimIndex_EstimateInitialSize(const VecSimParams *params) {
     (void)params;

@@ -16,6 +16,7 @@
 #include <unordered_set>
 
 #include "blob_prep.h"
+#include "sq8_prep.h"
 
 namespace vsa {
 
@@ -86,6 +87,60 @@ FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
     return ix;
 }
 
+FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
+    if (p.dim == 0 || p.type != VecSimType_FLOAT32 || p.metric > VecSimMetric_Cosine) return nullptr;
+    vsgpu_ctx *ctx = vsgpu_ctx_create(resolve_device());
+    if (!ctx) return nullptr;
+    FlatIndex *ix = new FlatIndex();
+    ix->type_ = p.type;
+    ix->sq8_ = true;
+    ix->metric_ = p.metric;
+    ix->dim_ = p.dim;
+    ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
+    ix->stored_bytes_ = sq8_storage_bytes(p.dim, p.metric);
+    ix->query_bytes_ = sq8_query_bytes(p.dim, p.metric);
+    ix->multi_ = p.multi;
+    ix->log_ctx_ = logCtx;
+    ix->ctx_ = ctx;
+    ix->table_ = vsgpu_table_create(ctx, VSGPU_SQ8, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    if (!ix->table_) {
+        vsgpu_ctx_destroy(ctx);
+        ix->ctx_ = nullptr;
+        delete ix;
+        return nullptr;
+    }
+    return ix;
+}
+
+// caller's vector -> stored blob.  Cosine: normalise (vec_sim_index.h:397-402); SQ8: then quantise (preprocessors.h:270-390)
+void FlatIndex::toStored(const void *blob, char *out) const {
+    if (sq8_) {
+        std::vector<float> tmp(dim_);
+        std::memcpy(tmp.data(), blob, dim_ * sizeof(float));
+        if (metric_ == VecSimMetric_Cosine) normalize_blob(tmp.data(), dim_, type_);
+        sq8_quantize(tmp.data(), dim_, metric_, reinterpret_cast<uint8_t *>(out));
+        return;
+    }
+    std::memcpy(out, blob, dim_ * type_size(type_));
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(out, dim_, type_);
+}
+void FlatIndex::toQuery(const void *query, char *out) const {
+    std::memcpy(out, query, dim_ * type_size(type_));
+    if (metric_ == VecSimMetric_Cosine) normalize_blob(out, dim_, type_);
+    if (sq8_) sq8_query_blob(reinterpret_cast<const float *>(out), dim_, metric_, reinterpret_cast<float *>(out));
+}
+
+double FlatIndex::storedDistance(size_t label_a, size_t label_b) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (!sq8_ || multi_) return std::numeric_limits<double>::quiet_NaN();
+    auto ia = label_to_id_.find(label_a), ib = label_to_id_.find(label_b);
+    if (ia == label_to_id_.end() || ib == label_to_id_.end() || flush()) return std::numeric_limits<double>::quiet_NaN();
+    const uint32_t a = ia->second, b = ib->second;
+    double sc = 0;
+    if (vsgpu_sq8_pair_scores(table_, &a, &b, 1, &sc)) return std::numeric_limits<double>::quiet_NaN();
+    return sc;
+}
+
 FlatIndex::~FlatIndex() {
     if (table_) vsgpu_table_destroy(table_);
     if (ctx_) vsgpu_ctx_destroy(ctx_);
@@ -129,7 +184,11 @@ int FlatIndex::addVector(const void *blob, size_t label) {
         // stored size, so we do the same; for int8/uint8 Cosine the reference would read 4 bytes
         // past the caller's blob for the norm -- we recompute the norm instead.
         if (flush()) return 0;
-        if (metric_ == VecSimMetric_Cosine && is_int_type(type_)) {
+        if (sq8_) {   // (no reference behaviour to follow here: SQ8 rows are only ever written by the preprocessor)
+            std::vector<char> tmp(stored_bytes_);
+            toStored(blob, tmp.data());
+            vsgpu_table_write(table_, it->second, tmp.data());
+        } else if (metric_ == VecSimMetric_Cosine && is_int_type(type_)) {
             std::vector<char> tmp(stored_bytes_);
             std::memcpy(tmp.data(), blob, dim_);
             normalize_blob(tmp.data(), dim_, type_);
@@ -140,10 +199,9 @@ int FlatIndex::addVector(const void *blob, size_t label) {
         return 0;
     }
     // appendVector (brute_force.h:175-193): preprocess for storage, next id, maps
-    if (metric_ == VecSimMetric_Cosine) {
+    if (metric_ == VecSimMetric_Cosine || sq8_) {
         std::vector<char> tmp(stored_bytes_);
-        std::memcpy(tmp.data(), blob, dim_ * type_size(type_));
-        normalize_blob(tmp.data(), dim_, type_);
+        toStored(blob, tmp.data());
         stageRow(tmp.data());
     } else {
         stageRow(blob);
@@ -172,7 +230,7 @@ long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
 long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
     // device-generated rows are stored as generated: fp Cosine would need normalisation, so only int8 Cosine
     // (norm appended by the fill kernel) is accepted among the Cosine indexes
-    if (type_ == VecSimType_FLOAT64 || type_ == VecSimType_UINT8 || multi_) return -1;
+    if (type_ == VecSimType_FLOAT64 || type_ == VecSimType_UINT8 || multi_ || sq8_) return -1;
     if (metric_ == VecSimMetric_Cosine && type_ != VecSimType_INT8) return -1;
     if (flush()) return -1;
     const size_t first = count_;
@@ -282,8 +340,7 @@ long FlatIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
 // ---- queries ----
 std::vector<char> FlatIndex::preprocessQuery(const void *query) const {
     std::vector<char> q(query_bytes_);
-    std::memcpy(q.data(), query, dim_ * type_size(type_));
-    if (metric_ == VecSimMetric_Cosine) normalize_blob(q.data(), dim_, type_);
+    toQuery(query, q.data());
     return q;
 }
 
@@ -556,8 +613,8 @@ std::vector<char> FlatIndex::packQueries(const void *queries, size_t nq, size_t 
     const size_t in_bytes = dim_ * type_size(type_);
     for (size_t q = 0; q < nq; q++) {
         char *dst = qbuf.data() + q * query_bytes_;
-        std::memcpy(dst, static_cast<const char *>(queries) + q * stride, in_bytes);
-        if (metric_ == VecSimMetric_Cosine) normalize_blob(dst, dim_, type_);
+        (void)in_bytes;
+        toQuery(static_cast<const char *>(queries) + q * stride, dst);
     }
     return qbuf;
 }
@@ -674,7 +731,12 @@ double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
     if (flush()) return std::numeric_limits<double>::quiet_NaN();
     // "Unsafe": the blob is used as given (caller normalises for Cosine), brute_force_single.h:202-212
     std::vector<char> q(query_bytes_);
-    std::memcpy(q.data(), blob, query_bytes_);
+    if (sq8_) {   // an fp32 vector as given; only the query metadata (y_sum, y_sum_squares) is appended
+        std::memcpy(q.data(), blob, dim_ * sizeof(float));
+        sq8_query_blob(reinterpret_cast<const float *>(q.data()), dim_, metric_, reinterpret_cast<float *>(q.data()));
+    } else {
+        std::memcpy(q.data(), blob, query_bytes_);
+    }
     uint32_t id = it->second;
     double s = std::numeric_limits<double>::quiet_NaN();
     if (vsgpu_scores_of(table_, q.data(), &id, 1, &s)) return std::numeric_limits<double>::quiet_NaN();

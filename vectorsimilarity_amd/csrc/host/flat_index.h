@@ -91,6 +91,12 @@ class FlatIndex final : public VecSimIndexInterface {
 public:
     // returns nullptr (with VecSimGpu_LastError set) when the GPU context cannot be created
     static FlatIndex *create(const BFParams &p, void *logCtx);
+    // SQ8 storage (types/sq8.h, QuantPreprocessor): callers add and query fp32 vectors, rows are uint8 codes + FP32
+    // metadata, every distance is the reference's asymmetric SQ8 x FP32 kernel.  p.type must be FLOAT32.
+    static FlatIndex *createSQ8(const BFParams &p, void *logCtx);
+    bool isSQ8() const { return sq8_; }
+    // symmetric SQ8 x SQ8 distance between the stored vectors of two labels (NaN for an unknown label)
+    double storedDistance(size_t label_a, size_t label_b);
     ~FlatIndex() override;
 
     int addVector(const void *blob, size_t label) override;
@@ -160,6 +166,10 @@ private:
     // one GPU context (staging buffers, stream) per index: concurrent readers take turns
     mutable std::recursive_mutex gpu_mu_;
     bool multi_ = false;
+    bool sq8_ = false;
+    // fp32 vector (dim_ floats) -> stored blob / query blob of this index (Cosine: normalised first; SQ8: quantised)
+    void toStored(const void *blob, char *out) const;
+    void toQuery(const void *query, char *out) const;
     std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     std::vector<char> staged_;  // rows appended but not yet uploaded
     size_t staged_rows_ = 0;

@@ -1,0 +1,80 @@
+// sq8_prep.h -- host-side SQ8 blob preprocessing: once per stored vector / per query, O(dim).
+//
+// Restates QuantPreprocessor<float, Metric, WithNorm = false> (spaces/computer/preprocessors.h:259-649), because it
+// decides the stored bytes and the query metadata the kernels consume:
+//   storage  | codes[dim] u8 | min | delta | sum | sum_squares (L2 only) |   quantize()               :270-390
+//   query    | y[dim] f32    | y_sum | y_sum_squares (L2 only) |            assign_query_metadata()  :398-470
+// (types/sq8.h:19-62 for the layouts).  Cosine indexes normalise the fp32 vector first (blob_prep.h), then quantise.
+// Not built: FP16 inputs / queries and the mean-centred (WithNorm) variants.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "VecSim/vec_sim_common.h"
+
+namespace vsa {
+
+inline size_t sq8_storage_bytes(size_t dim, VecSimMetric m) { return dim + (m == VecSimMetric_L2 ? 4 : 3) * sizeof(float); }
+inline size_t sq8_query_bytes(size_t dim, VecSimMetric m) { return (dim + (m == VecSimMetric_L2 ? 2 : 1)) * sizeof(float); }
+
+// bounded conversion, then +0.5 and truncate (preprocessors.h:287-299): zero / negative / NaN -> 0, >= 255 / +inf -> 255
+inline uint8_t sq8_to_byte(float scaled) {
+    if (!(scaled > 0.0f)) return 0;
+    if (scaled >= 255.0f) return 255;
+    return (uint8_t)(scaled + 0.5f);
+}
+
+inline void sq8_quantize(const float *x, size_t dim, VecSimMetric metric, uint8_t *out) {
+    // std::minmax_element: the first smallest, the last largest (:620-622)
+    float min_val = x[0], max_val = x[0];
+    for (size_t i = 1; i < dim; i++) {
+        if (x[i] < min_val) min_val = x[i];
+        if (!(x[i] < max_val)) max_val = x[i];
+    }
+    const float diff = max_val - min_val;
+    const float delta = (diff == 0.0f) ? 1.0f : diff / 255.0f;
+    const float inv_delta = 1.0f / delta;
+    // byte sums as exact integers (four chains like the reference; integer sums do not depend on the order)
+    uint32_t q_sum = 0;
+    uint64_t q_sq = 0;
+    for (size_t i = 0; i < dim; i++) {
+        const uint8_t a = sq8_to_byte((x[i] - min_val) * inv_delta);
+        out[i] = a;
+        q_sum += a;
+        q_sq += (uint64_t)a * a;
+    }
+    // sums of the reconstruction min + delta * a[i], expanded in double (:369-381), stored as FP32
+    const double d_min = min_val, d_delta = delta, d_dim = (double)dim;
+    float meta[4] = {min_val, delta, (float)(d_dim * d_min + d_delta * (double)q_sum), 0.0f};
+    size_t n = 3;
+    if (metric == VecSimMetric_L2) {
+        const double t0 = d_dim * d_min * d_min, t1 = 2.0 * d_min * d_delta * (double)q_sum, t2 = d_delta * d_delta * (double)q_sq;
+        meta[3] = (float)((t0 + t1) + t2);
+        n = 4;
+    }
+    std::memcpy(out + dim, meta, n * sizeof(float));   // the metadata offset is not 4-byte aligned in general
+}
+
+// query values followed by y_sum (and y_sum_squares for L2): four fp32 chains, (s0 + s1) + (s2 + s3), tail added after
+inline void sq8_query_blob(const float *y, size_t dim, VecSimMetric metric, float *out) {
+    if (out != y) std::memmove(out, y, dim * sizeof(float));
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const size_t d4 = dim & ~(size_t)3;
+    size_t i = 0;
+    for (; i < d4; i += 4)
+        for (int j = 0; j < 4; j++) {
+            const float v = out[i + j];
+            s[j] += v;
+            q[j] += v * v;
+        }
+    float sum = (s[0] + s[1]) + (s[2] + s[3]);
+    float sq = (q[0] + q[1]) + (q[2] + q[3]);
+    for (; i < dim; i++) {
+        sum += out[i];
+        sq += out[i] * out[i];
+    }
+    out[dim] = sum;
+    if (metric == VecSimMetric_L2) out[dim + 1] = sq;
+}
+
+}  // namespace vsa

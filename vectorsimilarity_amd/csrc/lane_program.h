@@ -59,7 +59,7 @@ inline int elem_bytes_of(int type) {
     case VSGPU_F64: return 8;
     case VSGPU_BF16:
     case VSGPU_F16: return 2;
-    default: return 1;
+    default: return 1;  // int8, uint8, SQ8 codes
     }
 }
 
@@ -73,6 +73,7 @@ inline bool uses_scalar_tier(int type, int tier, size_t dim) {
     case VSGPU_F64: return dim < 4;
     case VSGPU_BF16: return dim < 32;
     case VSGPU_F16: return dim < 8;
+    case VSGPU_SQ8: return dim < 8;  // L2_space.cpp:71-75, IP_space.cpp:72-76
     default: return false;  // integer kernels are exact in any order
     }
 }
@@ -103,6 +104,21 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         return p;
     }
 
+    if (type == VSGPU_SQ8 && uses_scalar_tier(type, tier, dim)) {
+        // SQ8_FP32_InnerProduct_Impl (IP.cpp:34-58): four chains over elements i % 4, the dim % 4 tail into chain 0,
+        // separate multiply and add, then (s0 + s1) + (s2 + s3).  The halving tree adds lane 0 + lane 2 and lane 1 +
+        // lane 3 before the last step, so chains 0, 1, 2, 3 sit on lanes 0, 2, 1, 3 (the other lanes hold +0).
+        static const int lane_of[4] = {0, 2, 1, 3};
+        p.fused = false;
+        p.scalar_tier = true;
+        const size_t d4 = dim & ~(size_t)3;
+        for (size_t e = 0; e < d4; e += 4) {
+            int s = new_step();
+            for (int j = 0; j < 4; j++) put(s, lane_of[j], e + j);
+        }
+        for (size_t e = d4; e < dim; e++) put(new_step(), 0, e);
+        return p;
+    }
     if (uses_scalar_tier(type, tier, dim)) {
         // one sequential chain, separate multiply and add
         p.fused = false;
@@ -123,9 +139,10 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         return p;
     }
 
-    if (type == VSGPU_F32 || type == VSGPU_F16 || type == VSGPU_F64) {
+    if (type == VSGPU_F32 || type == VSGPU_F16 || type == VSGPU_F64 || type == VSGPU_SQ8) {
         // two accumulators of h lanes each (h = 16 for 32-bit math, 8 for fp64):
-        // L2_AVX512F_FP32.h:21-59, L2_AVX512F_FP16.h, L2_AVX512F_FP64.h:21-59 and the IP twins.
+        // L2_AVX512F_FP32.h:21-59, L2_AVX512F_FP16.h, L2_AVX512F_FP64.h:21-59 and the IP twins; the SQ8 x FP32
+        // kernel (IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104) has the same shape over float(code) * y.
         const size_t h = vl / 2, chunk = vl;
         const size_t residual = dim % chunk, rh = residual % h;
         size_t pos = 0;

@@ -160,8 +160,9 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         fail(VSGPU_ERR_ARG, "null context");
         return nullptr;
     }
-    if (type < VSGPU_F32 || type > VSGPU_U8 || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
-        row_bytes < dim * (size_t)elem_bytes_of(type)) {
+    if (type < VSGPU_F32 || type > VSGPU_SQ8 || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
+        row_bytes < dim * (size_t)elem_bytes_of(type) ||
+        (type == VSGPU_SQ8 && row_bytes != dim + (metric == VSGPU_L2 ? 16 : 12))) {
         fail(VSGPU_ERR_ARG, "bad table parameters (type %d metric %d dim %zu row_bytes %zu)", type, metric,
              dim, row_bytes);
         return nullptr;
@@ -182,7 +183,10 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     // bf16 IP on the avx512_bf16 tier: the vdpbf16ps step (odd element, then even, each with FTZ)
     if (t->prog.dpbf16) t->opk = OP_IP_DPBF16;
     if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
+    else if (type == VSGPU_SQ8) t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
     else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
+    // SQ8 accumulates the code dot product in the IP order whatever the metric (L2 is algebraic: L2.cpp:30-45)
+    if (type == VSGPU_SQ8) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
     // LDS budget 64 KiB: offs + BT query images
     size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
     size_t q_b = (size_t)t->prog.steps * t->prog.vl * acc_bytes(type);
@@ -390,7 +394,8 @@ extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
     return VSGPU_OK;
 }
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
-    if (t->type == VSGPU_F64 || t->type == VSGPU_U8) return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32/bf16/fp16/int8 only");
+    if (t->type == VSGPU_F64 || t->type == VSGPU_U8 || t->type == VSGPU_SQ8)
+        return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32/bf16/fp16/int8 only");
     if (n == 0) return VSGPU_OK;
     HIPCHK(hipSetDevice(t->ctx->device));
     if (t->n + n > 0xFFFFFFF0ull) return fail(VSGPU_ERR_UNSUPPORTED, "more than 2^32 rows per device table");
@@ -432,7 +437,7 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
     const size_t per_q = (size_t)pg.steps * pg.vl;
     const size_t ab = acc_bytes(t->type);
     const size_t bytes = nq * per_q * ab;
-    int rc = ensure_pinned(c, bytes + nq * 4);
+    int rc = ensure_pinned(c, bytes + nq * 8);
     if (rc) return rc;
     rc = ensure(c, c->qperm, bytes);
     if (rc) return rc;
@@ -487,6 +492,15 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
             for (size_t i = 0; i < per_q; i++) oi[i] = offs[i] >= 0 ? (int)*(const int8_t *)(src + offs[i]) : 0;
             break;
         }
+        case VSGPU_SQ8: {   // table offsets address the one-byte codes: element e of the fp32 query sits at 4 e
+            float *of = (float *)o;
+            for (size_t i = 0; i < per_q; i++) {
+                float v = 0;
+                if (offs[i] >= 0) memcpy(&v, src + 4 * (size_t)offs[i], 4);
+                of[i] = v;
+            }
+            break;
+        }
         default: {
             int *oi = (int *)o;
             for (size_t i = 0; i < per_q; i++) oi[i] = offs[i] >= 0 ? (int)*(const uint8_t *)(src + offs[i]) : 0;
@@ -495,6 +509,20 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
         }
     }
     HIPCHK(hipMemcpyAsync(c->qperm.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    if (t->type == VSGPU_SQ8) {   // {y_sum, y_sum_squares} of every query blob (the second only exists for L2)
+        rc = ensure_pinned(c, bytes + nq * 8);
+        if (rc) return rc;
+        float *qm = (float *)((char *)c->pinned + bytes);
+        for (size_t q = 0; q < nq; q++) {
+            const char *src = (const char *)queries + q * qstride + 4 * t->dim;
+            memcpy(&qm[2 * q], src, 4);
+            qm[2 * q + 1] = 0.f;
+            if (t->epi == EPI_SQ8_L2) memcpy(&qm[2 * q + 1], src + 4, 4);
+        }
+        rc = ensure(c, c->qnorm, nq * 8);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->qnorm.p, qm, nq * 8, hipMemcpyHostToDevice, c->stream));
+    }
     if (t->epi == EPI_INT_COS) {
         float *qn = (float *)((char *)c->pinned + bytes);
         for (size_t q = 0; q < nq; q++) memcpy(&qn[q], (const char *)queries + q * qstride + t->dim, 4);
@@ -532,6 +560,10 @@ static void launch_scan(int ek, int opk, int bt, const ScanParams &P, dim3 grid,
     case EK_BF16: launch_scan_op<EK_BF16>(opk, bt, P, grid, lds, s); break;
     case EK_F16: launch_scan_op<EK_F16>(opk, bt, P, grid, lds, s); break;
     case EK_I8: launch_scan_op<EK_I8>(opk, bt, P, grid, lds, s); break;
+    case EK_SQ8:
+        if (opk == OP_IP_FMA) launch_scan_bt<EK_SQ8, OP_IP_FMA>(bt, P, grid, lds, s);
+        else launch_scan_t<EK_SQ8, OP_IP_MULADD, 1>(P, grid, lds, s);
+        break;
     default: launch_scan_op<EK_U8>(opk, bt, P, grid, lds, s); break;
     }
 }
@@ -562,6 +594,7 @@ int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     P.epilogue = t->epi;
     P.norm_off = (uint32_t)t->dim;
     P.qnorm = (const float *)c->qnorm.p;
+    P.sq8_fused = t->prog.fused ? 1 : 0;
     const int bt = pick_bt(t, nq);
     const int tile_rows = tile_rows_of(t->ek);
     const uint32_t n_tiles = (P.n_compact + tile_rows - 1) / tile_rows;
@@ -809,6 +842,82 @@ extern "C" int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t
     HIPCHK(hipMemcpyAsync(c->ids.p, ids, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));  // ids is caller memory: finish the copy before returning paths diverge
     return dense_to_host(t, 1, (const uint32_t *)c->ids.p, 0, n, scores);
+}
+
+// ------------------------------------------------------------------ SQ8 symmetric distances
+// SQ8_SQ8_InnerProduct / _Cosine / _L2Sqr between two stored rows (IP.cpp:146-183, L2.cpp:185-201; AVX-512 VNNI tier from
+// dim 64: IP_AVX512F_BW_VL_VNNI_SQ8_SQ8.h:38-65).  One wave per pair.  mode 0: VNNI tier (exact int32 dot, epilogue fused
+// the way gcc fuses it, see oracle/vso_sq8.c); 1: scalar tier with dim < 64 (float accumulation of integers below 2^24 is
+// exact, so the same int dot serves); 2: scalar tier beyond the 32-bit bound (dim > 33025): sequential float accumulation.
+static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *slabs, uint32_t slab_shift, uint32_t slab_mask,
+                                                         uint32_t row_stride, uint32_t dim, int is_l2, int mode,
+                                                         const uint32_t *ids_a, const uint32_t *ids_b, uint32_t n, float *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n) return;
+    const uint32_t ra = ids_a[pair], rb = ids_b[pair];
+    const unsigned char *a = reinterpret_cast<const unsigned char *>(slabs[ra >> slab_shift] + (size_t)(ra & slab_mask) * row_stride);
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(slabs[rb >> slab_shift] + (size_t)(rb & slab_mask) * row_stride);
+    float fdot;
+    if (mode == 2) {
+        float product = 0.f;
+        if (lane == 0)
+            for (uint32_t i = 0; i < dim; i++) product = __fadd_rn(product, (float)((int)a[i] * (int)b[i]));
+        fdot = product;
+    } else {
+        int dot = 0;
+        for (uint32_t i = lane; i < dim; i += 64) dot += (int)a[i] * (int)b[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+        fdot = (float)dot;
+    }
+    if (lane != 0) return;
+    const char *ma = reinterpret_cast<const char *>(a) + dim, *mb = reinterpret_cast<const char *>(b) + dim;
+    const float min1 = load_f32_unaligned(ma), delta1 = load_f32_unaligned(ma + 4), sum1 = load_f32_unaligned(ma + 8);
+    const float min2 = load_f32_unaligned(mb), delta2 = load_f32_unaligned(mb + 4), sum2 = load_f32_unaligned(mb + 8);
+    const float fdim = (float)dim;
+    float ip;
+    if (mode == 0) {
+        const float A = __fmaf_rn(min1, sum2, __fmul_rn(min2, sum1));
+        const float B = __fmaf_rn(__fmul_rn(delta1, delta2), fdot, A);
+        ip = __fmaf_rn(-__fmul_rn(fdim, min1), min2, B);
+    } else {
+        const float t0 = __fmul_rn(min1, sum2), t1 = __fmul_rn(min2, sum1);
+        const float t2 = __fmul_rn(__fmul_rn(fdim, min1), min2);
+        const float t3 = __fmul_rn(__fmul_rn(delta1, delta2), fdot);
+        ip = __fadd_rn(__fsub_rn(__fadd_rn(t0, t1), t2), t3);
+    }
+    float sc;
+    if (!is_l2) sc = __fsub_rn(1.0f, ip);
+    else sc = __fsub_rn(__fadd_rn(load_f32_unaligned(ma + 12), load_f32_unaligned(mb + 12)), __fmul_rn(2.0f, ip));
+    out[pair] = sc;
+}
+
+extern "C" int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t *ids_b, size_t n, double *scores) {
+    if (t->type != VSGPU_SQ8) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
+    if (n == 0) return VSGPU_OK;
+    for (size_t i = 0; i < n; i++)
+        if (ids_a[i] >= t->n || ids_b[i] >= t->n) return fail(VSGPU_ERR_ARG, "row id beyond table size %zu", t->n);
+    vsgpu_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure(c, c->ids, 2 * n * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->dense, n * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->ids.p, ids_a, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync((uint32_t *)c->ids.p + n, ids_b, n * 4, hipMemcpyHostToDevice, c->stream));
+    const bool scalar = t->tier == VSGPU_TIER_SCALAR || t->dim < 64 || t->dim > 33025;   // L2_space.cpp:529-566
+    const int mode = !scalar ? 0 : (t->dim > 33025 ? 2 : 1);
+    hipLaunchKernelGGL(k_sq8_pairs, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, (const char *const *)t->d_slabs,
+                       t->slab_shift, (uint32_t)(((size_t)1 << t->slab_shift) - 1), (uint32_t)t->row_bytes, (uint32_t)t->dim,
+                       t->epi == EPI_SQ8_L2 ? 1 : 0, mode, (const uint32_t *)c->ids.p, (const uint32_t *)c->ids.p + n,
+                       (uint32_t)n, (float *)c->dense.p);
+    HIPCHK(hipGetLastError());
+    std::vector<float> h(n);
+    HIPCHK(hipMemcpyAsync(h.data(), c->dense.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) scores[i] = (double)h[i];
+    return VSGPU_OK;
 }
 
 // ------------------------------------------------------------------ selection helpers (host, on GPU scores)
