@@ -198,7 +198,34 @@ def sq8():
                                         "reconstruct-then-dot baseline (tests/utils/tests_utils.h:76-170, 244-270)"))
 
 
+def hnsw():
+    """The reference's deterministic HNSW unit tests (tests/unit/test_hnsw.cpp) as data: how the index is filled, the query,
+    and the closed form every result must satisfy.  Vectors {v,v,v,v} (GenerateAndAddVector: every element = the value)."""
+    cases = []
+    cases.append(dict(name="hnsw_vector_search_test", src="test_hnsw.cpp:225-248", dim=4, metric="L2", M=16, efConstruction=200,
+                      vectors=[[float(i)] * 4 for i in range(100)], labels=list(range(100)), query=[50.0] * 4, k=11, order="score",
+                      expect_labels_abs_diff_from=50, expect_scores=[4.0 * ((r + 1) // 2) ** 2 for r in range(11)],
+                      expect_abs_diff=[(r + 1) // 2 for r in range(11)]))
+    cases.append(dict(name="hnsw_vector_search_by_id_test", src="test_hnsw.cpp:250-269", dim=4, metric="L2", M=16, efConstruction=200,
+                      vectors=[[float(i)] * 4 for i in range(100)], labels=list(range(100)), query=[50.0] * 4, k=11, order="id",
+                      expect_labels=[r + 45 for r in range(11)]))
+    cases.append(dict(name="hnsw_indexing_same_vector", src="test_hnsw.cpp:271-293", dim=4, metric="L2", M=16, efConstruction=200,
+                      vectors=[[float(i // 10)] * 4 for i in range(100)], labels=list(range(100)),
+                      query=[4.9, 4.95, 5.05, 5.1], k=10, order="score", expect_label_range=[50, 60], expect_score_max=1.0))
+    n = 100
+    cases.append(dict(name="testCosine", src="test_hnsw.cpp:1580-1632", dim=4, metric="Cosine", M=16, efConstruction=200,
+                      vectors=[[i / n, 1.0, 1.0, 1.0] for i in range(1, n + 1)], labels=list(range(1, n + 1)),
+                      query=[1.0] * 4, k=10, order="score", expect_labels=[n - r for r in range(10)]))
+    rq = dict(name="rangeQuery", src="test_hnsw.cpp:1801-1845", dim=4, metric="L2", M=16, efConstruction=200, n=5000, pivot=2500,
+              radius=4.0 * 5 ** 2, expect_count=11, expect_scores_by_score=[4.0 * ((r + 1) // 2) ** 2 for r in range(11)],
+              expect_abs_diff_by_score=[(r + 1) // 2 for r in range(11)], expect_labels_by_id=[2500 - 5 + r for r in range(11)],
+              epsilons=[0.01, 1.0])
+    return dict(topk=cases, range=rq)
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "kat_hnsw.json"), "w") as f:
+        json.dump(hnsw(), f, indent=0)
     with open(os.path.join(HERE, "kat_sq8.json"), "w") as f:
         json.dump(sq8(), f, indent=1)
     with open(os.path.join(HERE, "kat_flat_multi.json"), "w") as f:

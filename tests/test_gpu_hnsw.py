@@ -324,3 +324,78 @@ def test_topk_beyond_the_lds_heaps_and_beyond_the_index(vso):
     labels, dists = small.knn_query(rows2[0], 200)
     got = labels[0][labels[0] >= 0]
     assert len(got) == 49 and 7 not in got and np.all(np.diff(dists[0][:49]) >= 0) and np.all(labels[0][49:] == -1)
+
+
+# ---------------------------------------------------------------- the reference's deterministic HNSW tests
+def _kats():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat_hnsw.json")) as f:
+        return json.load(f)
+
+
+MET = {"L2": VecSim.VecSimMetric_L2, "IP": VecSim.VecSimMetric_IP, "Cosine": VecSim.VecSimMetric_Cosine}
+
+
+@pytest.mark.parametrize("case", _kats()["topk"], ids=lambda c: c["name"])
+def test_reference_hnsw_known_answers(vso, case):
+    """tests/unit/test_hnsw.cpp closed forms (tests/golden/kat_hnsw.json), asserted twice: on the product (host-built graph,
+    GPU search, through the C API) and on oracle/vso_hnsw.c searching the same graph -- which pins the oracle's search loops on
+    answers the reference's own tests hold."""
+    rows = np.array(case["vectors"], dtype=np.float32)
+    labels = np.array(case["labels"])
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction = VecSim.VecSimType_FLOAT32, case["dim"], MET[case["metric"]], case["M"], case["efConstruction"]
+    ix = VecSim.HNSWIndex(p)
+    for v, lab in zip(rows, labels):
+        ix.add_vector(v, int(lab))
+    assert ix.index_size() == len(rows)
+    q = np.array(case["query"], dtype=np.float32)
+    k = case["k"]
+    order = VecSim.BY_ID if case["order"] == "id" else VecSim.BY_SCORE
+    gl, gd = ix.knn_query(q[None, :], k, order=order)
+    assert ix.knn_query(q[None, :], 0)[0].shape[1] == 0          # "search for nothing" (test_hnsw.cpp:246)
+    g = ix.graph()
+    srows = stored(vso, rows, MET[case["metric"]])
+    sq = stored(vso, q[None, :].copy(), MET[case["metric"]])[0]
+    km = 0 if case["metric"] == "L2" else 1
+    ol, od, _ = vso.hnsw_search(0, km, srows, g, sq, k, max(k, 10), case["dim"])   # default efRuntime 10 (hnsw.h:2073: max(ef, k))
+    if case["order"] == "id":
+        srt = np.argsort(ol, kind="stable")
+        ol, od = ol[srt], od[srt]
+    for got_l, got_d, who in ((gl[0], gd[0], "gpu"), (ol.astype(np.int64), od, "oracle")):
+        assert len(got_l) == k, who
+        if "expect_labels" in case:
+            assert list(got_l) == case["expect_labels"], (who, got_l)
+        if "expect_abs_diff" in case:
+            assert [abs(int(x) - case["expect_labels_abs_diff_from"]) for x in got_l] == case["expect_abs_diff"], (who, got_l)
+            assert list(got_d) == case["expect_scores"], (who, got_d)
+        if "expect_label_range" in case:
+            lo, hi = case["expect_label_range"]
+            assert all(lo <= int(x) < hi for x in got_l) and all(float(s) <= case["expect_score_max"] for s in got_d), (who, got_l, got_d)
+    if case["name"] == "testCosine":   # score == getDistanceFrom_Unsafe(id, normalised query) (test_hnsw.cpp:1606-1608)
+        for lab, sc in zip(gl[0], gd[0]):
+            assert sc == ix.get_distance_from(int(lab), sq)
+
+
+def test_reference_hnsw_range_known_answers(vso):
+    c = _kats()["range"]
+    n, dim = c["n"], c["dim"]
+    rows = np.repeat(np.arange(n, dtype=np.float32)[:, None], dim, axis=1)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2
+    ix = VecSim.HNSWIndex(p)
+    for i in range(n):
+        ix.add_vector(rows[i], i)
+    q = np.full(dim, float(c["pivot"]), dtype=np.float32)
+    g = ix.graph()
+    for eps in c["epsilons"]:
+        qp = VecSim.VecSimQueryParams()
+        qp.hnswRuntimeParams.epsilon = eps
+        l, d = ix.range_query(q, c["radius"], qp, VecSim.BY_SCORE)
+        assert l.shape[1] == c["expect_count"]
+        assert [abs(int(x) - c["pivot"]) for x in l[0]] == c["expect_abs_diff_by_score"] and list(d[0]) == c["expect_scores_by_score"]
+        l, d = ix.range_query(q, c["radius"], qp, VecSim.BY_ID)
+        assert list(l[0]) == c["expect_labels_by_id"]
+        ol, od, _ = vso.hnsw_range(0, 0, rows, g, q, c["radius"], eps, dim)
+        assert sorted(int(x) for x in ol) == c["expect_labels_by_id"]

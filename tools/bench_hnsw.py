@@ -26,7 +26,13 @@ ap.add_argument("--data", default="uniform", choices=["uniform", "lowrank"],
                 help="uniform: BASELINE's U[-1,1) i.i.d. rows (intrinsic dimension = d, hard for any graph index); "
                      "lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
 ap.add_argument("--slots", default="", help="comma list of hnsw_slots values to time (waves per CU)")
+ap.add_argument("--efs", default="", help="comma list of further efRuntime values: recall and QPS at each (same graph)")
+ap.add_argument("--threads", type=int, default=0, help="host linking threads (VECSIM_HNSW_BUILD_THREADS); 1 = the sequential insert path")
+ap.add_argument("--chunk", type=int, default=0, help="add the rows in chunks of this many (progress lines); 0 = one bulk call")
+ap.add_argument("--exact-queries", type=int, default=0, help="recall on the first this-many queries only (0 = all)")
 a = ap.parse_args()
+if a.threads:
+    os.environ["VECSIM_HNSW_BUILD_THREADS"] = str(a.threads)
 
 # rows are generated in slices so the generator's temporaries stay small at millions of rows
 rows = np.empty((a.rows, a.dim), dtype=np.float32)
@@ -44,7 +50,13 @@ p = VecSim.HNSWParams()
 p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2, a.M, a.efc, a.ef
 ix = VecSim.HNSWIndex(p)
 t0 = time.perf_counter()
-ix.add_vectors(rows, np.arange(a.rows))
+if a.chunk:
+    for r0 in range(0, a.rows, a.chunk):
+        r1 = min(a.rows, r0 + a.chunk)
+        ix.add_vectors(rows[r0:r1], np.arange(r0, r1))
+        print("built %d rows in %.0f s" % (r1, time.perf_counter() - t0), flush=True)
+else:
+    ix.add_vectors(rows, np.arange(a.rows))
 build_s = time.perf_counter() - t0
 ix.knn_query(q[:64], a.k)          # uploads rows + graph
 ix.reset_stats()
@@ -70,10 +82,25 @@ bp = VecSim.BFParams()
 bp.type, bp.dim, bp.metric = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2
 bf = VecSim.BFIndex(bp)
 bf.add_vectors(rows, np.arange(a.rows))
-exact = np.concatenate([bf.knn_query(q[i:i + 64], a.k)[0] for i in range(0, a.queries, 64)])
-recall = sum(len(set(labels[i]) & set(exact[i])) for i in range(a.queries)) / (a.queries * a.k)
+nx = a.exact_queries or a.queries
+exact = np.concatenate([bf.knn_query(q[i:i + 64], a.k)[0] for i in range(0, nx, 64)])[:nx]
+recall = sum(len(set(labels[i]) & set(exact[i])) for i in range(nx)) / (nx * a.k)
+ef_curve = []
+for ef in [int(x) for x in a.efs.split(",") if x]:
+    qp = VecSim.VecSimQueryParams()
+    qp.hnswRuntimeParams.efRuntime = ef
+    ix.knn_query(q, a.k, qp)
+    tb = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        le, _ = ix.knn_query(q, a.k, qp)
+        dt = time.perf_counter() - t0
+        tb = dt if tb is None else min(tb, dt)
+    ef_curve.append({"ef": ef, "qps": a.queries / tb, "recall": sum(len(set(le[i]) & set(exact[i])) for i in range(nx)) / (nx * a.k),
+                     "dist_evals_per_query": ix.last_distance_evals() / a.queries})
 kms = st["scan_ms"] / max(1, st["scan_launches"])
 print(json.dumps({"config": "HNSW fp32 L2 N=%d d=%d M=%d efC=%d efR=%d k=%d data=%s" % (a.rows, a.dim, a.M, a.efc, a.ef, a.k, a.data),
                   "host_build_s": build_s, "queries": a.queries, "batch_ms": best * 1e3, "qps": a.queries / best,
                   "recall_at_%d" % a.k: recall, "dist_evals_per_query": evals / a.queries,
-                  "search_kernel_ms": kms, "gather_GBps": evals * a.dim * 4 / (kms * 1e-3) / 1e9}))
+                  "search_kernel_ms": kms, "gather_GBps": evals * a.dim * 4 / (kms * 1e-3) / 1e9,
+                  "build_threads": a.threads or "all cores (<= 64)", "ef_curve": ef_curve}))

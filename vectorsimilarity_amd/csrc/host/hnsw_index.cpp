@@ -240,8 +240,20 @@ void HnswIndex::connect(uint32_t id, int level, const std::vector<std::pair<floa
         uint32_t dummy = 0, *mine_cnt = &dummy;
         if (level == 0) mine = links0_.data() + (size_t)id * M0_;
         else mine = linksAt(id, level, &mine_cnt);
+        // Parallel build: another thread may already have appended a back link to this node (it met the node through
+        // the level above, or through a neighbour written a moment ago).  Those links stay: the selected neighbours
+        // first, then what was there, up to the list's capacity -- writing from index 0 would leave one-way edges
+        // (hnswlib holds the element lock for the whole insert instead).
+        uint32_t had[64];
+        const uint32_t had_n = level == 0 ? cnt0_[id] : *mine_cnt;
+        for (uint32_t i = 0; i < had_n; i++) had[i] = mine[i];
         uint32_t c = 0;
         for (const auto &s : selected) mine[c++] = s.second;
+        for (uint32_t i = 0; i < had_n && c < max_links; i++) {
+            bool dup = false;
+            for (uint32_t j = 0; j < c; j++) dup |= (mine[j] == had[i]);
+            if (!dup) mine[c++] = had[i];
+        }
         if (level == 0) cnt0_[id] = (uint16_t)c;
         else *mine_cnt = c;
     }
@@ -388,6 +400,12 @@ long HnswIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
 long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     for (size_t i = 0; i < n; i++)
         if (label_to_id_.count(labels[i])) return -1;
+    {   // a label may appear once per batch (the sequential path would overwrite; the parallel one would keep both alive)
+        std::unordered_map<size_t, char> seen;
+        seen.reserve(n * 2);
+        for (size_t i = 0; i < n; i++)
+            if (!seen.emplace(labels[i], 1).second) return -1;
+    }
     size_t threads = std::thread::hardware_concurrency();
     if (const char *e = std::getenv("VECSIM_HNSW_BUILD_THREADS")) threads = (size_t)std::max(1, std::atoi(e));
     // (more threads link faster but see less of each other's nodes: at 256 threads recall on a 20 K-row graph fell
