@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mfma", type=int, default=1)
+    ap.add_argument("--readers", type=int, default=2,
+                    help="threads submitting batches (the reference's readers: bindings.cpp:250-283 knn_parallel); 2 lets one "
+                         "batch's upload / probe / re-rank / download / host replay overlap with the next batch's scan kernel")
     a = ap.parse_args()
     typ, metric, dim, rows, batch, k, tag, gen, cpu_rows = CONFIGS[a.config]
     a.type_name, a.metric_name, a.dtype, a.gen = typ, metric, tag, gen
@@ -179,16 +182,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # the sharded exchange is a collective: every rank must issue its batches in the same order, so one reader there
+    readers = 1 if distributed else max(1, min(args.readers, args.steps))
     for w in range(args.warmup):
         ix.knn_query(qsets[w % nb_distinct], args.topk)
+    pool = None
+    if readers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(readers)
+        list(pool.map(lambda w: ix.knn_query(qsets[w % nb_distinct], args.topk), range(2 * readers)))   # lanes warm
     local.reset_stats()
     sync()
     t0 = time.perf_counter()
     last = None
-    for s in range(args.steps):
-        last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk)
+    if pool is None:
+        for s in range(args.steps):
+            last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk)
+    else:
+        # exactly `steps` batches, each answered end to end by one of the reader threads (ctypes drops the GIL in the call)
+        last = list(pool.map(lambda s: ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk), range(args.steps)))[-1]
     sync()
     dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.shutdown()
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -236,6 +252,7 @@ def main():
             "config": {"workload": "%s: flat_%s_%s_top%d" % (args.config, args.dtype, args.metric_name.lower(), args.topk),
                        "rows_per_gpu": args.rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
+                       "reader_threads": readers,
                        "exchange": "rccl ncclAllGather of per-shard candidate records + exact host merge (C++ host library)"
                        if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
             "roofline": roof,

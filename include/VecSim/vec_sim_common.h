@@ -4,10 +4,10 @@
  * Binary-compatible restatement of the reference's public types (src/VecSim/vec_sim_common.h:60-502):
  * identical names, field order, enum values and therefore identical sizeof/offsetof, so a caller
  * compiled against the reference headers can link against libvecsim_amd.so unchanged.
- * tests/test_abi_layout.py checks every size and offset below against a fixture generated from the
- * reference header (tests/golden/abi_layout.json).
+ * tests/test_abi.py checks every size and offset below against a fixture generated from the
+ * reference header (tests/golden/abi_layout.json, made by tests/golden/make_abi_layout.py).
  *
- * Only Flat (VecSimAlgo_BF) indexes are constructible in this build; the HNSW / tiered / SVS
+ * Flat (VecSimAlgo_BF) and HNSW (VecSimAlgo_HNSWLIB) indexes are constructible in this build; the tiered / SVS
  * parameter blocks are declared because they fix the size of the AlgoParams union.
  */
 #pragma once

@@ -67,6 +67,13 @@ int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row);   /* upd
 int vsgpu_table_move(vsgpu_table *t, size_t dst_id, size_t src_id);       /* swap-delete copy */
 int vsgpu_table_truncate(vsgpu_table *t, size_t new_size);
 int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row);          /* getElement */
+/* Reader lanes: a view shares the parent's rows but runs its queries on another context (own stream and scratch), so
+ * concurrent readers -- which the reference allows on one index (vec_sim.h, bindings.cpp:250-283 knn_parallel) -- overlap
+ * one reader's small kernels, copies and host work with another reader's scan kernel.  The table-wide scan kernels of all
+ * lanes are chained on the GPU in submission order.  The caller keeps writers out while views are queried and calls
+ * _view_sync after the parent's rows changed; vsgpu_table_destroy frees a view (before its parent). */
+vsgpu_table *vsgpu_table_view_create(vsgpu_table *parent, vsgpu_ctx *ctx);
+int vsgpu_table_view_sync(vsgpu_table *view);
 /* append n synthetic rows generated on the device: element j of row i is
  * synth(seed, (first_id+i)*dim + j), bit-identical to oracle/vso.c:vso_synth_f32 (fp32 only) */
 int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed);

@@ -910,3 +910,39 @@ def test_batch_iterator_device_state_equals_host_array(vso, typ, ties):
     # and the first batch is the exact top-k
     sc = vso.scan(TYPES[typ], 0, rows, q, dim)
     assert np.array_equal(a[0][1], np.sort(sc)[:10])
+
+
+# ---------------------------------------------------------------- concurrent readers (reader lanes)
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [("f32", "L2", 256, 60_000, 64, 10), ("bf16", "IP", 256, 60_000, 128, 10),
+                                                    ("i8", "Cosine", 512, 40_000, 70, 20)])
+def test_concurrent_readers_get_the_single_reader_replies(vso, typ, metric, dim, n, nq, k):
+    """The reference lets several readers query one index at once (vec_sim.h; bindings.cpp:250-283 knn_parallel).  Four
+    threads x 12 batches on one index: a reader that finds the index's own context busy runs on a reader lane (a view of the
+    same rows with its own stream and scratch).  Every reply must equal the reply of the same batch asked alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(n + dim)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    qs = [random_vectors(rng, nq, dim, typ, vso) for _ in range(6)]
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    alone = [ix.knn_query(q, k) for q in qs]
+    el, es = oracle_topk(vso, typ, metric, rows, qs[0][0], k)
+    assert np.array_equal(alone[0][0][0], el.astype(np.int64)) and np.array_equal(alone[0][1][0], es)
+    ix.reset_stats()
+    with ThreadPoolExecutor(4) as pool:
+        got = list(pool.map(lambda i: ix.knn_query(qs[i % 6], k), range(48)))
+    for i, (l, d) in enumerate(got):
+        assert np.array_equal(l, alone[i % 6][0]) and np.array_equal(d, alone[i % 6][1]), i
+    assert ix.stats()["scan_launches"] == 48
+    # an add between query rounds reaches every lane
+    extra = random_vectors(rng, 500, dim, typ, vso)
+    ix.add_vectors(extra, np.arange(n, n + 500))
+    alone2 = [ix.knn_query(q, k) for q in qs[:2]]
+    with ThreadPoolExecutor(4) as pool:
+        got2 = list(pool.map(lambda i: ix.knn_query(qs[i % 2], k), range(8)))
+    for i, (l, d) in enumerate(got2):
+        assert np.array_equal(l, alone2[i % 2][0]) and np.array_equal(d, alone2[i % 2][1]), i
+    allrows = np.concatenate([rows, extra])
+    el, es = oracle_topk(vso, typ, metric, allrows, qs[1][3], k)
+    assert np.array_equal(alone2[1][0][3], el.astype(np.int64)) and np.array_equal(alone2[1][1][3], es)

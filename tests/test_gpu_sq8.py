@@ -84,7 +84,14 @@ def test_sq8_topk_filtered_path(vso, metric, dim, n, nq, k):
     ix = make(metric, dim)
     ix.add_vectors(rows, np.arange(n))
     ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
     labels, dists = ix.knn_query(q, k)
+    stt = ix.stats()
+    # dims up to 1024 ride the int8 MFMA filter (one int8 piece per query element, rigorous bound, exact re-rank)
+    assert stt["scan_kernel"] == "k_mfma_filter_lowp(sq8)" and stt["fallbacks"] == 0, stt
+    ix.set_option("mfma", 0)
+    l0, d0 = ix.knn_query(q[:4], k)
+    assert np.array_equal(l0, labels[:4]) and np.array_equal(d0, dists[:4])
     st, qb = oracle_blobs(vso, rows, q, metric)
     for j in range(0, nq, 3):
         sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
@@ -163,3 +170,28 @@ def test_sq8_stored_blob_is_the_preprocessors(vso):
         for i in range(5):
             got = ix.get_vector(i)
             assert got.shape == (1, st.shape[1]) and np.array_equal(got[0], st[i]), (metric, i)
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+def test_sq8_mfma_filter_hard_inputs(vso, metric):
+    """what the bound has to survive: rows of very different scale (delta from 1e-4 to 40), near-duplicates of the query
+    (scores crowd around the threshold), queries with one dominant component (coarse int8 piece), k = 100"""
+    rng = np.random.default_rng(77)
+    dim, n, nq, k = 320, 30_000, 24, 100
+    scale = np.exp(rng.uniform(np.log(1e-2), np.log(5e3), n)).astype(np.float32) if metric != "Cosine" else np.ones(n, np.float32)
+    rows = (rng.uniform(-1, 1, (n, dim)) * scale[:, None]).astype(np.float32)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    q[::3, 5] *= 300.0                                     # a dominant component: every other Y_i rounds to 0 or +-1
+    rows[1000:1400] = q[1] + rng.normal(0, 1e-3, (400, dim)).astype(np.float32)   # near-duplicates of one query
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(sq8)"
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(nq):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, j)
+        assert np.array_equal(dists[j], es), (metric, j)

@@ -153,6 +153,7 @@ GPU_EXPORTS = [
     "vsgpu_ctx_device", "vsgpu_ctx_sync", "vsgpu_table_create", "vsgpu_table_destroy",
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
     "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_append_synthetic",
+    "vsgpu_table_view_create", "vsgpu_table_view_sync",
     "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",

@@ -340,15 +340,36 @@ extern "C" int VecSimGpu_SetDevice(int device) {
 }
 extern "C" int VecSimGpu_DeviceCount(void) { return vsgpu_device_count(); }
 extern "C" const char *VecSimGpu_LastError(void) { return vsgpu_last_error(); }
-extern "C" void VecSimGpu_ResetStats(VecSimIndex *index) { vsgpu_stats_reset(index->gpu()); }
+extern "C" void VecSimGpu_ResetStats(VecSimIndex *index) {
+    for (vsgpu_ctx *c : index->gpus()) vsgpu_stats_reset(c);
+}
 extern "C" void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out) {
     static_assert(sizeof(VecSimGpuStats) == sizeof(vsgpu_stats), "stats structs must stay in sync");
-    vsgpu_stats s;
-    vsgpu_stats_get(index->gpu(), &s);
+    vsgpu_stats s{};
+    bool first = true;
+    for (vsgpu_ctx *c : index->gpus()) {   // summed over the reader lanes
+        vsgpu_stats l;
+        vsgpu_stats_get(c, &l);
+        if (first) {
+            s = l;
+            first = false;
+            continue;
+        }
+        s.scan_ms += l.scan_ms;
+        s.scan_launches += l.scan_launches;
+        s.scan_rows += l.scan_rows;
+        s.scan_bytes += l.scan_bytes;
+        s.other_ms += l.other_ms;
+        s.candidates += l.candidates;
+        s.fallbacks += l.fallbacks;
+        if (!s.scan_kernel[0]) std::memcpy(s.scan_kernel, l.scan_kernel, sizeof s.scan_kernel);
+    }
     std::memcpy(out, &s, sizeof s);
 }
 extern "C" int VecSimGpu_SetOption(VecSimIndex *index, const char *name, long value) {
-    return vsgpu_set_option(index->gpu(), name, value);
+    int rc = 0;
+    for (vsgpu_ctx *c : index->gpus()) rc |= vsgpu_set_option(c, name, value);
+    return rc;
 }
 
 extern "C" int VecSimGpu_HnswGraphInfo(VecSimIndex *index, uint64_t info[6]) {

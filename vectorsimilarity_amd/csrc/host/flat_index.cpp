@@ -63,6 +63,11 @@ static int resolve_tier() {
     return VSGPU_TIER_AVX512;
 }
 
+static size_t reader_lanes() {
+    if (const char *e = std::getenv("VECSIM_GPU_READER_LANES")) return (size_t)std::max(1, std::min(8, std::atoi(e)));
+    return 2;
+}
+
 FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
     if (p.dim == 0 || p.type > VecSimType_UINT8 || p.metric > VecSimMetric_Cosine) return nullptr;
     vsgpu_ctx *ctx = vsgpu_ctx_create(resolve_device());
@@ -84,7 +89,29 @@ FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
         delete ix;
         return nullptr;
     }
+    for (size_t i = 1; i < reader_lanes(); i++) {   // extra reader lanes (best effort: without them readers take turns)
+        auto lane = std::make_unique<Lane>();
+        lane->ctx = vsgpu_ctx_create(vsgpu_ctx_device(ctx));
+        if (!lane->ctx) break;
+        lane->view = vsgpu_table_view_create(ix->table_, lane->ctx);
+        if (!lane->view) {
+            vsgpu_ctx_destroy(lane->ctx);
+            break;
+        }
+        ix->lanes_.push_back(std::move(lane));
+    }
     return ix;
+}
+
+FlatIndex::Lane *FlatIndex::tryLane() {
+    for (auto &l : lanes_)
+        if (l->mu.try_lock()) return l.get();
+    return nullptr;
+}
+std::vector<vsgpu_ctx *> FlatIndex::gpus() {
+    std::vector<vsgpu_ctx *> v{ctx_};
+    for (auto &l : lanes_) v.push_back(l->ctx);
+    return v;
 }
 
 FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
@@ -108,6 +135,17 @@ FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
         ix->ctx_ = nullptr;
         delete ix;
         return nullptr;
+    }
+    for (size_t i = 1; i < reader_lanes(); i++) {   // extra reader lanes (best effort: without them readers take turns)
+        auto lane = std::make_unique<Lane>();
+        lane->ctx = vsgpu_ctx_create(vsgpu_ctx_device(ctx));
+        if (!lane->ctx) break;
+        lane->view = vsgpu_table_view_create(ix->table_, lane->ctx);
+        if (!lane->view) {
+            vsgpu_ctx_destroy(lane->ctx);
+            break;
+        }
+        ix->lanes_.push_back(std::move(lane));
     }
     return ix;
 }
@@ -142,6 +180,10 @@ double FlatIndex::storedDistance(size_t label_a, size_t label_b) {
 }
 
 FlatIndex::~FlatIndex() {
+    for (auto &l : lanes_) {
+        if (l->view) vsgpu_table_destroy(l->view);
+        if (l->ctx) vsgpu_ctx_destroy(l->ctx);
+    }
     if (table_) vsgpu_table_destroy(table_);
     if (ctx_) vsgpu_ctx_destroy(ctx_);
 }
@@ -166,13 +208,13 @@ void FlatIndex::stageRow(const void *processed) {
 
 int FlatIndex::flush() {
     if (staged_rows_ == 0) return 0;
-    int rc = vsgpu_table_append(table_, staged_.data(), staged_rows_);
+    int rc = vsgpu_table_append(table_, staged_.data(), staged_rows_.load());
     if (rc) {
         log("warning", "device append failed: %s", vsgpu_last_error());
         return rc;
     }
     staged_.clear();
-    staged_rows_ = 0;
+    staged_rows_.store(0, std::memory_order_release);
     return 0;
 }
 
@@ -486,7 +528,25 @@ void FlatIndex::iteratorDeviceEnd(vsgpu_scorebuf *b) {
 
 int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                               VecSimQueryReply_Order order, VecSimQueryReply **out) {
-    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    // readers may call concurrently (vec_sim.h contract): the first one runs on the index's own context, one that finds
+    // it busy on a reader lane (flat_index.h), the rest take turns
+    std::unique_lock<std::recursive_mutex> gpu_lock(gpu_mu_, std::defer_lock);
+    Lane *lane = nullptr;
+    if (!gpu_lock.try_lock()) {
+        if (!multi_ && staged_rows_.load(std::memory_order_acquire) == 0) lane = tryLane();
+        if (!lane) gpu_lock.lock();
+    }
+    struct LaneRelease {
+        Lane *l;
+        ~LaneRelease() {
+            if (l) l->mu.unlock();
+        }
+    } lane_release{lane};
+    vsgpu_table *tbl = table_;
+    if (lane) {
+        vsgpu_table_view_sync(lane->view);
+        tbl = lane->view;
+    }
     void *tctx = qp ? qp->timeoutCtx : nullptr;
     last_mode_ = STANDARD_KNN;
     if (nq == 0) return 0;
@@ -503,7 +563,7 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
         return finish();
     }
-    if (flush()) {
+    if (!lane && flush()) {
         for (auto *r : reps) delete r;
         return -1;
     }
@@ -558,7 +618,7 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     const size_t cap = std::max<size_t>(2 * kk, kk + 64);
     std::vector<uint32_t> ids(nq * cap), counts(nq);
     std::vector<double> sc(nq * cap);
-    int rc = vsgpu_topk(table_, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
+    int rc = vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
     if (rc) {
         log("warning", "GPU top-k failed: %s", vsgpu_last_error());
         for (auto *r : reps) delete r;
@@ -592,7 +652,7 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     for (size_t q = 0; q < nq; q++) {
         if (counts[q] != VSGPU_COUNT_OVERFLOW) continue;
         // more than `cap` rows tie at the k-th score: replay over every row's GPU score
-        rc = vsgpu_scores(table_, qbuf.data() + q * query_bytes_, 0, count_, (all.resize(count_), all.data()));
+        rc = vsgpu_scores(tbl, qbuf.data() + q * query_bytes_, 0, count_, (all.resize(count_), all.data()));
         if (rc) {
             for (auto *r : reps) delete r;
             return rc;

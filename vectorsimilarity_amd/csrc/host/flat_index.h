@@ -7,6 +7,7 @@
 // hot path and the calls either side of it.
 #pragma once
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <unordered_map>
@@ -82,6 +83,8 @@ struct VecSimIndexInterface {
     virtual void iteratorDeviceEnd(vsgpu_scorebuf *) {}
     virtual size_t rowLabel(size_t) const { return 0; }
     virtual vsgpu_ctx *gpu() = 0;
+    // every GPU context of the index (reader lanes included): options go to all, statistics are summed over them
+    virtual std::vector<vsgpu_ctx *> gpus() { return {gpu()}; }
     virtual void setLastMode(VecSearchMode m) = 0;
 };
 
@@ -121,6 +124,7 @@ public:
     long storedVectors(size_t label, void *out, size_t cap_bytes) override;
     size_t storedBlobBytes() const override { return stored_bytes_; }
     vsgpu_ctx *gpu() override { return ctx_; }
+    std::vector<vsgpu_ctx *> gpus() override;
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
     int iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) override;
@@ -172,7 +176,19 @@ private:
     void toQuery(const void *query, char *out) const;
     std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     std::vector<char> staged_;  // rows appended but not yet uploaded
-    size_t staged_rows_ = 0;
+    std::atomic<size_t> staged_rows_{0};
+    // Reader lanes: the reference lets any number of readers query one index at a time (vec_sim.h threading contract,
+    // bindings.cpp:250-283).  The first reader uses the index's own context; a reader that finds it busy takes a lane --
+    // another context (stream + scratch) over a view of the same rows (vsgpu_table_view_create) -- so its query upload,
+    // probe, re-rank, download and host replay overlap with the other reader's scan kernel.  VECSIM_GPU_READER_LANES
+    // (default 2) counts the contexts; writers are the caller's to keep out, as upstream.
+    struct Lane {
+        vsgpu_ctx *ctx = nullptr;
+        vsgpu_table *view = nullptr;
+        std::mutex mu;
+    };
+    std::vector<std::unique_ptr<Lane>> lanes_;
+    Lane *tryLane();
     mutable VecSearchMode last_mode_ = EMPTY_MODE;
 };
 

@@ -24,7 +24,7 @@
 
 namespace vsg {
 
-enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3 };
+enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3, LP_SQ8 = 4 };
 enum LowpEpi { LE_FP_L2 = 0, LE_FP_IP = 1, LE_I8_L2 = 2, LE_I8_IP = 3, LE_I8_COS = 4, LE_U8_IP = 5 };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -55,6 +55,18 @@ template <> struct LowpOps<LP_U8> {
         return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
     }
 };
+// SQ8 storage x FP32 query (types/sq8.h; IP.cpp:34-80, L2.cpp:30-45): the codes ride the signed MFMA re-centred by 128
+// like uint8 rows; the fp32 query is quantised to ONE int8 piece per element on the host, y_i = s Y_i + e_i with
+// |Y_i| <= 127, so  sum c_i y_i = s (D + 128 sum Y) + sum c_i e_i,  D = sum (c_i - 128) Y_i exact in int32.  The kernel
+// turns that into bounds on the reference's score (per-row {min, delta, sum_squares}, 16 B of aux per row; per-query
+// {s, 128 sum Y, y_sum, y_sum_squares, W}), W >= 255 sum |e_i| + the reference's own fp32 rounding of the dot product;
+// survivors are re-scored by k_exact_pairs in the reference's lane order.
+template <> struct LowpOps<LP_SQ8> {
+    using acc_t = i32x4_t;
+    __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
+    }
+};
 template <> struct LowpOps<LP_I8> {
     using acc_t = i32x4_t;
     __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
@@ -71,6 +83,7 @@ struct LowpParams {
     uint32_t tile_first, tile_step, n_tiles;   // tile t covers rows (tile_first + t*tile_step)*RT ...
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
+    const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, W, 0, 0, 0}
     int epi;
     float cE, absE;
     float *tilemin;                      // MF_PROBE: [queries][tilemin_stride]
@@ -119,6 +132,9 @@ template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
+    constexpr bool SQ8 = (LK == LP_SQ8);
+    constexpr int AUXBUF = SQ8 ? 1024 : 256;   // bytes of per-tile aux values: 4 B per row, 16 B per row for SQ8
+    static_assert(!SQ8 || (!SKEW && NQW == 1 && RT * 16 <= AUXBUF && NWAVES * 256 >= AUXBUF), "SQ8 aux geometry");
     // units requested ahead.  DIST = NS-2 leaves one slot of slack: the slot refilled after a barrier was last read
     // a whole unit earlier, so the plain s_barrier is enough and hipcc may keep pipelining LDS reads across it
     constexpr int D = DIST ? DIST : NS - 1;
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     // piece costs its wave hundreds of issue cycles, and 16 waves each fetching the same 256 bytes was a third of all
     // pieces of the int8 kernel.  (SKEW keeps a private copy per wave: its halves pass different barriers.)
     const bool aux_loader = SKEW || wave == 0;
-    char *aux_lds = lds + NS * STAGE + (SKEW ? wave : 0) * (256 * NAUX);
+    char *aux_lds = lds + NS * STAGE + (SKEW ? wave : 0) * (AUXBUF * NAUX);
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * STAGE + NWAVES * 256 * NAUX);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * STAGE + NWAVES * 256 * NAUX + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq), aux_lds_off = mf_lds_offset(aux_lds);
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         }
         uint32_t arow = r0 + lane;
         if (arow >= P.n_rows) arow = P.n_rows - 1;
-        ap = abase + (arow & P.slab_mask);
+        ap = abase + (size_t)(arow & P.slab_mask) * (SQ8 ? 4 : 1);
     };
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
                      uint32_t abuf_i) {
@@ -288,7 +304,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
             }
         }
-        if (with_aux && aux_loader) glds4(apt, abuf_i * 256, aux_lds);
+        if (with_aux && aux_loader) {
+            if (SQ8) glds16<0>(apt, abuf_i * AUXBUF, aux_lds);
+            else glds4(apt, abuf_i * 256, aux_lds);
+        }
     };
 
     uint32_t tile = pair_map ? ((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : blockIdx.x;
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
                     const int p = (4 * (j % 4) + kq) ^ m16;
                     afr[f - F0] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
-                    if (LK == LP_U8) afr[f - F0] ^= 0x80808080u;
+                    if (LK == LP_U8 || LK == LP_SQ8) afr[f - F0] ^= 0x80808080u;
                 }
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
             } else if (!SKEW && DLATE > 0) request_ahead();
             stamp(3);
-            if (c == KCH - 1) {
+            if (c == KCH - 1 && !SQ8) {
                 // this tile's aux values (landed with unit 0): plain asm so that hipcc does not tie the read to
                 // the LDS-DMA stream and drain vmcnt in front of it
                 const uint32_t aoff = aux_lds_off + abuf * 256 + kq * 16;
@@ -460,7 +479,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
         for (int nt = 0; nt < NQW; nt++) tmin[nt] = INFINITY;
         // aux values were requested by the asm reads above (invisible to hipcc's own lgkmcnt bookkeeping)
-        if (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]));
+        if (SQ8) {
+        } else if (MT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]));
         else if (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]), "+v"(auxv[1]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0]), "+v"(auxv[1]), "+v"(auxv[2]), "+v"(auxv[3]));
         auto epilogue = [&](auto epi_tag) {
@@ -541,7 +561,58 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
             }
         };
-        if (!(dbg & 1)) {
+        // SQ8: bounds on the reference's score from the exact code dot product (LowpOps<LP_SQ8>).  With A = |min y_sum|,
+        // B = |delta s (D + K)|:  |score_ref - score| <= delta W + kU (2A + 2B + C), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
+        // covers every fp32 rounding on either side (a dozen at most, each relative to one of those magnitudes).
+        auto epilogue_sq8 = [&](auto l2_tag) {
+            constexpr bool L2 = decltype(l2_tag)::value;
+            constexpr float kU = 64.0f / 16777216.0f;
+            const float *qm = P.qmeta + (size_t)qidx[0] * 8;
+            const float qs = qm[0], ysum = qm[2], ysq = qm[3], W = qm[4];
+            const int K = (int)__float_as_uint(qm[1]);
+            const float tq = tau[0];
+            const uint32_t arow_off = aux_lds_off + abuf * AUXBUF;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                u32x4_t am[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(am[i]) : "v"(arow_off + (uint32_t)((mt * 16 + kq * 4 + i) * 16)));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lrow = mt * 16 + kq * 4 + i;
+                    const float mn = __uint_as_float(am[i][0]), dl = __uint_as_float(am[i][1]), xsq = __uint_as_float(am[i][2]);
+                    const float f = (float)((int)acc[mt][0][i] + K);
+                    const float dq = (dl * qs) * f;
+                    const float my = mn * ysum;
+                    const float ip = my + dq;
+                    const float C = L2 ? (xsq + ysq) : 1.0f;
+                    const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
+                    const float E = dl * W + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);
+                    const float low = sc - E, up = sc + E;
+                    if (MODE == MF_PROBE) {
+                        if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
+                    } else if (lrow < nvalid && !(low > tq)) {   // (a NaN bound goes on to the exact re-rank)
+                        const uint32_t row = r0 + lrow;
+                        const uint32_t pos = mf_queue_reserve(q_cnt_off);
+                        if (pos < Q_CAP) {
+                            mf_queue_write(q_rec_off + pos * 16, row, (uint32_t)qidx[0], __float_as_uint(low));
+                        } else {
+                            uint32_t s = atomicAdd(&P.counts[qidx[0]], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx[0] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            emitted = true;
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (SQ8) {
+            if (!(dbg & 1)) {
+                if (P.epi == LE_FP_L2) epilogue_sq8(std::true_type{});
+                else epilogue_sq8(std::false_type{});
+            }
+        } else if (!(dbg & 1)) {
             if (LK == LP_U8) {
                 if (P.epi == LE_U8_IP) epilogue(std::integral_constant<int, LE_U8_IP>{});
                 else epilogue(std::integral_constant<int, LE_I8_L2>{});
@@ -611,6 +682,16 @@ static __global__ __launch_bounds__(256) void k_row_norms_h16(const char *rows, 
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) out[row] = __float_as_uint((float)s);
+}
+// SQ8: {min, delta, sum_squares, 0} of every row, copied out of the (unaligned) metadata behind the codes into 16-byte
+// aux records (sum_squares only exists in L2 blobs)
+static __global__ __launch_bounds__(256) void k_row_aux_sq8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
+                                                     int is_l2, uint4 *out) {
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const unsigned char *m = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride + dim);
+    auto ld = [&](int o) { return (uint32_t)m[o] | ((uint32_t)m[o + 1] << 8) | ((uint32_t)m[o + 2] << 16) | ((uint32_t)m[o + 3] << 24); };
+    out[row] = make_uint4(ld(0), ld(4), is_l2 ? ld(12) : 0u, 0u);
 }
 // int8: sum x^2 as int32 (mode 0) or the float norm stored after the elements (mode 1, Cosine rows)
 static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,

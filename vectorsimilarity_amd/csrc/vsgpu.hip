@@ -110,7 +110,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2, &c->sel, &c->selcnt})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2, &c->sel, &c->selcnt, &c->qmeta})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
@@ -231,6 +231,15 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
                     break;
                 }
         }
+        if (type == VSGPU_SQ8 && !t->prog.scalar_tier && dim <= 1024) {
+            // SQ8 x FP32 on the int8 MFMA filter (mfma_lowp_kernels.hpp LP_SQ8): 8 waves x 16 queries, 64-row tiles
+            t->lowp_ok = true;
+            t->lp_kind = LP_SQ8;
+            t->lp_ksteps = dim <= 512 ? 8 : (dim <= 768 ? 12 : 16);
+            t->lp_rt = 64;
+            t->lp_qtile = 128;
+            t->aux_bytes = 16;
+        }
         if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && dim <= 1024) {
             t->lowp_ok = true;
             t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;  // uint8 Cosine would need two aux values per row: exact path
@@ -256,10 +265,51 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     return t;
 }
 
+// A view of `parent` for another context (reader lane): same rows, own stream + scratch.  The caller keeps writers away
+// while a view is in use and calls vsgpu_table_view_sync after the parent changed.
+extern "C" vsgpu_table *vsgpu_table_view_create(vsgpu_table *parent, vsgpu_ctx *ctx) {
+    if (!parent || !ctx || parent->parent || ctx->device != parent->ctx->device) {
+        fail(VSGPU_ERR_ARG, "bad view parameters");
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (!parent->chain) {
+        parent->chain = new ScanChain();
+        if (hipEventCreateWithFlags(&parent->chain_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    vsgpu_table *v = new vsgpu_table(*parent);
+    v->ctx = ctx;
+    v->parent = parent;
+    v->chain_ev = nullptr;
+    if (hipEventCreateWithFlags(&v->chain_ev, hipEventDisableTiming) != hipSuccess) {
+        delete v;
+        return nullptr;
+    }
+    parent->chain->users++;
+    return v;
+}
+extern "C" int vsgpu_table_view_sync(vsgpu_table *v) {
+    if (!v || !v->parent) return fail(VSGPU_ERR_ARG, "not a view");
+    const vsgpu_table *p = v->parent;
+    v->slabs = p->slabs;
+    v->d_slabs = p->d_slabs;
+    v->d_slabs_cap = p->d_slabs_cap;
+    v->norm_slabs = p->norm_slabs;
+    v->d_norm_slabs = p->d_norm_slabs;
+    v->n = p->n;
+    return VSGPU_OK;
+}
+
 extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->chain_ev) (void)hipEventDestroy(t->chain_ev);
+    if (t->chain && --t->chain->users == 0) delete t->chain;
+    if (t->parent) {   // a view owns nothing else
+        delete t;
+        return;
+    }
     for (char *s : t->slabs) (void)hipFree(s);
     for (float *s : t->norm_slabs) (void)hipFree(s);
     if (t->d_slabs) (void)hipFree(t->d_slabs);
@@ -284,8 +334,8 @@ static int grow_to(vsgpu_table *t, size_t rows) {
         t->slabs.push_back(p);
         if (t->mfma_ok || t->lowp_ok) {
             float *np = nullptr;
-            HIPCHK(hipMalloc((void **)&np, slab_rows * sizeof(float)));
-            poison(np, slab_rows * sizeof(float));
+            HIPCHK(hipMalloc((void **)&np, slab_rows * t->aux_bytes));
+            poison(np, slab_rows * t->aux_bytes);
             t->norm_slabs.push_back(np);
         }
         changed = true;
@@ -323,9 +373,13 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
     size_t id = first, left = n;
     while (left) {
         size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
-        float *np = t->norm_slabs[id >> t->slab_shift] + (id & (slab_rows - 1));
+        float *np = t->norm_slabs[id >> t->slab_shift] + (id & (slab_rows - 1)) * (t->aux_bytes / 4);
         const dim3 g((unsigned)((in_slab + 3) / 4));
-        if (t->mfma_ok)
+        if (t->lowp_ok && t->lp_kind == LP_SQ8)
+            hipLaunchKernelGGL(k_row_aux_sq8, dim3((unsigned)((in_slab + 255) / 256)), dim3(256), 0, t->ctx->stream,
+                               (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
+                               t->epi == EPI_SQ8_L2 ? 1 : 0, (uint4 *)np);
+        else if (t->mfma_ok)
             hipLaunchKernelGGL(k_row_norms_f32, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
         else if (t->lp_kind == LP_I8 || t->lp_kind == LP_U8)
@@ -1098,7 +1152,12 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     S.cap = (uint32_t)ccap;
     dim3 grid(64, (unsigned)nq);
     const bool l2 = (t->opk == OP_L2_FMA);
-    if (t->type == VSGPU_F32) {
+    S.norm_off = (uint32_t)t->dim;
+    S.qnorm = (const float *)c->qnorm.p;
+    S.sq8_fused = t->prog.fused ? 1 : 0;
+    if (t->type == VSGPU_SQ8) {
+        hipLaunchKernelGGL((k_exact_pairs<EK_SQ8, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+    } else if (t->type == VSGPU_F32) {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
         else hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else if (t->type == VSGPU_BF16) {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -38,7 +39,7 @@ struct vsgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt, qmeta;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     vsgpu_stats stats{};
@@ -82,8 +83,21 @@ struct WallMarks {
 int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes);
 int ensure_pinned(vsgpu_ctx *c, size_t bytes);
 
+// Reader lanes (vsgpu_table_view_create): several contexts -- each with its own stream and scratch -- query one set of
+// rows.  The big scan kernels of the lanes are chained on the GPU in submission order (each waits for the event the previous
+// one recorded), so they run one after the other at full bandwidth while a lane's small kernels, copies and host work
+// overlap with another lane's scan.
+struct ScanChain {
+    std::mutex mu;
+    hipEvent_t last = nullptr;   // recorded behind the most recently submitted scan kernel (owned by that lane's table)
+    int users = 1;
+};
+
 struct vsgpu_table {
     vsgpu_ctx *ctx = nullptr;
+    vsgpu_table *parent = nullptr;   // non-null: a view (shares the parent's slabs, lane table and aux arrays)
+    ScanChain *chain = nullptr;
+    hipEvent_t chain_ev = nullptr;
     int type = 0, metric = 0, tier = 0;
     size_t dim = 0, row_bytes = 0;
     vsg::LaneProgram prog;
@@ -101,6 +115,7 @@ struct vsgpu_table {
     // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
     bool lowp_ok = false;
     int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
+    size_t aux_bytes = 4;   // per-row aux record of the MFMA filters: 4 B, or 16 B {min, delta, sum_squares, 0} for SQ8 rows
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;
 };
@@ -126,6 +141,27 @@ static inline uint16_t bf16_rne(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+// around the launch of a table-wide scan kernel (between the timing events): orders it behind the other lanes' scans
+struct ScanChainGuard {
+    vsgpu_table *t;
+    bool held = false;
+    explicit ScanChainGuard(vsgpu_table *tt) : t(tt) {
+        if (!t->chain) return;
+        t->chain->mu.lock();
+        held = true;
+        if (t->chain->last && t->chain->last != t->chain_ev) (void)hipStreamWaitEvent(t->ctx->stream, t->chain->last, 0);
+    }
+    void submitted() {   // the scan is in the stream
+        if (!held) return;
+        (void)hipEventRecord(t->chain_ev, t->ctx->stream);
+        t->chain->last = t->chain_ev;
+        t->chain->mu.unlock();
+        held = false;
+    }
+    ~ScanChainGuard() {
+        if (held) t->chain->mu.unlock();
+    }
+};
 int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride);
 int tile_rows_of(int ek);
 int run_scan(vsgpu_table *t, vsg::ScanParams &P, size_t nq, bool timed);

@@ -184,7 +184,13 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
 #endif
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
-    else if (t->lp_kind == LP_U8) {
+    else if (t->lp_kind == LP_SQ8) {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_t<LP_SQ8, 8, 64, 1>(mode, P, grid, s); break;
+        case 12: launch_lowp_t<LP_SQ8, 12, 64, 1>(mode, P, grid, s); break;
+        default: launch_lowp_t<LP_SQ8, 16, 64, 1>(mode, P, grid, s); break;
+        }
+    } else if (t->lp_kind == LP_U8) {
         switch (t->lp_ksteps) {
         case 8: launch_lowp_i8<8, 64, LP_U8>(mode, P, grid, s); break;
         case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
@@ -236,10 +242,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
     const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
-    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);
+    const bool is_sq8 = (t->lp_kind == LP_SQ8);
+    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);   // exact integer scores, no re-rank
     const bool is_u8 = (t->lp_kind == LP_U8);
-    const size_t eb = is_int ? 1 : 2;
-    const size_t kelem = is_int ? 64 : 32;        // elements per MFMA k-step
+    const size_t eb = (is_int || is_sq8) ? 1 : 2;
+    const size_t kelem = (is_int || is_sq8) ? 64 : 32;        // elements per MFMA k-step
     const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
 
     int rc = VSGPU_OK;
@@ -252,8 +259,44 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     std::vector<unsigned char> frag(nqp * kdim * eb, 0);
     std::vector<uint32_t> qaux(nqp, 0);
     std::vector<float> tau0(nqp, -INFINITY);
+    std::vector<float> qmeta(is_sq8 ? nqp * 8 : 0, 0.0f);
+    std::vector<signed char> yq(is_sq8 ? dim : 0);
     for (size_t q = 0; q < nq; q++) {
         const unsigned char *src = (const unsigned char *)queries + q * qstride;
+        if (is_sq8) {
+            // one int8 piece per query element: y_i = s Y_i + e_i, |Y_i| <= 127 (LowpOps<LP_SQ8>).  W bounds, per unit of
+            // the row's delta, everything the kernel's dot product can be off the reference's by:
+            //   sum c_i e_i   <= 255 sum |e_i|
+            //   the reference's fp32 accumulation (dim/32 fused steps per lane + the tree; IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104)
+            //                 <= 2 (dim/32 + 8) 2^-24 * 255 sum |y_i|
+            const float *y = reinterpret_cast<const float *>(src);
+            double ymax = 0, yabs = 0;
+            for (size_t i = 0; i < dim; i++) {
+                ymax = std::max(ymax, (double)std::fabs(y[i]));
+                yabs += std::fabs((double)y[i]);
+            }
+            float sf = (float)(ymax / 127.0);
+            if (!(sf > 0.0f) || !std::isfinite(sf)) sf = 1.0f;
+            double e1 = 0;
+            long sy = 0;
+            for (size_t i = 0; i < dim; i++) {
+                double r = std::nearbyint((double)y[i] / (double)sf);
+                if (!(r >= -127.0)) r = -127.0;   // (also NaN)
+                if (r > 127.0) r = 127.0;
+                yq[i] = (signed char)r;
+                sy += (long)r;
+                e1 += std::fabs((double)y[i] - (double)sf * r);
+            }
+            const double W = (255.0 * e1 + 2.0 * ((double)dim / 32.0 + 8.0) * std::ldexp(1.0, -24) * 255.0 * yabs) * (1.0 + 1e-6);
+            float *qm = &qmeta[q * 8];
+            const int K = (int)(128 * sy);
+            qm[0] = sf;
+            memcpy(&qm[1], &K, 4);
+            memcpy(&qm[2], src + 4 * dim, 4);                                 // y_sum
+            if (t->metric == VSGPU_L2) memcpy(&qm[3], src + 4 * dim + 4, 4);  // y_sum_squares
+            qm[4] = std::nextafter((float)W, INFINITY);
+            src = reinterpret_cast<const unsigned char *>(yq.data());
+        }
         const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
         for (int s = 0; s < KS; s++)
             for (int kq = 0; kq < 4; kq++) {
@@ -264,7 +307,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 if (is_u8)
                     for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;  // q - 128 as int8 (columns past dim stay 0)
             }
-        if (is_u8) {
+        if (is_sq8) {
+        } else if (is_u8) {
             int s1 = 0, s2 = 0;
             for (size_t i = 0; i < dim; i++) {
                 const int v = (int)src[i] - 128;
@@ -306,6 +350,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
+    if (is_sq8) {
+        rc = ensure(c, c->qmeta, qmeta.size() * 4);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->qmeta.p, qmeta.data(), qmeta.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
@@ -320,7 +369,10 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     P.n_rows = (uint32_t)n;
     P.qfrag = (const uint4 *)c->qfrag.p;
     P.qaux = (const uint32_t *)c->qn2.p;
-    if (is_int) {
+    P.qmeta = (const float *)c->qmeta.p;
+    if (is_sq8) {
+        P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
+    } else if (is_int) {
         P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
     } else {
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
@@ -360,6 +412,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    ScanChainGuard chain(t);   // behind the other reader lanes' scans (no-op for a table without views)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {
         LowpParams Q = P;
@@ -397,6 +450,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    chain.submitted();
     if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
@@ -408,7 +462,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
-                              !is_int ? "k_mfma_filter_lowp(h16)"
+                              is_sq8 ? "k_mfma_filter_lowp(sq8)" : !is_int ? "k_mfma_filter_lowp(h16)"
 #ifdef VSGPU_TUNING
                               : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
 #endif

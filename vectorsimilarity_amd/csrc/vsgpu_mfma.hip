@@ -205,6 +205,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    ScanChainGuard chain(t);   // behind the other reader lanes' scans (no-op for a table without views)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {   // filter: every tile once
         MfmaParams Q = P;
@@ -217,6 +218,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    chain.submitted();
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
