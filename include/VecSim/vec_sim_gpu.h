@@ -118,8 +118,9 @@ uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
  * The reference defines the layouts (src/VecSim/types/sq8.h:19-62), the quantising preprocessor
  * (spaces/computer/preprocessors.h:259-649) and the distance kernels (spaces/IP/IP.cpp:34-183, spaces/L2/L2.cpp:30-45,
  * 185-201 and the AVX-512 twins chosen by L2_space.cpp:41-107, 518-571 / IP_space.cpp:41-176), but none of its RAM index
- * factories selects them, so the constructor is an extension.  A FlatSQ8 index takes fp32 vectors (params->type must be
- * VecSimType_FLOAT32) through the ordinary VecSimIndex_AddVector / _TopKQuery / _RangeQuery / batch-iterator calls:
+ * factories selects them, so the constructor is an extension.  A FlatSQ8 index takes fp32 vectors (params->type =
+ * VecSimType_FLOAT32), or fp16 vectors (VecSimType_FLOAT16: QuantPreprocessor<float16>, scores = SQ8_FP16_*,
+ * IP.cpp:82-144 / IP_AVX512F_SQ8_FP16.h), through the ordinary VecSimIndex_AddVector / _TopKQuery / _RangeQuery / batch-iterator calls:
  * rows are stored as SQ8 blobs (Cosine: normalised first), queries get y_sum / y_sum_squares appended, every score is the
  * reference's asymmetric SQ8_FP32 distance in its AVX-512 tier order (scalar tier below dim 8), evaluated on the GPU.
  * VecSimIndex_GetDistanceFrom_Unsafe takes the fp32 vector as given (caller-normalised for Cosine).

@@ -29,7 +29,10 @@ enum { VSGPU_F32 = 0, VSGPU_F64 = 1, VSGPU_BF16 = 2, VSGPU_F16 = 3, VSGPU_I8 = 4
        /* SQ8 storage rows (types/sq8.h:19-62): dim uint8 codes + FP32 {min, delta, sum[, sum_squares for L2]}, scored
         * against FP32 query blobs {y[dim], y_sum[, y_sum_squares]} by the asymmetric kernels of IP.cpp:34-80,
         * L2.cpp:30-45 and their AVX-512 twins.  Not a VecSimType: reached through VecSimGpu_NewFlatSQ8. */
-       VSGPU_SQ8 = 6 };
+       VSGPU_SQ8 = 6,
+       /* the same SQ8 rows scored against FP16 query blobs {y[dim] fp16, y_sum[, y_sum_squares] FP32}: SQ8_FP16_*
+        * (IP.cpp:82-144, L2.cpp:47-74, IP_AVX512F_SQ8_FP16.h: four 16-lane accumulators, scalar below dim 16) */
+       VSGPU_SQ8H = 7 };
 enum { VSGPU_L2 = 0, VSGPU_IP = 1, VSGPU_COSINE = 2 };
 /* which reference ISA tier's summation order the kernels reproduce */
 enum { VSGPU_TIER_AVX512 = 0, VSGPU_TIER_SCALAR = 1, VSGPU_TIER_AVX512_BF16 = 2 };

@@ -88,6 +88,14 @@ double vso_sq8_fp32_distance(int metric, int tier, size_t dim, const void *stora
 double vso_sq8_sq8_distance(int metric, int tier, size_t dim, const void *a, const void *b);
 void vso_sq8_fp32_scan(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
                        double *out);
+/* FP16 inputs / queries (QuantPreprocessor<float16>, SQ8_FP16_*): query blob = dim fp16 values + FP32 metadata */
+size_t vso_sq8_query_size_f16(int metric, size_t dim);
+void vso_sq8_quantize_f16(const uint16_t *x, size_t dim, int metric, uint8_t *out);
+void vso_sq8_query_blob_f16(const uint16_t *y, size_t dim, int metric, void *out);
+int vso_sq8_fp16_uses_scalar(int tier, size_t dim);
+double vso_sq8_fp16_distance(int metric, int tier, size_t dim, const void *storage, const void *query);
+void vso_sq8_fp16_scan(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                       double *out);
 
 /* whole Flat query on host rows (scan + replay) */
 size_t vso_flat_topk(int type, int metric, int tier, size_t dim, const void *rows, size_t n,

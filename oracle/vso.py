@@ -90,6 +90,16 @@ def lib():
         L.vso_sq8_sq8_distance.argtypes = [i, i, sz, vp, vp]
         L.vso_sq8_fp32_scan.restype = None
         L.vso_sq8_fp32_scan.argtypes = [i, i, sz, vp, sz, sz, vp, vp]
+        L.vso_sq8_query_size_f16.restype = sz
+        L.vso_sq8_query_size_f16.argtypes = [i, sz]
+        L.vso_sq8_quantize_f16.restype = None
+        L.vso_sq8_quantize_f16.argtypes = [vp, sz, i, vp]
+        L.vso_sq8_query_blob_f16.restype = None
+        L.vso_sq8_query_blob_f16.argtypes = [vp, sz, i, vp]
+        L.vso_sq8_fp16_distance.restype = dbl
+        L.vso_sq8_fp16_distance.argtypes = [i, i, sz, vp, vp]
+        L.vso_sq8_fp16_scan.restype = None
+        L.vso_sq8_fp16_scan.argtypes = [i, i, sz, vp, sz, sz, vp, vp]
         L.vso_has_avx512.restype = i
         L.vso_has_f16c.restype = i
         L.vso_f16c_distance.restype = dbl
@@ -177,6 +187,36 @@ def sq8_fp32_scan(metric, rows, query, dim, tier=TIER_AVX512):
     query = np.ascontiguousarray(query)
     out = np.empty(rows.shape[0], dtype=np.float64)
     lib().vso_sq8_fp32_scan(metric, tier, dim, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(query), _ptr(out))
+    return out
+
+
+def sq8_quantize_f16(x, metric):
+    """storage blob of one fp16 vector (uint16 bit patterns): QuantPreprocessor<float16, metric>"""
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    out = np.zeros(lib().vso_sq8_storage_size(metric, x.size), dtype=np.uint8)
+    lib().vso_sq8_quantize_f16(_ptr(x), x.size, metric, _ptr(out))
+    return out
+
+
+def sq8_query_blob_f16(y, metric):
+    """query blob of one fp16 vector: the fp16 values followed by FP32 y_sum (y_sum_squares), as raw bytes"""
+    y = np.ascontiguousarray(y, dtype=np.uint16)
+    out = np.zeros(lib().vso_sq8_query_size_f16(metric, y.size), dtype=np.uint8)
+    lib().vso_sq8_query_blob_f16(_ptr(y), y.size, metric, _ptr(out))
+    return out
+
+
+def sq8_fp16_distance(metric, storage, query, dim, tier=TIER_AVX512):
+    storage = np.ascontiguousarray(storage)
+    query = np.ascontiguousarray(query)
+    return lib().vso_sq8_fp16_distance(metric, tier, dim, _ptr(storage), _ptr(query))
+
+
+def sq8_fp16_scan(metric, rows, query, dim, tier=TIER_AVX512):
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    out = np.empty(rows.shape[0], dtype=np.float64)
+    lib().vso_sq8_fp16_scan(metric, tier, dim, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(query), _ptr(out))
     return out
 
 

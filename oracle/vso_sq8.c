@@ -21,7 +21,11 @@
  *         a*b + c*d                      ->  fma(a, b, c*d)
  *         a*b + c*d + e*f*g - h*i*j      ->  fnma(h*i, j, fma(e*f, g, fma(a, b, c*d)))
  *         x + y - 2*ip                   ->  fnma(2, ip, x + y)   (== (x + y) - 2 ip: 2 ip is exact)
- * Not restated: the FP16-query kernels (SQ8_FP16), the mean-centred WithNorm variants and the calculator built on them.
+ * FP16 inputs / queries (QuantPreprocessor<float16, ...>, SQ8_FP16_*: IP.cpp:82-144, L2.cpp:47-74,
+ * IP/IP_AVX512F_SQ8_FP16.h:29-120, L2/L2_AVX512F_SQ8_FP16.h:18-34, choosers L2_space.cpp:109-180): every fp16 value is
+ * widened exactly (types/float16.h:33-52) and all arithmetic is FP32, so the quantiser equals the FP32 one on the widened
+ * vector; the AVX-512F kernel keeps FOUR 16-lane accumulators.
+ * Not restated: the mean-centred WithNorm variants and the calculator built on them.
  */
 #include <math.h>
 #include <string.h>
@@ -206,4 +210,96 @@ void vso_sq8_fp32_scan(int metric, int tier, size_t dim, const void *rows, size_
                        double *out) {
 #pragma omp parallel for schedule(static) if (n * dim > (1u << 22))
     for (size_t i = 0; i < n; i++) out[i] = vso_sq8_fp32_distance(metric, tier, dim, (const char *)rows + i * stride, query);
+}
+
+/* ---- FP16 inputs and queries ---- */
+size_t vso_sq8_query_size_f16(int metric, size_t dim) { return dim * 2 + (metric == VSO_L2 ? 2 : 1) * sizeof(float); }
+
+/* QuantPreprocessor<float16>::quantize: min / max by FP32 comparison of the widened values (float16.h:54-61),
+ * transformed_value = to_fp32 (preprocessors.h:247-252, 611-617): the FP32 quantiser on the widened vector */
+void vso_sq8_quantize_f16(const uint16_t *x, size_t dim, int metric, uint8_t *out) {
+    float w[dim ? dim : 1];
+    for (size_t i = 0; i < dim; i++) w[i] = vso_f16_to_f32(x[i]);
+    vso_sq8_quantize(w, dim, metric, out);
+}
+/* query blob: the fp16 values, then FP32 y_sum (y_sum_squares) of the widened values at an unaligned offset */
+void vso_sq8_query_blob_f16(const uint16_t *y, size_t dim, int metric, void *out) {
+    memcpy(out, y, dim * 2);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const size_t d4 = dim & ~(size_t)3;
+    size_t i = 0;
+    for (; i < d4; i += 4)
+        for (int j = 0; j < 4; j++) {
+            const float v = vso_f16_to_f32(y[i + j]);
+            s[j] += v;
+            q[j] += v * v;
+        }
+    float sum = (s[0] + s[1]) + (s[2] + s[3]);
+    float sq = (q[0] + q[1]) + (q[2] + q[3]);
+    for (; i < dim; i++) {
+        const float v = vso_f16_to_f32(y[i]);
+        sum += v;
+        sq += v * v;
+    }
+    float meta[2] = {sum, sq};
+    memcpy((char *)out + dim * 2, meta, (metric == VSO_L2 ? 2 : 1) * sizeof(float));
+}
+int vso_sq8_fp16_uses_scalar(int tier, size_t dim) { return tier == VSO_TIER_SCALAR || dim < 16; } /* L2_space.cpp:121-123 */
+
+double vso_sq8_fp16_distance(int metric, int tier, size_t dim, const void *storage, const void *query) {
+    const uint8_t *c = (const uint8_t *)storage;
+    const uint16_t *y = (const uint16_t *)query;
+    const uint8_t *qm = (const uint8_t *)query + dim * 2;
+    const float min_val = ldf(c + dim), delta = ldf(c + dim + 4);
+    const float y_sum = ldf(qm);
+    float ip;
+    if (vso_sq8_fp16_uses_scalar(tier, dim)) {   /* IP.cpp:97-132 */
+        float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const size_t d4 = dim & ~(size_t)3;
+        size_t i = 0;
+        for (; i < d4; i += 4) {
+            s0 += (float)c[i] * vso_f16_to_f32(y[i]);
+            s1 += (float)c[i + 1] * vso_f16_to_f32(y[i + 1]);
+            s2 += (float)c[i + 2] * vso_f16_to_f32(y[i + 2]);
+            s3 += (float)c[i + 3] * vso_f16_to_f32(y[i + 3]);
+        }
+        for (; i < dim; i++) s0 += (float)c[i] * vso_f16_to_f32(y[i]);
+        const float qd = (s0 + s1) + (s2 + s3);
+        const float a = min_val * y_sum, b = delta * qd;
+        ip = a + b;
+    } else {
+        /* IP_AVX512F_SQ8_FP16.h:42-101: dim % 16 head = masked multiply into sum0; 64 elements per round over
+         * sum0..sum3; up to three 16-chunks of tail into sum0, sum1, sum2; (sum0 + sum1) + (sum2 + sum3); reduce tree */
+        float acc[4][16];
+        for (int a = 0; a < 4; a++)
+            for (int j = 0; j < 16; j++) acc[a][j] = 0.0f;
+        const size_t residual = dim % 16;
+        size_t pos = 0;
+        for (size_t j = 0; j < residual; j++) acc[0][j] = (float)c[j] * vso_f16_to_f32(y[j]);
+        pos = residual;
+        while (dim - pos >= 64) {
+            for (int a = 0; a < 4; a++, pos += 16)
+                for (size_t j = 0; j < 16; j++) acc[a][j] = fmaf((float)c[pos + j], vso_f16_to_f32(y[pos + j]), acc[a][j]);
+        }
+        const size_t remaining = dim - pos;
+        for (int a = 0; a < 3; a++)
+            if (remaining >= (size_t)(16 * (a + 1))) {
+                for (size_t j = 0; j < 16; j++) acc[a][j] = fmaf((float)c[pos + j], vso_f16_to_f32(y[pos + j]), acc[a][j]);
+                pos += 16;
+            }
+        float v[16];
+        for (int j = 0; j < 16; j++) v[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+        for (int o = 8; o >= 1; o >>= 1)
+            for (int j = 0; j < o; j++) v[j] = v[j] + v[j + o];
+        ip = fmaf(min_val, y_sum, delta * v[0]);   /* functions/AVX512F.cpp is an FMA translation unit (header note) */
+    }
+    if (metric != VSO_L2) return (double)(1.0f - ip);
+    const float x_sq = ldf(c + dim + 12), y_sq = ldf(qm + 4);
+    const float t = x_sq + y_sq;
+    return (double)(t - 2.0f * ip);
+}
+void vso_sq8_fp16_scan(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                       double *out) {
+#pragma omp parallel for schedule(static) if (n * dim > (1u << 22))
+    for (size_t i = 0; i < n; i++) out[i] = vso_sq8_fp16_distance(metric, tier, dim, (const char *)rows + i * stride, query);
 }

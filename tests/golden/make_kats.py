@@ -193,6 +193,10 @@ def sq8():
                   query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="L2", expect=5.0, src="test_spaces.cpp:485-530"))
     d.append(dict(name="ip_closed_form", dim=5, codes=[1, 2, 3, 4, 5], meta=[0.0, 1.0, 15.0, 55.0],
                   query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="IP", expect=-69.0, src="test_spaces.cpp:485-530"))
+    # the FP16-query kernel's own closed form (the only exact distance the reference's SQ8 tests state)
+    d.append(dict(name="l2_closed_form_fp16_query", dim=5, codes=[1, 2, 3, 4, 5], meta=[0.0, 1.0, 15.0, 55.0],
+                  query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="L2", expect=5.0, query_type="f16",
+                  src="test_spaces.cpp:485-530"))
     return dict(quantize=q, distance=d,
                 tolerance_property=dict(abs=0.01, src="test_spaces.cpp:326-410, 2330-2700: every tier within 0.01 of the "
                                         "reconstruct-then-dot baseline (tests/utils/tests_utils.h:76-170, 244-270)"))

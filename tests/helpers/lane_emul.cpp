@@ -153,3 +153,34 @@ extern "C" double lane_emul_sq8(int metric, int tier, size_t dim, const void *st
     const float two_ip = 2.0f * ip;
     return (double)(t - two_ip);
 }
+
+// SQ8 storage x FP16 query (VSGPU_SQ8H): 64 virtual lanes, fp16 query values widened exactly, metadata behind 2 dim bytes
+extern "C" double lane_emul_sq8h(int metric, int tier, size_t dim, const void *storage, const void *query_blob) {
+    vsg::LaneProgram p = vsg::build_lane_program(VSGPU_SQ8H, VSGPU_IP, tier, dim);
+    const unsigned char *c = (const unsigned char *)storage;
+    const char *y = (const char *)query_blob;
+    std::vector<float> acc(p.vl, 0.0f);
+    for (int s = 0; s < p.steps; s++)
+        for (int l = 0; l < p.vl; l++) {
+            int off = p.offs[(size_t)s * p.vl + l];
+            if (off < 0) continue;
+            const float x = (float)c[off];
+            uint16_t h;
+            std::memcpy(&h, y + 2 * (size_t)off, 2);
+            const float q = widen16(VSGPU_F16, h);
+            if (p.fused) acc[l] = std::fma(x, q, acc[l]);
+            else { float m = x * q; acc[l] = acc[l] + m; }
+        }
+    const float qdot = tree(acc, p.vl);
+    float meta[4] = {0, 0, 0, 0}, qm[2] = {0, 0};
+    std::memcpy(meta, c + dim, metric == 0 ? 16 : 12);
+    std::memcpy(qm, y + 2 * dim, metric == 0 ? 8 : 4);
+    const float dq = meta[1] * qdot;
+    float ip;
+    if (p.fused) ip = std::fma(meta[0], qm[0], dq);
+    else { float a = meta[0] * qm[0]; ip = a + dq; }
+    if (metric != 0) return (double)(1.0f - ip);
+    const float t = meta[3] + qm[1];
+    const float two_ip = 2.0f * ip;
+    return (double)(t - two_ip);
+}

@@ -529,6 +529,9 @@ def test_reply_objects_and_array_entry_points_agree():
     ("i8", "L2", 100, 50_000, 64, 10),
     ("i8", "Cosine", 600, 20_000, 300, 10),
     ("u8", "IP", 333, 30_000, 17, 5),
+    ("u8", "Cosine", 1024, 30_000, 70, 10),     # uint8 Cosine: two aux values per row (sum x', stored norm) in 16-byte records
+    ("u8", "Cosine", 768, 20_000, 260, 100),
+    ("u8", "Cosine", 300, 40_000, 33, 5),
 ])
 def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     rng = np.random.default_rng(dim * 3 + n)

@@ -195,3 +195,61 @@ def test_sq8_mfma_filter_hard_inputs(vso, metric):
         el, es = vso.topk_replay(sc, k)
         assert np.array_equal(labels[j], el.astype(np.int64)), (metric, j)
         assert np.array_equal(dists[j], es), (metric, j)
+
+
+# ---------------------------------------------------------------- fp16 vectors / queries (QuantPreprocessor<float16>, SQ8_FP16_*)
+def make_f16(metric, dim):
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT16, dim, MET[metric]
+    return VecSim.SQ8Index(p)
+
+
+def oracle_blobs_f16(vso, rows, queries, metric):
+    m = MET[metric]
+    rows = np.array(rows, dtype=np.uint16, copy=True)
+    queries = np.array(queries, dtype=np.uint16, copy=True)
+    if metric == "Cosine":
+        for v in rows:
+            vso.normalize(v, v.size, vso.F16)
+        for v in queries:
+            vso.normalize(v, v.size, vso.F16)
+    st = np.stack([vso.sq8_quantize_f16(v, m) for v in rows])
+    qb = np.stack([vso.sq8_query_blob_f16(v, m) for v in queries])
+    return st, qb
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+@pytest.mark.parametrize("dim", [5, 15, 16, 17, 48, 63, 64, 100, 129])
+def test_sq8_fp16_all_scores_bit_exact(vso, metric, dim):
+    rng = np.random.default_rng(dim * 3 + len(metric))
+    n = 300
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float16).view(np.uint16)
+    q = rng.uniform(-1, 1, (3, dim)).astype(np.float16).view(np.uint16)
+    ix = make_f16(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    labels, dists = ix.knn_query(q, n)
+    st, qb = oracle_blobs_f16(vso, rows, q, metric)
+    for j in range(3):
+        sc = vso.sq8_fp16_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, n)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, dim, j)
+        assert np.array_equal(dists[j], es), (metric, dim, j)
+        assert np.array_equal(ix.get_vector(j)[0], st[j])
+
+
+@pytest.mark.parametrize("metric,dim,n,nq,k", [("L2", 768, 20_000, 40, 10), ("Cosine", 200, 30_000, 9, 20)])
+def test_sq8_fp16_filtered_path(vso, metric, dim, n, nq, k):
+    rng = np.random.default_rng(dim + n)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float16).view(np.uint16)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float16).view(np.uint16)
+    ix = make_f16(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(sq8)"
+    st, qb = oracle_blobs_f16(vso, rows, q, metric)
+    for j in range(0, nq, 3):
+        sc = vso.sq8_fp16_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (metric, j)

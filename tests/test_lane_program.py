@@ -27,6 +27,8 @@ def emul():
     L.lane_emul.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
     L.lane_emul_sq8.restype = C.c_double
     L.lane_emul_sq8.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.lane_emul_sq8h.restype = C.c_double
+    L.lane_emul_sq8h.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -76,4 +78,19 @@ def test_sq8_lane_tables_reproduce_oracle(emul, vso):
             for tier in (0, 1):
                 got = emul.lane_emul_sq8(0 if metric == 0 else 1, tier, d, st.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p))
                 want = vso.sq8_fp32_distance(metric, st, qb, d, tier=tier)
+                assert got == want, (d, metric, tier, got, want)
+
+
+def test_sq8_fp16_query_lane_tables_reproduce_oracle(emul, vso):
+    """SQ8 storage x FP16 query (four 16-lane accumulators on 64 virtual lanes; scalar below dim 16)"""
+    rng = np.random.default_rng(12)
+    for d in list(range(1, 200)) + [768, 1000, 1024]:
+        for metric in (0, 1):
+            x = rng.uniform(-1, 1, d).astype(np.float32)
+            y = rng.uniform(-1, 1, d).astype(np.float16).view(np.uint16)
+            st = vso.sq8_quantize(x, metric)
+            qb = vso.sq8_query_blob_f16(y, metric)
+            for tier in (0, 1):
+                got = emul.lane_emul_sq8h(metric, tier, d, st.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p))
+                want = vso.sq8_fp16_distance(metric, st, qb, d, tier=tier)
                 assert got == want, (d, metric, tier, got, want)

@@ -245,6 +245,13 @@ def test_sq8_distance_kats(vso):
         st[:dim] = c["codes"]
         st[dim:].view(np.float32)[:] = c["meta"]
         q = np.array(c["query"] + c["qmeta"], dtype=np.float32)
+        if c.get("query_type") == "f16":   # fp16 values, then the FP32 metadata at an unaligned offset
+            qb = np.zeros(dim * 2 + 8, dtype=np.uint8)
+            qb[:dim * 2].view(np.uint16)[:] = vso.f32_to_f16(np.array(c["query"], dtype=np.float32))
+            qb[dim * 2:] = np.array(c["qmeta"], dtype=np.float32).view(np.uint8)
+            for tier in (vso.TIER_AVX512, vso.TIER_SCALAR):
+                assert vso.sq8_fp16_distance(SQ8_METRIC[c["metric"]], st, qb, dim, tier=tier) == c["expect"], (c["name"], tier)
+            continue
         for tier in (vso.TIER_AVX512, vso.TIER_SCALAR):
             got = vso.sq8_fp32_distance(SQ8_METRIC[c["metric"]], st, q, dim, tier=tier)
             assert got == c["expect"], (c["name"], tier, got)

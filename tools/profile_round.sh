@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-end evidence: the default bench line, rocprofv3 kernel stats of the same command, and the two PMC passes for
-# HBM traffic (separate runs, --kernel-trace only).  Outputs under gpurun_out/prof_$1; profiles/summarize.py turns them
-# into the text files kept in profiles/.
+# Round-end evidence: the default bench line, rocprofv3 kernel stats of the same command, the two PMC passes for
+# HBM traffic (separate runs, --kernel-trace only), and -- with a second argument "all" -- the bench lines and kernel
+# stats of the other BASELINE configs.  Outputs under gpurun_out/prof_$1; profiles/summarize.py turns them into the
+# text files kept in profiles/.
 TAG=${1:-r1}
+ALL=${2:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -11,6 +13,15 @@ python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.db" | head
 python $R/profiles/summarize.py $OUT $OUT/summary || true
+if [ "$ALL" = "all" ]; then
+  for c in c1 c3 c4; do
+    timeout 600 python $R/bench.py --config $c --steps 20 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  done
+  for c in c3 c4; do
+    mkdir -p $OUT/cfg_$c
+    rocprofv3 --kernel-trace --stats -d $OUT/cfg_$c/trace -o r1 -- python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $OUT/cfg_$c/trace.log 2>&1
+    python $R/profiles/summarize.py $OUT/cfg_$c $OUT/cfg_$c/summary || true
+  done
+fi
 tail -1 $OUT/bench_line.json | cut -c1-1200

@@ -19,6 +19,8 @@ a = ap.parse_args()
 CASES = [("i8 cos 1024 B256", VecSim.VecSimType_INT8, VecSim.VecSimMetric_Cosine, 1024, int(50_000_000 * a.scale), 256, 100, synth.rows_i8, 1028),
          ("bf16 ip 768 B128", VecSim.VecSimType_BFLOAT16, VecSim.VecSimMetric_IP, 768, 6_000_000, 128, 10, synth.rows_bf16, 1536)]
 for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
+    if not (a.i8 if 'i8' in name else a.bf16):
+        continue
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = typ, dim, metric
     ix = VecSim.BFIndex(p)
@@ -27,7 +29,9 @@ for name, typ, metric, dim, n, nq, k, gen, rb in CASES:
     base = [ix.knn_query(x, k) for x in q]
     res = {}
     for r in range(a.rounds):
-        combos = [(v, 1) for v in ([int(x) for x in (a.i8 if 'i8' in name else a.bf16).split(',') if x])]
+        # "v" (one workgroup per CU in the grid) or "v:w" (w workgroups per CU)
+        combos = [(int(x.split(':')[0]), int(x.split(':')[1]) if ':' in x else 1)
+                  for x in (a.i8 if 'i8' in name else a.bf16).split(',') if x]
         for v, w in combos:
             ix.set_option("lowp_qsplit", 1 if v == 100 else 0)
             ix.set_option("lowp_variant", 0 if v == 100 else v)

@@ -17,7 +17,7 @@
 
 namespace vsg {
 
-enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5, EK_SQ8 = 6 };
+enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5, EK_SQ8 = 6, EK_SQ8H = 7 };
 enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3, OP_IP_DPBF16 = 4 };
 enum ScanMode { MODE_DENSE = 0, MODE_FILTER = 1 };
 // how the reduced accumulator becomes a score
@@ -67,6 +67,11 @@ template <> struct Elem<EK_U8> {
     using acc_t = int; using score_t = float;
     static constexpr int VL = 32;
     __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const uint8_t *>(p)); }
+};
+template <> struct Elem<EK_SQ8H> {   // SQ8 rows against fp16 queries: four 16-lane accumulators = 64 virtual lanes
+    using acc_t = float; using score_t = float;
+    static constexpr int VL = 64;
+    __device__ static inline float load(const char *p) { return (float)(*reinterpret_cast<const uint8_t *>(p)); }
 };
 template <> struct Elem<EK_SQ8> {   // uint8 code widened exactly to float; the query side is fp32
     using acc_t = float; using score_t = float;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
                     const int q = q0 + b;
                     const float nq = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
                     score_t sc;
-                    if constexpr (EK == EK_SQ8) {
+                    if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) {
                         sc = sq8_score(acc[r][b], P.epilogue, P.sq8_fused, rp[r] + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
                     } else {
                         sc = epilogue_score<score_t>(acc[r][b], P.epilogue, nrow, nq);

@@ -115,9 +115,10 @@ std::vector<vsgpu_ctx *> FlatIndex::gpus() {
 }
 
 FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
-    if (p.dim == 0 || p.type != VecSimType_FLOAT32 || p.metric > VecSimMetric_Cosine) return nullptr;
+    if (p.dim == 0 || (p.type != VecSimType_FLOAT32 && p.type != VecSimType_FLOAT16) || p.metric > VecSimMetric_Cosine) return nullptr;
     vsgpu_ctx *ctx = vsgpu_ctx_create(resolve_device());
     if (!ctx) return nullptr;
+    const bool f16 = p.type == VecSimType_FLOAT16;
     FlatIndex *ix = new FlatIndex();
     ix->type_ = p.type;
     ix->sq8_ = true;
@@ -125,11 +126,11 @@ FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
     ix->dim_ = p.dim;
     ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     ix->stored_bytes_ = sq8_storage_bytes(p.dim, p.metric);
-    ix->query_bytes_ = sq8_query_bytes(p.dim, p.metric);
+    ix->query_bytes_ = f16 ? sq8_query_bytes_f16(p.dim, p.metric) : sq8_query_bytes(p.dim, p.metric);
     ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->table_ = vsgpu_table_create(ctx, VSGPU_SQ8, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    ix->table_ = vsgpu_table_create(ctx, f16 ? VSGPU_SQ8H : VSGPU_SQ8, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
     if (!ix->table_) {
         vsgpu_ctx_destroy(ctx);
         ix->ctx_ = nullptr;
@@ -154,8 +155,15 @@ FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
 void FlatIndex::toStored(const void *blob, char *out) const {
     if (sq8_) {
         std::vector<float> tmp(dim_);
-        std::memcpy(tmp.data(), blob, dim_ * sizeof(float));
-        if (metric_ == VecSimMetric_Cosine) normalize_blob(tmp.data(), dim_, type_);
+        if (type_ == VecSimType_FLOAT16) {   // normalise in fp16 as a Cosine fp16 index does, then widen exactly
+            std::vector<uint16_t> h(dim_);
+            std::memcpy(h.data(), blob, dim_ * 2);
+            if (metric_ == VecSimMetric_Cosine) normalize_blob(h.data(), dim_, type_);
+            for (size_t i = 0; i < dim_; i++) tmp[i] = fp16_widen(h[i]);
+        } else {
+            std::memcpy(tmp.data(), blob, dim_ * sizeof(float));
+            if (metric_ == VecSimMetric_Cosine) normalize_blob(tmp.data(), dim_, type_);
+        }
         sq8_quantize(tmp.data(), dim_, metric_, reinterpret_cast<uint8_t *>(out));
         return;
     }
@@ -165,7 +173,17 @@ void FlatIndex::toStored(const void *blob, char *out) const {
 void FlatIndex::toQuery(const void *query, char *out) const {
     std::memcpy(out, query, dim_ * type_size(type_));
     if (metric_ == VecSimMetric_Cosine) normalize_blob(out, dim_, type_);
-    if (sq8_) sq8_query_blob(reinterpret_cast<const float *>(out), dim_, metric_, reinterpret_cast<float *>(out));
+    if (sq8_ && type_ == VecSimType_FLOAT16) {
+        std::vector<float> wide(dim_);
+        for (size_t i = 0; i < dim_; i++) {
+            uint16_t h;
+            std::memcpy(&h, out + 2 * i, 2);
+            wide[i] = fp16_widen(h);
+        }
+        sq8_query_meta_f16(wide.data(), dim_, metric_, out);
+    } else if (sq8_) {
+        sq8_query_blob(reinterpret_cast<const float *>(out), dim_, metric_, reinterpret_cast<float *>(out));
+    }
 }
 
 double FlatIndex::storedDistance(size_t label_a, size_t label_b) {
@@ -791,7 +809,16 @@ double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
     if (flush()) return std::numeric_limits<double>::quiet_NaN();
     // "Unsafe": the blob is used as given (caller normalises for Cosine), brute_force_single.h:202-212
     std::vector<char> q(query_bytes_);
-    if (sq8_) {   // an fp32 vector as given; only the query metadata (y_sum, y_sum_squares) is appended
+    if (sq8_ && type_ == VecSimType_FLOAT16) {
+        std::memcpy(q.data(), blob, dim_ * 2);
+        std::vector<float> wide(dim_);
+        for (size_t i = 0; i < dim_; i++) {
+            uint16_t h;
+            std::memcpy(&h, q.data() + 2 * i, 2);
+            wide[i] = fp16_widen(h);
+        }
+        sq8_query_meta_f16(wide.data(), dim_, metric_, q.data());
+    } else if (sq8_) {   // an fp32 vector as given; only the query metadata (y_sum, y_sum_squares) is appended
         std::memcpy(q.data(), blob, dim_ * sizeof(float));
         sq8_query_blob(reinterpret_cast<const float *>(q.data()), dim_, metric_, reinterpret_cast<float *>(q.data()));
     } else {

@@ -5,7 +5,9 @@
 //   storage  | codes[dim] u8 | min | delta | sum | sum_squares (L2 only) |   quantize()               :270-390
 //   query    | y[dim] f32    | y_sum | y_sum_squares (L2 only) |            assign_query_metadata()  :398-470
 // (types/sq8.h:19-62 for the layouts).  Cosine indexes normalise the fp32 vector first (blob_prep.h), then quantise.
-// Not built: FP16 inputs / queries and the mean-centred (WithNorm) variants.
+// FP16 inputs (QuantPreprocessor<float16, ...>): every value is widened exactly and all arithmetic is FP32, so storage
+// blobs are the FP32 quantiser's on the widened vector; a query blob keeps the fp16 values and appends FP32 metadata (at an
+// offset that is not 4-byte aligned in general).  Not built: the mean-centred (WithNorm) variants.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -16,6 +18,7 @@ namespace vsa {
 
 inline size_t sq8_storage_bytes(size_t dim, VecSimMetric m) { return dim + (m == VecSimMetric_L2 ? 4 : 3) * sizeof(float); }
 inline size_t sq8_query_bytes(size_t dim, VecSimMetric m) { return (dim + (m == VecSimMetric_L2 ? 2 : 1)) * sizeof(float); }
+inline size_t sq8_query_bytes_f16(size_t dim, VecSimMetric m) { return dim * 2 + (m == VecSimMetric_L2 ? 2 : 1) * sizeof(float); }
 
 // bounded conversion, then +0.5 and truncate (preprocessors.h:287-299): zero / negative / NaN -> 0, >= 255 / +inf -> 255
 inline uint8_t sq8_to_byte(float scaled) {
@@ -75,6 +78,25 @@ inline void sq8_query_blob(const float *y, size_t dim, VecSimMetric metric, floa
     }
     out[dim] = sum;
     if (metric == VecSimMetric_L2) out[dim + 1] = sq;
+}
+
+// fp16 query blob: `blob` holds dim fp16 values (already normalised for Cosine) and room for the metadata behind them;
+// `wide` = the same values widened to FP32
+inline void sq8_query_meta_f16(const float *wide, size_t dim, VecSimMetric metric, char *blob) {
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const size_t d4 = dim & ~(size_t)3;
+    size_t i = 0;
+    for (; i < d4; i += 4)
+        for (int j = 0; j < 4; j++) {
+            s[j] += wide[i + j];
+            q[j] += wide[i + j] * wide[i + j];
+        }
+    float meta[2] = {(s[0] + s[1]) + (s[2] + s[3]), (q[0] + q[1]) + (q[2] + q[3])};
+    for (; i < dim; i++) {
+        meta[0] += wide[i];
+        meta[1] += wide[i] * wide[i];
+    }
+    std::memcpy(blob + dim * 2, meta, (metric == VecSimMetric_L2 ? 2 : 1) * sizeof(float));
 }
 
 }  // namespace vsa

@@ -22,7 +22,7 @@
 namespace vsg {
 
 struct LaneProgram {
-    int vl = 32;        // virtual lanes per row (32: fp32/fp16/int8/uint8, 16: fp64/bf16)
+    int vl = 32;        // virtual lanes per row (32: fp32/fp16/int8/uint8/SQ8, 16: fp64/bf16, 64: SQ8 with fp16 queries)
     int steps = 0;      // table height
     bool fused = true;  // true: acc = fma(a,b,acc); false: acc = acc + a*b (scalar tier, L2.cpp:76-133)
     bool is_l2 = true;  // L2: (x-q)^2 terms; otherwise x*q terms
@@ -74,6 +74,7 @@ inline bool uses_scalar_tier(int type, int tier, size_t dim) {
     case VSGPU_BF16: return dim < 32;
     case VSGPU_F16: return dim < 8;
     case VSGPU_SQ8: return dim < 8;  // L2_space.cpp:71-75, IP_space.cpp:72-76
+    case VSGPU_SQ8H: return dim < 16;  // L2_space.cpp:121-123, IP_space.cpp:191
     default: return false;  // integer kernels are exact in any order
     }
 }
@@ -82,7 +83,7 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
     LaneProgram p;
     p.elem_bytes = elem_bytes_of(type);
     p.is_l2 = (kernel_metric == VSGPU_L2);
-    p.vl = (type == VSGPU_F64 || type == VSGPU_BF16) ? 16 : 32;
+    p.vl = (type == VSGPU_F64 || type == VSGPU_BF16) ? 16 : (type == VSGPU_SQ8H ? 64 : 32);
     const int vl = p.vl;
     const int eb = p.elem_bytes;
     auto new_step = [&]() {
@@ -104,7 +105,32 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         return p;
     }
 
-    if (type == VSGPU_SQ8 && uses_scalar_tier(type, tier, dim)) {
+    if (type == VSGPU_SQ8H && !uses_scalar_tier(type, tier, dim)) {
+        // SQ8 x FP16 AVX-512F kernel (IP_AVX512F_SQ8_FP16.h:42-101): FOUR 16-lane accumulators.  The dim % 16 head is a
+        // masked multiply into sum0, then 64 elements per round over sum0..sum3, up to three 16-chunks of tail into sum0,
+        // sum1, sum2, and (sum0 + sum1) + (sum2 + sum3) before the 16-lane tree.  The 64-lane halving tree adds lanes
+        // j + 32 and then j + 16, so sum0, sum2, sum1, sum3 sit on lanes 0-15, 16-31, 32-47, 48-63.
+        static const int base_of[4] = {0, 32, 16, 48};
+        const size_t residual = dim % 16;
+        size_t pos = 0;
+        if (residual) {
+            int s = new_step();
+            for (size_t j = 0; j < residual; j++) put(s, (int)j, j);
+            pos = residual;
+        }
+        while (dim - pos >= 64) {
+            int s = new_step();
+            for (int a = 0; a < 4; a++, pos += 16)
+                for (size_t j = 0; j < 16; j++) put(s, base_of[a] + (int)j, pos + j);
+        }
+        if (dim - pos >= 16) {
+            int s = new_step();
+            for (int a = 0; a < 3 && dim - pos >= 16; a++, pos += 16)
+                for (size_t j = 0; j < 16; j++) put(s, base_of[a] + (int)j, pos + j);
+        }
+        return p;
+    }
+    if ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && uses_scalar_tier(type, tier, dim)) {
         // SQ8_FP32_InnerProduct_Impl (IP.cpp:34-58): four chains over elements i % 4, the dim % 4 tail into chain 0,
         // separate multiply and add, then (s0 + s1) + (s2 + s3).  The halving tree adds lane 0 + lane 2 and lane 1 +
         // lane 3 before the last step, so chains 0, 1, 2, 3 sit on lanes 0, 2, 1, 3 (the other lanes hold +0).

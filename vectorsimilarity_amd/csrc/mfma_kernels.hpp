@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
         acc = lane_reduce<VL>(acc, P.reduce);
         if (lane == 0) {
             float sc;
-            if constexpr (EK == EK_SQ8) sc = sq8_score(acc, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
+            if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) sc = sq8_score(acc, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
             else sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
             rec.y = __float_as_uint(sc);
             P.cand[(size_t)q * P.cap + s] = rec;

@@ -24,7 +24,7 @@
 
 namespace vsg {
 
-enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3, LP_SQ8 = 4 };
+enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3, LP_SQ8 = 4, LP_U8C = 5 };
 enum LowpEpi { LE_FP_L2 = 0, LE_FP_IP = 1, LE_I8_L2 = 2, LE_I8_IP = 3, LE_I8_COS = 4, LE_U8_IP = 5 };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -67,6 +67,15 @@ template <> struct LowpOps<LP_SQ8> {
         return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
     }
 };
+// uint8 Cosine: the re-centred dot needs TWO per-row values, sum x' for  sum x q = sum x'q' + 128 sum x' + (128 sum q' +
+// 128^2 d)  and the stored float norm for the reference's epilogue 1 - float(dot) / (norm_x norm_q) (IP.cpp:264-271 twin for
+// uint8) -- the 16-byte aux records of the SQ8 path carry both.  Exact integer dot, exact score: no re-rank.
+template <> struct LowpOps<LP_U8C> {
+    using acc_t = i32x4_t;
+    __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
+    }
+};
 template <> struct LowpOps<LP_I8> {
     using acc_t = i32x4_t;
     __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
@@ -84,6 +93,7 @@ struct LowpParams {
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
     const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, W, 0, 0, 0}
+                                         // LP_U8C: {norm_q, bits(int 128 sum q' + 16384 dim), 0 ...}
     int epi;
     float cE, absE;
     float *tilemin;                      // MF_PROBE: [queries][tilemin_stride]
@@ -132,8 +142,9 @@ template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
     using Ops = LowpOps<LK>;
     using acc_t = typename Ops::acc_t;
-    constexpr bool SQ8 = (LK == LP_SQ8);
-    constexpr int AUXBUF = SQ8 ? 1024 : 256;   // bytes of per-tile aux values: 4 B per row, 16 B per row for SQ8
+    constexpr bool U8C = (LK == LP_U8C);
+    constexpr bool SQ8 = (LK == LP_SQ8) || U8C;   // (the 16-byte aux record path; the name stuck)
+    constexpr int AUXBUF = SQ8 ? 1024 : 256;   // bytes of per-tile aux values: 4 B per row, 16 B per row for SQ8 / uint8 Cosine
     static_assert(!SQ8 || (!SKEW && NQW == 1 && RT * 16 <= AUXBUF && NWAVES * 256 >= AUXBUF), "SQ8 aux geometry");
     // units requested ahead.  DIST = NS-2 leaves one slot of slack: the slot refilled after a barrier was last read
     // a whole unit earlier, so the plain s_barrier is enough and hipcc may keep pipelining LDS reads across it
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
                     const int p = (4 * (j % 4) + kq) ^ m16;
                     afr[f - F0] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
-                    if (LK == LP_U8 || LK == LP_SQ8) afr[f - F0] ^= 0x80808080u;
+                    if (LK == LP_U8 || LK == LP_SQ8 || LK == LP_U8C) afr[f - F0] ^= 0x80808080u;
                 }
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
@@ -607,7 +618,47 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
             }
         };
-        if constexpr (SQ8) {
+        auto epilogue_u8c = [&]() {
+            const float *qm = P.qmeta + (size_t)qidx[0] * 8;
+            const float nq = qm[0];
+            const int K = (int)__float_as_uint(qm[1]);
+            const float tq = tau[0];
+            const float omt = 1.0f - tq;
+            const float cq = (omt - 1e-5f * (1.0f + fabsf(omt))) * nq;   // screen with a margin, as for int8 Cosine
+            const uint32_t arow_off = aux_lds_off + abuf * AUXBUF;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                u32x4_t am[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(am[i]) : "v"(arow_off + (uint32_t)((mt * 16 + kq * 4 + i) * 16)));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lrow = mt * 16 + kq * 4 + i;
+                    const float nx = __uint_as_float(am[i][0]);
+                    const int dot = (int)acc[mt][0][i] + 128 * (int)am[i][1] + K;
+                    if (MODE == MF_FILTER && (float)dot < cq * nx) continue;   // NaN thresholds fall through to the exact test
+                    const float sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(nx, nq)));
+                    if (MODE == MF_PROBE) {
+                        if (lrow < nvalid && sc < tmin[0]) tmin[0] = sc;
+                    } else if (lrow < nvalid && sc <= tq) {
+                        const uint32_t row = r0 + lrow;
+                        const uint32_t pos = mf_queue_reserve(q_cnt_off);
+                        if (pos < Q_CAP) {
+                            mf_queue_write(q_rec_off + pos * 16, row, (uint32_t)qidx[0], __float_as_uint(sc));
+                        } else {
+                            uint32_t s = atomicAdd(&P.counts[qidx[0]], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx[0] * P.cap + s] = make_uint2(row, __float_as_uint(sc));
+                            emitted = true;
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (U8C) {
+            if (!(dbg & 1)) epilogue_u8c();
+        } else if constexpr (SQ8) {
             if (!(dbg & 1)) {
                 if (P.epi == LE_FP_L2) epilogue_sq8(std::true_type{});
                 else epilogue_sq8(std::false_type{});
@@ -692,6 +743,21 @@ static __global__ __launch_bounds__(256) void k_row_aux_sq8(const char *rows, ui
     const unsigned char *m = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride + dim);
     auto ld = [&](int o) { return (uint32_t)m[o] | ((uint32_t)m[o + 1] << 8) | ((uint32_t)m[o + 2] << 16) | ((uint32_t)m[o + 3] << 24); };
     out[row] = make_uint4(ld(0), ld(4), is_l2 ? ld(12) : 0u, 0u);
+}
+// uint8 Cosine: {stored float norm, sum (x - 128), 0, 0} per row
+static __global__ __launch_bounds__(256) void k_row_aux_u8c(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n, uint4 *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride);
+    int s = 0;
+    for (uint32_t i = lane; i < dim; i += 64) s += (int)p[i] - 128;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const unsigned char *np = p + dim;
+        out[row] = make_uint4((uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24), (uint32_t)s, 0u, 0u);
+    }
 }
 // int8: sum x^2 as int32 (mode 0) or the float norm stored after the elements (mode 1, Cosine rows)
 static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,

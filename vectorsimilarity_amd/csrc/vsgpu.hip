@@ -160,9 +160,9 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         fail(VSGPU_ERR_ARG, "null context");
         return nullptr;
     }
-    if (type < VSGPU_F32 || type > VSGPU_SQ8 || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
+    if (type < VSGPU_F32 || type > VSGPU_SQ8H || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
         row_bytes < dim * (size_t)elem_bytes_of(type) ||
-        (type == VSGPU_SQ8 && row_bytes != dim + (metric == VSGPU_L2 ? 16 : 12))) {
+        ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && row_bytes != dim + (metric == VSGPU_L2 ? 16 : 12))) {
         fail(VSGPU_ERR_ARG, "bad table parameters (type %d metric %d dim %zu row_bytes %zu)", type, metric,
              dim, row_bytes);
         return nullptr;
@@ -183,10 +183,10 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     // bf16 IP on the avx512_bf16 tier: the vdpbf16ps step (odd element, then even, each with FTZ)
     if (t->prog.dpbf16) t->opk = OP_IP_DPBF16;
     if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
-    else if (type == VSGPU_SQ8) t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
+    else if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
     else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
     // SQ8 accumulates the code dot product in the IP order whatever the metric (L2 is algebraic: L2.cpp:30-45)
-    if (type == VSGPU_SQ8) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
+    if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
     // LDS budget 64 KiB: offs + BT query images
     size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
     size_t q_b = (size_t)t->prog.steps * t->prog.vl * acc_bytes(type);
@@ -231,7 +231,7 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
                     break;
                 }
         }
-        if (type == VSGPU_SQ8 && !t->prog.scalar_tier && dim <= 1024) {
+        if ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && !t->prog.scalar_tier && dim <= 1024) {
             // SQ8 x FP32 on the int8 MFMA filter (mfma_lowp_kernels.hpp LP_SQ8): 8 waves x 16 queries, 64-row tiles
             t->lowp_ok = true;
             t->lp_kind = LP_SQ8;
@@ -240,9 +240,11 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_qtile = 128;
             t->aux_bytes = 16;
         }
-        if ((type == VSGPU_I8 || (type == VSGPU_U8 && metric != VSGPU_COSINE)) && dim <= 1024) {
+        if ((type == VSGPU_I8 || type == VSGPU_U8) && dim <= 1024) {
             t->lowp_ok = true;
-            t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;  // uint8 Cosine would need two aux values per row: exact path
+            // uint8 Cosine needs two aux values per row (sum x', the stored norm): the 16-byte aux records
+            t->lp_kind = type == VSGPU_I8 ? LP_I8 : (metric == VSGPU_COSINE ? LP_U8C : LP_U8);
+            if (t->lp_kind == LP_U8C) t->aux_bytes = 16;
             t->lp_ksteps = dim <= 512 ? 8 : (dim <= 768 ? 12 : 16);
             t->lp_rt = t->lp_ksteps == 16 ? 32 : 64;
             t->lp_qtile = 256;
@@ -375,7 +377,10 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
         size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
         float *np = t->norm_slabs[id >> t->slab_shift] + (id & (slab_rows - 1)) * (t->aux_bytes / 4);
         const dim3 g((unsigned)((in_slab + 3) / 4));
-        if (t->lowp_ok && t->lp_kind == LP_SQ8)
+        if (t->lowp_ok && t->lp_kind == LP_U8C)
+            hipLaunchKernelGGL(k_row_aux_u8c, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, (uint4 *)np);
+        else if (t->lowp_ok && t->lp_kind == LP_SQ8)
             hipLaunchKernelGGL(k_row_aux_sq8, dim3((unsigned)((in_slab + 255) / 256)), dim3(256), 0, t->ctx->stream,
                                (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
                                t->epi == EPI_SQ8_L2 ? 1 : 0, (uint4 *)np);
@@ -448,7 +453,7 @@ extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
     return VSGPU_OK;
 }
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
-    if (t->type == VSGPU_F64 || t->type == VSGPU_U8 || t->type == VSGPU_SQ8)
+    if (t->type == VSGPU_F64 || t->type == VSGPU_U8 || t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H)
         return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32/bf16/fp16/int8 only");
     if (n == 0) return VSGPU_OK;
     HIPCHK(hipSetDevice(t->ctx->device));
@@ -546,6 +551,19 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
             for (size_t i = 0; i < per_q; i++) oi[i] = offs[i] >= 0 ? (int)*(const int8_t *)(src + offs[i]) : 0;
             break;
         }
+        case VSGPU_SQ8H: {   // fp16 query elements, widened exactly (types/float16.h:33-52)
+            float *of = (float *)o;
+            for (size_t i = 0; i < per_q; i++) {
+                float v = 0;
+                if (offs[i] >= 0) {
+                    uint16_t h;
+                    memcpy(&h, src + 2 * (size_t)offs[i], 2);
+                    v = widen_f16(h);
+                }
+                of[i] = v;
+            }
+            break;
+        }
         case VSGPU_SQ8: {   // table offsets address the one-byte codes: element e of the fp32 query sits at 4 e
             float *of = (float *)o;
             for (size_t i = 0; i < per_q; i++) {
@@ -563,12 +581,12 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
         }
     }
     HIPCHK(hipMemcpyAsync(c->qperm.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
-    if (t->type == VSGPU_SQ8) {   // {y_sum, y_sum_squares} of every query blob (the second only exists for L2)
+    if (t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H) {   // {y_sum, y_sum_squares} of every query blob (the second only exists for L2)
         rc = ensure_pinned(c, bytes + nq * 8);
         if (rc) return rc;
         float *qm = (float *)((char *)c->pinned + bytes);
         for (size_t q = 0; q < nq; q++) {
-            const char *src = (const char *)queries + q * qstride + 4 * t->dim;
+            const char *src = (const char *)queries + q * qstride + (t->type == VSGPU_SQ8H ? 2 : 4) * t->dim;
             memcpy(&qm[2 * q], src, 4);
             qm[2 * q + 1] = 0.f;
             if (t->epi == EPI_SQ8_L2) memcpy(&qm[2 * q + 1], src + 4, 4);
@@ -618,10 +636,14 @@ static void launch_scan(int ek, int opk, int bt, const ScanParams &P, dim3 grid,
         if (opk == OP_IP_FMA) launch_scan_bt<EK_SQ8, OP_IP_FMA>(bt, P, grid, lds, s);
         else launch_scan_t<EK_SQ8, OP_IP_MULADD, 1>(P, grid, lds, s);
         break;
+    case EK_SQ8H:
+        if (opk == OP_IP_FMA) launch_scan_bt<EK_SQ8H, OP_IP_FMA>(bt, P, grid, lds, s);
+        else launch_scan_t<EK_SQ8H, OP_IP_MULADD, 1>(P, grid, lds, s);
+        break;
     default: launch_scan_op<EK_U8>(opk, bt, P, grid, lds, s); break;
     }
 }
-int tile_rows_of(int ek) { return (ek == EK_F64 || ek == EK_BF16) ? (256 / 16) * 4 : (256 / 32) * 4; }
+int tile_rows_of(int ek) { return (ek == EK_F64 || ek == EK_BF16) ? (256 / 16) * 4 : (ek == EK_SQ8H ? (256 / 64) * 4 : (256 / 32) * 4); }
 
 static int pick_bt(const vsgpu_table *t, size_t nq) {
     int bt = t->bt_max;
@@ -948,7 +970,7 @@ static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *sla
 }
 
 extern "C" int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t *ids_b, size_t n, double *scores) {
-    if (t->type != VSGPU_SQ8) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
+    if (t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
     if (n == 0) return VSGPU_OK;
     for (size_t i = 0; i < n; i++)
         if (ids_a[i] >= t->n || ids_b[i] >= t->n) return fail(VSGPU_ERR_ARG, "row id beyond table size %zu", t->n);
@@ -1155,7 +1177,9 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     S.norm_off = (uint32_t)t->dim;
     S.qnorm = (const float *)c->qnorm.p;
     S.sq8_fused = t->prog.fused ? 1 : 0;
-    if (t->type == VSGPU_SQ8) {
+    if (t->type == VSGPU_SQ8H) {
+        hipLaunchKernelGGL((k_exact_pairs<EK_SQ8H, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+    } else if (t->type == VSGPU_SQ8) {
         hipLaunchKernelGGL((k_exact_pairs<EK_SQ8, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else if (t->type == VSGPU_F32) {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F32, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);

@@ -95,6 +95,11 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
         case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
         case 60: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
+        // two independent 4-wave workgroups per CU, 32 queries per wave (192 registers of query fragments, 2 waves per SIMD)
+        case 70: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 3>);
+        case 71: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 4>);
+        case 72: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 4, 2, 2, 4, 24576>);   // 16 whole rows per unit
+        case 73: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 3, 24576>);   // 32 rows x 768 B per unit
         case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
         case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
         case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
@@ -184,7 +189,16 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
 #endif
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
-    else if (t->lp_kind == LP_SQ8) {
+    else if (t->lp_kind == LP_U8C) {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_i8<8, 64, LP_U8C>(mode, P, grid, s); break;
+        case 12: launch_lowp_i8<12, 64, LP_U8C>(mode, P, grid, s); break;
+        default:
+            if (mode == MF_FILTER) launch_lowp_k<LP_U8C, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
+            else launch_lowp_i8<16, 32, LP_U8C>(mode, P, grid, s);
+            break;
+        }
+    } else if (t->lp_kind == LP_SQ8) {
         switch (t->lp_ksteps) {
         case 8: launch_lowp_t<LP_SQ8, 8, 64, 1>(mode, P, grid, s); break;
         case 12: launch_lowp_t<LP_SQ8, 12, 64, 1>(mode, P, grid, s); break;
@@ -243,8 +257,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
-    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8);   // exact integer scores, no re-rank
-    const bool is_u8 = (t->lp_kind == LP_U8);
+    const bool is_u8c = (t->lp_kind == LP_U8C);
+    const bool is_int = (t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || is_u8c);   // exact integer scores, no re-rank
+    const bool is_u8 = (t->lp_kind == LP_U8 || is_u8c);
     const size_t eb = (is_int || is_sq8) ? 1 : 2;
     const size_t kelem = (is_int || is_sq8) ? 64 : 32;        // elements per MFMA k-step
     const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
@@ -259,7 +274,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     std::vector<unsigned char> frag(nqp * kdim * eb, 0);
     std::vector<uint32_t> qaux(nqp, 0);
     std::vector<float> tau0(nqp, -INFINITY);
-    std::vector<float> qmeta(is_sq8 ? nqp * 8 : 0, 0.0f);
+    std::vector<float> qmeta((is_sq8 || is_u8c) ? nqp * 8 : 0, 0.0f);
     std::vector<signed char> yq(is_sq8 ? dim : 0);
     for (size_t q = 0; q < nq; q++) {
         const unsigned char *src = (const unsigned char *)queries + q * qstride;
@@ -269,7 +284,17 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             //   sum c_i e_i   <= 255 sum |e_i|
             //   the reference's fp32 accumulation (dim/32 fused steps per lane + the tree; IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104)
             //                 <= 2 (dim/32 + 8) 2^-24 * 255 sum |y_i|
-            const float *y = reinterpret_cast<const float *>(src);
+            const size_t qeb = t->type == VSGPU_SQ8H ? 2 : 4;   // fp16 queries are widened first (exactly)
+            std::vector<float> ywide;
+            if (qeb == 2) {
+                ywide.resize(dim);
+                for (size_t i = 0; i < dim; i++) {
+                    uint16_t h;
+                    memcpy(&h, src + 2 * i, 2);
+                    ywide[i] = widen_f16(h);
+                }
+            }
+            const float *y = qeb == 2 ? ywide.data() : reinterpret_cast<const float *>(src);
             double ymax = 0, yabs = 0;
             for (size_t i = 0; i < dim; i++) {
                 ymax = std::max(ymax, (double)std::fabs(y[i]));
@@ -292,8 +317,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             const int K = (int)(128 * sy);
             qm[0] = sf;
             memcpy(&qm[1], &K, 4);
-            memcpy(&qm[2], src + 4 * dim, 4);                                 // y_sum
-            if (t->metric == VSGPU_L2) memcpy(&qm[3], src + 4 * dim + 4, 4);  // y_sum_squares
+            memcpy(&qm[2], src + qeb * dim, 4);                                 // y_sum
+            if (t->metric == VSGPU_L2) memcpy(&qm[3], src + qeb * dim + 4, 4);  // y_sum_squares
             qm[4] = std::nextafter((float)W, INFINITY);
             src = reinterpret_cast<const unsigned char *>(yq.data());
         }
@@ -317,6 +342,10 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             }
             const int aux = t->epi == EPI_INT_L2 ? s2 : 128 * s1 + 16384 * (int)dim;
             memcpy(&qaux[q], &aux, 4);
+            if (is_u8c) {   // {norm_q, 128 sum q' + 128^2 dim}
+                memcpy(&qmeta[q * 8], src + dim, 4);
+                memcpy(&qmeta[q * 8 + 1], &aux, 4);
+            }
         } else if (is_int) {
             if (t->epi == EPI_INT_COS) memcpy(&qaux[q], src + dim, 4);
             else if (t->epi == EPI_INT_L2) {
@@ -350,7 +379,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
-    if (is_sq8) {
+    if (is_sq8 || is_u8c) {
         rc = ensure(c, c->qmeta, qmeta.size() * 4);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->qmeta.p, qmeta.data(), qmeta.size() * 4, hipMemcpyHostToDevice, c->stream));
