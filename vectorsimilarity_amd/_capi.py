@@ -7,8 +7,11 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvecsim_amd.so")
-GPU_LIB_PATH = os.path.join(_PKG, "libvsgpu.so")
+# VECSIM_AMD_LIBDIR: another build of the two libraries (the TUNING=1 build with its extra kernel variants lives in
+# vectorsimilarity_amd/tuning/: make -C vectorsimilarity_amd/csrc TUNING=1 OUT=../tuning OBJ=build_tuning)
+_LIBDIR = os.environ.get("VECSIM_AMD_LIBDIR", _PKG)
+LIB_PATH = os.path.join(_LIBDIR, "libvecsim_amd.so")
+GPU_LIB_PATH = os.path.join(_LIBDIR, "libvsgpu.so")
 
 # ---- enums (vec_sim_common.h) ----
 VecSimType_FLOAT32, VecSimType_FLOAT64, VecSimType_BFLOAT16, VecSimType_FLOAT16, \
