@@ -330,8 +330,11 @@ static int grow_to(vsgpu_table *t, size_t rows) {
     bool changed = false;
     while (t->slabs.size() < need) {
         char *p = nullptr;
-        // + slack: the MFMA filter reads a row out to its kernel width (< 128 extra floats past the last row)
-        HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes + 1024));
+        // + slack: the MFMA filters read a row out to their compiled kernel width (the next width at or above dim: up to
+        // 511 floats more at the fp32 widths 64 / 80 / 96 k-steps), so the last row of a slab is over-read by less than
+        // that width
+        const size_t width = t->mfma_ok ? (size_t)t->ksteps * 128 : (t->lowp_ok ? (size_t)t->lp_ksteps * 64 : 0);
+        HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes + std::max<size_t>(1024, width + 256)));
         poison(p, slab_rows * t->row_bytes);
         t->slabs.push_back(p);
         if (t->mfma_ok || t->lowp_ok) {
