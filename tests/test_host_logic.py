@@ -78,3 +78,59 @@ def test_sq8_host_preprocessor_matches_the_oracle_and_the_reference_kats(vso):
         if c.get("exact_meta"):
             meta = blob[x.size:].view(np.float32)
             assert meta[0] == np.float32(c["min"]) and meta[1] == np.float32(c["delta"]) and meta[2] == np.float32(c["sum"]), c["name"]
+
+
+def test_sq8_mfma_filter_bound_holds(vso):
+    """The SQ8 MFMA filter (csrc/mfma_lowp_kernels.hpp epilogue_sq8, host half in csrc/vsgpu_lowp.hip) replaces the fp32 query
+    by one int8 piece per element and must bracket the reference's score: |score_ref - score| <= E.  Restated here in numpy
+    with the kernel's fp32 operation order and checked against the oracle on random and hostile inputs (wide row scales,
+    a dominant query component, near-constant rows)."""
+    rng = np.random.default_rng(8)
+    u = np.float32(2.0 ** -24)
+    kU = np.float32(64.0) * u
+    worst = 0.0
+    for trial in range(400):
+        dim = int(rng.choice([8, 33, 100, 128, 320, 768, 1024]))
+        metric = int(rng.integers(0, 3))
+        x = (rng.uniform(-1, 1, dim) * np.exp(rng.uniform(-4, 6))).astype(np.float32)
+        if trial % 7 == 0:
+            x = (np.float32(3.0) + rng.uniform(-1e-4, 1e-4, dim)).astype(np.float32)
+        y = rng.uniform(-1, 1, dim).astype(np.float32)
+        if trial % 3 == 0:
+            y[rng.integers(0, dim)] *= np.float32(500.0)
+        if metric == 2:
+            x /= np.float32(np.linalg.norm(x))
+            y /= np.float32(np.linalg.norm(y))
+        st = vso.sq8_quantize(x, metric)
+        qb = vso.sq8_query_blob(y, metric)
+        ref = vso.sq8_fp32_distance(metric, st, qb, dim)
+        # host half: s, Y, W
+        ymax = float(np.max(np.abs(y.astype(np.float64))))
+        sf = np.float32(ymax / 127.0)
+        if not (sf > 0) or not np.isfinite(sf):
+            sf = np.float32(1.0)
+        Y = np.clip(np.rint(y.astype(np.float64) / float(sf)), -127, 127)
+        e1 = float(np.sum(np.abs(y.astype(np.float64) - float(sf) * Y)))
+        yabs = float(np.sum(np.abs(y.astype(np.float64))))
+        W = np.nextafter(np.float32((255.0 * e1 + 2.0 * (dim / 32.0 + 8.0) * 2.0 ** -24 * 255.0 * yabs) * (1 + 1e-6)), np.float32(np.inf))
+        K = int(128 * np.sum(Y))
+        c = st[:dim].astype(np.int64)
+        D = int(np.sum((c - 128) * Y.astype(np.int64)))
+        meta = st[dim:].view(np.float32)
+        mn, dl = meta[0], meta[1]
+        ysum = qb[dim]
+        f = np.float32(D + K)
+        dq = np.float32(np.float32(dl * sf) * f)
+        my = np.float32(mn * ysum)
+        ip = np.float32(my + dq)
+        if metric == 0:
+            C = np.float32(meta[3] + qb[dim + 1])
+            sc = np.float32(C - np.float32(np.float32(2.0) * ip))
+        else:
+            C = np.float32(1.0)
+            sc = np.float32(np.float32(1.0) - ip)
+        g = np.float32(2.0 if metric == 0 else 1.0)
+        E = np.float32(np.float32(np.float32(g * dl) * W) + np.float32(kU * np.float32(np.float32(2.0) * np.float32(abs(my) + abs(dq)) + C)))
+        assert float(sc) - float(E) <= ref <= float(sc) + float(E), (trial, dim, metric, ref, float(sc), float(E))
+        worst = max(worst, abs(ref - float(sc)) / max(float(E), 1e-30))
+    assert worst <= 1.0

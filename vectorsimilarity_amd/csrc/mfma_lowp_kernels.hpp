@@ -573,7 +573,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             }
         };
         // SQ8: bounds on the reference's score from the exact code dot product (LowpOps<LP_SQ8>).  With A = |min y_sum|,
-        // B = |delta s (D + K)|:  |score_ref - score| <= delta W + kU (2A + 2B + C), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
+        // B = |delta s (D + K)|:  |score_ref - score| <= g delta W + kU (2A + 2B + C), g = 1 (IP) or 2 (L2: the score carries 2 ip), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
         // covers every fp32 rounding on either side (a dozen at most, each relative to one of those magnitudes).
         auto epilogue_sq8 = [&](auto l2_tag) {
             constexpr bool L2 = decltype(l2_tag)::value;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     const float ip = my + dq;
                     const float C = L2 ? (xsq + ysq) : 1.0f;
                     const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
-                    const float E = dl * W + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);
+                    const float E = (L2 ? 2.0f : 1.0f) * dl * W + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
                     const float low = sc - E, up = sc + E;
                     if (MODE == MF_PROBE) {
                         if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
