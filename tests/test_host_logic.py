@@ -83,7 +83,7 @@ def test_sq8_host_preprocessor_matches_the_oracle_and_the_reference_kats(vso):
 def test_sq8_mfma_filter_bound_holds(vso):
     """The SQ8 MFMA filter (csrc/mfma_lowp_kernels.hpp epilogue_sq8, host half in csrc/vsgpu_lowp.hip) replaces the fp32 query
     by one int8 piece per element and must bracket the reference's score: |score_ref - score| <= E.  Restated here in numpy
-    with the kernel's fp32 operation order and checked against the oracle on random and hostile inputs (wide row scales,
+    (Cauchy-Schwarz on the centred codes: |sum (c_i - 128) e_i| <= |c - 128|_2 |e|_2) with the kernel's fp32 operation order and checked against the oracle on random and hostile inputs (wide row scales,
     a dominant query component, near-constant rows)."""
     rng = np.random.default_rng(8)
     u = np.float32(2.0 ** -24)
@@ -110,17 +110,21 @@ def test_sq8_mfma_filter_bound_holds(vso):
         if not (sf > 0) or not np.isfinite(sf):
             sf = np.float32(1.0)
         Y = np.clip(np.rint(y.astype(np.float64) / float(sf)), -127, 127)
-        e1 = float(np.sum(np.abs(y.astype(np.float64) - float(sf) * Y)))
+        e = y.astype(np.float64) - float(sf) * Y
         yabs = float(np.sum(np.abs(y.astype(np.float64))))
-        W = np.nextafter(np.float32((255.0 * e1 + 2.0 * (dim / 32.0 + 8.0) * 2.0 ** -24 * 255.0 * yabs) * (1 + 1e-6)), np.float32(np.inf))
+        se = float(np.sum(e))
+        ce = np.float32(128.0 * se)
+        Wref = np.nextafter(np.float32((2.0 * (dim / 32.0 + 8.0) * 2.0 ** -24 * 255.0 * yabs + 2.0 ** -22 * abs(128.0 * se)) * (1 + 1e-6)), np.float32(np.inf))
+        ne = np.nextafter(np.float32(np.sqrt(np.sum(e * e)) * (1 + 1e-6)), np.float32(np.inf))
         K = int(128 * np.sum(Y))
         c = st[:dim].astype(np.int64)
         D = int(np.sum((c - 128) * Y.astype(np.int64)))
         meta = st[dim:].view(np.float32)
         mn, dl = meta[0], meta[1]
         ysum = qb[dim]
+        nc = np.nextafter(np.float32(np.sqrt(float(np.sum((c - 128) ** 2))) * 1.000001), np.float32(np.inf))
         f = np.float32(D + K)
-        dq = np.float32(np.float32(dl * sf) * f)
+        dq = np.float32(dl * np.float32(np.float32(sf * f) + ce))
         my = np.float32(mn * ysum)
         ip = np.float32(my + dq)
         if metric == 0:
@@ -130,7 +134,7 @@ def test_sq8_mfma_filter_bound_holds(vso):
             C = np.float32(1.0)
             sc = np.float32(np.float32(1.0) - ip)
         g = np.float32(2.0 if metric == 0 else 1.0)
-        E = np.float32(np.float32(np.float32(g * dl) * W) + np.float32(kU * np.float32(np.float32(2.0) * np.float32(abs(my) + abs(dq)) + C)))
+        E = np.float32(np.float32(np.float32(g * dl) * np.float32(np.float32(nc * ne) + Wref)) + np.float32(kU * np.float32(np.float32(2.0) * np.float32(abs(my) + abs(dq)) + C)))
         assert float(sc) - float(E) <= ref <= float(sc) + float(E), (trial, dim, metric, ref, float(sc), float(E))
         worst = max(worst, abs(ref - float(sc)) / max(float(E), 1e-30))
     assert worst <= 1.0

@@ -57,10 +57,12 @@ template <> struct LowpOps<LP_U8> {
 };
 // SQ8 storage x FP32 query (types/sq8.h; IP.cpp:34-80, L2.cpp:30-45): the codes ride the signed MFMA re-centred by 128
 // like uint8 rows; the fp32 query is quantised to ONE int8 piece per element on the host, y_i = s Y_i + e_i with
-// |Y_i| <= 127, so  sum c_i y_i = s (D + 128 sum Y) + sum c_i e_i,  D = sum (c_i - 128) Y_i exact in int32.  The kernel
-// turns that into bounds on the reference's score (per-row {min, delta, sum_squares}, 16 B of aux per row; per-query
-// {s, 128 sum Y, y_sum, y_sum_squares, W}), W >= 255 sum |e_i| + the reference's own fp32 rounding of the dot product;
-// survivors are re-scored by k_exact_pairs in the reference's lane order.
+// |Y_i| <= 127, so with c'_i = c_i - 128
+//     sum c_i y_i = s (D + 128 sum Y) + 128 sum e_i + sum c'_i e_i,      D = sum c'_i Y_i exact in int32,
+// and |sum c'_i e_i| <= |c'|_2 |e|_2 (Cauchy-Schwarz).  The kernel turns that into bounds on the reference's score from
+// per-row {min, delta, sum_squares, |c'|_2} (16 B of aux per row) and per-query {s, 128 sum Y, y_sum, y_sum_squares,
+// 128 sum e, |e|_2, Wref} (Wref: the reference's own fp32 rounding of the dot product); survivors are re-scored by
+// k_exact_pairs in the reference's lane order.
 template <> struct LowpOps<LP_SQ8> {
     using acc_t = i32x4_t;
     __device__ static inline acc_t mma(u32x4_t a, u32x4_t b, acc_t c) {
@@ -92,7 +94,7 @@ struct LowpParams {
     uint32_t tile_first, tile_step, n_tiles;   // tile t covers rows (tile_first + t*tile_step)*RT ...
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
-    const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, W, 0, 0, 0}
+    const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, Wref, 128 sum e, |e|_2, 0}
                                          // LP_U8C: {norm_q, bits(int 128 sum q' + 16384 dim), 0 ...}
     int epi;
     float cE, absE;
@@ -195,6 +197,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         qidx[nt] = qtile * (NWAVES * 16 * NQW) + wave * (16 * NQW) + nt * 16 + m16;
         qaux[nt] = P.qaux[qidx[nt]];
         tau[nt] = (MODE == MF_FILTER) ? P.tau[qidx[nt]] : 0.f;
+    }
+    // SQ8 / uint8 Cosine: the per-query constants of the epilogue, loaded once (a global load inside the tile loop would put
+    // a vmcnt(0) -- a drain of the DMA ring -- into every tile)
+    float qm_r[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (SQ8) {
+        const float *qm = P.qmeta + (size_t)qidx[0] * 8;
+#pragma unroll
+        for (int j = 0; j < 7; j++) qm_r[j] = qm[j];
+#pragma unroll
+        for (int j = 0; j < 7; j++) asm volatile("" : "+v"(qm_r[j]));
     }
     // pin the ordinary loads before the first DMA (see k_mfma_filter)
 #pragma unroll
@@ -573,14 +585,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             }
         };
         // SQ8: bounds on the reference's score from the exact code dot product (LowpOps<LP_SQ8>).  With A = |min y_sum|,
-        // B = |delta s (D + K)|:  |score_ref - score| <= g delta W + kU (2A + 2B + C), g = 1 (IP) or 2 (L2: the score carries 2 ip), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
+        // B = |delta (s (D + K) + 128 sum e)|:  |score_ref - score| <= g delta (|c'| |e| + Wref) + kU (2A + 2B + C), g = 1 (IP) or 2 (L2: the score carries 2 ip), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
         // covers every fp32 rounding on either side (a dozen at most, each relative to one of those magnitudes).
         auto epilogue_sq8 = [&](auto l2_tag) {
             constexpr bool L2 = decltype(l2_tag)::value;
             constexpr float kU = 64.0f / 16777216.0f;
-            const float *qm = P.qmeta + (size_t)qidx[0] * 8;
-            const float qs = qm[0], ysum = qm[2], ysq = qm[3], W = qm[4];
-            const int K = (int)__float_as_uint(qm[1]);
+            const float qs = qm_r[0], ysum = qm_r[2], ysq = qm_r[3], Wref = qm_r[4], ce = qm_r[5], ne = qm_r[6];
+            const int K = (int)__float_as_uint(qm_r[1]);
             const float tq = tau[0];
             const uint32_t arow_off = aux_lds_off + abuf * AUXBUF;
 #pragma unroll
@@ -594,13 +605,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 for (int i = 0; i < 4; i++) {
                     const uint32_t lrow = mt * 16 + kq * 4 + i;
                     const float mn = __uint_as_float(am[i][0]), dl = __uint_as_float(am[i][1]), xsq = __uint_as_float(am[i][2]);
+                    const float nc = __uint_as_float(am[i][3]);
                     const float f = (float)((int)acc[mt][0][i] + K);
-                    const float dq = (dl * qs) * f;
+                    const float dq = dl * (qs * f + ce);
                     const float my = mn * ysum;
                     const float ip = my + dq;
                     const float C = L2 ? (xsq + ysq) : 1.0f;
                     const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
-                    const float E = (L2 ? 2.0f : 1.0f) * dl * W + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
+                    const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
                     const float low = sc - E, up = sc + E;
                     if (MODE == MF_PROBE) {
                         if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
@@ -619,9 +631,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             }
         };
         auto epilogue_u8c = [&]() {
-            const float *qm = P.qmeta + (size_t)qidx[0] * 8;
-            const float nq = qm[0];
-            const int K = (int)__float_as_uint(qm[1]);
+            const float nq = qm_r[0];
+            const int K = (int)__float_as_uint(qm_r[1]);
             const float tq = tau[0];
             const float omt = 1.0f - tq;
             const float cq = (omt - 1e-5f * (1.0f + fabsf(omt))) * nq;   // screen with a margin, as for int8 Cosine
@@ -740,9 +751,16 @@ static __global__ __launch_bounds__(256) void k_row_aux_sq8(const char *rows, ui
                                                      int is_l2, uint4 *out) {
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
-    const unsigned char *m = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride + dim);
+    const unsigned char *cd = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride);
+    const unsigned char *m = cd + dim;
     auto ld = [&](int o) { return (uint32_t)m[o] | ((uint32_t)m[o + 1] << 8) | ((uint32_t)m[o + 2] << 16) | ((uint32_t)m[o + 3] << 24); };
-    out[row] = make_uint4(ld(0), ld(4), is_l2 ? ld(12) : 0u, 0u);
+    unsigned long long ss = 0;   // |c - 128|_2, rounded up: the row's factor of the Cauchy-Schwarz term of the filter bound
+    for (uint32_t i = 0; i < dim; i++) {
+        const int v = (int)cd[i] - 128;
+        ss += (unsigned long long)(v * v);
+    }
+    const float nc = (float)(sqrt((double)ss) * 1.000001);   // (the factor dwarfs the two roundings)
+    out[row] = make_uint4(ld(0), ld(4), is_l2 ? ld(12) : 0u, __float_as_uint(nc));
 }
 // uint8 Cosine: {stored float norm, sum (x - 128), 0, 0} per row
 static __global__ __launch_bounds__(256) void k_row_aux_u8c(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n, uint4 *out) {

@@ -279,11 +279,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     for (size_t q = 0; q < nq; q++) {
         const unsigned char *src = (const unsigned char *)queries + q * qstride;
         if (is_sq8) {
-            // one int8 piece per query element: y_i = s Y_i + e_i, |Y_i| <= 127 (LowpOps<LP_SQ8>).  W bounds, per unit of
-            // the row's delta, everything the kernel's dot product can be off the reference's by:
-            //   sum c_i e_i   <= 255 sum |e_i|
-            //   the reference's fp32 accumulation (dim/32 fused steps per lane + the tree; IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104)
-            //                 <= 2 (dim/32 + 8) 2^-24 * 255 sum |y_i|
+            // one int8 piece per query element: y_i = s Y_i + e_i, |Y_i| <= 127 (LowpOps<LP_SQ8>): 128 sum e_i and |e|_2 go to
+            // the kernel; Wref bounds, per unit of the row's delta, the reference's own fp32 accumulation (dim/32 fused steps
+            // per lane + the tree; IP_AVX512F_BW_VL_VNNI_SQ8_FP32.h:49-104): <= 2 (dim/32 + 8) 2^-24 * 255 sum |y_i|
             const size_t qeb = t->type == VSGPU_SQ8H ? 2 : 4;   // fp16 queries are widened first (exactly)
             std::vector<float> ywide;
             if (qeb == 2) {
@@ -302,7 +300,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             }
             float sf = (float)(ymax / 127.0);
             if (!(sf > 0.0f) || !std::isfinite(sf)) sf = 1.0f;
-            double e1 = 0;
+            double se = 0, se2 = 0;
             long sy = 0;
             for (size_t i = 0; i < dim; i++) {
                 double r = std::nearbyint((double)y[i] / (double)sf);
@@ -310,16 +308,23 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 if (r > 127.0) r = 127.0;
                 yq[i] = (signed char)r;
                 sy += (long)r;
-                e1 += std::fabs((double)y[i] - (double)sf * r);
+                const double e = (double)y[i] - (double)sf * r;
+                se += e;
+                se2 += e * e;
             }
-            const double W = (255.0 * e1 + 2.0 * ((double)dim / 32.0 + 8.0) * std::ldexp(1.0, -24) * 255.0 * yabs) * (1.0 + 1e-6);
+            // Wref: the reference's fp32 accumulation + the rounding of `ce` below, per unit of the row's delta
+            const float ce = (float)(128.0 * se);
+            const double Wref = (2.0 * ((double)dim / 32.0 + 8.0) * std::ldexp(1.0, -24) * 255.0 * yabs +
+                                 std::ldexp(1.0, -22) * std::fabs(128.0 * se)) * (1.0 + 1e-6);
             float *qm = &qmeta[q * 8];
             const int K = (int)(128 * sy);
             qm[0] = sf;
             memcpy(&qm[1], &K, 4);
             memcpy(&qm[2], src + qeb * dim, 4);                                 // y_sum
             if (t->metric == VSGPU_L2) memcpy(&qm[3], src + qeb * dim + 4, 4);  // y_sum_squares
-            qm[4] = std::nextafter((float)W, INFINITY);
+            qm[4] = std::nextafter((float)Wref, INFINITY);
+            qm[5] = ce;
+            qm[6] = std::nextafter((float)(std::sqrt(se2) * (1.0 + 1e-6)), INFINITY);   // |e|_2
             src = reinterpret_cast<const unsigned char *>(yq.data());
         }
         const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
@@ -376,7 +381,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, !is_int), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
-    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT);
+    // (the one-piece SQ8 bound is looser than the others: several times the candidates for the same probe)
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT) * (is_sq8 ? 6 : 1);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
     if (is_sq8 || is_u8c) {
@@ -426,6 +432,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     if (rc) return rc;
     const uint32_t wgs = (uint32_t)c->n_cu * 2;
 
+    ScanChainGuard chain(t);   // behind the other reader lanes' probe + scan (see topk_mfma)
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     {
         LowpParams Q = P;
@@ -441,7 +448,6 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
-    ScanChainGuard chain(t);   // behind the other reader lanes' scans (no-op for a table without views)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {
         LowpParams Q = P;

@@ -191,6 +191,10 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     P.cap = (uint32_t)ccap;
     const uint32_t wg_cap = (uint32_t)c->n_cu * 2;
 
+    // behind the other reader lanes' probe + scan (no-op for a table without views): the table-wide kernels of all lanes run
+    // one after the other, so each streams at full bandwidth and its HIP-event time is its own; what overlaps with another
+    // lane's scan is this lane's query upload before, and its re-rank, selection, download and host replay after
+    ScanChainGuard chain(t);
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     {   // probe: strided tiles -> per (tile, query) upper bounds
         MfmaParams Q = P;
@@ -205,7 +209,6 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
-    ScanChainGuard chain(t);   // behind the other reader lanes' scans (no-op for a table without views)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {   // filter: every tile once
         MfmaParams Q = P;
