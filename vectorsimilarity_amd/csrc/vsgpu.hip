@@ -1035,7 +1035,8 @@ static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *i
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride);
 int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
-                              size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name) {
+                              size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
+                              ScanChainGuard *chain) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
     // GPU: keep, per query, the candidates with exact score <= T_k; only those travel to the host
@@ -1048,6 +1049,10 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
                        (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)c->sel.p,
                        (uint32_t *)c->selcnt.p, (uint32_t)ocap);
     HIPCHK(hipGetLastError());
+    // the last kernel of this batch is in the stream: the next reader lane's kernels may follow (its probe and scan then
+    // overlap with this lane's downloads and host replay, not with its kernels -- a re-rank or select kernel sharing the
+    // CUs with another lane's scan cost that scan more than the overlap saved: bf16 config 4, 3.18 -> 3.33 ms)
+    if (chain) chain->submitted();
     // raw candidate counts ride along (statistics + "fewer than k" sanity check)
     HIPCHK(hipMemcpyAsync((uint32_t *)c->selcnt.p + nq, c->counts.p, nq * 4, hipMemcpyDeviceToDevice, c->stream));
     rc = ensure_pinned(c, nq * 8 + nq * ocap * sizeof(uint2));

@@ -182,7 +182,8 @@ template <typename F> static void host_parallel(size_t n, size_t grain, F f) {
     for (auto &th : pool) th.join();
 }
 int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
-                       size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name);
+                       size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
+                       ScanChainGuard *chain = nullptr);
 uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank);
 size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows);
 // stage 2 of the filter paths: reference-order exact re-score of the candidate lists in ctx->cand (in place)

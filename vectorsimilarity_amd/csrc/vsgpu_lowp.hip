@@ -485,7 +485,6 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    chain.submitted();
     if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
@@ -501,5 +500,5 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 #ifdef VSGPU_TUNING
                               : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
 #endif
-                              : "k_mfma_filter_lowp(i8)");
+                              : "k_mfma_filter_lowp(i8)", &chain);
 }

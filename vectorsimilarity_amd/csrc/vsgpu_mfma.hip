@@ -221,8 +221,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    chain.submitted();
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
-    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter");
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter", &chain);
 }
