@@ -21,7 +21,10 @@ if [ "$ALL" = "all" ]; then
   for c in c3 c4; do
     mkdir -p $OUT/cfg_$c
     rocprofv3 --kernel-trace --stats -d $OUT/cfg_$c/trace -o r1 -- python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $OUT/cfg_$c/trace.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_fetch -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $OUT/cfg_$c/pmc_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_write -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $OUT/cfg_$c/pmc_write.log 2>&1
     python $R/profiles/summarize.py $OUT/cfg_$c $OUT/cfg_$c/summary || true
   done
 fi
+python $R/profiles/make_pmc_traffic.py $OUT > $OUT/pmc_traffic.json || true
 tail -1 $OUT/bench_line.json | cut -c1-1200
