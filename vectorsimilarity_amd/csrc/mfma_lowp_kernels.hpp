@@ -594,6 +594,41 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             const int K = (int)__float_as_uint(qm_r[1]);
             const float tq = tau[0];
             const uint32_t arow_off = aux_lds_off + abuf * AUXBUF;
+            // score and bound of one (row, query) value from the row's aux record {min, delta, sum_squares, |c'|_2}
+            auto bounds = [&](const u32x4_t a, int d, float &low, float &up) {
+                const float mn = __uint_as_float(a[0]), dl = __uint_as_float(a[1]), xsq = __uint_as_float(a[2]);
+                const float nc = __uint_as_float(a[3]);
+                const float f = (float)(d + K);
+                const float dq = dl * (qs * f + ce);
+                const float my = mn * ysum;
+                const float ip = my + dq;
+                const float C = L2 ? (xsq + ysq) : 1.0f;
+                const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
+                const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
+                low = sc - E;
+                up = sc + E;
+            };
+            if (MODE == MF_FILTER) {
+                // survivors are rare: one branch-free pass over the lane's 4 MT values decides whether any lane of the wave has
+                // one (the per-value emission branches below cost an exec-mask save and a jump each, 16 of them per tile)
+                bool any = false;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    u32x4_t am[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(am[i]) : "v"(arow_off + (uint32_t)((mt * 16 + kq * 4 + i) * 16)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]));
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float low, up;
+                        bounds(am[i], (int)acc[mt][0][i], low, up);
+                        any |= !(low > tq);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one M-block at a time: 16 values in flight at once spilled
+                }
+                if (!__any(any)) return;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 u32x4_t am[4];
@@ -604,16 +639,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t lrow = mt * 16 + kq * 4 + i;
-                    const float mn = __uint_as_float(am[i][0]), dl = __uint_as_float(am[i][1]), xsq = __uint_as_float(am[i][2]);
-                    const float nc = __uint_as_float(am[i][3]);
-                    const float f = (float)((int)acc[mt][0][i] + K);
-                    const float dq = dl * (qs * f + ce);
-                    const float my = mn * ysum;
-                    const float ip = my + dq;
-                    const float C = L2 ? (xsq + ysq) : 1.0f;
-                    const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
-                    const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
-                    const float low = sc - E, up = sc + E;
+                    float low, up;
+                    bounds(am[i], (int)acc[mt][0][i], low, up);
                     if (MODE == MF_PROBE) {
                         if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
                     } else if (lrow < nvalid && !(low > tq)) {   // (a NaN bound goes on to the exact re-rank)
