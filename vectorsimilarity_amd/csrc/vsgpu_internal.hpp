@@ -52,6 +52,10 @@ struct vsgpu_ctx {
     long opt_lowp_ksplit = 0;  // int8/uint8 1 KiB rows: K-split filter kernel (mfma_i8ks_kernels.hpp); 2 = with s_setprio
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;
+    // the bf16 / fp16 / int8 / SQ8 filters hold ONE workgroup per CU (query fragments fill the register file): a grid of one
+    // workgroup per CU avoids the tail a second round of workgroups leaves (bf16 config-4 shape: 6.3 against 6.0 TB/s,
+    // profiles/r01_tuning_lowp.txt round-2 block)
+    long opt_lowp_wg_per_cu = 1;
     long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
                                       // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel

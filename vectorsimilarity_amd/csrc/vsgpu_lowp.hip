@@ -454,7 +454,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tile_first = 0;
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
-        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
+        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_lowp_wg_per_cu;
         Q.dbg = (int)c->opt_lowp_dbg;
         uint32_t *d_ph = nullptr;
         const size_t ph_words = (size_t)fw * q_tiles * 16 * 8;
