@@ -489,7 +489,8 @@ long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     // (more threads link faster but see less of each other's nodes: at 256 threads recall on a 20 K-row graph fell
     // from 0.93 to 0.88 and the 1 M-row build was slower, 636 s vs 379 s; software prefetch of the next row: 108 s vs 91 s
     // at 300 K rows -- measured, not kept)
-    threads = std::max<size_t>(1, std::min<size_t>(threads, 64));
+    // default: at most 64 linking threads; VECSIM_HNSW_BUILD_THREADS may ask for up to 256
+    threads = std::max<size_t>(1, std::min<size_t>(threads, std::getenv("VECSIM_HNSW_BUILD_THREADS") ? 256 : 64));
     if (n < 2048 || threads == 1) {
         host_vecs_.reserve(host_vecs_.size() + n * dim_);
         for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * elem_bytes_, labels[i]);
