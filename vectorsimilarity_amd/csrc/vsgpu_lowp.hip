@@ -148,6 +148,7 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 34: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 32>);
         case 15: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 2>);  // 4 slots, 2 ahead: plain barrier
         case 16: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 2>);
+        // (64 whole rows per unit with 2 slots -- half the barriers per row -- spills 76 VGPRs at the 128-register budget: not built)
         case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
         case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
         case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
