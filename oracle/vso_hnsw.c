@@ -9,9 +9,14 @@
  * The graph is an input (exported from the index under test), distances come from vso_distance (the
  * pinned kernel oracle).  The two heaps are kept as plain arrays with linear-scan "pop the maximum",
  * which is trivially the same element std::priority_queue<pair> pops: candidate_set orders by
- * (-dist, id), top_candidates by (dist, label).  There is no reference fixture for HNSW results (the
- * reference's own tests check recall against brute force), so parity for this path is: GPU search ==
- * this restatement on the same graph, bit for bit, plus recall vs the exact Flat answer.
+ * (-dist, id), top_candidates by (dist, label).
+ *
+ * Parity pin: the reference's deterministic HNSW unit tests (tests/unit/test_hnsw.cpp:225-293, 1580-1632, 1801-1845:
+ * closed forms over {i,i,i,i} vectors, the Cosine ranking, the range query with two epsilons) restated as data in
+ * tests/golden/kat_hnsw.json; tests/test_gpu_hnsw.py asserts them on this restatement searching the graph the index under
+ * test exports, and on the GPU search itself.  Beyond those: GPU search == this restatement on the same graph, bit for bit
+ * (labels, order, scores, number of distance evaluations), plus recall against the exact Flat answer.  The graph is built by
+ * the product's host builder, so those known answers pin the search loops on that graph, not the reference's build order.
  */
 #include <math.h>
 #include <stdlib.h>
