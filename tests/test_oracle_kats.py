@@ -283,3 +283,60 @@ def test_sq8_tiers_within_the_reference_tolerance(vso, dim):
             assert abs(vso.sq8_sq8_distance(metric, st, st2, dim, tier=tier) - base2) < tol, (metric, tier)
         # the stored sums describe the reconstruction (preprocessors.h:369-381)
         assert abs(meta[2] - xr.sum()) <= 1e-4 * max(1.0, abs(xr.sum()))
+
+
+def _hnsw_graph(z, name):
+    g = {}
+    for key in ("n", "M", "M0", "entry", "max_level"):
+        g[key] = int(z["%s/%s" % (name, key)])
+    for key in ("links0", "cnt0", "upper_off", "upper", "deleted", "labels"):
+        g[key] = np.ascontiguousarray(z["%s/%s" % (name, key)])
+    return g, np.ascontiguousarray(z["%s/stored" % name])
+
+
+def test_hnsw_search_oracle_on_the_reference_known_answers(vso):
+    """oracle/vso_hnsw.c searching the graphs of tests/golden/kat_hnsw_graphs.npz (the product's host builder on the inputs of
+    tests/unit/test_hnsw.cpp, exported by tests/golden/make_hnsw_graphs.py on an MI355X) must give the closed forms the
+    reference's own tests assert (kat_hnsw.json) -- the same pin tests/test_gpu_hnsw.py applies, here without a GPU."""
+    z = np.load(os.path.join(GOLD, "kat_hnsw_graphs.npz"))
+    kats = _load("kat_hnsw.json")
+    assert len(kats["topk"]) >= 4
+    for case in kats["topk"]:
+        g, srows = _hnsw_graph(z, case["name"])
+        assert g["n"] == len(case["vectors"]) and list(g["labels"]) == case["labels"]
+        q = np.array(case["query"], dtype=np.float32)
+        rows = np.array(case["vectors"], dtype=np.float32)
+        if case["metric"] == "Cosine":      # stored blobs are the oracle's own normalisation of the inputs, bit for bit
+            vso.normalize(q, case["dim"], 0)
+            for r in rows:
+                vso.normalize(r, case["dim"], 0)
+        assert srows.tobytes() == rows.tobytes(), case["name"]
+        k = case["k"]
+        ol, od, _ = vso.hnsw_search(0, 0 if case["metric"] == "L2" else 1, srows, g, q, k, max(k, 10), case["dim"])
+        if case["order"] == "id":
+            srt = np.argsort(ol, kind="stable")
+            ol, od = ol[srt], od[srt]
+        assert len(ol) == k, case["name"]
+        if "expect_labels" in case:
+            assert [int(x) for x in ol] == case["expect_labels"], case["name"]
+        if "expect_abs_diff" in case:
+            assert [abs(int(x) - case["expect_labels_abs_diff_from"]) for x in ol] == case["expect_abs_diff"], case["name"]
+            assert list(od) == case["expect_scores"], case["name"]
+        if "expect_label_range" in case:
+            lo, hi = case["expect_label_range"]
+            assert all(lo <= int(x) < hi for x in ol) and all(float(s) <= case["expect_score_max"] for s in od), case["name"]
+
+
+def test_hnsw_range_oracle_on_the_reference_known_answers(vso):
+    z = np.load(os.path.join(GOLD, "kat_hnsw_graphs.npz"))
+    c = _load("kat_hnsw.json")["range"]
+    g, srows = _hnsw_graph(z, "rangeQuery")
+    assert g["n"] == c["n"]
+    q = np.full(c["dim"], float(c["pivot"]), dtype=np.float32)
+    for eps in c["epsilons"]:
+        ol, od, _ = vso.hnsw_range(0, 0, srows, g, q, c["radius"], eps, c["dim"])
+        assert len(ol) == c["expect_count"]
+        assert sorted(int(x) for x in ol) == c["expect_labels_by_id"]
+        srt = np.lexsort((ol, od))
+        assert [abs(int(x) - c["pivot"]) for x in ol[srt]] == c["expect_abs_diff_by_score"]
+        assert list(od[srt]) == c["expect_scores_by_score"]
