@@ -606,31 +606,44 @@ static int item_less(const heap_item *x, const heap_item *y) {
     if (y->score < x->score) return 0;
     return x->label < y->label;
 }
-static void sift_up(heap_item *h, size_t i) {
-    while (i > 0) {
-        size_t p = (i - 1) / 2;
-        if (!item_less(&h[p], &h[i])) break;
-        heap_item t = h[p];
-        h[p] = h[i];
-        h[i] = t;
-        i = p;
+/* std::priority_queue<pair<DistType, labelType>> (utils/vecsim_stl.h:66-72) is std::push_heap / std::pop_heap over a
+ * vector.  Under a strict weak order any correct heap pops the same items, but a NaN score is unordered (item_less
+ * falls through to the labels), and then WHICH item sits where depends on the heap algorithm itself.  The reference's
+ * platform is gcc/libstdc++, so the two routines below follow libstdc++'s published algorithm (bits/stl_heap.h,
+ * GCC 11: __push_heap, __adjust_heap, __pop_heap) move for move; tests/test_oracle_kats.py checks them against the
+ * real std::priority_queue on inputs with NaNs (tests/helpers/heap_probe.cpp). */
+static void heap_push_hole(heap_item *h, size_t hole, size_t top, heap_item value) { /* __push_heap */
+    while (hole > top) {
+        size_t parent = (hole - 1) / 2;
+        if (!item_less(&h[parent], &value)) break;
+        h[hole] = h[parent];
+        hole = parent;
     }
+    h[hole] = value;
 }
-static void sift_down(heap_item *h, size_t n, size_t i) {
-    for (;;) {
-        size_t l = 2 * i + 1, r = l + 1, m = i;
-        if (l < n && item_less(&h[m], &h[l])) m = l;
-        if (r < n && item_less(&h[m], &h[r])) m = r;
-        if (m == i) break;
-        heap_item t = h[m];
-        h[m] = h[i];
-        h[i] = t;
-        i = m;
+static void sift_up(heap_item *h, size_t i) { heap_push_hole(h, i, 0, h[i]); } /* push_heap of the appended item */
+/* pop_heap + pop_back: h[0 .. n) -> h[0 .. n-1) */
+static void heap_pop(heap_item *h, size_t n) {
+    if (n < 2) return;
+    const heap_item value = h[n - 1]; /* __pop_heap: the last item is re-inserted from the root hole */
+    const size_t len = n - 1;
+    size_t hole = 0, child = 0;
+    while (child < (len - 1) / 2) { /* __adjust_heap: walk the hole down along the larger children ... */
+        child = 2 * (child + 1);
+        if (item_less(&h[child], &h[child - 1])) child--;
+        h[hole] = h[child];
+        hole = child;
     }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    heap_push_hole(h, hole, 0, value); /* ... then push the saved item up from there */
 }
 
-/* brute_force.h:257-288.  The max element of a set under a strict weak order is unique here
- * (labels are distinct), so any correct heap pops the same item std::priority_queue would. */
+/* brute_force.h:257-288, NaN scores included: `score < upperBound` is false for a NaN, so a NaN-score row enters only
+ * while the heap is not full, and once a NaN is the top nothing else enters. */
 size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, size_t k,
                        size_t *out_labels, double *out_scores) {
     if (k == 0 || n == 0) return 0;
@@ -647,9 +660,8 @@ size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, siz
             sift_up(h, hs);
             hs++;
             if (hs > k) {
-                h[0] = h[hs - 1];
+                heap_pop(h, hs);
                 hs--;
-                sift_down(h, hs, 0);
             }
             upper = h[0].score;
             upper_init = 1;
@@ -659,9 +671,8 @@ size_t vso_topk_replay(const double *scores, const size_t *labels, size_t n, siz
     for (size_t i = cnt; i-- > 0;) {
         out_labels[i] = h[0].label;
         out_scores[i] = h[0].score;
-        h[0] = h[hs - 1];
+        heap_pop(h, hs);
         hs--;
-        if (hs) sift_down(h, hs, 0);
     }
     free(h);
     return cnt;

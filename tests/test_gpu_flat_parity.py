@@ -875,6 +875,93 @@ def test_nan_and_inf_rows_do_not_hide_their_neighbours(vso, typ, dim):
         assert labels[j][0] == b - 1
 
 
+def _check_against_every_row_replay(vso, ix, typ, metric, rows, labels, q, k):
+    st = stored_rows(vso, rows, typ, metric)
+    got_l, got_s = ix.knn_query(q, k)
+    for j in range(len(q)):
+        qq = stored_rows(vso, q[j][None, :], typ, metric)[0]
+        sc = vso.scan(TYPES[typ], kernel_metric(typ, metric), st, qq, rows.shape[1])
+        el, es = vso.topk_replay(sc, k, np.asarray(labels, dtype=np.uint64))
+        c = len(el)
+        assert np.array_equal(got_l[j][:c], el.astype(np.int64)), (typ, metric, j, got_l[j], el)
+        assert np.array_equal(got_s[j][:c], es, equal_nan=True), (typ, metric, j, got_s[j], es)
+        assert (got_l[j][c:] == -1).all()
+    return got_l, got_s
+
+
+@pytest.mark.parametrize("typ,metric,dim,k", [("f32", "L2", 64, 10), ("f32", "Cosine", 32, 5), ("bf16", "IP", 72, 10),
+                                               ("i8", "Cosine", 64, 8), ("f16", "L2", 40, 6), ("f64", "IP", 24, 7)])
+def test_nan_scores_enter_while_the_heap_fills_like_the_reference(vso, typ, metric, dim, k):
+    """brute_force.h:272: `score < upperBound || size < k` lets a NaN-score row in only while the heap is not full, i.e.
+    for internal ids below k; from there on std::priority_queue's own moves decide the reply (a NaN on top blocks every
+    later row).  Rows with such scores among the first k ids, queries that are NaN / Inf / zero (Cosine) themselves, and a
+    swap-delete that carries a NaN row from the tail into the head: the reply must equal the sequential loop over every
+    row's score on libstdc++'s heap (oracle, pinned against the real container in tests/test_oracle_kats.py)."""
+    rng = np.random.default_rng(dim + k)
+    n = 3000
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 5, dim, typ, vso)
+    if metric == "Cosine":                   # a zero vector normalises to 0/0 (fp) or divides by a zero norm (int8)
+        rows[1] = 0
+        rows[4] = 0
+        rows[n - 1] = 0
+        q[3] = 0
+    else:
+        nan = {"f32": np.float32(np.nan), "f64": np.nan, "f16": np.uint16(0x7E00), "bf16": np.uint16(0x7FC0)}[typ]
+        inf = {"f32": np.float32(np.inf), "f64": np.inf, "f16": np.uint16(0x7C00), "bf16": np.uint16(0x7F80)}[typ]
+        rows[1, 3] = nan
+        rows[4, 0] = nan
+        if metric == "L2":
+            rows[6, :] = inf                   # score +Inf: ordered, but the row still must not disturb its neighbours
+        rows[n - 1, 2] = nan
+        q[3, 1] = nan
+        q[4, 0] = inf
+    labels = np.arange(n) * 3 + 1
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, labels)
+    _check_against_every_row_replay(vso, ix, typ, metric, rows, labels, q, k)
+    _check_against_every_row_replay(vso, ix, typ, metric, rows, labels, q, 1)
+    _check_against_every_row_replay(vso, ix, typ, metric, rows, labels, q[:1], n + 5)     # heap never fills: every NaN row enters
+    for lab in (labels[1], labels[4]):
+        ix.delete_vector(int(lab))
+    keep = list(range(n))
+    for dead in (1, 4):                       # swap-delete: the last row moves into the hole (brute_force.h:196-224)
+        keep[dead] = keep[-1]
+        keep.pop()
+    _check_against_every_row_replay(vso, ix, typ, metric, rows[keep], labels[keep], q, k)
+    assert keep[1] == n - 1                   # ... which carried the NaN tail row to id 1
+    ix.delete_vector(int(labels[n - 1]))
+    keep[1] = keep[-1]
+    keep.pop()
+    ix.reset_stats()
+    gl, gs = _check_against_every_row_replay(vso, ix, typ, metric, rows[keep], labels[keep], q, k)
+    assert not np.isnan(gs[:3]).any()
+
+
+@pytest.mark.parametrize("typ,metric,dim", [("f32", "IP", 96), ("bf16", "IP", 128), ("f32", "Cosine", 64), ("i8", "Cosine", 128)])
+def test_nan_rows_past_the_head_on_the_filter_path(vso, typ, metric, dim):
+    """rows whose score is NaN (1 - NaN carries either sign) at ids >= k never enter the reference's heap; on the MFMA
+    filter path they must neither be returned nor become the k-th score of the GPU selection (k = 1 included)"""
+    rng = np.random.default_rng(dim)
+    n = 30_000
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 8, dim, typ, vso)
+    for b in (777, 9000, 9001, 20_001, n - 1):
+        if metric == "Cosine":
+            rows[b] = 0
+        else:
+            rows[b, b % dim] = {"f32": np.float32(np.nan), "bf16": np.uint16(0xFFC0 if b & 1 else 0x7FC0)}[typ]
+    labels = np.arange(n)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, labels)
+    ix.set_option("dense_pairs", 0)
+    for k in (1, 10, 100):
+        ix.reset_stats()
+        _, gs = _check_against_every_row_replay(vso, ix, typ, metric, rows, labels, q, k)
+        assert not np.isnan(gs).any()
+        assert ix.stats()["scan_kernel"].startswith("k_mfma_filter"), ix.stats()["scan_kernel"]
+
+
 @pytest.mark.parametrize("typ,ties", [("f32", False), ("f32", True), ("i8", True)])
 def test_batch_iterator_device_state_equals_host_array(vso, typ, ties):
     """sparse mode (scores stay in HBM, GPU picks the rows at or below the batch threshold, host replays the

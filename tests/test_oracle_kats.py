@@ -340,3 +340,36 @@ def test_hnsw_range_oracle_on_the_reference_known_answers(vso):
         srt = np.lexsort((ol, od))
         assert [abs(int(x) - c["pivot"]) for x in ol[srt]] == c["expect_abs_diff_by_score"]
         assert list(od[srt]) == c["expect_scores_by_score"]
+
+
+def test_topk_replay_follows_libstdcxx_heap_moves_with_nan_scores(vso):
+    """The reference keeps its top-k in std::priority_queue<pair<score, label>> (utils/vecsim_stl.h:66-72).  With NaN scores
+    the pair order is no strict weak order and the reply depends on the heap algorithm's own moves, so the oracle restates
+    libstdc++'s (oracle/vso.c heap_push_hole / heap_pop).  Checked here against the real container on scores with NaNs, +-Inf
+    and ties; labels both ascending and shuffled."""
+    import ctypes as C
+    import subprocess
+    helpers = os.path.join(os.path.dirname(__file__), "helpers")
+    so, src = os.path.join(helpers, "libheap_probe.so"), os.path.join(helpers, "heap_probe.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, src], check=True)
+    L = C.CDLL(so)
+    L.heap_probe_topk.restype = C.c_size_t
+    L.heap_probe_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    cases = 0
+    for trial in range(400):
+        n = int(rng.integers(1, 120))
+        k = int(rng.integers(1, 40))
+        sc = rng.integers(-6, 7, n).astype(np.float64) if trial % 2 else rng.normal(size=n)
+        for frac, val in ((0.15, np.nan), (0.05, np.inf), (0.05, -np.inf)):
+            sc[rng.random(n) < frac * (trial % 5)] = val
+        labels = np.arange(n, dtype=np.uint64) if trial % 3 else rng.permutation(n).astype(np.uint64) * 7
+        ol, osc = np.zeros(max(k, 1), dtype=np.uint64), np.zeros(max(k, 1), dtype=np.float64)
+        c = L.heap_probe_topk(sc.ctypes.data, labels.ctypes.data, n, k, ol.ctypes.data, osc.ctypes.data)
+        gl, gs = vso.topk_replay(sc, k, labels)
+        assert len(gl) == c == min(n, k)
+        assert np.array_equal(gl, ol[:c]), (trial, sc, gl, ol[:c])
+        assert np.array_equal(gs, osc[:c], equal_nan=True)
+        cases += bool(np.isnan(sc).any())
+    assert cases > 200

@@ -58,6 +58,45 @@ inline float fp16_widen(uint16_t h) {
     else out = em + ((127u - 15u) << 23);
     return bits_to_f32(out | sign);
 }
+
+// Can a score computed from these values be NaN?  Conservative: true for NaN / Inf elements and for magnitudes whose
+// products could overflow to +-Inf (and then cancel) in the accumulation type.  With every element of both vectors
+// below the bound no partial sum of the reference kernels overflows, so no score is NaN.  (fp16 tops out at 65504.)
+inline bool values_may_nan(const void *p, VecSimType t, size_t n) {
+    const char *b = static_cast<const char *>(p);
+    bool w = false;
+    switch (t) {
+    case VecSimType_FLOAT32:
+        for (size_t i = 0; i < n; i++) {
+            float f;
+            std::memcpy(&f, b + 4 * i, 4);
+            w |= !(std::fabs(f) <= 1e15f);
+        }
+        return w;
+    case VecSimType_FLOAT64:
+        for (size_t i = 0; i < n; i++) {
+            double f;
+            std::memcpy(&f, b + 8 * i, 8);
+            w |= !(std::fabs(f) <= 1e150);
+        }
+        return w;
+    case VecSimType_BFLOAT16:
+        for (size_t i = 0; i < n; i++) {
+            uint16_t h;
+            std::memcpy(&h, b + 2 * i, 2);
+            w |= !(std::fabs(bf16_widen(h)) <= 1e15f);
+        }
+        return w;
+    case VecSimType_FLOAT16:
+        for (size_t i = 0; i < n; i++) {
+            uint16_t h;
+            std::memcpy(&h, b + 2 * i, 2);
+            w |= (h & 0x7C00u) == 0x7C00u;
+        }
+        return w;
+    default: return false;
+    }
+}
 // The reference's narrowing is not plain IEEE round-to-nearest-even: it drops the low 12 mantissa
 // bits, rescales by 2^-112 (letting fp32 subnormals model fp16 subnormals), clamps, adds 0x1000
 // and shifts.  Stored Cosine fp16 bytes depend on exactly this.

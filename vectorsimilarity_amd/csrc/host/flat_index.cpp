@@ -186,6 +186,25 @@ void FlatIndex::toQuery(const void *query, char *out) const {
     }
 }
 
+// stored blobs and query blobs start with dim_ elements of the same kind (SQ8 storage: codes, then FP32 metadata)
+bool FlatIndex::mayScoreNaN(const char *b) const {
+    if (is_int_type(type_)) {
+        if (metric_ != VecSimMetric_Cosine) return false;
+        float norm;  // 1 - dot / (norm_x * norm_q): a zero vector makes 0 / 0
+        std::memcpy(&norm, b + dim_, 4);
+        return !(norm > 0.0f && norm <= 1e15f);
+    }
+    return values_may_nan(b, type_, dim_);
+}
+void FlatIndex::noteRow(uint32_t id, const void *stored) {
+    const char *b = static_cast<const char *>(stored);
+    bool w;
+    if (sq8_) w = values_may_nan(b + dim_, VecSimType_FLOAT32, metric_ == VecSimMetric_L2 ? 4 : 3);
+    else w = mayScoreNaN(b);
+    if (w) nan_ids_.insert(id);
+    else if (!nan_ids_.empty()) nan_ids_.erase(id);
+}
+
 double FlatIndex::storedDistance(size_t label_a, size_t label_b) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
     if (!sq8_ || multi_) return std::numeric_limits<double>::quiet_NaN();
@@ -247,13 +266,16 @@ int FlatIndex::addVector(const void *blob, size_t label) {
         if (sq8_) {   // (no reference behaviour to follow here: SQ8 rows are only ever written by the preprocessor)
             std::vector<char> tmp(stored_bytes_);
             toStored(blob, tmp.data());
+            noteRow(it->second, tmp.data());
             vsgpu_table_write(table_, it->second, tmp.data());
         } else if (metric_ == VecSimMetric_Cosine && is_int_type(type_)) {
             std::vector<char> tmp(stored_bytes_);
             std::memcpy(tmp.data(), blob, dim_);
             normalize_blob(tmp.data(), dim_, type_);
+            noteRow(it->second, tmp.data());
             vsgpu_table_write(table_, it->second, tmp.data());
         } else {
+            noteRow(it->second, blob);
             vsgpu_table_write(table_, it->second, blob);
         }
         return 0;
@@ -263,8 +285,10 @@ int FlatIndex::addVector(const void *blob, size_t label) {
         std::vector<char> tmp(stored_bytes_);
         toStored(blob, tmp.data());
         stageRow(tmp.data());
+        noteRow((uint32_t)count_, tmp.data());
     } else {
         stageRow(blob);
+        noteRow((uint32_t)count_, blob);
     }
     const uint32_t id = (uint32_t)count_++;
     if (id_to_label_.size() < count_) {
@@ -311,6 +335,11 @@ long FlatIndex::addSynthetic(size_t n, uint64_t seed) {
 // removeVector (brute_force.h:196-224): move the last row into the hole, shrink by one
 void FlatIndex::removeRow(uint32_t id) {
     const uint32_t last = (uint32_t)(--count_);
+    if (!nan_ids_.empty()) {  // the last row's flag travels with it into the hole
+        const bool last_flag = nan_ids_.erase(last) > 0;
+        nan_ids_.erase(id);
+        if (last_flag && id != last) nan_ids_.insert(id);
+    }
     if (id != last) {
         const size_t last_label = id_to_label_[last];
         id_to_label_[id] = last_label;
@@ -370,6 +399,7 @@ int FlatIndex::overwriteRow(uint32_t id, const void *stored_blob, size_t new_lab
     label_to_id_.erase(id_to_label_[id]);
     id_to_label_[id] = new_label;
     label_to_id_[new_label] = id;
+    noteRow(id, stored_blob);
     return vsgpu_table_write(table_, id, stored_blob);
 }
 int FlatIndex::dropLastRow() {
@@ -636,7 +666,17 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     const size_t cap = std::max<size_t>(2 * kk, kk + 64);
     std::vector<uint32_t> ids(nq * cap), counts(nq);
     std::vector<double> sc(nq * cap);
-    int rc = vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
+    // queries that can meet a NaN score while the reference's heap is still filling (see nan_ids_) take the every-row replay
+    const bool nan_head = !nan_ids_.empty() && *nan_ids_.begin() < k;
+    std::vector<char> every_row(nq, (char)nan_head);
+    size_t n_every = nan_head ? nq : 0;
+    if (!nan_head)
+        for (size_t q = 0; q < nq; q++)
+            if (mayScoreNaN(qbuf.data() + q * query_bytes_)) every_row[q] = 1, n_every++;
+    int rc = n_every == nq ? 0 : vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
+    if (n_every)
+        for (size_t q = 0; q < nq; q++)
+            if (every_row[q]) counts[q] = VSGPU_COUNT_OVERFLOW;
     if (rc) {
         log("warning", "GPU top-k failed: %s", vsgpu_last_error());
         for (auto *r : reps) delete r;

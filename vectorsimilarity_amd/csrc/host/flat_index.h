@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include <utility>
 #include <mutex>
+#include <set>
 #include <vector>
 
 #include "VecSim/vec_sim.h"
@@ -176,6 +177,13 @@ private:
     void toQuery(const void *query, char *out) const;
     std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     std::vector<char> staged_;  // rows appended but not yet uploaded
+    // Rows whose score may be NaN for some query (NaN / Inf / huge elements, a Cosine zero vector).  The reference's loop
+    // (brute_force.h:272) lets a NaN score in only while its heap is not full, i.e. for rows with id < k; a query that can
+    // meet such a row -- or is such a vector itself -- replays the sequential heap over every row's score instead of over
+    // the GPU's candidate set, so that even those replies equal the reference's.  Everything else is unaffected.
+    std::set<uint32_t> nan_ids_;
+    bool mayScoreNaN(const char *stored_or_query) const;
+    void noteRow(uint32_t id, const void *stored);
     std::atomic<size_t> staged_rows_{0};
     // Reader lanes: the reference lets any number of readers query one index at a time (vec_sim.h threading contract,
     // bindings.cpp:250-283).  The first reader uses the index's own context; a reader that finds it busy takes a lane --

@@ -464,7 +464,10 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
 // integer image of the float), then every candidate with score <= T is compacted to out[q][...].
 // The host only sorts those few by id and replays the sequential heap.
 __device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
-    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);  // unsigned order == float order
+    // unsigned order == float order; a NaN of either sign sorts after everything (a negative NaN -- 1 - NaN, 0 / 0 --
+    // would otherwise be the smallest key and become the k-th score nothing compares below)
+    if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
+    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
 }
 static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
                                                          uint32_t k, uint2 *out, uint32_t *out_counts,
@@ -558,6 +561,7 @@ struct SelRec64 {
     unsigned long long bits;
 };
 __device__ __forceinline__ unsigned long long double_sort_key(unsigned long long b) {
+    if ((b & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) return ~0ull;  // NaN: after everything, see float_sort_key
     return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
 }
 static __global__ __launch_bounds__(1024) void k_select_dense_upto_kth_f64(const double *dense, size_t stride, uint32_t n, uint32_t k,
