@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--readers", type=int, default=2,
                     help="threads submitting batches (the reference's readers: bindings.cpp:250-283 knn_parallel); 2 lets one "
                          "batch's upload / probe / re-rank / download / host replay overlap with the next batch's scan kernel")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning: VecSimGpu_SetOption on the index (e.g. probe_div=64); not used by the default run")
     a = ap.parse_args()
     typ, metric, dim, rows, batch, k, tag, gen, cpu_rows = CONFIGS[a.config]
     a.type_name, a.metric_name, a.dtype, a.gen = typ, metric, tag, gen
@@ -172,6 +174,9 @@ def main():
         ix = local = VecSim.BFIndex(p)
         ix.add_synthetic(args.rows, args.seed)
     local.set_option("mfma", args.mfma)
+    for o in args.opt:
+        name, val = o.split("=", 1)
+        local.set_option(name, int(val))
 
     n_batches = args.warmup + args.steps
     gen = getattr(synth, args.gen)

@@ -469,10 +469,12 @@ __device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
     if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
     return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
 }
+constexpr uint32_t SEL_LDS_KEYS = 8192;   // candidate keys kept in LDS for the 32 counting passes (the rest is re-read from L2)
 static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
                                                          uint32_t k, uint2 *out, uint32_t *out_counts,
                                                          uint32_t out_cap) {
-    __shared__ uint32_t red[4];
+    __shared__ uint32_t keys[SEL_LDS_KEYS];
+    __shared__ uint32_t red[2][4];
     __shared__ uint32_t wpos;
     const int q = blockIdx.x;
     const uint32_t raw = counts[q];
@@ -484,17 +486,21 @@ static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *can
     const uint2 *c = cand + (size_t)q * cap;
     uint32_t T = 0xFFFFFFFFu;
     if (n > k) {
+        const uint32_t nl = min(n, SEL_LDS_KEYS);
+        for (uint32_t i = threadIdx.x; i < nl; i += 256) keys[i] = float_sort_key(c[i].y);
+        __syncthreads();
         T = 0;
         for (int bit = 31; bit >= 0; bit--) {
             const uint32_t trial = T | (1u << bit);
             uint32_t cnt = 0;
-            for (uint32_t i = threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
+            for (uint32_t i = threadIdx.x; i < nl; i += 256) cnt += (keys[i] < trial) ? 1u : 0u;
+            for (uint32_t i = nl + threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            uint32_t *r = red[bit & 1];   // (alternating buffers: one barrier per pass)
+            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = cnt;
             __syncthreads();
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-            __syncthreads();
-            const uint32_t total = red[0] + red[1] + red[2] + red[3];
+            const uint32_t total = r[0] + r[1] + r[2] + r[3];
             if (total < k) T = trial;  // fewer than k keys below `trial`: the k-th smallest has this bit set
         }
     }

@@ -428,7 +428,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // k_probe_threshold sorts M group minima per query in LDS; more probe tiles than that are grouped (the k-th
     // smallest group minimum still has k distinct rows at or below it, and with k << M grouping costs nothing)
     uint32_t M = 64;
-    while (M < probe_tiles && M < 8192) M <<= 1;
+    while (M < probe_tiles && M < 8192 && M < 64 * k) M <<= 1;   // (64 k groups: two of the k best rows rarely share one)
     rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
     if (rc) return rc;
     const uint32_t wgs = (uint32_t)c->n_cu * 2;

@@ -168,7 +168,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 
     const uint32_t tile_step = total_tiles / probe_tiles;
     uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
-    while (M < probe_tiles && M < 8192) M <<= 1;
+    while (M < probe_tiles && M < 8192 && M < 64 * k) M <<= 1;   // (64 k groups: two of the k best rows rarely share one)
 
     rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
     if (rc) return rc;
