@@ -133,6 +133,16 @@ size_t VecSimGpu_SQ8_StorageBlobSize(size_t dim, VecSimMetric metric);
 size_t VecSimGpu_SQ8_QueryBlobSize(size_t dim, VecSimMetric metric);
 void VecSimGpu_SQ8_Quantize(const float *vector, size_t dim, VecSimMetric metric, void *storage_blob);
 void VecSimGpu_SQ8_QueryBlob(const float *vector, size_t dim, VecSimMetric metric, float *query_blob);
+/* Mean-centred SQ8 (QuantPreprocessor<..., WithNorm = true>, preprocessors.h:484-495, 574-640, + DistanceCalculatorWithNorm,
+ * spaces/computer/calculator.h:126-232; metric L2 or IP): rows are SQ8 blobs of x - mean (IP rows carry x_mean_ip in a
+ * fourth FP32 slot), L2 queries are centred, IP queries stay raw and carry y_mean_ip; every score is the calculator's
+ * calcDistanceForQuery (base kernel, minus y_mean_ip for IP), VecSimGpu_SQ8_StoredDistance its calcDistance
+ * (base - x_mean_ip - y_mean_ip + mean_sum_squares for IP).  mean: dim FP32 values, copied. */
+VecSimIndex *VecSimGpu_NewFlatSQ8Centered(const BFParams *params, const float *mean, float mean_sum_squares, void *logCtx);
+size_t VecSimGpu_SQ8_StorageBlobSizeCentered(size_t dim, VecSimMetric metric);   /* dim + 16 bytes */
+size_t VecSimGpu_SQ8_QueryBlobSizeCentered(size_t dim, VecSimMetric metric);     /* (dim + 2) floats */
+void VecSimGpu_SQ8_QuantizeCentered(const float *vector, const float *mean, size_t dim, VecSimMetric metric, void *storage_blob);
+void VecSimGpu_SQ8_QueryBlobCentered(const float *vector, const float *mean, size_t dim, VecSimMetric metric, float *query_blob);
 
 /* Stored (preprocessed) blobs of a label in internal-id order -- what the reference's Python `get_vector`
  * reads through getStoredVectorDataByLabel (bindings.cpp:201-214).  *blob_bytes receives the stored blob size;

@@ -116,6 +116,11 @@ int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t *ids, size
 /* SQ8 tables only: symmetric distances (SQ8_SQ8_InnerProduct / _Cosine / _L2Sqr, IP.cpp:146-183, L2.cpp:185-201 and the
  * AVX-512 VNNI twins) between stored rows ids_a[i] and ids_b[i]. */
 int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t *ids_b, size_t n, double *scores);
+/* Mean-centred SQ8 (QuantPreprocessor<..., WithNorm = true> + DistanceCalculatorWithNorm, calculator.h:126-232).  L2 tables
+ * need nothing: blobs keep their layout and the base kernels give the distance.  An IP table created with row_bytes = dim + 16
+ * holds rows {codes, min, delta, sum, x_mean_ip}; its query blobs are {y[dim], y_sum, y_mean_ip} and every score is
+ * base - y_mean_ip; pair scores are base - x_mean_ip - y_mean_ip + mean_sum_squares with the constant set here. */
+int vsgpu_table_set_sq8_mean_sum_squares(vsgpu_table *t, float mean_sum_squares);
 
 /* ---- HNSW query loops (algorithms/hnsw/hnsw.h:530-613, 1210-1258, 1967-2084) ----
  * A device snapshot of the graph the host index built (vectors stay in the vsgpu_table): level-0

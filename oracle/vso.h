@@ -89,6 +89,21 @@ double vso_sq8_sq8_distance(int metric, int tier, size_t dim, const void *a, con
 void vso_sq8_fp32_scan(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
                        double *out);
 /* FP16 inputs / queries (QuantPreprocessor<float16>, SQ8_FP16_*): query blob = dim fp16 values + FP32 metadata */
+/* mean-centred blobs (QuantPreprocessor<..., WithNorm = true> + DistanceCalculatorWithNorm; metric L2 or IP) */
+size_t vso_sq8_storage_size_norm(int metric, size_t dim);
+size_t vso_sq8_query_size_norm(int metric, size_t dim);
+size_t vso_sq8_query_size_norm_f16(int metric, size_t dim);
+void vso_sq8_quantize_norm(const float *x, const float *mean, size_t dim, int metric, uint8_t *out);
+void vso_sq8_quantize_norm_f16(const uint16_t *x, const float *mean, size_t dim, int metric, uint8_t *out);
+void vso_sq8_query_blob_norm(const float *y, const float *mean, size_t dim, int metric, float *out);
+void vso_sq8_query_blob_norm_f16(const uint16_t *y, const float *mean, size_t dim, int metric, void *out);
+double vso_sq8_fp32_distance_norm(int metric, int tier, size_t dim, const void *storage, const void *query);
+double vso_sq8_fp16_distance_norm(int metric, int tier, size_t dim, const void *storage, const void *query);
+double vso_sq8_sq8_distance_norm(int metric, int tier, size_t dim, const void *a, const void *b, float mean_sum_squares);
+void vso_sq8_fp32_scan_norm(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                            double *out);
+void vso_sq8_fp16_scan_norm(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                            double *out);
 size_t vso_sq8_query_size_f16(int metric, size_t dim);
 void vso_sq8_quantize_f16(const uint16_t *x, size_t dim, int metric, uint8_t *out);
 void vso_sq8_query_blob_f16(const uint16_t *y, size_t dim, int metric, void *out);

@@ -100,6 +100,20 @@ def lib():
         L.vso_sq8_fp16_distance.argtypes = [i, i, sz, vp, vp]
         L.vso_sq8_fp16_scan.restype = None
         L.vso_sq8_fp16_scan.argtypes = [i, i, sz, vp, sz, sz, vp, vp]
+        for name in ("vso_sq8_storage_size_norm", "vso_sq8_query_size_norm", "vso_sq8_query_size_norm_f16"):
+            getattr(L, name).restype = sz
+            getattr(L, name).argtypes = [i, sz]
+        for name in ("vso_sq8_quantize_norm", "vso_sq8_quantize_norm_f16", "vso_sq8_query_blob_norm", "vso_sq8_query_blob_norm_f16"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [vp, vp, sz, i, vp]
+        for name in ("vso_sq8_fp32_distance_norm", "vso_sq8_fp16_distance_norm"):
+            getattr(L, name).restype = dbl
+            getattr(L, name).argtypes = [i, i, sz, vp, vp]
+        L.vso_sq8_sq8_distance_norm.restype = dbl
+        L.vso_sq8_sq8_distance_norm.argtypes = [i, i, sz, vp, vp, C.c_float]
+        for name in ("vso_sq8_fp32_scan_norm", "vso_sq8_fp16_scan_norm"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [i, i, sz, vp, sz, sz, vp, vp]
         L.vso_has_avx512.restype = i
         L.vso_has_f16c.restype = i
         L.vso_f16c_distance.restype = dbl
@@ -217,6 +231,47 @@ def sq8_fp16_scan(metric, rows, query, dim, tier=TIER_AVX512):
     query = np.ascontiguousarray(query)
     out = np.empty(rows.shape[0], dtype=np.float64)
     lib().vso_sq8_fp16_scan(metric, tier, dim, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(query), _ptr(out))
+    return out
+
+
+# mean-centred blobs (QuantPreprocessor<..., WithNorm = true> + DistanceCalculatorWithNorm); metric L2 or IP; f16 = uint16 input
+def sq8_quantize_norm(x, mean, metric, f16=False):
+    x = np.ascontiguousarray(x, dtype=np.uint16 if f16 else np.float32)
+    mean = np.ascontiguousarray(mean, dtype=np.float32)
+    out = np.zeros(lib().vso_sq8_storage_size_norm(metric, x.size), dtype=np.uint8)
+    (lib().vso_sq8_quantize_norm_f16 if f16 else lib().vso_sq8_quantize_norm)(_ptr(x), _ptr(mean), x.size, metric, _ptr(out))
+    return out
+
+
+def sq8_query_blob_norm(y, mean, metric, f16=False):
+    """raw bytes: the query body (centred for L2) followed by { y_sum, y_sum_squares | y_mean_ip }"""
+    y = np.ascontiguousarray(y, dtype=np.uint16 if f16 else np.float32)
+    mean = np.ascontiguousarray(mean, dtype=np.float32)
+    size = (lib().vso_sq8_query_size_norm_f16 if f16 else lib().vso_sq8_query_size_norm)(metric, y.size)
+    out = np.zeros(size, dtype=np.uint8)
+    (lib().vso_sq8_query_blob_norm_f16 if f16 else lib().vso_sq8_query_blob_norm)(_ptr(y), _ptr(mean), y.size, metric, _ptr(out))
+    return out
+
+
+def sq8_distance_norm(metric, storage, query, dim, f16=False, tier=TIER_AVX512):
+    storage = np.ascontiguousarray(storage)
+    query = np.ascontiguousarray(query)
+    fn = lib().vso_sq8_fp16_distance_norm if f16 else lib().vso_sq8_fp32_distance_norm
+    return fn(metric, tier, dim, _ptr(storage), _ptr(query))
+
+
+def sq8_sq8_distance_norm(metric, a, b, dim, mean_sum_squares, tier=TIER_AVX512):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return lib().vso_sq8_sq8_distance_norm(metric, tier, dim, _ptr(a), _ptr(b), float(mean_sum_squares))
+
+
+def sq8_scan_norm(metric, rows, query, dim, f16=False, tier=TIER_AVX512):
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    out = np.empty(rows.shape[0], dtype=np.float64)
+    fn = lib().vso_sq8_fp16_scan_norm if f16 else lib().vso_sq8_fp32_scan_norm
+    fn(metric, tier, dim, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(query), _ptr(out))
     return out
 
 

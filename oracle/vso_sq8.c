@@ -25,7 +25,10 @@
  * IP/IP_AVX512F_SQ8_FP16.h:29-120, L2/L2_AVX512F_SQ8_FP16.h:18-34, choosers L2_space.cpp:109-180): every fp16 value is
  * widened exactly (types/float16.h:33-52) and all arithmetic is FP32, so the quantiser equals the FP32 one on the widened
  * vector; the AVX-512F kernel keeps FOUR 16-lane accumulators.
- * Not restated: the mean-centred WithNorm variants and the calculator built on them.
+ * Mean-centred blobs (QuantPreprocessor<..., WithNorm = true>, preprocessors.h:484-495, 574-640; the calculator on top:
+ * spaces/computer/calculator.h:126-232): storage = SQ8 of x - mean (+ x_mean_ip for IP), L2 queries are centred, IP queries
+ * stay raw and carry y_mean_ip; distances = the base kernels above plus the calculator's correction terms.  See the
+ * *_norm functions at the end.
  */
 #include <math.h>
 #include <string.h>
@@ -48,14 +51,10 @@ static uint8_t to_byte(float scaled) {
     return (uint8_t)(scaled + 0.5f);
 }
 
-/* QuantPreprocessor::quantize (preprocessors.h:270-390), DataType = float, WithNorm = false */
-void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out) {
-    /* std::minmax_element (:620-622): the first smallest and the LAST largest element */
-    float min_val = x[0], max_val = x[0];
-    for (size_t i = 1; i < dim; i++) {
-        if (x[i] < min_val) min_val = x[i];
-        if (!(x[i] < max_val)) max_val = x[i];
-    }
+/* QuantPreprocessor::quantize (preprocessors.h:270-390) after find_min_max: `t` holds transformed_value() of every
+ * element (the input, or input - mean for WithNorm); `tail` = the extra x_mean_ip slot of WithNorm IP blobs, or NULL */
+static void quantize_core(const float *t, size_t dim, int metric, float min_val, float max_val, const float *tail,
+                          uint8_t *out) {
     const float diff = max_val - min_val;
     const float delta = (diff == 0.0f) ? 1.0f : diff / 255.0f;
     const float inv_delta = 1.0f / delta;
@@ -65,7 +64,7 @@ void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out) {
     size_t i = 0;
     for (; i < d4; i += 4)
         for (int j = 0; j < 4; j++) {
-            const uint8_t a = to_byte((x[i + j] - min_val) * inv_delta);
+            const uint8_t a = to_byte((t[i + j] - min_val) * inv_delta);
             out[i + j] = a;
             s[j] += a;
             q[j] += (uint64_t)a * a;
@@ -73,7 +72,7 @@ void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out) {
     uint32_t q_sum = (s[0] + s[1]) + (s[2] + s[3]);
     uint64_t q_sq = (q[0] + q[1]) + (q[2] + q[3]);
     for (; i < dim; i++) {
-        const uint8_t a = to_byte((x[i] - min_val) * inv_delta);
+        const uint8_t a = to_byte((t[i] - min_val) * inv_delta);
         out[i] = a;
         q_sum += a;
         q_sq += (uint64_t)a * a;
@@ -81,16 +80,27 @@ void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out) {
     /* reconstruction sums from the exact byte sums, in double (:369-381); this code is not in an FMA translation unit */
     const double d_min = min_val, d_delta = delta, d_dim = (double)dim;
     const float sum = (float)(d_dim * d_min + d_delta * (double)q_sum);
-    float meta[4] = {min_val, delta, sum, 0.0f};
+    float meta[5] = {min_val, delta, sum, 0.0f, 0.0f};
     size_t n = 3;
     if (metric == VSO_L2) {
         const double t0 = d_dim * d_min * d_min;
         const double t1 = 2.0 * d_min * d_delta * (double)q_sum;
         const double t2 = d_delta * d_delta * (double)q_sq;
-        meta[3] = (float)((t0 + t1) + t2);
-        n = 4;
+        meta[n++] = (float)((t0 + t1) + t2);
     }
+    if (tail) meta[n++] = *tail;
     memcpy(out + dim, meta, n * sizeof(float));
+}
+
+/* DataType = float, WithNorm = false */
+void vso_sq8_quantize(const float *x, size_t dim, int metric, uint8_t *out) {
+    /* std::minmax_element (:620-622): the first smallest and the LAST largest element */
+    float min_val = x[0], max_val = x[0];
+    for (size_t i = 1; i < dim; i++) {
+        if (x[i] < min_val) min_val = x[i];
+        if (!(x[i] < max_val)) max_val = x[i];
+    }
+    quantize_core(x, dim, metric, min_val, max_val, NULL, out);
 }
 
 /* QuantPreprocessor::preprocessQuery + assign_query_metadata (preprocessors.h:398-470, 574-598) */
@@ -302,4 +312,116 @@ void vso_sq8_fp16_scan(int metric, int tier, size_t dim, const void *rows, size_
                        double *out) {
 #pragma omp parallel for schedule(static) if (n * dim > (1u << 22))
     for (size_t i = 0; i < n; i++) out[i] = vso_sq8_fp16_distance(metric, tier, dim, (const char *)rows + i * stride, query);
+}
+
+/* ------------------------------------------------------------------ mean-centred blobs (WithNorm = true; L2 and IP only)
+ * types/sq8.h:38-58: IP blobs grow by one FP32 slot -- storage | codes | min | delta | sum | x_mean_ip |, query
+ * | y | y_sum | y_mean_ip | -- and L2 blobs keep their layout. */
+size_t vso_sq8_storage_size_norm(int metric, size_t dim) { return dim + 4 * sizeof(float); }
+size_t vso_sq8_query_size_norm(int metric, size_t dim) { (void)metric; return (dim + 2) * sizeof(float); }
+size_t vso_sq8_query_size_norm_f16(int metric, size_t dim) { (void)metric; return dim * 2 + 2 * sizeof(float); }
+
+/* find_min_max, WithNorm branch (preprocessors.h:623-640) + quantize: w = the input widened to FP32 */
+static void quantize_norm(const float *w, const float *mean, size_t dim, int metric, uint8_t *out) {
+    float t[dim ? dim : 1];
+    float value = w[0] - mean[0];
+    float min_val = value, max_val = value;
+    float x_mean_ip = w[0] * mean[0];          /* sequential, separate multiply and add (no FMA in this translation unit) */
+    t[0] = value;
+    for (size_t i = 1; i < dim; i++) {
+        value = w[i] - mean[i];
+        t[i] = value;
+        min_val = (value < min_val) ? value : min_val; /* std::min(min_val, value) */
+        max_val = (max_val < value) ? value : max_val; /* std::max(max_val, value) */
+        const float p = w[i] * mean[i];
+        x_mean_ip += p;
+    }
+    quantize_core(t, dim, metric, min_val, max_val, metric == VSO_IP ? &x_mean_ip : NULL, out);
+}
+void vso_sq8_quantize_norm(const float *x, const float *mean, size_t dim, int metric, uint8_t *out) {
+    quantize_norm(x, mean, dim, metric, out);
+}
+void vso_sq8_quantize_norm_f16(const uint16_t *x, const float *mean, size_t dim, int metric, uint8_t *out) {
+    float w[dim ? dim : 1];
+    for (size_t i = 0; i < dim; i++) w[i] = vso_f16_to_f32(x[i]);
+    quantize_norm(w, mean, dim, metric, out);
+}
+
+/* assign_query_metadata (preprocessors.h:398-470): v = the query body widened to FP32 (centred for L2), orig = the original
+ * input widened; meta = { y_sum, y_sum_squares (L2) | y_mean_ip (IP) } */
+static void query_meta_norm(const float *v, const float *orig, const float *mean, size_t dim, int metric, float *meta) {
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+    const size_t d4 = dim & ~(size_t)3;
+    size_t i = 0;
+    for (; i < d4; i += 4)
+        for (int j = 0; j < 4; j++) {
+            s[j] += v[i + j];
+            const float sq = v[i + j] * v[i + j];
+            q[j] += sq;
+            const float mp = mean[i + j] * orig[i + j];
+            m[j] += mp;
+        }
+    float sum = (s[0] + s[1]) + (s[2] + s[3]);
+    float ssq = (q[0] + q[1]) + (q[2] + q[3]);
+    float mip = (m[0] + m[1]) + (m[2] + m[3]);
+    for (; i < dim; i++) {
+        sum += v[i];
+        const float sq = v[i] * v[i];
+        ssq += sq;
+        const float mp = mean[i] * orig[i];
+        mip += mp;
+    }
+    meta[0] = sum;
+    meta[1] = metric == VSO_L2 ? ssq : mip;
+}
+/* preprocessQuery (preprocessors.h:574-598) */
+void vso_sq8_query_blob_norm(const float *y, const float *mean, size_t dim, int metric, float *out) {
+    float body[dim ? dim : 1];
+    for (size_t i = 0; i < dim; i++) body[i] = metric == VSO_L2 ? y[i] - mean[i] : y[i];
+    float meta[2];
+    query_meta_norm(body, y, mean, dim, metric, meta);
+    memcpy(out, body, dim * sizeof(float));
+    out[dim] = meta[0];
+    out[dim + 1] = meta[1];
+}
+void vso_sq8_query_blob_norm_f16(const uint16_t *y, const float *mean, size_t dim, int metric, void *out) {
+    uint16_t body[dim ? dim : 1];
+    float v[dim ? dim : 1], orig[dim ? dim : 1];
+    for (size_t i = 0; i < dim; i++) {
+        orig[i] = vso_f16_to_f32(y[i]);
+        body[i] = metric == VSO_L2 ? vso_f32_to_f16(orig[i] - mean[i]) : y[i]; /* from_fp32(to_fp32(input) - mean) */
+        v[i] = vso_f16_to_f32(body[i]);
+    }
+    float meta[2];
+    query_meta_norm(v, orig, mean, dim, metric, meta);
+    memcpy(out, body, dim * 2);
+    memcpy((char *)out + dim * 2, meta, sizeof meta);
+}
+
+/* DistanceCalculatorWithNorm (calculator.h:168-204).  The base kernels read their metadata at the unchanged offsets. */
+double vso_sq8_fp32_distance_norm(int metric, int tier, size_t dim, const void *storage, const void *query) {
+    const float base = (float)vso_sq8_fp32_distance(metric, tier, dim, storage, query);
+    if (metric == VSO_L2) return (double)base;
+    const float y_mean_ip = ((const float *)query)[dim + 1];
+    return (double)(base - y_mean_ip);
+}
+double vso_sq8_fp16_distance_norm(int metric, int tier, size_t dim, const void *storage, const void *query) {
+    const float base = (float)vso_sq8_fp16_distance(metric, tier, dim, storage, query);
+    if (metric == VSO_L2) return (double)base;
+    const float y_mean_ip = ldf((const uint8_t *)query + dim * 2 + 4);
+    return (double)(base - y_mean_ip);
+}
+double vso_sq8_sq8_distance_norm(int metric, int tier, size_t dim, const void *a, const void *b, float mean_sum_squares) {
+    const float base = (float)vso_sq8_sq8_distance(metric, tier, dim, a, b);
+    if (metric == VSO_L2) return (double)base;
+    const float x_mean_ip = ldf((const uint8_t *)a + dim + 12), y_mean_ip = ldf((const uint8_t *)b + dim + 12);
+    return (double)(((base - x_mean_ip) - y_mean_ip) + mean_sum_squares);
+}
+void vso_sq8_fp32_scan_norm(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                            double *out) {
+    for (size_t i = 0; i < n; i++) out[i] = vso_sq8_fp32_distance_norm(metric, tier, dim, (const char *)rows + i * stride, query);
+}
+void vso_sq8_fp16_scan_norm(int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride, const void *query,
+                            double *out) {
+    for (size_t i = 0; i < n; i++) out[i] = vso_sq8_fp16_distance_norm(metric, tier, dim, (const char *)rows + i * stride, query);
 }

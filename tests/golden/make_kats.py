@@ -197,7 +197,42 @@ def sq8():
     d.append(dict(name="l2_closed_form_fp16_query", dim=5, codes=[1, 2, 3, 4, 5], meta=[0.0, 1.0, 15.0, 55.0],
                   query=[2.0, 3.0, 4.0, 5.0, 6.0], qmeta=[20.0, 90.0], metric="L2", expect=5.0, query_type="f16",
                   src="test_spaces.cpp:485-530"))
-    return dict(quantize=q, distance=d,
+    # mean-centred blobs (QuantPreprocessor<..., WithNorm = true>, DistanceCalculatorWithNorm): test_components.cpp:1820-2020
+    # (blob layout + metadata, FLOAT_EQ = 4 ulp; storage = the plain quantiser on x - mean) and :2095-2366 (calculator
+    # results within 0.05 / 0.001 of the brute-force distance of the ORIGINAL vectors; zero mean == the base kernels)
+    def seqsum(v):
+        a = 0.0
+        for x in v:
+            a = f32(a + f32(x))
+        return a
+    src5, mean5 = [1.0, 2.0, 3.0, 4.0, 5.0], [f32(0.1), f32(0.2), f32(0.3), f32(0.4), f32(0.5)]
+    wn = []
+    for metric in ("L2", "IP"):
+        centred = [f32(x - m) for x, m in zip(src5, mean5)]
+        body = centred if metric == "L2" else src5
+        wn.append(dict(name="with_norm_blob_" + metric.lower(), metric=metric, input=src5, mean=mean5, centred=centred,
+                       storage_bytes=5 + 16, query_bytes=5 * 4 + 8, query_body=body,
+                       x_mean_ip=seqsum(f32(x * m) for x, m in zip(src5, mean5)) if metric == "IP" else None,
+                       y_sum=seqsum(body), y_sum_squares=seqsum(f32(b * b) for b in body) if metric == "L2" else None,
+                       y_mean_ip=seqsum(f32(x * m) for x, m in zip(src5, mean5)) if metric == "IP" else None,
+                       src="test_components.cpp:1820-2020"))
+    x8 = [1.0, 2.0, 3.0, 4.0, 1.0, 2.0, 3.0, 4.0]
+    y8 = [0.5, 1.5, 2.5, 3.5, 0.5, 1.5, 2.5, 3.5]
+    m8 = [0.5, 1.0, 1.5, 2.0, 0.5, 1.0, 1.5, 2.0]
+    calc = []
+    for metric in ("L2", "IP"):
+        exp = sum((a - b) ** 2 for a, b in zip(x8, y8)) if metric == "L2" else 1.0 - sum(a * b for a, b in zip(x8, y8))
+        for mode, inp in (("asymmetric", "f32"), ("symmetric", "f32"), ("asymmetric", "f16")):
+            calc.append(dict(name="calc_%s_%s_%s" % (metric.lower(), mode, inp), metric=metric, mode=mode, input_type=inp,
+                             x=x8, y=y8, mean=m8, mean_sum_squares=sum(m * m for m in m8), expect=exp, tol=0.05,
+                             src="test_components.cpp:2095-2366"))
+    calc.append(dict(name="l2_large_offset_small_distance", metric="L2", mode="asymmetric", input_type="f32",
+                     x=[1001.0] * 128, y=[f32(1001.1)] * 128, mean=[1000.0] * 128, mean_sum_squares=128 * 1e6,
+                     expect=seqsum([f32(f32(1001.0 - f32(1001.1)) ** 2)] * 128), tol=0.001, nonnegative=True,
+                     src="test_components.cpp:2164-2200"))
+    zero = dict(name="zero_mean_matches_base", x=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], y=[0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5],
+                src="test_components.cpp:2369-2415")
+    return dict(quantize=q, distance=d, with_norm=dict(blobs=wn, calculator=calc, zero_mean=zero),
                 tolerance_property=dict(abs=0.01, src="test_spaces.cpp:326-410, 2330-2700: every tier within 0.01 of the "
                                         "reconstruct-then-dot baseline (tests/utils/tests_utils.h:76-170, 244-270)"))
 

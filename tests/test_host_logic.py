@@ -68,6 +68,11 @@ def test_sq8_host_preprocessor_matches_the_oracle_and_the_reference_kats(vso):
                 assert np.array_equal(VecSim.sq8_quantize(x, metric), vso.sq8_quantize(x, metric)), (dim, metric)
                 assert np.array_equal(VecSim.sq8_query_blob(x, metric).view(np.uint32),
                                       vso.sq8_query_blob(x, metric).view(np.uint32)), (dim, metric)
+                if metric != 2:   # mean-centred blobs (WithNorm = true; L2 and IP)
+                    mean = (rng.uniform(-1, 1, dim) * scale).astype(np.float32)
+                    assert np.array_equal(VecSim.sq8_quantize_centred(x, mean, metric), vso.sq8_quantize_norm(x, mean, metric)), (dim, metric)
+                    assert np.array_equal(VecSim.sq8_query_blob_centred(x, mean, metric).view(np.uint8),
+                                          vso.sq8_query_blob_norm(x, mean, metric)), (dim, metric)
     with open(os.path.join(os.path.dirname(__file__), "golden", "kat_sq8.json")) as f:
         kats = json.load(f)["quantize"]
     mcode = {"L2": 0, "IP": 1, "Cosine": 2}

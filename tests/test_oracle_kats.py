@@ -257,6 +257,66 @@ def test_sq8_distance_kats(vso):
             assert got == c["expect"], (c["name"], tier, got)
 
 
+def test_sq8_mean_centred_blob_kats(vso):
+    """QuantPreprocessor<..., WithNorm = true> (test_components.cpp:1820-2020): blob sizes, storage == the plain quantiser
+    on x - mean (+ x_mean_ip for IP), query body (centred for L2), query metadata; fp32 and fp16 inputs."""
+    for c in _load("kat_sq8.json")["with_norm"]["blobs"]:
+        m = SQ8_METRIC[c["metric"]]
+        x = np.array(c["input"], dtype=np.float32)
+        mean = np.array(c["mean"], dtype=np.float32)
+        dim = x.size
+        for f16 in (False, True):
+            xin = vso.f32_to_f16(x) if f16 else x
+            blob = vso.sq8_quantize_norm(xin, mean, m, f16=f16)
+            assert blob.size == c["storage_bytes"]
+            base = vso.sq8_quantize(np.array(c["centred"], dtype=np.float32), m)
+            assert np.array_equal(blob[:base.size], base), c["name"]          # CompareVectors on the common prefix
+            meta = blob[dim:].view(np.float32)
+            if c["metric"] == "IP":
+                assert _ulps(meta[3], np.float32(c["x_mean_ip"])) <= 4
+            qb = vso.sq8_query_blob_norm(xin, mean, m, f16=f16)
+            eb = 2 if f16 else 4
+            assert qb.size == dim * eb + 8 and (f16 or qb.size == c["query_bytes"])
+            body = qb[:dim * eb].view(np.uint16 if f16 else np.float32)
+            want = np.array(c["query_body"], dtype=np.float32)
+            if f16:
+                assert np.array_equal(body, vso.f32_to_f16(want)), c["name"]
+                continue                                                            # (metadata of the re-rounded body: below, fp32 only)
+            assert np.array_equal(body, want), c["name"]
+            qm = qb[dim * eb:].view(np.float32)
+            assert _ulps(qm[0], np.float32(c["y_sum"])) <= 4
+            other = c["y_sum_squares"] if c["metric"] == "L2" else c["y_mean_ip"]
+            assert _ulps(qm[1], np.float32(other)) <= 4
+
+
+def test_sq8_mean_centred_calculator_kats(vso):
+    """DistanceCalculatorWithNorm (test_components.cpp:2095-2415): asymmetric and symmetric distances land within the
+    tolerance the reference states of the brute-force distance between the ORIGINAL vectors; with a zero mean the
+    results are the base kernels' bit for bit."""
+    kats = _load("kat_sq8.json")["with_norm"]
+    for c in kats["calculator"]:
+        m = SQ8_METRIC[c["metric"]]
+        x, y, mean = (np.array(c[k], dtype=np.float32) for k in ("x", "y", "mean"))
+        dim = x.size
+        f16 = c["input_type"] == "f16"
+        xin, yin = (vso.f32_to_f16(x), vso.f32_to_f16(y)) if f16 else (x, y)
+        sb = vso.sq8_quantize_norm(xin, mean, m, f16=f16)
+        for tier in (vso.TIER_AVX512, vso.TIER_SCALAR):
+            if c["mode"] == "asymmetric":
+                got = vso.sq8_distance_norm(m, sb, vso.sq8_query_blob_norm(yin, mean, m, f16=f16), dim, f16=f16, tier=tier)
+            else:
+                got = vso.sq8_sq8_distance_norm(m, sb, vso.sq8_quantize_norm(yin, mean, m, f16=f16), dim, c["mean_sum_squares"], tier=tier)
+            assert abs(got - c["expect"]) <= c["tol"], (c["name"], tier, got, c["expect"])
+            assert not c.get("nonnegative") or got >= 0.0
+    z = kats["zero_mean"]
+    x, y = np.array(z["x"], dtype=np.float32), np.array(z["y"], dtype=np.float32)
+    zero = np.zeros(x.size, dtype=np.float32)
+    sb, sy = vso.sq8_quantize_norm(x, zero, 1), vso.sq8_quantize_norm(y, zero, 1)
+    qb = vso.sq8_query_blob_norm(y, zero, 1)
+    assert vso.sq8_distance_norm(1, sb, qb, x.size) == vso.sq8_fp32_distance(1, sb, qb.view(np.float32), x.size)
+    assert vso.sq8_sq8_distance_norm(1, sb, sy, x.size, 0.0) == vso.sq8_sq8_distance(1, sb, sy, x.size)
+
+
 @pytest.mark.parametrize("dim", [1, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 777])
 def test_sq8_tiers_within_the_reference_tolerance(vso, dim):
     """The reference's SQ8 tests (test_spaces.cpp:326-410, 2330-4111) demand every tier within 0.01 of the

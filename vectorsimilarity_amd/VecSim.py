@@ -69,10 +69,15 @@ class BatchIterator:
 class VecSimIndex:
     _owned = True
 
-    def __init__(self, params, borrowed_handle=None, sq8=False):
+    def __init__(self, params, borrowed_handle=None, sq8=False, sq8_mean=None, sq8_mean_sum_squares=0.0):
         self._lib = _capi.load()
         if borrowed_handle is not None:   # a shard of a sharded index: the owner frees it
             self._h, self._owned = borrowed_handle, False
+        elif sq8 and sq8_mean is not None:   # mean-centred SQ8 (params: BFParams)
+            mean = np.ascontiguousarray(sq8_mean, dtype=np.float32)
+            assert mean.size == params.dim
+            self._h = self._lib.VecSimGpu_NewFlatSQ8Centered(C.byref(params), mean.ctypes.data_as(C.c_void_p),
+                                                             float(sq8_mean_sum_squares), None)
         elif sq8:                         # params is a BFParams here
             self._h = self._lib.VecSimGpu_NewFlatSQ8(C.byref(params), None)
         else:
@@ -291,8 +296,16 @@ class SQ8Index(VecSimIndex):
     """Flat index over SQ8 storage (include/VecSim/vec_sim_gpu.h: VecSimGpu_NewFlatSQ8): fp32 vectors in, uint8 codes + FP32
     metadata in HBM, the reference's asymmetric SQ8 x FP32 distances (types/sq8.h, IP.cpp:34-80, L2.cpp:30-45) out."""
 
-    def __init__(self, params):
-        super().__init__(params, sq8=True)
+    def __init__(self, params, mean=None, mean_sum_squares=None):
+        """mean (dim fp32 values): mean-centred blobs and DistanceCalculatorWithNorm scores (L2 / IP; vec_sim_gpu.h:
+        VecSimGpu_NewFlatSQ8Centered); mean_sum_squares defaults to the sequential fp32 sum of squares the reference's
+        tests use (test_components.cpp computeMeanSumSquares)"""
+        if mean is not None and mean_sum_squares is None:
+            acc = np.float32(0)
+            for m in np.asarray(mean, dtype=np.float32):
+                acc = np.float32(acc + np.float32(m * m))
+            mean_sum_squares = float(acc)
+        super().__init__(params, sq8=True, sq8_mean=mean, sq8_mean_sum_squares=mean_sum_squares or 0.0)
 
     def stored_distance(self, label_a, label_b):
         """symmetric SQ8 x SQ8 distance between two stored vectors (IP.cpp:146-183, L2.cpp:185-201)"""
@@ -324,6 +337,28 @@ def sq8_query_blob(vector, metric):
     v = np.ascontiguousarray(vector, dtype=np.float32)
     out = np.zeros(lib.VecSimGpu_SQ8_QueryBlobSize(v.size, int(metric)) // 4, dtype=np.float32)
     lib.VecSimGpu_SQ8_QueryBlob(v.ctypes.data_as(C.c_void_p), v.size, int(metric), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def sq8_quantize_centred(vector, mean, metric):
+    """mean-centred storage blob (QuantPreprocessor<float, metric, WithNorm = true>): dim + 16 bytes"""
+    lib = _capi.load()
+    v = np.ascontiguousarray(vector, dtype=np.float32)
+    m = np.ascontiguousarray(mean, dtype=np.float32)
+    out = np.zeros(lib.VecSimGpu_SQ8_StorageBlobSizeCentered(v.size, int(metric)), dtype=np.uint8)
+    lib.VecSimGpu_SQ8_QuantizeCentered(v.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), v.size, int(metric),
+                                       out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def sq8_query_blob_centred(vector, mean, metric):
+    """mean-centred query blob: the values (centred for L2), y_sum, then y_sum_squares (L2) or y_mean_ip (IP)"""
+    lib = _capi.load()
+    v = np.ascontiguousarray(vector, dtype=np.float32)
+    m = np.ascontiguousarray(mean, dtype=np.float32)
+    out = np.zeros(lib.VecSimGpu_SQ8_QueryBlobSizeCentered(v.size, int(metric)) // 4, dtype=np.float32)
+    lib.VecSimGpu_SQ8_QueryBlobCentered(v.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), v.size, int(metric),
+                                        out.ctypes.data_as(C.c_void_p))
     return out
 
 

@@ -140,7 +140,8 @@ EXPORTS = [
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
     "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors",
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
-    "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob",
+    "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
+    "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
     "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
@@ -160,7 +161,7 @@ GPU_EXPORTS = [
     "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",
-    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_stats_reset",
+    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
     "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
     "vsgpu_comm_allgather", "vsgpu_comm_broadcast",
@@ -230,6 +231,16 @@ def load():
     L.VecSimGpu_SQ8_Quantize.argtypes = [vp, C.c_size_t, C.c_int, vp]
     L.VecSimGpu_SQ8_QueryBlob.restype = None
     L.VecSimGpu_SQ8_QueryBlob.argtypes = [vp, C.c_size_t, C.c_int, vp]
+    L.VecSimGpu_NewFlatSQ8Centered.restype = vp
+    L.VecSimGpu_NewFlatSQ8Centered.argtypes = [vp, vp, C.c_float, vp]
+    L.VecSimGpu_SQ8_StorageBlobSizeCentered.restype = C.c_size_t
+    L.VecSimGpu_SQ8_StorageBlobSizeCentered.argtypes = [C.c_size_t, C.c_int]
+    L.VecSimGpu_SQ8_QueryBlobSizeCentered.restype = C.c_size_t
+    L.VecSimGpu_SQ8_QueryBlobSizeCentered.argtypes = [C.c_size_t, C.c_int]
+    L.VecSimGpu_SQ8_QuantizeCentered.restype = None
+    L.VecSimGpu_SQ8_QuantizeCentered.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.VecSimGpu_SQ8_QueryBlobCentered.restype = None
+    L.VecSimGpu_SQ8_QueryBlobCentered.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     L.VecSimGpu_GetStoredVectors.restype = C.c_long
     L.VecSimGpu_GetStoredVectors.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.VecSimIndex_StatsInfo.restype = VecSimIndexStatsInfo

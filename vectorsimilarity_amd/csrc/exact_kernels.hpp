@@ -173,12 +173,14 @@ __device__ inline float load_f32_unaligned(const char *p) {
     const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
     return __uint_as_float((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
 }
-// SQ8 x FP32 score from the reduced code dot product; `meta` = the row's {min, delta, sum, sum_squares} (unaligned)
+// SQ8 x FP32 score from the reduced code dot product; `meta` = the row's {min, delta, sum, sum_squares} (unaligned).
+// y_sum_sq: the query's second metadata slot -- y_sum_squares for L2; for IP the shift DistanceCalculatorWithNorm applies to
+// the base score (calculator.h:188-204: base - y_mean_ip; 0 for plain SQ8, and x - 0 is x for every x)
 __device__ inline float sq8_score(float qdot, int epi, int fused, const char *meta, float y_sum, float y_sum_sq) {
     const float min_val = load_f32_unaligned(meta), delta = load_f32_unaligned(meta + 4);
     const float dq = __fmul_rn(delta, qdot);
     const float ip = fused ? __fmaf_rn(min_val, y_sum, dq) : __fadd_rn(__fmul_rn(min_val, y_sum), dq);
-    if (epi == EPI_SQ8_IP) return __fsub_rn(1.0f, ip);
+    if (epi == EPI_SQ8_IP) return __fsub_rn(__fsub_rn(1.0f, ip), y_sum_sq);
     const float x_sq = load_f32_unaligned(meta + 12);
     return __fsub_rn(__fadd_rn(x_sq, y_sum_sq), __fmul_rn(2.0f, ip));
 }

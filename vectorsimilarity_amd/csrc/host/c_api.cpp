@@ -53,6 +53,27 @@ extern "C" VecSimIndex *VecSimGpu_NewFlatSQ8(const BFParams *params, void *logCt
     if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create SQ8 GPU index: %s\n", vsgpu_last_error());
     return ix;
 }
+extern "C" VecSimIndex *VecSimGpu_NewFlatSQ8Centered(const BFParams *params, const float *mean, float mean_sum_squares, void *logCtx) {
+    if (!params || !mean) return nullptr;
+    FlatIndex *ix = FlatIndex::createSQ8(*params, logCtx, mean, mean_sum_squares);
+    if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create mean-centred SQ8 GPU index: %s\n", vsgpu_last_error());
+    return ix;
+}
+extern "C" size_t VecSimGpu_SQ8_StorageBlobSizeCentered(size_t dim, VecSimMetric metric) { return vsa::sq8_storage_bytes(dim, metric, true); }
+extern "C" size_t VecSimGpu_SQ8_QueryBlobSizeCentered(size_t dim, VecSimMetric metric) { return vsa::sq8_query_bytes(dim, metric, true, false); }
+extern "C" void VecSimGpu_SQ8_QuantizeCentered(const float *vector, const float *mean, size_t dim, VecSimMetric metric, void *storage_blob) {
+    std::vector<float> scratch(dim);
+    vsa::sq8_quantize_centred(vector, mean, dim, metric, static_cast<uint8_t *>(storage_blob), scratch.data());
+}
+extern "C" void VecSimGpu_SQ8_QueryBlobCentered(const float *vector, const float *mean, size_t dim, VecSimMetric metric, float *query_blob) {
+    std::vector<float> body(dim);
+    for (size_t i = 0; i < dim; i++) body[i] = metric == VecSimMetric_L2 ? vector[i] - mean[i] : vector[i];
+    float meta[2];
+    vsa::sq8_query_meta_centred(body.data(), vector, mean, dim, metric, meta);
+    std::memcpy(query_blob, body.data(), dim * sizeof(float));
+    query_blob[dim] = meta[0];
+    query_blob[dim + 1] = meta[1];
+}
 extern "C" double VecSimGpu_SQ8_StoredDistance(VecSimIndex *index, size_t label_a, size_t label_b) {
     auto *f = dynamic_cast<FlatIndex *>(index);
     return f ? f->storedDistance(label_a, label_b) : std::numeric_limits<double>::quiet_NaN();

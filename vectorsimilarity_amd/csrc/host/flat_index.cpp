@@ -114,8 +114,9 @@ std::vector<vsgpu_ctx *> FlatIndex::gpus() {
     return v;
 }
 
-FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
+FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx, const float *mean, float mean_sum_squares) {
     if (p.dim == 0 || (p.type != VecSimType_FLOAT32 && p.type != VecSimType_FLOAT16) || p.metric > VecSimMetric_Cosine) return nullptr;
+    if (mean && p.metric == VecSimMetric_Cosine) return nullptr;   // "WithNorm does not support Cosine metric" (preprocessors.h:267)
     vsgpu_ctx *ctx = vsgpu_ctx_create(resolve_device());
     if (!ctx) return nullptr;
     const bool f16 = p.type == VecSimType_FLOAT16;
@@ -125,12 +126,15 @@ FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx) {
     ix->metric_ = p.metric;
     ix->dim_ = p.dim;
     ix->block_size_ = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
-    ix->stored_bytes_ = sq8_storage_bytes(p.dim, p.metric);
-    ix->query_bytes_ = f16 ? sq8_query_bytes_f16(p.dim, p.metric) : sq8_query_bytes(p.dim, p.metric);
+    if (mean) ix->sq8_mean_.assign(mean, mean + p.dim);
+    ix->sq8_mss_ = mean_sum_squares;
+    ix->stored_bytes_ = sq8_storage_bytes(p.dim, p.metric, mean != nullptr);
+    ix->query_bytes_ = sq8_query_bytes(p.dim, p.metric, mean != nullptr, f16);
     ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
     ix->table_ = vsgpu_table_create(ctx, f16 ? VSGPU_SQ8H : VSGPU_SQ8, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    if (ix->table_ && mean) vsgpu_table_set_sq8_mean_sum_squares(ix->table_, mean_sum_squares);
     if (!ix->table_) {
         vsgpu_ctx_destroy(ctx);
         ix->ctx_ = nullptr;
@@ -164,7 +168,12 @@ void FlatIndex::toStored(const void *blob, char *out) const {
             std::memcpy(tmp.data(), blob, dim_ * sizeof(float));
             if (metric_ == VecSimMetric_Cosine) normalize_blob(tmp.data(), dim_, type_);
         }
-        sq8_quantize(tmp.data(), dim_, metric_, reinterpret_cast<uint8_t *>(out));
+        if (!sq8_mean_.empty()) {
+            std::vector<float> scratch(dim_);
+            sq8_quantize_centred(tmp.data(), sq8_mean_.data(), dim_, metric_, reinterpret_cast<uint8_t *>(out), scratch.data());
+        } else {
+            sq8_quantize(tmp.data(), dim_, metric_, reinterpret_cast<uint8_t *>(out));
+        }
         return;
     }
     std::memcpy(out, blob, dim_ * type_size(type_));
@@ -173,6 +182,32 @@ void FlatIndex::toStored(const void *blob, char *out) const {
 void FlatIndex::toQuery(const void *query, char *out) const {
     std::memcpy(out, query, dim_ * type_size(type_));
     if (metric_ == VecSimMetric_Cosine) normalize_blob(out, dim_, type_);
+    if (sq8_ && !sq8_mean_.empty()) {
+        // preprocessQuery, WithNorm (preprocessors.h:574-598): L2 stores the centred query (fp16: re-rounded), IP the raw
+        // one; metadata over the stored body, y_mean_ip over the original input
+        const bool f16 = type_ == VecSimType_FLOAT16;
+        std::vector<float> orig(dim_), body(dim_);
+        for (size_t i = 0; i < dim_; i++) {
+            if (f16) {
+                uint16_t h;
+                std::memcpy(&h, out + 2 * i, 2);
+                orig[i] = fp16_widen(h);
+                if (metric_ == VecSimMetric_L2) {
+                    h = fp16_round(orig[i] - sq8_mean_[i]);
+                    std::memcpy(out + 2 * i, &h, 2);
+                }
+                body[i] = fp16_widen(h);
+            } else {
+                std::memcpy(&orig[i], out + 4 * i, 4);
+                body[i] = metric_ == VecSimMetric_L2 ? orig[i] - sq8_mean_[i] : orig[i];
+                std::memcpy(out + 4 * i, &body[i], 4);
+            }
+        }
+        float meta[2];
+        sq8_query_meta_centred(body.data(), orig.data(), sq8_mean_.data(), dim_, metric_, meta);
+        std::memcpy(out + dim_ * (f16 ? 2 : 4), meta, sizeof meta);
+        return;
+    }
     if (sq8_ && type_ == VecSimType_FLOAT16) {
         std::vector<float> wide(dim_);
         for (size_t i = 0; i < dim_; i++) {
@@ -832,11 +867,28 @@ VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSim
 
 double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    // "Unsafe": the blob is used as given (caller normalises for Cosine), brute_force_single.h:202-212
+    std::vector<char> q(query_bytes_);
+    if (sq8_ && metric_ != VecSimMetric_Cosine) {   // no normalisation involved: the query preprocessing of the index
+        toQuery(blob, q.data());
+    } else if (sq8_ && type_ == VecSimType_FLOAT16) {
+        std::memcpy(q.data(), blob, dim_ * 2);
+        std::vector<float> wide(dim_);
+        for (size_t i = 0; i < dim_; i++) {
+            uint16_t h;
+            std::memcpy(&h, q.data() + 2 * i, 2);
+            wide[i] = fp16_widen(h);
+        }
+        sq8_query_meta_f16(wide.data(), dim_, metric_, q.data());
+    } else if (sq8_) {   // an fp32 vector as given; only the query metadata (y_sum) is appended
+        std::memcpy(q.data(), blob, dim_ * sizeof(float));
+        sq8_query_blob(reinterpret_cast<const float *>(q.data()), dim_, metric_, reinterpret_cast<float *>(q.data()));
+    } else {
+        std::memcpy(q.data(), blob, query_bytes_);
+    }
     if (multi_) {  // lowest distance over the label's vectors (brute_force_multi.h:224-239)
         auto f = label_to_ids_.find(label);
         if (f == label_to_ids_.end() || flush()) return std::numeric_limits<double>::quiet_NaN();
-        std::vector<char> q(query_bytes_);
-        std::memcpy(q.data(), blob, query_bytes_);
         std::vector<double> s(f->second.size());
         if (vsgpu_scores_of(table_, q.data(), f->second.data(), f->second.size(), s.data()))
             return std::numeric_limits<double>::quiet_NaN();
@@ -847,23 +899,6 @@ double FlatIndex::getDistanceFrom(size_t label, const void *blob) {
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end()) return std::numeric_limits<double>::quiet_NaN();
     if (flush()) return std::numeric_limits<double>::quiet_NaN();
-    // "Unsafe": the blob is used as given (caller normalises for Cosine), brute_force_single.h:202-212
-    std::vector<char> q(query_bytes_);
-    if (sq8_ && type_ == VecSimType_FLOAT16) {
-        std::memcpy(q.data(), blob, dim_ * 2);
-        std::vector<float> wide(dim_);
-        for (size_t i = 0; i < dim_; i++) {
-            uint16_t h;
-            std::memcpy(&h, q.data() + 2 * i, 2);
-            wide[i] = fp16_widen(h);
-        }
-        sq8_query_meta_f16(wide.data(), dim_, metric_, q.data());
-    } else if (sq8_) {   // an fp32 vector as given; only the query metadata (y_sum, y_sum_squares) is appended
-        std::memcpy(q.data(), blob, dim_ * sizeof(float));
-        sq8_query_blob(reinterpret_cast<const float *>(q.data()), dim_, metric_, reinterpret_cast<float *>(q.data()));
-    } else {
-        std::memcpy(q.data(), blob, query_bytes_);
-    }
     uint32_t id = it->second;
     double s = std::numeric_limits<double>::quiet_NaN();
     if (vsgpu_scores_of(table_, q.data(), &id, 1, &s)) return std::numeric_limits<double>::quiet_NaN();

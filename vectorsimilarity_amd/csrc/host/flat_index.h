@@ -97,7 +97,9 @@ public:
     static FlatIndex *create(const BFParams &p, void *logCtx);
     // SQ8 storage (types/sq8.h, QuantPreprocessor): callers add and query fp32 vectors, rows are uint8 codes + FP32
     // metadata, every distance is the reference's asymmetric SQ8 x FP32 kernel.  p.type must be FLOAT32.
-    static FlatIndex *createSQ8(const BFParams &p, void *logCtx);
+    // mean != nullptr: mean-centred blobs (QuantPreprocessor<..., WithNorm = true>, L2 and IP only); mean_sum_squares is the
+    // constant DistanceCalculatorWithNorm takes for its symmetric IP correction (calculator.h:204-214)
+    static FlatIndex *createSQ8(const BFParams &p, void *logCtx, const float *mean = nullptr, float mean_sum_squares = 0.0f);
     bool isSQ8() const { return sq8_; }
     // symmetric SQ8 x SQ8 distance between the stored vectors of two labels (NaN for an unknown label)
     double storedDistance(size_t label_a, size_t label_b);
@@ -172,6 +174,8 @@ private:
     mutable std::recursive_mutex gpu_mu_;
     bool multi_ = false;
     bool sq8_ = false;
+    std::vector<float> sq8_mean_;   // empty: plain SQ8
+    float sq8_mss_ = 0.0f;
     // fp32 vector (dim_ floats) -> stored blob / query blob of this index (Cosine: normalised first; SQ8: quantised)
     void toStored(const void *blob, char *out) const;
     void toQuery(const void *query, char *out) const;

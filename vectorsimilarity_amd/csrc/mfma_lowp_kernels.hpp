@@ -603,8 +603,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 const float my = mn * ysum;
                 const float ip = my + dq;
                 const float C = L2 ? (xsq + ysq) : 1.0f;
-                const float sc = L2 ? (C - 2.0f * ip) : (1.0f - ip);
-                const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C);   // L2 carries 2 ip
+                const float sc = L2 ? (C - 2.0f * ip) : ((1.0f - ip) - ysq);   // IP: ysq holds the shift (y_mean_ip or 0, exact_kernels.hpp sq8_score)
+                const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C + (L2 ? 0.0f : fabsf(ysq)));   // L2 carries 2 ip
                 low = sc - E;
                 up = sc + E;
             };

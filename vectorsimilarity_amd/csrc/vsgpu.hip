@@ -163,7 +163,8 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     }
     if (type < VSGPU_F32 || type > VSGPU_SQ8H || metric < VSGPU_L2 || metric > VSGPU_COSINE || dim == 0 ||
         row_bytes < dim * (size_t)elem_bytes_of(type) ||
-        ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && row_bytes != dim + (metric == VSGPU_L2 ? 16 : 12))) {
+        ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && row_bytes != dim + (metric == VSGPU_L2 ? 16 : 12) &&
+         !(metric == VSGPU_IP && row_bytes == dim + 16))) {   // (IP rows of dim + 16 bytes: mean-centred, see vsgpu.h)
         fail(VSGPU_ERR_ARG, "bad table parameters (type %d metric %d dim %zu row_bytes %zu)", type, metric,
              dim, row_bytes);
         return nullptr;
@@ -184,7 +185,10 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     // bf16 IP on the avx512_bf16 tier: the vdpbf16ps step (odd element, then even, each with FTZ)
     if (t->prog.dpbf16) t->opk = OP_IP_DPBF16;
     if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
-    else if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
+    else if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) {
+        t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
+        t->sq8_centred = metric == VSGPU_IP && row_bytes == dim + 16;
+    }
     else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
     // SQ8 accumulates the code dot product in the IP order whatever the metric (L2 is algebraic: L2.cpp:30-45)
     if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
@@ -592,8 +596,8 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
         for (size_t q = 0; q < nq; q++) {
             const char *src = (const char *)queries + q * qstride + (t->type == VSGPU_SQ8H ? 2 : 4) * t->dim;
             memcpy(&qm[2 * q], src, 4);
-            qm[2 * q + 1] = 0.f;
-            if (t->epi == EPI_SQ8_L2) memcpy(&qm[2 * q + 1], src + 4, 4);
+            qm[2 * q + 1] = 0.f;   // IP: the value the score is shifted by (y_mean_ip of a mean-centred table, else nothing)
+            if (t->epi == EPI_SQ8_L2 || t->sq8_centred) memcpy(&qm[2 * q + 1], src + 4, 4);
         }
         rc = ensure(c, c->qnorm, nq * 8);
         if (rc) return rc;
@@ -931,7 +935,8 @@ extern "C" int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t
 // exact, so the same int dot serves); 2: scalar tier beyond the 32-bit bound (dim > 33025): sequential float accumulation.
 static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *slabs, uint32_t slab_shift, uint32_t slab_mask,
                                                          uint32_t row_stride, uint32_t dim, int is_l2, int mode,
-                                                         const uint32_t *ids_a, const uint32_t *ids_b, uint32_t n, float *out) {
+                                                         const uint32_t *ids_a, const uint32_t *ids_b, uint32_t n, float *out,
+                                                         int centred, float mss) {
     const int lane = threadIdx.x & 63;
     const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= n) return;
@@ -970,7 +975,15 @@ static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *sla
     float sc;
     if (!is_l2) sc = __fsub_rn(1.0f, ip);
     else sc = __fsub_rn(__fadd_rn(load_f32_unaligned(ma + 12), load_f32_unaligned(mb + 12)), __fmul_rn(2.0f, ip));
+    // mean-centred IP rows (calculator.h:168-186): base - x_mean_ip - y_mean_ip + mean_sum_squares, left to right
+    if (centred) sc = __fadd_rn(__fsub_rn(__fsub_rn(sc, load_f32_unaligned(ma + 12)), load_f32_unaligned(mb + 12)), mss);
     out[pair] = sc;
+}
+
+extern "C" int vsgpu_table_set_sq8_mean_sum_squares(vsgpu_table *t, float mean_sum_squares) {
+    if (!t || (t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H)) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
+    t->sq8_mss = mean_sum_squares;
+    return VSGPU_OK;
 }
 
 extern "C" int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t *ids_b, size_t n, double *scores) {
@@ -991,7 +1004,7 @@ extern "C" int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, cons
     hipLaunchKernelGGL(k_sq8_pairs, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, (const char *const *)t->d_slabs,
                        t->slab_shift, (uint32_t)(((size_t)1 << t->slab_shift) - 1), (uint32_t)t->row_bytes, (uint32_t)t->dim,
                        t->epi == EPI_SQ8_L2 ? 1 : 0, mode, (const uint32_t *)c->ids.p, (const uint32_t *)c->ids.p + n,
-                       (uint32_t)n, (float *)c->dense.p);
+                       (uint32_t)n, (float *)c->dense.p, t->sq8_centred ? 1 : 0, t->sq8_mss);
     HIPCHK(hipGetLastError());
     std::vector<float> h(n);
     HIPCHK(hipMemcpyAsync(h.data(), c->dense.p, n * 4, hipMemcpyDeviceToHost, c->stream));

@@ -119,6 +119,8 @@ struct vsgpu_table {
     // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
     bool lowp_ok = false;
     int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
+    bool sq8_centred = false;   // mean-centred IP rows (dim + 16 bytes: x_mean_ip behind the three base slots), queries carry y_mean_ip
+    float sq8_mss = 0.f;        // sum mean_i^2, the symmetric IP correction constant
     size_t aux_bytes = 4;   // per-row aux record of the MFMA filters: 4 B, or 16 B {min, delta, sum_squares, 0} for SQ8 rows
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;

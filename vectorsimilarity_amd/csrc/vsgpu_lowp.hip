@@ -322,7 +322,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             qm[0] = sf;
             memcpy(&qm[1], &K, 4);
             memcpy(&qm[2], src + qeb * dim, 4);                                 // y_sum
-            if (t->metric == VSGPU_L2) memcpy(&qm[3], src + qeb * dim + 4, 4);  // y_sum_squares
+            if (t->metric == VSGPU_L2 || t->sq8_centred) memcpy(&qm[3], src + qeb * dim + 4, 4);  // y_sum_squares | IP: the shift y_mean_ip
             qm[4] = std::nextafter((float)Wref, INFINITY);
             qm[5] = ce;
             qm[6] = std::nextafter((float)(std::sqrt(se2) * (1.0 + 1e-6)), INFINITY);   // |e|_2
