@@ -433,6 +433,54 @@ def test_mfma_filter_path_bit_exact(vso, metric, dim, n, nq, k):
     assert np.array_equal(l1, l2) and np.array_equal(d1, d2), ix.stats()
 
 
+@pytest.mark.parametrize("metric,dim,n,nq,k", [
+    ("L2", 128, 100_000, 64, 10),
+    ("L2", 768, 40_000, 64, 10),       # 16-row x 1-KiB stages (k-steps % 8 == 0)
+    ("IP", 256, 60_003, 40, 100),      # ragged last tile, padded query tile
+    ("Cosine", 384, 40_000, 130, 10),  # three query tiles; next width 512
+    ("L2", 100, 70_001, 33, 5),        # padded to 128 inside LDS, 64-row stages
+    ("L2", 1000, 12_345, 64, 1),
+    ("IP", 2048, 6_000, 20, 10),
+    ("L2", 33, 40_000, 64, 3),
+])
+def test_mfma_filter_path_fp64(vso, metric, dim, n, nq, k):
+    """fp64 rows on the MFMA filter (k_mfma_filter<..., EB = 8>: f64 -> f32 -> bf16 between LDS and the matrix unit), survivors
+    re-scored in double in the reference's two-accumulator order (L2_AVX512F_FP64.h:11-59), 64-bit selection: labels, order
+    and scores equal the oracle's, and the dense fp64 path's"""
+    rng = np.random.default_rng(dim + n + 1)
+    rows = rng.uniform(-1, 1, (n, dim))
+    q = rng.uniform(-1, 1, (nq, dim))
+    if dim == 1000:                     # magnitudes the float conversion cannot hold: those rows must reach the re-rank
+        rows[17] *= 1e200
+        rows[4000] *= 1e-200
+        rows[9000, 3] = np.nan
+    ix = make_index("f64", metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"] == "k_mfma_filter" and st["fallbacks"] == 0, st
+    srows = stored_rows(vso, rows, "f64", metric)
+    sq = stored_rows(vso, q, "f64", metric)
+    el, es, _ = vso.flat_topk_batch_fast(TYPES["f64"], kernel_metric("f64", metric), srows, sq, k, dim, threads=min(64, os.cpu_count() or 1))
+    assert np.array_equal(l1, el.astype(np.int64)), (metric, dim, np.argwhere(l1 != el.astype(np.int64))[:5])
+    assert np.array_equal(d1, es)
+    ix.set_option("mfma", 0)
+    l2, d2 = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"].startswith("k_exact_scan")
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2)
+    # overwrite + delete keep the row norms the filter uses in step
+    ix.set_option("mfma", 1)
+    ix.add_vector(q[0], 5)
+    ix.delete_vector(7)
+    l3, d3 = ix.knn_query(q[:8], k)
+    assert l3[0][0] == 5 and d3[0][0] == (0.0 if metric == "L2" else d3[0][0])
+    ix.set_option("mfma", 0)
+    l4, d4 = ix.knn_query(q[:8], k)
+    assert np.array_equal(l3, l4) and np.array_equal(d3, d4)
+
+
 def test_mfma_filter_adversarial_near_duplicates(vso):
     """rows within the bf16 error band of each other: the filter cannot separate them, the candidate
     lists overflow and the exact fallback must still give the reference answer (with ties)"""

@@ -126,16 +126,21 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_byte_off, c
 // x 1 KiB, dim % 256 == 0: every DMA instruction moves 1 KiB of ONE row, which HBM likes better).
 // XOPT (tuning bits): 1 = slab pointers by cached scalar loads, 2 = one norm copy per workgroup (wave 0 requests it),
 // 4 = branch-free "any survivor?" pass in front of the emitting loop
-template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64, int XOPT = 0>
+// EB = 8: fp64 rows (L2_AVX512F_FP64.h:11-59 / IP twin are the reference kernels; their scores come from the exact re-rank).
+// Same ring and swizzle over bytes; a 256-byte window holds 32 doubles = one MFMA k-step, a lane's 8 elements are four
+// 16-byte pieces, converted f64 -> f32 -> bf16 in registers.  The bound E covers that rounding like the fp32 one (the
+// reference's own accumulation error, in double, is far below the fp32 figure the constant budgets for).
+template <int KSTEPS, int MODE, int NS = 3, int AUX = 0, int MINW = 1, int RT = 64, int XOPT = 0, int EB = 4>
 __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     constexpr int MF_NSTAGE = NS;
     constexpr bool SLOAD = (XOPT & 1) != 0, SNORM = (XOPT & 2) != 0, PRESCREEN = (XOPT & 4) != 0;
     static_assert(NS == 3 || NS == 4, "ring depth");
     static_assert(RT == 64 || RT == 16, "tile rows");
     constexpr int MT = RT / 16;                      // MFMA M-tiles per tile
-    constexpr int KC = (MF_STAGE_BYTES / 4) / RT;    // floats per row per stage: 64 or 256
-    constexpr int SEG = KC * 4;                      // bytes per row per stage: 256 or 1024
-    constexpr int KSUB = KC / 32;                    // MFMA k-steps per stage: 2 or 8
+    static_assert(EB == 4 || EB == 8, "fp32 or fp64 rows");
+    constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // elements per row per stage: fp32 64 or 256, fp64 32 or 128
+    constexpr int SEG = KC * EB;                     // bytes per row per stage: 256 or 1024
+    constexpr int KSUB = KC / 32;                    // MFMA k-steps per stage: fp32 2 or 8, fp64 1 or 4
     static_assert(KSTEPS % KSUB == 0, "dim must be a multiple of the stage width");
     constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
     static_assert(KCH >= NS - 1, "tile shorter than the ring");
@@ -302,12 +307,24 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
             for (int j = 0; j < KSUB; j++) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 2) * 256;
-                    const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
-                    const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
-                    f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
-                    f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
-                    f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    f32x8_t x;
+                    if constexpr (EB == 4) {
+                        const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 2) * 256;
+                        const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
+                        const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
+                        f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+                        f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+                        x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    } else {
+                        typedef double f64x2_t __attribute__((ext_vector_type(2)));
+                        const char *rowp = sbase + (mt * 16 + m16) * SEG + j * 256;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const f64x2_t d = *reinterpret_cast<const f64x2_t *>(rowp + (((4 * kq + i) ^ m16) * 16));
+                            x[2 * i] = (float)d[0];
+                            x[2 * i + 1] = (float)d[1];
+                        }
+                    }
                     bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[c * KSUB + j], acc[mt], 0, 0, 0);
                 }
@@ -412,6 +429,19 @@ static __global__ __launch_bounds__(256) void k_row_norms_f32(const char *rows, 
     if (lane == 0) out[row] = (float)s;
 }
 
+static __global__ __launch_bounds__(256) void k_row_norms_f64(const char *rows, uint32_t row_stride, uint32_t dim,
+                                                       uint32_t n, float *out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double *p = reinterpret_cast<const double *>(rows + (size_t)row * row_stride);
+    double s = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) s += p[i] * p[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = (float)s;   // (+inf beyond the float range: the bound turns NaN and the row goes to the re-rank)
+}
+
 // ---- stage 2: exact reference-order scores of the surviving (row, query) pairs ----
 // One VL-lane group per pair; pairs of query q are cand[q][0 .. min(counts[q], cap)).
 template <int EK, int OPK>
@@ -449,11 +479,15 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
         }
         acc = lane_reduce<VL>(acc, P.reduce);
         if (lane == 0) {
-            float sc;
-            if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) sc = sq8_score(acc, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
-            else sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
-            rec.y = __float_as_uint(sc);
-            P.cand[(size_t)q * P.cap + s] = rec;
+            if constexpr (EK == EK_F64) {   // double scores live beside the candidate list: P.out[q][slot]
+                reinterpret_cast<double *>(P.out)[(size_t)q * P.cap + s] = epilogue_score<double>(acc, P.epilogue, 0.f, 0.f);
+            } else {
+                float sc;
+                if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) sc = sq8_score(acc, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
+                else sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
+                rec.y = __float_as_uint(sc);
+                P.cand[(size_t)q * P.cap + s] = rec;
+            }
         }
     }
 }
@@ -570,6 +604,57 @@ __device__ __forceinline__ unsigned long long double_sort_key(unsigned long long
     if ((b & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) return ~0ull;  // NaN: after everything, see float_sort_key
     return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
 }
+// candidate-list twin of k_select_upto_kth for fp64 tables: rows in cand[q][i].x, exact double scores in sc[q][i]
+constexpr uint32_t SEL64_LDS_KEYS = 4096;
+static __global__ __launch_bounds__(256) void k_select_upto_kth_f64(const uint2 *cand, const double *sc, const uint32_t *counts,
+                                                             uint32_t cap, uint32_t k, SelRec64 *out, uint32_t *out_counts,
+                                                             uint32_t out_cap) {
+    __shared__ unsigned long long keys[SEL64_LDS_KEYS];
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t wpos;
+    const int q = blockIdx.x;
+    const uint32_t raw = counts[q];
+    if (raw > cap) {
+        if (threadIdx.x == 0) out_counts[q] = 0xFFFFFFFFu;
+        return;
+    }
+    const uint32_t n = raw;
+    const uint2 *c = cand + (size_t)q * cap;
+    const unsigned long long *v = reinterpret_cast<const unsigned long long *>(sc + (size_t)q * cap);
+    unsigned long long T = ~0ull;
+    if (n > k) {
+        const uint32_t nl = min(n, SEL64_LDS_KEYS);
+        for (uint32_t i = threadIdx.x; i < nl; i += 256) keys[i] = double_sort_key(v[i]);
+        __syncthreads();
+        T = 0;
+        for (int bit = 63; bit >= 0; bit--) {
+            const unsigned long long trial = T | (1ull << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = threadIdx.x; i < nl; i += 256) cnt += (keys[i] < trial) ? 1u : 0u;
+            for (uint32_t i = nl + threadIdx.x; i < n; i += 256) cnt += (double_sort_key(v[i]) < trial) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            uint32_t *r = red[bit & 1];
+            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            const uint32_t total = r[0] + r[1] + r[2] + r[3];
+            if (total < k) T = trial;
+        }
+    }
+    if (threadIdx.x == 0) wpos = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long bits = v[i];
+        const bool is_nan = (bits & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull;
+        if (!is_nan && double_sort_key(bits) <= T) {
+            const uint32_t p = atomicAdd(&wpos, 1u);
+            if (p < out_cap) out[(size_t)q * out_cap + p] = SelRec64{c[i].x, bits};
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
+}
+
 static __global__ __launch_bounds__(1024) void k_select_dense_upto_kth_f64(const double *dense, size_t stride, uint32_t n, uint32_t k,
                                                                     SelRec64 *out, uint32_t *out_counts, uint32_t out_cap) {
     __shared__ uint32_t red[16];

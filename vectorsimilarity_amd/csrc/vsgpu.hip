@@ -215,7 +215,17 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
                 ks = (size_t)v;
                 break;
             }
-        t->mfma_ok = (type == VSGPU_F32 && !t->prog.scalar_tier && row_bytes == dim * 4 && ks != 0);
+        if (type == VSGPU_F64) {   // fp64 rows on the same filter (mfma_kernels.hpp EB = 8): fewer compiled widths
+            static const int kInst64[] = {4, 8, 16, 24, 32, 48, 64};
+            ks = 0;
+            for (int v : kInst64)
+                if ((size_t)v * 32 >= dim) {
+                    ks = (size_t)v;
+                    break;
+                }
+        }
+        t->mfma_ok = ((type == VSGPU_F32 || type == VSGPU_F64) && !t->prog.scalar_tier &&
+                      row_bytes == dim * (size_t)elem_bytes_of(type) && ks != 0);
         t->ksteps = (int)ks;
         const size_t data_bytes = dim * (size_t)elem_bytes_of(type);
         // low-precision rows: like fp32, any dim runs at the next compiled width (bf16/fp16: 256, 512, 768, 1024,
@@ -338,7 +348,7 @@ static int grow_to(vsgpu_table *t, size_t rows) {
         // + slack: the MFMA filters read a row out to their compiled kernel width (the next width at or above dim: up to
         // 511 floats more at the fp32 widths 64 / 80 / 96 k-steps), so the last row of a slab is over-read by less than
         // that width
-        const size_t width = t->mfma_ok ? (size_t)t->ksteps * 128 : (t->lowp_ok ? (size_t)t->lp_ksteps * 64 : 0);
+        const size_t width = t->mfma_ok ? (size_t)t->ksteps * 32 * (size_t)elem_bytes_of(t->type) : (t->lowp_ok ? (size_t)t->lp_ksteps * 64 : 0);
         HIPCHK(hipMalloc((void **)&p, slab_rows * t->row_bytes + std::max<size_t>(1024, width + 256)));
         poison(p, slab_rows * t->row_bytes);
         t->slabs.push_back(p);
@@ -392,6 +402,9 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
             hipLaunchKernelGGL(k_row_aux_sq8, dim3((unsigned)((in_slab + 255) / 256)), dim3(256), 0, t->ctx->stream,
                                (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
                                t->epi == EPI_SQ8_L2 ? 1 : 0, (uint4 *)np);
+        else if (t->mfma_ok && t->type == VSGPU_F64)
+            hipLaunchKernelGGL(k_row_norms_f64, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
+                               (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
         else if (t->mfma_ok)
             hipLaunchKernelGGL(k_row_norms_f32, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
@@ -1048,9 +1061,62 @@ static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *i
 // {score <= T_k} in id order; queries whose list overflowed fall back to a dense exact pass.
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride);
+// fp64 tables: the exact pair scores are doubles in c->dense ([nq][ccap], launch_exact_pairs), selection on 64-bit keys
+static int collect_candidates_f64(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
+                                  size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
+                                  ScanChainGuard *chain) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, ocap = cap;
+    int rc = ensure(c, c->sel, nq * ocap * sizeof(SelRec64));
+    if (rc) return rc;
+    rc = ensure(c, c->selcnt, nq * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_upto_kth_f64, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
+                       (const double *)c->dense.p, (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n),
+                       (SelRec64 *)c->sel.p, (uint32_t *)c->selcnt.p, (uint32_t)ocap);
+    HIPCHK(hipGetLastError());
+    if (chain) chain->submitted();
+    HIPCHK(hipMemcpyAsync((uint32_t *)c->selcnt.p + nq, c->counts.p, nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    std::vector<uint32_t> hsel(2 * nq);
+    std::vector<SelRec64> hrec(nq * ocap);
+    HIPCHK(hipMemcpyAsync(hsel.data(), c->selcnt.p, nq * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hrec.data(), c->sel.p, nq * ocap * sizeof(SelRec64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        account_scan(c, t, n, 1, scan_name);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
+    }
+    const uint32_t *hraw = hsel.data() + nq;
+    std::vector<Hit> hits;
+    for (size_t q = 0; q < nq; q++) {
+        if (hraw[q] > ccap || hraw[q] < std::min(k, n)) {   // more candidates than slots: exact dense fallback
+            c->stats.fallbacks++;
+            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
+            if (rc) return rc;
+            continue;
+        }
+        c->stats.candidates += hraw[q];
+        if (hsel[q] == VSGPU_COUNT_OVERFLOW) {
+            counts[q] = VSGPU_COUNT_OVERFLOW;
+            continue;
+        }
+        hits.resize(hsel[q]);
+        for (size_t i = 0; i < hsel[q]; i++) {
+            double d;
+            memcpy(&d, &hrec[q * ocap + i].bits, 8);
+            hits[i] = Hit{(uint32_t)hrec[q * ocap + i].row, d};
+        }
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
+        emit(hits, q, cap, ids, scores, counts);
+    }
+    return VSGPU_OK;
+}
+
 int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                               size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
                               ScanChainGuard *chain) {
+    if (t->type == VSGPU_F64) return collect_candidates_f64(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, scan_name, chain);
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
     // GPU: keep, per query, the candidates with exact score <= T_k; only those travel to the host
@@ -1199,7 +1265,11 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     S.norm_off = (uint32_t)t->dim;
     S.qnorm = (const float *)c->qnorm.p;
     S.sq8_fused = t->prog.fused ? 1 : 0;
-    if (t->type == VSGPU_SQ8H) {
+    if (t->type == VSGPU_F64) {   // double scores beside the candidate list (topk_mfma sized c->dense for them)
+        S.out = c->dense.p;
+        if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F64, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
+        else hipLaunchKernelGGL((k_exact_pairs<EK_F64, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+    } else if (t->type == VSGPU_SQ8H) {
         hipLaunchKernelGGL((k_exact_pairs<EK_SQ8H, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
     } else if (t->type == VSGPU_SQ8) {
         hipLaunchKernelGGL((k_exact_pairs<EK_SQ8, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
@@ -1255,8 +1325,9 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
     const size_t n = t->n;
     const bool f64 = (t->type == VSGPU_F64);
 
-    // small problems (and fp64): one dense score matrix, selection on the host
-    if (f64 || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k) {
+    // small problems (and fp64 without the MFMA filter: narrow batches, scalar-tier dims): one dense score matrix
+    const bool f64_filter = f64 && t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q;
+    if ((f64 && !f64_filter) || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k) {
         if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) {
             int rc = stage_queries(t, queries, nq, qstride);
             if (rc) return rc;

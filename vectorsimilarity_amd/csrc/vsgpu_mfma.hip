@@ -8,20 +8,43 @@ using namespace vsg;
 // the filter uses 16-row x 1-KiB stages with non-temporal DMA when dim % 256 == 0 and the tile is at
 // least as long as the ring (dim >= 512), else 64-row x 256-B stages.  Measured on 10M x 768 (profiles/):
 // 64-row default policy 5.5 ms, 64-row nt 5.16 ms, 16-row nt 4.99 ms.
-template <int KS> static uint32_t launch_filter_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+template <int KS, int EB = 4> static uint32_t launch_filter_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
     if constexpr (KS % 8 == 0 && KS >= 16) {
         Q.n_tiles = (uint32_t)((n + 15) / 16);
-        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 16>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 16, 0, EB>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
                            mf_lds_bytes(3), s, Q);
     } else {
         Q.n_tiles = (uint32_t)((n + 63) / 64);
-        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 64>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
+        hipLaunchKernelGGL((k_mfma_filter<KS, MF_FILTER, 3, 2, 1, 64, 0, EB>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256),
                            mf_lds_bytes(3), s, Q);
     }
     return Q.n_tiles;
 }
-template <int KS> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64>), grid, dim3(256), mf_lds_bytes(3), s, P);
+template <int KS, int EB = 4> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64, 0, EB>), grid, dim3(256), mf_lds_bytes(3), s, P);
+}
+// fp64 rows: the widths vsgpu_table_create picks from for VSGPU_F64 (k-steps of 32 doubles)
+static void launch_filter_f64(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_filter_ks<4, 8>(P, n, wgs, q_tiles, s); break;
+    case 8: launch_filter_ks<8, 8>(P, n, wgs, q_tiles, s); break;
+    case 16: launch_filter_ks<16, 8>(P, n, wgs, q_tiles, s); break;
+    case 24: launch_filter_ks<24, 8>(P, n, wgs, q_tiles, s); break;
+    case 32: launch_filter_ks<32, 8>(P, n, wgs, q_tiles, s); break;
+    case 48: launch_filter_ks<48, 8>(P, n, wgs, q_tiles, s); break;
+    default: launch_filter_ks<64, 8>(P, n, wgs, q_tiles, s); break;
+    }
+}
+static void launch_probe_f64(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    switch (ksteps) {
+    case 4: launch_probe_ks<4, 8>(P, grid, s); break;
+    case 8: launch_probe_ks<8, 8>(P, grid, s); break;
+    case 16: launch_probe_ks<16, 8>(P, grid, s); break;
+    case 24: launch_probe_ks<24, 8>(P, grid, s); break;
+    case 32: launch_probe_ks<32, 8>(P, grid, s); break;
+    case 48: launch_probe_ks<48, 8>(P, grid, s); break;
+    default: launch_probe_ks<64, 8>(P, grid, s); break;
+    }
 }
 #ifdef VSGPU_TUNING
 // tuning variants of the d=768 filter kernel (option "mfma_variant"): ring depth / cache policy /
@@ -124,10 +147,21 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
     std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
     std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
+    const bool f64 = t->type == VSGPU_F64;
+    std::vector<float> narrow(f64 ? dim : 0);
     for (size_t q = 0; q < nq; q++) {
         const float *src = (const float *)((const char *)queries + q * qstride);
         double ss = 0;
-        for (size_t i = 0; i < dim; i++) ss += (double)src[i] * (double)src[i];
+        if (f64) {   // the filter sees the query through float, then bf16; the re-rank sees the doubles (stage_queries)
+            const double *d = (const double *)((const char *)queries + q * qstride);
+            for (size_t i = 0; i < dim; i++) {
+                ss += d[i] * d[i];
+                narrow[i] = (float)d[i];
+            }
+            src = narrow.data();
+        } else {
+            for (size_t i = 0; i < dim; i++) ss += (double)src[i] * (double)src[i];
+        }
         qn2[q] = (float)ss;
         const size_t qt = q / MF_QTILE, w = (q % MF_QTILE) / 16, nn = q % 16;
         for (int s = 0; s < KS; s++)
@@ -170,7 +204,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
     while (M < probe_tiles && M < 8192 && M < 64 * k) M <<= 1;   // (64 k groups: two of the k best rows rarely share one)
 
-    rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
+    // (fp64: the exact pair scores -- doubles, [nq][ccap] -- reuse this buffer once the thresholds are out)
+    rc = ensure(c, c->dense, std::max(nqp * (size_t)probe_tiles * 4, f64 ? nqp * ccap * 8 : (size_t)0));
     if (rc) return rc;
 
     MfmaParams P{};
@@ -203,7 +238,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
         if (rc) return rc;
@@ -216,7 +252,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
         const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
-        if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
+        if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
+        else if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
             launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         HIPCHK(hipGetLastError());
     }
