@@ -44,6 +44,11 @@ constexpr int MF_NORM_BYTES = 4 * 2 * 256;  // [wave][parity][64 floats]
 constexpr int MF_EQ_CAP = 384;                     // queued {row, query, score bits} records
 constexpr int MF_EQ_BYTES = 16 + MF_EQ_CAP * 16;
 constexpr int mf_lds_bytes(int nstage) { return nstage * MF_STAGE_BYTES + MF_NORM_BYTES + MF_EQ_BYTES; }
+// MF_PROBE: the (tile, query) minima wait in LDS and leave in batches (a global store per tile shares the VM counter with
+// the ring: one full drain per tile; batching them measured neutral, the probe's rate is set by its short per-workgroup
+// runs): 4 waves x MF_PM_TILES tiles x 16 queries
+constexpr int MF_PM_TILES = 16;   // (keeps the probe within the default 64 KiB of dynamic LDS)
+constexpr int mf_probe_lds_bytes(int nstage) { return mf_lds_bytes(nstage) + 4 * MF_PM_TILES * 64; }
 
 // The queue is touched with inline-asm DS instructions on purpose: for a compiler-visible LDS store or
 // atomic hipcc inserts `s_waitcnt vmcnt(0)` while LDS-DMA writes are in flight (it cannot prove the
@@ -95,6 +100,9 @@ struct MfmaParams {
     uint32_t n_rows;
     // tiles processed by this launch: tile t (0 <= t < n_tiles) covers rows (tile_first + t*tile_step)*64 ...
     uint32_t tile_first, tile_step, n_tiles;
+    // Probe launches sample the table in RUNS of 2^tile_run_shift consecutive tiles, a run every tile_step runs: tile t is
+    // table tile tile_first + (t >> s) * (tile_step << s) + (t & (2^s - 1)); s = 0: one tile every tile_step tiles.
+    uint32_t tile_run_shift;
     const uint4 *qfrag;              // [q_tile][wave][KSTEPS][lane] bf16x8 B-operand fragments
     const float *qn2;                // [q_tiles*64] |q|^2 (0 for padding queries)
     float cE;                        // E = cE * (|x|^2 + |q|^2) + absE
@@ -199,7 +207,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
 
-    auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {
+        return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
+    };
     const char *rp_cur[4], *rp_nxt[4];
     const float *np_cur, *np_nxt;
     uint32_t cur_slab = 0xFFFFFFFFu;          // SLOAD: slab pointers cached in SGPRs, inline-asm scalar loads
@@ -263,6 +273,19 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         else issue(rp_nxt, np_nxt, u - KCH, u, u == KCH, 1);
     }
 
+    // MF_PROBE: this wave's buffered tile minima, [MF_PM_TILES][16 queries] floats behind the queue
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mf_lds_bytes(MF_NSTAGE) + (uint32_t)wave * (MF_PM_TILES * 64) + (uint32_t)m16 * 4u;
+    uint32_t pm_n = 0, pm_tile0 = 0;
+    auto flush_probe_minima = [&]() {   // lane (kq, m16) writes out the tiles kq, kq + 4, ... of query column m16
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
+            float v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + it * 64u) : "memory");
+            P.tilemin[(size_t)qidx * P.tilemin_stride + pm_tile0 + it * step] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pm_n = 0;
+    };
     for (; tile < P.n_tiles; tile += step) {
         f32x4_t acc[MT];
 #pragma unroll
@@ -386,8 +409,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
             // min over the 4 row quads (lanes m16, m16+16, m16+32, m16+48)
             tmin = fminf(tmin, __shfl_xor(tmin, 16));
             tmin = fminf(tmin, __shfl_xor(tmin, 32));
-            if (kq == 0) P.tilemin[(size_t)qidx * P.tilemin_stride + tile] = tmin;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + pm_n * 64u), "v"(tmin) : "memory");
+            if (pm_n == 0) pm_tile0 = tile;
+            if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
         } else {
             if (__any(emitted)) {
                 // stores/atomics share the VM counter with the staged loads: drain once so the counted
@@ -404,6 +428,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
         parity ^= 1u;
     }
+    if (MODE == MF_PROBE && pm_n) flush_probe_minima();
     // drain the stages still in flight before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER) {

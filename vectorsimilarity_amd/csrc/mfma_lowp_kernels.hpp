@@ -92,6 +92,7 @@ struct LowpParams {
     uint32_t row_stride;                 // bytes between rows (dim*elem, +4 for int8 Cosine)
     uint32_t n_rows;
     uint32_t tile_first, tile_step, n_tiles;   // tile t covers rows (tile_first + t*tile_step)*RT ...
+    uint32_t tile_run_shift;                   // ... probe: in runs of 2^shift consecutive tiles (see MfmaParams)
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
     const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, Wref, 128 sum e, |e|_2, 0}
@@ -118,9 +119,13 @@ constexpr int lowp_ta(int ksteps, int rt, int ns, int stage) {
     return (lowp_kch(ksteps, rt, stage) - 1 + (ns - 1)) / lowp_kch(ksteps, rt, stage);
 }
 constexpr int LOWP_WQ_CAP = 64;  // SKEW: records per wave-private queue (a 16-byte header holds the fill count)
-constexpr int lowp_lds_bytes(int nwaves, int ksteps, int rt, int ns, int stage = MF_STAGE_BYTES, bool skew = false) {
+// MF_PROBE: per (tile, query) minima wait in LDS and leave in batches of LOWP_PM_TILES tiles per wave -- a global store per
+// tile shares the VM counter with the ring and costs a full drain (s_waitcnt vmcnt(0)) per tile
+constexpr int LOWP_PM_TILES = 32;
+constexpr int lowp_pm_bytes(int nwaves, int nqw) { return LOWP_PM_TILES * nwaves * 16 * nqw * 4; }
+constexpr int lowp_lds_bytes(int nwaves, int ksteps, int rt, int ns, int stage = MF_STAGE_BYTES, bool skew = false, int probe_nqw = 0) {
     return ns * stage + nwaves * 256 * (lowp_ta(ksteps, rt, ns, stage) + 1) +
-           (skew ? nwaves * (16 + LOWP_WQ_CAP * 16) : MF_EQ_BYTES);
+           (skew ? nwaves * (16 + LOWP_WQ_CAP * 16) : MF_EQ_BYTES) + (probe_nqw ? lowp_pm_bytes(nwaves, probe_nqw) : 0);
 }
 
 // s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
@@ -279,7 +284,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     };
 
     const uint32_t step = pair_map ? gridDim.x / 2 : gridDim.x;
-    auto tile_row0 = [&](uint32_t t) -> uint32_t { return (P.tile_first + t * P.tile_step) * RT; };
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {
+        return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
+    };
     // Requests are issued strictly in unit order, so only the frontier tile's addresses are kept
     const char *rp_f[IPW];
     const uint32_t *ap_f;
@@ -368,6 +375,23 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         }
     };
     stamp(-1);
+    // MF_PROBE: this wave's buffered tile minima: [LOWP_PM_TILES][NQW][16 queries] floats behind everything else
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)(lowp_lds_bytes(NWAVES, KSTEPS, RT, NS, STAGE, SKEW)) +
+                            (uint32_t)wave * (uint32_t)(LOWP_PM_TILES * NQW * 64) + (uint32_t)m16 * 4u;
+    uint32_t pm_n = 0, pm_tile0 = 0;
+    auto flush_probe_minima = [&]() {   // lane (kq, m16) writes out the tiles kq, kq + 4, ... of query column m16
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
+#pragma unroll
+            for (int nt = 0; nt < NQW; nt++) {
+                float v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (uint32_t)((it * NQW + nt) * 64)) : "memory");
+                P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores share the VM counter with the ring: one drain per batch
+        pm_n = 0;
+    };
     for (; tile < P.n_tiles; tile += step) {
         acc_t acc[MT][NQW];
         u32x4_t auxv[MT];
@@ -720,9 +744,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 float v = tmin[nt];
                 v = fminf(v, __shfl_xor(v, 16));
                 v = fminf(v, __shfl_xor(v, 32));
-                if (kq == 0) P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + tile] = v;
+                if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + (uint32_t)((pm_n * NQW + nt) * 64)), "v"(v) : "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pm_n == 0) pm_tile0 = tile;
+            if (++pm_n == (uint32_t)LOWP_PM_TILES) flush_probe_minima();
         } else if (SKEW) {
             if (__any(emitted)) drain_wave_queue();
             {   // the request that the last unit postponed (same arithmetic as request_ahead with c = KCH-1)
@@ -747,6 +772,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         o[5] = tiles_done;
     }
     if (SKEW && half == 0) mf_ring_barrier();  // pairs with half 1's leading barrier
+    if (MODE == MF_PROBE && pm_n) flush_probe_minima();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER && !SKEW) {
         __builtin_amdgcn_s_barrier();

@@ -148,6 +148,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
     else if (n == "probe_div") c->opt_probe_div = std::max(0L, value);
     else if (n == "probe_cap") c->opt_probe_cap = std::min(1L << 20, std::max(64L, value));
+    else if (n == "probe_run") c->opt_probe_run = std::min(8L, std::max(-1L, value));
     else if (n == "cand_cap") c->opt_cand_cap = std::max(16L, value);
     else return fail(VSGPU_ERR_ARG, "unknown option %s", name);
     return VSGPU_OK;
@@ -1230,6 +1231,15 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
 // each re-scored from a randomly placed row at a fraction r ~ 0.15 of that speed: the sum is smallest at
 // div = sqrt(r * n / (nq * k)).  Measured optima (tools/sweep_probe.py, tools/bench_dims.py): 48 at 10 M x 768, batch 64,
 // k 10 (formula: 48); larger probes win on small tables.  Integer kinds have no re-rank and a flat optimum: fixed 48.
+// Probe tiles can come in runs of 2^shift consecutive tiles (MfmaParams::tile_run_shift, option "probe_run").  Measured
+// with ~2 MiB runs on the three BASELINE shapes: no faster than one tile every tile_step tiles (the probe is not bound by
+// address translation), and evenly spread tiles sample a table that was ingested in clusters better: default 0.
+uint32_t probe_run_shift(const vsgpu_ctx *c, size_t tile_bytes, uint32_t probe_tiles) {
+    (void)tile_bytes;
+    uint32_t s = c->opt_probe_run > 0 ? (uint32_t)c->opt_probe_run : 0;
+    while (s > 0 && (probe_tiles >> s) < 64) s--;
+    return s;
+}
 uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank) {
     if (c->opt_probe_div > 0) return (uint32_t)c->opt_probe_div;
     if (!rerank) return 48;

@@ -61,6 +61,7 @@ struct vsgpu_ctx {
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
     long opt_probe_div = 0;           // probe ~ n / probe_div rows; 0 = chosen per call by probe_divisor()
     long opt_probe_cap = 32768;       // ... but at most this many probe tiles
+    long opt_probe_run = -1;          // probe tiles per contiguous run, as a shift; -1 = about 2 MiB per run (probe_run_shift())
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
 };
@@ -190,6 +191,7 @@ template <typename F> static void host_parallel(size_t n, size_t grain, F f) {
 int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                        size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
                        ScanChainGuard *chain = nullptr);
+uint32_t probe_run_shift(const vsgpu_ctx *c, size_t tile_bytes, uint32_t probe_tiles);
 uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank);
 size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows);
 // stage 2 of the filter paths: reference-order exact re-score of the candidate lists in ctx->cand (in place)

@@ -13,7 +13,7 @@ using namespace vsg;
 // dynamic LDS, which HIP only grants after the attribute is raised.
 template <int LK, int KS, int MODE, int RT, int NW, int NQW, int MINW, int NS, int STAGE = MF_STAGE_BYTES, int DIST = 0, int DLATE = 0, int ISS = 0>
 static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE);
+    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, false, MODE == MF_PROBE ? NQW : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
     auto go = [&](auto kern) {
         if (lds_bytes > 64 * 1024)
@@ -196,7 +196,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         case 12: launch_lowp_i8<12, 64, LP_U8C>(mode, P, grid, s); break;
         default:
             if (mode == MF_FILTER) launch_lowp_k<LP_U8C, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
-            else launch_lowp_i8<16, 32, LP_U8C>(mode, P, grid, s);
+            else launch_lowp_k<LP_U8C, 16, MF_PROBE, 32, 16, 1, 1, 3, 32768>(P, grid, s);   // the filter's whole-row slots
             break;
         }
     } else if (t->lp_kind == LP_SQ8) {
@@ -211,7 +211,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
         default:
             if (mode == MF_FILTER) launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
-            else launch_lowp_i8<16, 32, LP_U8>(mode, P, grid, s);
+            else launch_lowp_k<LP_U8, 16, MF_PROBE, 32, 16, 1, 1, 3, 32768>(P, grid, s);   // the filter's whole-row slots
             break;
         }
     } else {
@@ -223,7 +223,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         case 12: launch_lowp_i8<12, 64>(mode, P, grid, s); break;
         default:
             if (mode == MF_FILTER) launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>(P, grid, s);
-            else launch_lowp_i8<16, 32>(mode, P, grid, s);
+            else launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 16, 1, 1, 3, 32768>(P, grid, s);   // the filter's whole-row slots
             break;
         }
     }
@@ -431,7 +431,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     while (M < probe_tiles && M < 8192 && M < 64 * k) M <<= 1;   // (64 k groups: two of the k best rows rarely share one)
     rc = ensure(c, c->dense, nqp * (size_t)probe_tiles * 4);
     if (rc) return rc;
-    const uint32_t wgs = (uint32_t)c->n_cu * 2;
+    // probe grid: as many workgroups as are resident at once (one per CU for these kernels) -- a second round of workgroups
+    // loads its query fragments and fills its ring again while the CUs wait
+    const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_lowp_wg_per_cu;
 
     ScanChainGuard chain(t);   // behind the other reader lanes' probe + scan (see topk_mfma)
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
@@ -439,6 +441,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         LowpParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;
+        Q.tile_run_shift = probe_run_shift(c, (size_t)RT * t->row_bytes, probe_tiles);
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;

@@ -21,7 +21,7 @@ template <int KS, int EB = 4> static uint32_t launch_filter_ks(MfmaParams Q, siz
     return Q.n_tiles;
 }
 template <int KS, int EB = 4> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64, 0, EB>), grid, dim3(256), mf_lds_bytes(3), s, P);
+    hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64, 0, EB>), grid, dim3(256), mf_probe_lds_bytes(3), s, P);
 }
 // fp64 rows: the widths vsgpu_table_create picks from for VSGPU_F64 (k-steps of 32 doubles)
 static void launch_filter_f64(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
@@ -235,6 +235,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         MfmaParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;
+        Q.tile_run_shift = probe_run_shift(c, (size_t)MF_TILE_ROWS * t->row_bytes, probe_tiles);
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
