@@ -249,13 +249,37 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
     }
 }
 
+// bf16 / fp16 rows of up to 768 elements with the batch split into 64-query tiles: 4 waves x 16 queries per workgroup, two
+// workgroups per CU (the fp32 filter's shape).  Both query tiles of a 128-query batch walk the same row tiles from the same
+// XCD (pair_map), so the rows cross HBM once and the partner's copy comes from L2.  Measured on config 4 (12.5 M x 768 bf16,
+// batch 128): bit-identical, 4.02 ms against 3.31 ms for the one 8-wave workgroup -- tuning build only (option lowp_qsplit).
+#ifdef VSGPU_TUNING
+template <int LK> static void launch_lowp_h16_split(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, 24, MF_PROBE, 32, 4, 1, 2, 3>(P, grid, s);
+    else if (grid.y == 2 && grid.x % 8 == 0) {
+        LowpParams Q = P;
+        Q.pair_map = 1;
+        launch_lowp_k<LK, 24, MF_FILTER, 32, 4, 1, 2, 3>(Q, dim3(grid.x * 2), s);
+    } else launch_lowp_k<LK, 24, MF_FILTER, 32, 4, 1, 2, 3>(P, grid, s);
+}
+#else
+template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim3, hipStream_t) {}
+#endif
+
 int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                      uint32_t *ids, double *scores, uint32_t *counts) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n, dim = t->dim;
     const int KS = t->lp_ksteps, RT = t->lp_rt;
     const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
-    const size_t QT = qsplit ? 128 : (size_t)t->lp_qtile, NQW = QT / 128;
+    // bf16 / fp16, kernel width 768: 64-query tiles when the batch fills exactly two of them (option lowp_qsplit)
+#ifdef VSGPU_TUNING
+    const bool hsplit = (t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && c->opt_lowp_qsplit && t->lp_ksteps == 24 &&
+                        t->lp_rt == 32 && nq > 64 && nq <= 128;
+#else
+    const bool hsplit = false;
+#endif
+    const size_t QT = hsplit ? 64 : (qsplit ? 128 : (size_t)t->lp_qtile);
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
     const bool is_u8c = (t->lp_kind == LP_U8C);
@@ -328,11 +352,13 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             qm[6] = std::nextafter((float)(std::sqrt(se2) * (1.0 + 1e-6)), INFINITY);   // |e|_2
             src = reinterpret_cast<const unsigned char *>(yq.data());
         }
-        const size_t qt = q / QT, w = (q % QT) / (16 * NQW), nt = ((q % QT) % (16 * NQW)) / 16, nn = q % 16;
+        // fragments are stored per group of 16 queries in batch order: the kernels index (q_tile * waves + wave) * NQW + nt,
+        // which is q / 16 for every tile shape
+        const size_t g16 = q / 16, nn = q % 16;
         for (int s = 0; s < KS; s++)
             for (int kq = 0; kq < 4; kq++) {
                 const size_t lane = (size_t)kq * 16 + nn;
-                unsigned char *dst = &frag[(((((qt * 8 + w) * NQW + nt) * KS + s) * 64) + lane) * 16];
+                unsigned char *dst = &frag[(((g16 * KS + s) * 64) + lane) * 16];
                 const size_t e0 = (kelem * s + per_lane * kq) * eb, have = e0 < dim * eb ? std::min<size_t>(16, dim * eb - e0) : 0;
                 if (have) memcpy(dst, src + e0, have);
                 if (is_u8)
@@ -446,6 +472,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
         if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
@@ -468,6 +496,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             Q.tilemin = reinterpret_cast<float *>(d_ph);
         }
         if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
             launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
