@@ -289,11 +289,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t kelem = (is_int || is_sq8) ? 64 : 32;        // elements per MFMA k-step
     const size_t per_lane = kelem / 4;            // elements per lane per k-step (16 bytes)
 
-    int rc = VSGPU_OK;
-    if (!is_int) {
-        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
-        if (rc) return rc;
-    }
+    int rc = VSGPU_OK;   // (the exact-order query images of the re-rank are staged behind the filter launch, under the scan)
     // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
     const size_t kdim = (size_t)KS * kelem;  // kernel width >= dim
     std::vector<unsigned char> frag(nqp * kdim * eb, 0);
@@ -526,6 +522,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         return VSGPU_OK;
     }
     if (!is_int) {
+        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
+        if (rc) return rc;
         rc = launch_exact_pairs(t, nq, ccap);
         if (rc) return rc;
     }

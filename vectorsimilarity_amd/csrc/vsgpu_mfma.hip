@@ -141,9 +141,9 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t q_tiles = (nq + MF_QTILE - 1) / MF_QTILE, nqp = q_tiles * MF_QTILE;
     const bool l2 = (t->metric == VSGPU_L2);
 
-    // (1) exact-order query images for the re-rank, (2) bf16 B-operand fragments + |q|^2 for the filter
-    int rc = stage_queries(t, queries, nq, qstride);
-    if (rc) return rc;
+    // (1) bf16 B-operand fragments + |q|^2 for the filter, (2) exact-order query images for the re-rank -- staged behind the
+    // filter launch, under the scan, since only the re-rank reads them
+    int rc = VSGPU_OK;
     const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
     std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
     std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
@@ -259,6 +259,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter", &chain);
