@@ -11,12 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vectorsimilarity_amd import VecSim  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-kind = sys.argv[2] if len(sys.argv) > 2 else "f32"      # f32 | f32odd | bf16 | i8
+kind = sys.argv[2] if len(sys.argv) > 2 else "f32"      # f32 | f32odd | f64 | f64odd | bf16 | i8
 opts = dict(kv.split("=") for kv in sys.argv[3:])
 dim, n, nq, k = {"f32": (128, 150_000, 64, 10), "f32odd": (100, 150_000, 64, 10), "bf16": (256, 120_000, 100, 10),
-                 "i8": (512, 100_000, 200, 10)}[kind]
+                 "i8": (512, 100_000, 200, 10), "f64": (256, 80_000, 64, 10), "f64odd": (100, 100_000, 40, 10)}[kind]
 VT = {"f32": VecSim.VecSimType_FLOAT32, "f32odd": VecSim.VecSimType_FLOAT32, "bf16": VecSim.VecSimType_BFLOAT16,
-      "i8": VecSim.VecSimType_INT8}[kind]
+      "i8": VecSim.VecSimType_INT8, "f64": VecSim.VecSimType_FLOAT64, "f64odd": VecSim.VecSimType_FLOAT64}[kind]
 rng = np.random.default_rng(1)
 sets = []
 for s in range(2):
@@ -24,8 +24,9 @@ for s in range(2):
         rows = rng.integers(-128, 128, (n, dim)).astype(np.int8)
         q = rng.integers(-128, 128, (nq, dim)).astype(np.int8)
     else:
-        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
-        q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+        ft = np.float64 if kind.startswith("f64") else np.float32
+        rows = rng.uniform(-1, 1, (n, dim)).astype(ft)
+        q = rng.uniform(-1, 1, (nq, dim)).astype(ft)
         if kind == "bf16":
             rows = (rows.view(np.uint32) >> 16).astype(np.uint16)
             q = (q.view(np.uint32) >> 16).astype(np.uint16)
