@@ -19,10 +19,13 @@ ap.add_argument("--batches", default="64,128")
 ap.add_argument("--metric", default="L2")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 p = VecSim.BFParams()
 p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, a.dim, getattr(VecSim, "VecSimMetric_" + a.metric)
 ix = VecSim.SQ8Index(p)
+for o in a.opt:
+    ix.set_option(o.split("=")[0], int(o.split("=")[1]))
 t0 = time.perf_counter()
 for r0 in range(0, a.rows, 500_000):
     r1 = min(a.rows, r0 + 500_000)

@@ -54,6 +54,29 @@ static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t 
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
     else launch_lowp_k<LK, KS, MF_FILTER, RT, 8, NQW, 1, 3>(P, grid, s);
 }
+// Batches of at most 64 queries: 4 waves x 16 queries per workgroup (two or more resident per CU, each streaming its own row
+// tiles, like the fp32 filter) instead of an 8-wave workgroup whose upper half multiplies and screens padding
+template <int LK, int KS, int RT>
+static void launch_lowp_narrow(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 4, 1, 2, 3>(P, grid, s);
+    else launch_lowp_k<LK, KS, MF_FILTER, RT, 4, 1, 2, 3>(P, grid, s);
+}
+// returns false when the table's shape has no 4-wave instance
+static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_kind == LP_SQ8) {
+        switch (t->lp_ksteps) {
+        case 8: launch_lowp_narrow<LP_SQ8, 8, 64>(mode, P, grid, s); return true;
+        case 12: launch_lowp_narrow<LP_SQ8, 12, 64>(mode, P, grid, s); return true;
+        default: launch_lowp_narrow<LP_SQ8, 16, 64>(mode, P, grid, s); return true;
+        }
+    }
+    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_BF16, 24, 32>(mode, P, grid, s); return true; }
+    if (t->lp_kind == LP_F16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_F16, 24, 32>(mode, P, grid, s); return true; }
+    return false;
+}
+static bool lowp_has_narrow(const vsgpu_table *t) {
+    return t->lp_kind == LP_SQ8 || ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps == 24);
+}
 template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
     else launch_lowp_k<LK, KS, MF_FILTER, RT, 16, 1, 1, 3>(P, grid, s);
@@ -279,7 +302,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 #else
     const bool hsplit = false;
 #endif
-    const size_t QT = hsplit ? 64 : (qsplit ? 128 : (size_t)t->lp_qtile);
+    const bool narrow = !hsplit && !qsplit && nq <= 64 && lowp_has_narrow(t) && c->opt_lowp_narrow;
+    const size_t QT = (hsplit || narrow) ? 64 : (qsplit ? 128 : (size_t)t->lp_qtile);
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
     const bool is_u8c = (t->lp_kind == LP_U8C);
@@ -470,6 +494,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        else if (narrow) launch_lowp_narrow_any(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs * 2), (unsigned)q_tiles), c->stream);
         else launch_lowp(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
@@ -494,6 +519,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        else if (narrow) launch_lowp_narrow_any(t, MF_FILTER, Q, dim3(std::min(total_tiles, (uint32_t)c->n_cu * 2), (unsigned)q_tiles), c->stream);
         else if (!launch_lowp_variant(t, (int)c->opt_lowp_variant, Q, fw, (unsigned)q_tiles, c->stream))
             launch_lowp(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
