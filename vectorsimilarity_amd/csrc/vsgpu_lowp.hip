@@ -72,10 +72,19 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
     }
     if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_BF16, 24, 32>(mode, P, grid, s); return true; }
     if (t->lp_kind == LP_F16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_F16, 24, 32>(mode, P, grid, s); return true; }
+    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16 && t->lp_rt == 32) {
+        // int8, width 1024, at most 128 queries: 8 waves x 16 queries at <= 128 VGPRs, two workgroups resident per CU
+        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
+        else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
+        return true;
+    }
     return false;
 }
-static bool lowp_has_narrow(const vsgpu_table *t) {
-    return t->lp_kind == LP_SQ8 || ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps == 24);
+// query-tile width of the narrow-batch kernels (0: none for this table)
+static size_t lowp_narrow_qtile(const vsgpu_table *t) {
+    if (t->lp_kind == LP_SQ8 || ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps == 24)) return 64;
+    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
+    return 0;
 }
 template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 16, 1, 1, 3>(P, grid, s);
@@ -302,8 +311,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 #else
     const bool hsplit = false;
 #endif
-    const bool narrow = !hsplit && !qsplit && nq <= 64 && lowp_has_narrow(t) && c->opt_lowp_narrow;
-    const size_t QT = (hsplit || narrow) ? 64 : (qsplit ? 128 : (size_t)t->lp_qtile);
+    const bool narrow = !hsplit && !qsplit && lowp_narrow_qtile(t) && nq <= lowp_narrow_qtile(t) && c->opt_lowp_narrow;
+    const size_t QT = hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
     const bool is_u8c = (t->lp_kind == LP_U8C);
