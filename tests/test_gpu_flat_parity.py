@@ -481,6 +481,31 @@ def test_mfma_filter_path_fp64(vso, metric, dim, n, nq, k):
     assert np.array_equal(l3, l4) and np.array_equal(d3, d4)
 
 
+@pytest.mark.parametrize("typ,metric,dim,nq", [("bf16", "L2", 200, 7), ("f16", "IP", 400, 64), ("bf16", "Cosine", 700, 33),
+                                                ("i8", "Cosine", 1024, 100), ("u8", "L2", 1000, 128), ("i8", "L2", 900, 5)])
+def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
+    """batches that fit half a query tile take the 4-wave (bf16 / fp16 / SQ8) or 8-wave (int8 / uint8 at width 1024) kernels,
+    two workgroups per CU: same replies as the full-tile kernel and as the exact path"""
+    rng = np.random.default_rng(dim + nq)
+    n, k = 50_000, 10
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    replies = []
+    for narrow, mfma in ((1, 1), (0, 1), (1, 0)):
+        ix.set_option("lowp_narrow", narrow)
+        ix.set_option("mfma", mfma)
+        ix.reset_stats()
+        replies.append(ix.knn_query(q, k))
+        assert ix.stats()["scan_kernel"].startswith("k_mfma_filter_lowp" if mfma else "k_exact_scan")
+    for r in replies[1:]:
+        assert np.array_equal(replies[0][0], r[0]) and np.array_equal(replies[0][1], r[1])
+    el, es = oracle_topk(vso, typ, metric, rows, q[0], k)
+    assert np.array_equal(replies[0][0][0], el.astype(np.int64)) and np.array_equal(replies[0][1][0], es)
+
+
 def test_mfma_filter_adversarial_near_duplicates(vso):
     """rows within the bf16 error band of each other: the filter cannot separate them, the candidate
     lists overflow and the exact fallback must still give the reference answer (with ties)"""

@@ -70,20 +70,33 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
         default: launch_lowp_narrow<LP_SQ8, 16, 64>(mode, P, grid, s); return true;
         }
     }
-    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_BF16, 24, 32>(mode, P, grid, s); return true; }
-    if (t->lp_kind == LP_F16 && t->lp_ksteps == 24) { launch_lowp_narrow<LP_F16, 24, 32>(mode, P, grid, s); return true; }
-    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16 && t->lp_rt == 32) {
-        // int8, width 1024, at most 128 queries: 8 waves x 16 queries at <= 128 VGPRs, two workgroups resident per CU
-        if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
-        else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
+    if (t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) {
+        const bool bf = t->lp_kind == LP_BF16;
+        switch (t->lp_ksteps) {
+        case 8: bf ? launch_lowp_narrow<LP_BF16, 8, 64>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 8, 64>(mode, P, grid, s); return true;
+        case 16: bf ? launch_lowp_narrow<LP_BF16, 16, 32>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 16, 32>(mode, P, grid, s); return true;
+        case 24: bf ? launch_lowp_narrow<LP_BF16, 24, 32>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 24, 32>(mode, P, grid, s); return true;
+        default: return false;
+        }
+    }
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) {
+        // int8 / uint8, width 1024, at most 128 queries: 8 waves x 16 queries at <= 128 VGPRs, two workgroups resident per CU
+        if (t->lp_kind == LP_I8) {
+            if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
+            else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
+        } else {
+            if (mode == MF_PROBE) launch_lowp_k<LP_U8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
+            else launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
+        }
         return true;
     }
     return false;
 }
 // query-tile width of the narrow-batch kernels (0: none for this table)
 static size_t lowp_narrow_qtile(const vsgpu_table *t) {
-    if (t->lp_kind == LP_SQ8 || ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps == 24)) return 64;
-    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
+    if (t->lp_kind == LP_SQ8) return 64;
+    if ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps <= 24) return 64;
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
     return 0;
 }
 template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
