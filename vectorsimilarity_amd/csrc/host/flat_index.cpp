@@ -319,12 +319,15 @@ int FlatIndex::addVector(const void *blob, size_t label) {
     if (metric_ == VecSimMetric_Cosine || sq8_) {
         std::vector<char> tmp(stored_bytes_);
         toStored(blob, tmp.data());
-        stageRow(tmp.data());
-        noteRow((uint32_t)count_, tmp.data());
-    } else {
-        stageRow(blob);
-        noteRow((uint32_t)count_, blob);
+        return appendStored(tmp.data(), label);
     }
+    return appendStored(blob, label);
+}
+
+// the append half of addVector, for a blob that already went through the storage preprocessing
+int FlatIndex::appendStored(const void *stored, size_t label) {
+    stageRow(stored);
+    noteRow((uint32_t)count_, stored);
     const uint32_t id = (uint32_t)count_++;
     if (id_to_label_.size() < count_) {
         // grow metadata by whole blocks, like growByBlock() (brute_force.h:109-117)
@@ -342,6 +345,25 @@ long FlatIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     if (!multi_)
         for (size_t i = 0; i < n; i++)
             if (label_to_id_.count(labels[i])) return -1;
+    if ((metric_ == VecSimMetric_Cosine || sq8_) && n >= 2048) {
+        // the storage preprocessing (normalise / quantise) is per row and pure: a few host threads do it, the maps and the
+        // staging buffer are then filled in order.  (SQ8 10 M x 768: 82 s of single-thread quantiser otherwise.)
+        std::vector<char> pre(n * stored_bytes_);
+        const size_t workers = std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency()));
+        const size_t per = (n + workers - 1) / workers;
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers && w * per < n; w++)
+            pool.emplace_back([&, w]() {
+                for (size_t i = w * per; i < std::min(n, (w + 1) * per); i++)
+                    toStored(static_cast<const char *>(blobs) + i * in_bytes, pre.data() + i * stored_bytes_);
+            });
+        for (auto &th : pool) th.join();
+        for (size_t i = 0; i < n; i++) {
+            if (!multi_ && label_to_id_.count(labels[i])) addVector(static_cast<const char *>(blobs) + i * in_bytes, labels[i]);   // a label repeated inside the batch: the overwrite path
+            else appendStored(pre.data() + i * stored_bytes_, labels[i]);
+        }
+        return flush() ? -1 : (long)n;
+    }
     for (size_t i = 0; i < n; i++) addVector(static_cast<const char *>(blobs) + i * in_bytes, labels[i]);
     return flush() ? -1 : (long)n;
 }

@@ -152,6 +152,7 @@ private:
     FlatIndex() = default;
     int flush();  // push host-staged rows to the device table
     void stageRow(const void *processed);
+    int appendStored(const void *stored, size_t label);
     void log(const char *level, const char *fmt, ...) const;
     std::vector<char> packQueries(const void *queries, size_t nq, size_t stride) const;
     void replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const;
