@@ -393,6 +393,75 @@ static __global__ __launch_bounds__(1024) void k_probe_threshold(const float *de
     }
 }
 
+// The same threshold for M > 2048 group minima (k around 100).  // One 1024-thread workgroup per query; M <= 8192 (power of two).  The k-th smallest minimum is found by a bitwise search
+// over the order-preserving integer image of the floats (16 counting passes of two bits over <= 8 register-held keys per
+// thread, one barrier each) -- the bitonic sort above takes 76 us at M = 8192, this 35-40 us; at M = 1024 the sort is the faster one (15 us).
+static __global__ __launch_bounds__(1024) void k_probe_threshold_wide(const float *dense, size_t stride,
+                                                          uint32_t n0, uint32_t k, uint32_t M,
+                                                          float *tau) {
+    __shared__ uint32_t red[2][48];
+    const float *src = dense + (size_t)blockIdx.x * stride;
+    const uint32_t ts = (n0 + M - 1) / M;  // rows per tile
+    uint32_t key[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t t = threadIdx.x + 1024u * (uint32_t)j;
+        float m = INFINITY;
+        if (t < M) {
+            const uint32_t lo = t * ts, hi = min(n0, lo + ts);
+            for (uint32_t i = lo; i < hi; i++) {
+                float s = src[i];
+                if (s < m) m = s;  // NaN never wins: a NaN row cannot lower the bound
+            }
+        }
+        const uint32_t bits = __float_as_uint(m);
+        key[j] = (t < M) ? (bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u)) : 0xFFFFFFFFu;   // unsigned order == float order
+    }
+    const uint32_t tiles = (n0 + ts - 1) / ts;   // non-empty tiles
+    if (!(k >= 1 && k <= tiles)) {
+        if (threadIdx.x == 0) tau[blockIdx.x] = INFINITY;
+        return;
+    }
+    uint32_t T = 0;
+    for (int bit = 30; bit >= 0; bit -= 2) {   // two bits per pass: counts below the three non-zero digits
+        uint32_t c1 = 0, c2 = 0, c3 = 0;
+        const uint32_t t1 = T | (1u << bit), t2 = T | (2u << bit), t3 = T | (3u << bit);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c1 += (key[j] < t1) ? 1u : 0u;
+            c2 += (key[j] < t2) ? 1u : 0u;
+            c3 += (key[j] < t3) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+            c3 += __shfl_xor(c3, o);
+        }
+        uint32_t *r = red[(bit >> 1) & 1];   // (alternating buffers: one barrier per pass)
+        if ((threadIdx.x & 63) == 0) {
+            r[(threadIdx.x >> 6) * 3] = c1;
+            r[(threadIdx.x >> 6) * 3 + 1] = c2;
+            r[(threadIdx.x >> 6) * 3 + 2] = c3;
+        }
+        __syncthreads();
+        uint32_t s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            s1 += r[w * 3];
+            s2 += r[w * 3 + 1];
+            s3 += r[w * 3 + 2];
+        }
+        // fewer than k keys below a trial value: the k-th smallest is at or above it (s1 <= s2 <= s3)
+        const uint32_t digit = (s1 < k ? 1u : 0u) + (s2 < k ? 1u : 0u) + (s3 < k ? 1u : 0u);
+        T |= digit << bit;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t bits = (T & 0x80000000u) ? (T ^ 0x80000000u) : ~T;
+        tau[blockIdx.x] = __uint_as_float(bits);
+    }
+}
+
 // ---- synthetic rows (bench / tests): identical to oracle/vso.c:vso_hash32 / vso_synth_f32 ----
 __device__ inline uint32_t hash32(uint64_t seed, uint64_t idx) {
     uint64_t x = seed + idx * 0x9E3779B97F4A7C15ull;

@@ -1299,8 +1299,12 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     return VSGPU_OK;
 }
 int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M) {
-    hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
-                       (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+    if (M > 2048)
+        hipLaunchKernelGGL(k_probe_threshold_wide, dim3((unsigned)nq), dim3(1024), 0, c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+    else
+        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
     HIPCHK(hipGetLastError());
     return VSGPU_OK;
 }
