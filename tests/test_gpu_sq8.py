@@ -197,6 +197,39 @@ def test_sq8_mfma_filter_hard_inputs(vso, metric):
         assert np.array_equal(dists[j], es), (metric, j)
 
 
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+@pytest.mark.parametrize("nq", [64, 128])
+@pytest.mark.parametrize("shape", ["offset", "uniform", "constant_rows"])
+def test_sq8_block_prescreen_tight_cases(vso, metric, nq, shape):
+    """the filter's block pre-screen (one bound per lane and 64-row tile from the extreme dots and the tile's aux summary) is
+    tightest on homogeneous rows: vectors far from the origin with a small spread (min * y_sum dominates, delta tiny),
+    plain uniform rows at a size where the k-th score is deep in the tail, and tiles holding constant vectors (delta = 1,
+    all codes 0) next to ordinary ones; 4-wave (nq 64) and 8-wave (nq 128) kernels"""
+    rng = np.random.default_rng(len(shape) + nq)
+    dim, n, k = 96, 120_000, 10
+    if shape == "offset":
+        rows = (5.0 + rng.normal(0, 0.01, (n, dim))).astype(np.float32)
+        q = (5.0 + rng.normal(0, 0.01, (nq, dim))).astype(np.float32)
+    else:
+        rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+        if shape == "constant_rows":
+            rows[::37] = rng.uniform(-2, 2, (len(rows[::37]), 1)).astype(np.float32)    # every component equal
+            rows[5000:5064] = 0.25
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(sq8)"
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(0, nq, 5):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, shape, j, labels[j], el)
+        assert np.array_equal(dists[j], es), (metric, shape, j)
+
+
 # ---------------------------------------------------------------- fp16 vectors / queries (QuantPreprocessor<float16>, SQ8_FP16_*)
 def make_f16(metric, dim):
     p = VecSim.BFParams()

@@ -20,6 +20,7 @@ ap.add_argument("--metric", default="L2")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--sweep", default="", help="NAME=V1,V2: repeat every MFMA measurement with this index option at each value")
 a = ap.parse_args()
 p = VecSim.BFParams()
 p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, a.dim, getattr(VecSim, "VecSimMetric_" + a.metric)
@@ -34,7 +35,11 @@ print("ingest (host quantiser + upload): %.1f s" % (time.perf_counter() - t0), f
 row_bytes = a.dim + (16 if a.metric == "L2" else 12)
 for b in [int(x) for x in a.batches.split(",")]:
     qs = [synth.rows_f32(48 + i, 0, b, a.dim) for i in range(3)]
-    for mf in (1, 0):
+    sweep = [(a.sweep.split("=")[0], int(v)) for v in a.sweep.split("=")[1].split(",")] if a.sweep else [None]
+    for mf, sw in [(1, x) for x in sweep] + ([(0, None)] if not a.sweep else []):
+        if sw:
+            ix.set_option(sw[0], sw[1])
+            print("option %s = %d:" % sw, end=" ")
         ix.set_option("mfma", mf)
         ix.knn_query(qs[0], a.k)
         ix.reset_stats()

@@ -161,7 +161,7 @@ GPU_EXPORTS = [
     "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",
-    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_stats_reset",
+    "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_table_set_sq8_block_bounds", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option",
     "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
     "vsgpu_comm_allgather", "vsgpu_comm_broadcast",

@@ -144,6 +144,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "hnsw_slots") c->opt_hnsw_slots = std::max(1L, std::min(64L, value));
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;
+    else if (n == "sq8_block") c->opt_sq8_block = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
@@ -316,6 +317,8 @@ extern "C" int vsgpu_table_view_sync(vsgpu_table *v) {
     v->norm_slabs = p->norm_slabs;
     v->d_norm_slabs = p->d_norm_slabs;
     v->n = p->n;
+    for (int i = 0; i < 6; i++) v->sq8_blk[i] = p->sq8_blk[i];
+    v->sq8_blk_set = p->sq8_blk_set;
     return VSGPU_OK;
 }
 
@@ -998,6 +1001,13 @@ static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *sla
 extern "C" int vsgpu_table_set_sq8_mean_sum_squares(vsgpu_table *t, float mean_sum_squares) {
     if (!t || (t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H)) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
     t->sq8_mss = mean_sum_squares;
+    return VSGPU_OK;
+}
+
+extern "C" int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[6]) {
+    if (!t || (t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H)) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
+    for (int i = 0; i < 6; i++) t->sq8_blk[i] = bounds ? bounds[i] : 0.f;
+    t->sq8_blk_set = bounds != nullptr;
     return VSGPU_OK;
 }
 

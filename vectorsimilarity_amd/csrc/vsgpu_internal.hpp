@@ -48,6 +48,7 @@ struct vsgpu_ctx {
     long opt_mfma_variant = 0;
     long opt_lowp_variant = 0;
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
+    long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
     long opt_lowp_ksplit = 0;  // int8/uint8 1 KiB rows: K-split filter kernel (mfma_i8ks_kernels.hpp); 2 = with s_setprio
@@ -123,6 +124,8 @@ struct vsgpu_table {
     int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
     bool sq8_centred = false;   // mean-centred IP rows (dim + 16 bytes: x_mean_ip behind the three base slots), queries carry y_mean_ip
     float sq8_mss = 0.f;        // sum mean_i^2, the symmetric IP correction constant
+    float sq8_blk[6] = {0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)
+    bool sq8_blk_set = false;
     size_t aux_bytes = 4;   // per-row aux record of the MFMA filters: 4 B, or 16 B {min, delta, sum_squares, 0} for SQ8 rows
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;
