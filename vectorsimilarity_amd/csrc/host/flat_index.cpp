@@ -247,8 +247,9 @@ void FlatIndex::noteRow(uint32_t id, const void *stored) {
         }
         const float nc = std::nextafter((float)(std::sqrt((double)ss) * 1.000001), std::numeric_limits<float>::infinity());
         const float xsq = metric_ == VecSimMetric_L2 ? meta[3] : 0.0f;
-        float nb[6] = {std::max(sq8_blk_[0], meta[1]), std::min(sq8_blk_[1], meta[1]), std::max(sq8_blk_[2], meta[0]),
-                       std::min(sq8_blk_[3], meta[0]), std::max(sq8_blk_[4], nc), std::min(sq8_blk_[5], xsq)};
+        float nb[8] = {std::max(sq8_blk_[0], meta[1]), std::min(sq8_blk_[1], meta[1]), std::max(sq8_blk_[2], meta[0]),
+                       std::min(sq8_blk_[3], meta[0]), std::max(sq8_blk_[4], nc), std::min(sq8_blk_[5], xsq),
+                       std::max(sq8_blk_[6], xsq), 0.0f};
         if (w) nb[0] = std::numeric_limits<float>::infinity();   // a row with non-finite metadata: no block test on this table
         if (std::memcmp(nb, sq8_blk_, sizeof nb) != 0) {   // (at once: the bounds must cover a row before a query can see it)
             std::memcpy(sq8_blk_, nb, sizeof nb);

@@ -95,7 +95,7 @@ struct LowpParams {
     uint32_t tile_run_shift;                   // ... probe: in runs of 2^shift consecutive tiles (see MfmaParams)
     // SQ8 filter, block pre-screen (epilogue_sq8): extremes of the aux values over the table {max delta, min delta, max min,
     // min min, max |c'|_2, min sum_squares}; sq8_blk_on = 0 switches the test off
-    float sq8_blk[6];
+    float sq8_blk[8];   // (+ max sum_squares, pad)
     int sq8_blk_on;
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
@@ -648,7 +648,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 // what 16 rows reach, so almost every block ends here: ~55 VALU operations instead of 18 per value.  The host
                 // switches the test off (sq8_blk_on = 0) for tables whose rows differ much in scale, where it cannot reject,
                 // and for L2 tables: measured on 10 M x 768 uniform rows, batch 128, IP 2.52 -> 2.13 ms, L2 2.57 -> 2.70 ms
-                // (the table-wide minimum of x_sq -- or the lane's own 16 rows' -- leaves the L2 bound too little room).
+                // (the table-wide minimum of x_sq -- or the lane's own 16 rows' -- leaves the L2 bound too little room; a
+                // bound that keeps x_sq and the dot paired per value, h_i = x_sq_i - 2 delta_i qs f_i, rejected well but its
+                // extra code pushed this 256-VGPR kernel into 118-190 spilled registers: DESIGN.md 9).
                 if (P.sq8_blk_on) {
                     int dmax = (int)acc[0][0][0], dmin = dmax;
 #pragma unroll

@@ -317,7 +317,7 @@ extern "C" int vsgpu_table_view_sync(vsgpu_table *v) {
     v->norm_slabs = p->norm_slabs;
     v->d_norm_slabs = p->d_norm_slabs;
     v->n = p->n;
-    for (int i = 0; i < 6; i++) v->sq8_blk[i] = p->sq8_blk[i];
+    for (int i = 0; i < 8; i++) v->sq8_blk[i] = p->sq8_blk[i];
     v->sq8_blk_set = p->sq8_blk_set;
     return VSGPU_OK;
 }
@@ -1004,9 +1004,9 @@ extern "C" int vsgpu_table_set_sq8_mean_sum_squares(vsgpu_table *t, float mean_s
     return VSGPU_OK;
 }
 
-extern "C" int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[6]) {
+extern "C" int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[8]) {
     if (!t || (t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H)) return fail(VSGPU_ERR_ARG, "not an SQ8 table");
-    for (int i = 0; i < 6; i++) t->sq8_blk[i] = bounds ? bounds[i] : 0.f;
+    for (int i = 0; i < 8; i++) t->sq8_blk[i] = bounds ? bounds[i] : 0.f;
     t->sq8_blk_set = bounds != nullptr;
     return VSGPU_OK;
 }

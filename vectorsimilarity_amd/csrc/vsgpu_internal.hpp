@@ -124,7 +124,7 @@ struct vsgpu_table {
     int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
     bool sq8_centred = false;   // mean-centred IP rows (dim + 16 bytes: x_mean_ip behind the three base slots), queries carry y_mean_ip
     float sq8_mss = 0.f;        // sum mean_i^2, the symmetric IP correction constant
-    float sq8_blk[6] = {0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)
+    float sq8_blk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)
     bool sq8_blk_set = false;
     size_t aux_bytes = 4;   // per-row aux record of the MFMA filters: 4 B, or 16 B {min, delta, sum_squares, 0} for SQ8 rows
     std::vector<float *> norm_slabs;

@@ -477,7 +477,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     if (is_sq8) {
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
         // block pre-screen: worth its ~55 operations per lane and tile only where it can reject, i.e. rows of one scale
-        for (int i = 0; i < 6; i++) P.sq8_blk[i] = t->sq8_blk[i];
+        for (int i = 0; i < 8; i++) P.sq8_blk[i] = t->sq8_blk[i];
         const float dh = t->sq8_blk[0], dlw = t->sq8_blk[1];
         P.sq8_blk_on = (t->sq8_blk_set && c->opt_sq8_block && t->metric != VSGPU_L2 && dlw > 0.0f && std::isfinite(dh) && dh <= 2.0f * dlw) ? 1 : 0;
     } else if (is_int) {
