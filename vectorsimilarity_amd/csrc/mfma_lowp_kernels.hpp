@@ -564,6 +564,28 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     }
                 if (!__any(any)) return;
             }
+            if (MODE == MF_PROBE && EPI == LE_I8_COS) {
+                // Probe, int8 Cosine: any row's score bounds the tile's minimum from above, so the IEEE divide is spent on one
+                // value per lane -- the one with the largest dot / norm, found by cross-multiplication (dot_a n_b > dot_b n_a;
+                // exact dots below 2^24) -- instead of on all MT x 4.  A zero-norm row (score NaN) never wins a comparison.
+#pragma unroll
+                for (int nt = 0; nt < NQW; nt++) {
+                    float bd = -3.0e38f, bn = 1.0f;
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t lrow = mt * 16 + kq * 4 + i;
+                            const float d = (float)(int)acc[mt][nt][i], nx = __uint_as_float(auxv[mt][i]);
+                            const bool better = lrow < nvalid && d * bn > bd * nx;
+                            bd = better ? d : bd;
+                            bn = better ? nx : bn;
+                        }
+                    const float sc = __fsub_rn(1.0f, __fdiv_rn(bd, __fmul_rn(bn, __uint_as_float(qaux[nt]))));
+                    if (bd > -3.0e38f && sc < tmin[nt]) tmin[nt] = sc;
+                }
+                return;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
