@@ -144,6 +144,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // (1) bf16 B-operand fragments + |q|^2 for the filter, (2) exact-order query images for the re-rank -- staged behind the
     // filter launch, under the scan, since only the re-rank reads them
     int rc = VSGPU_OK;
+    WallMarks wm0;
     const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
     std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
     std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
@@ -174,6 +175,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 }
             }
     }
+    wm0.mark("frag_build");
     rc = ensure(c, c->qfrag, frag.size() * 2);
     if (rc) return rc;
     rc = ensure(c, c->qn2, nqp * 4);
@@ -192,6 +194,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+    wm0.mark("uploads");
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
     const double u = std::ldexp(1.0, -24);
@@ -259,8 +262,11 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    wm0.mark("launches");
     rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
+    wm0.mark("stage_queries");
+    wm0.flush("mfma_pre");
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter", &chain);
