@@ -2,10 +2,11 @@
  * VecSim/vec_sim.h -- the index C API (drop-in boundary).
  *
  * Same symbols and signatures as the reference's src/VecSim/vec_sim.h:28-331.  Behind it, Flat
- * (VecSimAlgo_BF, single-label) indexes keep their vector blocks in MI355X HBM and every distance
- * is evaluated by the gfx950 kernels reached through include/vsgpu.h; there is no CPU distance
- * path.  VecSimIndex_New returns NULL for algorithms this build does not construct (HNSW, tiered,
- * SVS, multi-label Flat) and when no GPU is visible.
+ * (VecSimAlgo_BF, single- and multi-label) and HNSW (VecSimAlgo_HNSWLIB, single-label) indexes keep
+ * their vector blocks in MI355X HBM and every query-time distance is evaluated by the gfx950 kernels
+ * reached through include/vsgpu.h; there is no CPU distance path.  VecSimIndex_New returns NULL for
+ * algorithms this build does not construct (tiered, SVS, multi-label / fp64 HNSW) and when no GPU is
+ * visible.
  */
 #pragma once
 #include <stdlib.h>

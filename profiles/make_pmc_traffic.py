@@ -16,26 +16,26 @@ CONFIGS = {
 }
 
 
-def mean_of(db, pat, counter):
+def per_kernel(db, pat, counter):
     if not os.path.exists(db):
-        return None
+        return {}
     d = sqlite3.connect(db)
     rows = list(d.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
                           "group by kernel_name", (counter,)))
-    rows = [r for r in rows if pat in r[0]]
-    if not rows:
-        return None
-    return max(rows, key=lambda r: r[2])   # the filter launch moves far more than the probe launch of the same template
+    return {r[0]: r for r in rows if pat in r[0]}
 
 
 def main(src):
     out = {}
     for name, (sub, pat, workload) in CONFIGS.items():
         base = os.path.join(src, sub) if sub else src
-        f = mean_of(os.path.join(base, "pmc_fetch", "r1_results.db"), pat, "FETCH_SIZE")
-        w = mean_of(os.path.join(base, "pmc_write", "r1_results.db"), pat, "WRITE_SIZE")
-        if not f:
+        fetch = per_kernel(os.path.join(base, "pmc_fetch", "r1_results.db"), pat, "FETCH_SIZE")
+        if not fetch:
             continue
+        # the filter instance is the one that FETCHES the most (the probe instance of the same template reads 1/48 of the
+        # rows but writes more); its WRITE_SIZE is looked up under the same full kernel name, not as a maximum
+        f = max(fetch.values(), key=lambda r: r[2])
+        w = per_kernel(os.path.join(base, "pmc_write", "r1_results.db"), pat, "WRITE_SIZE").get(f[0])
         fetch_kb, write_kb = f[2], (w[2] if w else 0.0)
         out[name] = {"workload": workload, "fetch_size_kb_mean": round(fetch_kb, 1), "write_size_kb_mean": round(write_kb, 1),
                      "bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024), "launches": f[1],

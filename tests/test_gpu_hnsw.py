@@ -37,13 +37,15 @@ def stored(vso, rows, metric):
     (VecSim.VecSimMetric_IP, 64, 3000, 8, 40, 5),
     (VecSim.VecSimMetric_Cosine, 100, 3000, 12, 64, 20),
     (VecSim.VecSimMetric_L2, 20, 2000, 4, 10, 10),
+    (VecSim.VecSimMetric_L2, 768, 30_000, 16, 128, 10),   # BASELINE config 5's shape (efC 200 below), 24 row chunks per neighbour
+    (VecSim.VecSimMetric_Cosine, 768, 8_000, 16, 128, 10),
 ])
 def test_gpu_search_equals_reference_loops_on_same_graph(vso, metric, dim, n, M, ef, k):
-    ix, rows = build(dim, n, metric, M=M, efc=80, ef=ef)
+    ix, rows = build(dim, n, metric, M=M, efc=200 if dim == 768 else 80, ef=ef)
     g = ix.graph()
     assert g["n"] == n and g["max_level"] >= 1 and g["cnt0"].max() <= 2 * M
     rng = np.random.default_rng(99)
-    q = rng.uniform(-1, 1, (40, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (64 if dim == 768 else 40, dim)).astype(np.float32)
     labels, dists = ix.knn_query(q, k)
     evals = ix.last_distance_evals()
     srows = stored(vso, rows, metric)
