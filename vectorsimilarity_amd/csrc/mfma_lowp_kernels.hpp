@@ -145,6 +145,16 @@ __device__ static inline void lowp_wait_vmcnt(int n) {
     }
 }
 
+// s_waitcnt lgkmcnt(n) that also orders the consumer of `x` (an inline-asm ds_read's destination) behind the wait
+template <typename T> __device__ static inline void lowp_wait_lgkmcnt(int n, T &x) {
+    switch (n) {
+#define VSG_W(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x)); break;
+    VSG_W(1) VSG_W(2) VSG_W(3) VSG_W(4) VSG_W(5) VSG_W(6) VSG_W(7) VSG_W(8) VSG_W(9) VSG_W(10) VSG_W(11) VSG_W(12) VSG_W(13) VSG_W(14) VSG_W(15)
+#undef VSG_W
+    default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x)); break;
+    }
+}
+
 #ifndef LOWP_PF
 #define LOWP_PF 4
 #endif

@@ -110,7 +110,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qn2, &c->sel, &c->selcnt, &c->qmeta})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
@@ -141,6 +141,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "lowp_dbg") c->opt_lowp_dbg = value;
     else if (n == "lowp_wg_per_cu") c->opt_lowp_wg_per_cu = std::max(1L, value);
     else if (n == "lowp_ksplit") c->opt_lowp_ksplit = value;
+    else if (n == "lowp_x32") c->opt_lowp_x32 = value;
     else if (n == "hnsw_slots") c->opt_hnsw_slots = std::max(1L, std::min(64L, value));
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;

@@ -39,7 +39,7 @@ struct vsgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qn2, sel, selcnt, qmeta;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qfrag2, qn2, sel, selcnt, qmeta;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     vsgpu_stats stats{};
@@ -51,6 +51,7 @@ struct vsgpu_ctx {
     long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
+    long opt_lowp_x32 = 0;     // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); value - 1 = VAR bits
     long opt_lowp_ksplit = 0;  // int8/uint8 1 KiB rows: K-split filter kernel (mfma_i8ks_kernels.hpp); 2 = with s_setprio
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;

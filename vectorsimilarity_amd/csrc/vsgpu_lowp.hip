@@ -1,6 +1,7 @@
 // vsgpu_lowp.hip -- bf16 / fp16 / int8 / uint8 MFMA filter path of vsgpu_topk (kernels: mfma_lowp_kernels.hpp)
 #include "vsgpu_internal.hpp"
 #include "mfma_lowp_kernels.hpp"
+#include "mfma_i8x32_kernels.hpp"
 #ifdef VSGPU_TUNING
 #include "mfma_free_kernels.hpp"
 #include "mfma_i8ks_kernels.hpp"
@@ -274,6 +275,40 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
     }
 }
 
+// 32x32x32 filter for 1 KiB int8 / uint8 rows (mfma_i8x32_kernels.hpp); var = VAR bits of the kernel (+ 1024 x geometry code in the
+// tuning build: 0 = 4 slots / 3 ahead, 1 = 3 / 2, 2 = 4 / 2, 3 = 3 / 1, 4 = 4 / 1)
+template <int LK, int EPI> static void launch_i8_x32_e(int var, const LowpParams &P, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kern, int ns) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, x32_lds_bytes(ns));
+        hipLaunchKernelGGL(kern, grid, dim3(X32_NW * 64), x32_lds_bytes(ns), s, P);
+    };
+    switch (var) {
+#ifdef VSGPU_TUNING
+#define X32_CASE(V) case V: go(k_i8_filter_x32<LK, EPI, V>, 4); break;
+    X32_CASE(0) X32_CASE(2) X32_CASE(3) X32_CASE(8) X32_CASE(32) X32_CASE(64) X32_CASE(512) X32_CASE(256) X32_CASE(288)
+    X32_CASE(4096) X32_CASE(4097) X32_CASE(4096 + 512) X32_CASE(4097 + 512) X32_CASE(4096 + 256) X32_CASE(4097 + 256)
+    X32_CASE(8192) X32_CASE(8193) X32_CASE(8192 + 512) X32_CASE(8192 + 16) X32_CASE(8193 + 16)
+    X32_CASE(512 + 32) X32_CASE(512 + 32 + 1024) X32_CASE(512 + 32 + 128) X32_CASE(512 + 32 + 8) X32_CASE(32 + 8) X32_CASE(32 + 8 + 256) X32_CASE(32 + 16) X32_CASE(512 + 32 + 16)
+    X32_CASE(16384) X32_CASE(16385) X32_CASE(16384 + 8192) X32_CASE(16385 + 8192) X32_CASE(16384 + 512) X32_CASE(16384 + 32) X32_CASE(16384 + 256) X32_CASE(16384 + 16) X32_CASE(16384 + 2)
+    X32_CASE(32768) X32_CASE(32769) X32_CASE(32768 + 2) X32_CASE(32769 + 2) X32_CASE(32768 + 16384) X32_CASE(32769 + 16384) X32_CASE(32768 + 16384 + 2) X32_CASE(32769 + 16384 + 2) X32_CASE(32768 + 512) X32_CASE(32768 + 4096)
+    X32_CASE(65536) X32_CASE(131072) X32_CASE(65536 + 256) X32_CASE(131072 + 256) X32_CASE(65536 + 64) X32_CASE(65536 + 32768) X32_CASE(131072 + 32768)
+    X32_CASE(262144) X32_CASE(131072 + 524288)
+    X32_CASE(128) X32_CASE(128 + 256) X32_CASE(128 + 32768) X32_CASE(128 + 16384) X32_CASE(128 + 1)
+    X32_CASE(1024) X32_CASE(2048) X32_CASE(1024 + 32) X32_CASE(2048 + 32) X32_CASE(1024 + 256) X32_CASE(2048 + 256)
+#undef X32_CASE
+#endif
+    default: go(k_i8_filter_x32<LK, EPI, 1>, 4); break;
+    }
+}
+static void launch_i8_x32(const vsgpu_table *t, int var, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (t->lp_kind == LP_U8) {
+        if (P.epi == LE_U8_IP) launch_i8_x32_e<LP_U8, LE_U8_IP>(var, P, grid, s);
+        else launch_i8_x32_e<LP_U8, LE_I8_L2>(var, P, grid, s);
+    } else if (P.epi == LE_I8_COS) launch_i8_x32_e<LP_I8, LE_I8_COS>(var, P, grid, s);
+    else if (P.epi == LE_I8_L2) launch_i8_x32_e<LP_I8, LE_I8_L2>(var, P, grid, s);
+    else launch_i8_x32_e<LP_I8, LE_I8_IP>(var, P, grid, s);
+}
+
 // int8 with the query batch split over two 8-wave workgroups (blockIdx.y): both stream the same row tiles, the
 // second reader is expected to hit L2 (same XCD when gridDim.x % 8 == 0)
 static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
@@ -325,6 +360,13 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const bool hsplit = false;
 #endif
     const bool narrow = !hsplit && !qsplit && lowp_narrow_qtile(t) && nq <= lowp_narrow_qtile(t) && c->opt_lowp_narrow;
+    // int8 / uint8 rows of kernel width 1024, more than 128 queries: the filter pass runs on the 32 x 32 x 32 kernel
+    const bool x32 = c->opt_lowp_x32 && !narrow && !qsplit && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 &&
+                     t->lp_rt == 32 && t->lp_qtile == X32_QT && !c->opt_lowp_variant && !c->opt_lowp_dbg
+#ifdef VSGPU_TUNING
+                     && !c->opt_lowp_ksplit
+#endif
+        ;
     const size_t QT = hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
@@ -339,6 +381,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // fragments: [q_tile][wave 8][NQW][KSTEPS][lane 64][16 B]
     const size_t kdim = (size_t)KS * kelem;  // kernel width >= dim
     std::vector<unsigned char> frag(nqp * kdim * eb, 0);
+    // x32: [group of 32 queries][32 k-steps of 32 bytes][lane = 32 half + query][16 B] (mfma_i8x32_kernels.hpp)
+    std::vector<unsigned char> frag32(x32 ? nqp * kdim : 0, 0);
     std::vector<uint32_t> qaux(nqp, 0);
     std::vector<float> tau0(nqp, -INFINITY);
     std::vector<float> qmeta((is_sq8 || is_u8c) ? nqp * 8 : 0, 0.0f);
@@ -406,6 +450,17 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 if (is_u8)
                     for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;  // q - 128 as int8 (columns past dim stay 0)
             }
+        if (x32) {
+            const size_t g32 = q / 32, n32 = q % 32;
+            for (int s = 0; s < X32_KS; s++)
+                for (int hh = 0; hh < 2; hh++) {
+                    unsigned char *dst = &frag32[(((g32 * X32_KS + s) * 64) + (size_t)hh * 32 + n32) * 16];
+                    const size_t e0 = (size_t)32 * s + 16 * hh, have = e0 < dim ? std::min<size_t>(16, dim - e0) : 0;
+                    if (have) memcpy(dst, src + e0, have);
+                    if (is_u8)
+                        for (size_t b = 0; b < have; b++) dst[b] ^= 0x80;
+                }
+        }
         if (is_sq8) {
         } else if (is_u8) {
             int s1 = 0, s2 = 0;
@@ -460,6 +515,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipMemcpyAsync(c->qmeta.p, qmeta.data(), qmeta.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
+    if (x32) {
+        rc = ensure(c, c->qfrag2, frag32.size());
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->qfrag2.p, frag32.data(), frag32.size(), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
@@ -542,7 +602,53 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             HIPCHK(hipMemsetAsync(d_ph, 0, ph_words * 4, c->stream));
             Q.tilemin = reinterpret_cast<float *>(d_ph);
         }
-        if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
+        if (x32) {
+            Q.qfrag = (const uint4 *)c->qfrag2.p;
+            const int var = (int)c->opt_lowp_x32 - 1;
+            const uint32_t gx = std::min(total_tiles, (uint32_t)c->n_cu);
+            uint64_t *d_clk = nullptr;
+            const size_t clk_words = (size_t)gx * q_tiles * ((var & 512) ? X32_NW * 8 : 2);
+            if (var & (256 | 512)) {   // diagnosis: shader clock = s_memtime ticks per 100 MHz s_memrealtime tick; phase sums
+                HIPCHK(hipMalloc(&d_clk, clk_words * 8));
+                HIPCHK(hipMemsetAsync(d_clk, 0, clk_words * 8, c->stream));
+                Q.tilemin = reinterpret_cast<float *>(d_clk);
+            }
+            launch_i8_x32(t, var, Q, dim3(gx, (unsigned)q_tiles), c->stream);
+            if (d_clk) {
+                std::vector<uint64_t> h(clk_words);
+                HIPCHK(hipMemcpyAsync(h.data(), d_clk, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                HIPCHK(hipFree(d_clk));
+                if (var & 512) {
+                    double sum[4] = {0, 0, 0, 0}, units = 0;
+                    for (size_t w = 0; w < h.size() / 8; w++) {
+                        for (int i = 0; i < 4; i++) sum[i] += (double)h[w * 8 + i];
+                        units += (double)h[w * 8 + 4];
+                    }
+                    static int once = 0;
+                    if (!once++) {
+                        for (int wv = 0; wv < X32_NW; wv++) {
+                            double ws[6] = {0, 0, 0, 0, 0, 0}, wu = 0;
+                            for (size_t w = wv; w < h.size() / 8; w += X32_NW) {
+                                for (int i = 0; i < 4; i++) ws[i] += (double)h[w * 8 + i];
+                                ws[4] += (double)h[w * 8 + 5];
+                                ws[5] += (double)h[w * 8 + 6];
+                                wu += (double)h[w * 8 + 4];
+                            }
+                            if (wu > 0) fprintf(stderr, "  wave %d: top %.0f  requests %.0f  stream %.0f  tail %.0f  vmcnt %.0f  barrier %.0f\n", wv, ws[4] / wu, ws[0] / wu, ws[1] / wu, ws[5] / wu, ws[2] / wu, ws[3] / wu);
+                        }
+                    }
+                    if (units > 0)
+                        fprintf(stderr, "x32 phases, mean s_memtime ticks per wave and unit: requests %.0f  rest of the stream %.0f  vmcnt wait %.0f  barrier %.0f\n",
+                                sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units);
+                    h.resize(0);
+                }
+                double sc = 0, sr = 0;
+                for (size_t i = 0; i < h.size(); i += 2) sc += (double)h[i], sr += (double)h[i + 1];
+                if (!h.empty()) fprintf(stderr, "x32 clocks: %.0f shader ticks / %.0f ref ticks per workgroup = %.3f GHz (ref 100 MHz), %.3f ms\n",
+                        sc / (h.size() / 2), sr / (h.size() / 2), sc / sr * 0.1, sr / (h.size() / 2) * 1e-5);
+            }
+        } else if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (narrow) launch_lowp_narrow_any(t, MF_FILTER, Q, dim3(std::min(total_tiles, (uint32_t)c->n_cu * 2), (unsigned)q_tiles), c->stream);
@@ -567,6 +673,12 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512 | 1024 | 2048 | 65536 | 131072 | 262144))) {  // diagnosis variants of the 32x32x32 kernel: time only
+        HIPCHK(hipStreamSynchronize(c->stream));
+        account_scan(c, t, n, 1, "k_i8_filter_x32(dbg)");
+        for (size_t q = 0; q < nq; q++) counts[q] = 0;
+        return VSGPU_OK;
+    }
     if (c->opt_lowp_dbg) {  // diagnosis run: the kernel's output is meaningless, report its time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_mfma_filter_lowp(dbg)");
@@ -584,5 +696,5 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 #ifdef VSGPU_TUNING
                               : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
 #endif
-                              : "k_mfma_filter_lowp(i8)", &chain);
+                              : x32 ? "k_i8_filter_x32" : "k_mfma_filter_lowp(i8)", &chain);
 }
