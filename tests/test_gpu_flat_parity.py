@@ -499,7 +499,7 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
         ix.set_option("mfma", mfma)
         ix.reset_stats()
         replies.append(ix.knn_query(q, k))
-        assert ix.stats()["scan_kernel"].startswith("k_mfma_filter_lowp" if mfma else "k_exact_scan")
+        assert ix.stats()["scan_kernel"].startswith(("k_mfma_filter_lowp", "k_i8_filter_x32") if mfma else "k_exact_scan")
     for r in replies[1:]:
         assert np.array_equal(replies[0][0], r[0]) and np.array_equal(replies[0][1], r[1])
     el, es = oracle_topk(vso, typ, metric, rows, q[0], k)
@@ -618,7 +618,7 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)
     st = ix.stats()
-    assert st["scan_kernel"].startswith("k_mfma_filter_lowp"), st
+    assert st["scan_kernel"].startswith(("k_mfma_filter_lowp", "k_i8_filter_x32")), st
     # ints are heavy on exact ties (integer scores): the candidate lists may legitimately overflow
     if typ not in ("i8", "u8"):
         assert st["fallbacks"] == 0, st
@@ -633,6 +633,63 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     ix.set_option("mfma", 0)
     l2, d2 = ix.knn_query(q[:8], k)
     assert np.array_equal(l1[:8], l2) and np.array_equal(d1[:8], d2)
+
+
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [
+    ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's query tile
+    ("i8", "Cosine", 1024, 30_011, 140, 10),    # last tile partial, half-empty query tile
+    ("i8", "L2", 1024, 20_000, 300, 10),        # two query tiles
+    ("i8", "IP", 900, 25_013, 200, 10),         # zero query columns past dim
+    ("u8", "L2", 1024, 30_000, 256, 10),
+    ("u8", "IP", 800, 20_005, 130, 100),
+])
+def test_i8_x32_filter_bit_exact(vso, typ, metric, dim, n, nq, k):
+    """the 32 x 32 x 32 int8 filter (mfma_i8x32_kernels.hpp: kernel width 1024, more than 128 queries; wave-private candidate
+    queues finalised at flush) against the 16 x 16 x 64 filter and the oracle, exact integer scores both ways"""
+    rng = np.random.default_rng(dim * 7 + n + nq)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_i8_filter_x32", ix.stats()
+    ix.set_option("lowp_x32", 0)
+    ix.reset_stats()
+    l0, d0 = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(i8)", ix.stats()
+    assert np.array_equal(l0, l1) and np.array_equal(d0, d1)
+    srows = stored_rows(vso, rows, typ, metric)
+    sq = stored_rows(vso, q, typ, metric)
+    km = kernel_metric(typ, metric)
+    for j in range(0, nq, 3):
+        sc = vso.scan(TYPES[typ], km, srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l1[j], el.astype(np.int64)), (typ, metric, dim, j)
+        assert np.array_equal(d1[j], es), (typ, metric, dim, j)
+
+
+def test_i8_x32_many_tiles_per_workgroup_ties_and_queue_flushes(vso):
+    """every workgroup walks several tiles, rows repeat (exact score ties), and a loose threshold (k = 2000) makes the
+    wave-private candidate queues flush inside the scan"""
+    rng = np.random.default_rng(5)
+    dim, n, nq, k = 1024, 150_000, 160, 2000
+    base = random_vectors(rng, 5_000, dim, "i8", vso)
+    rows = base[rng.integers(0, 5_000, n)]
+    q = random_vectors(rng, nq, dim, "i8", vso)
+    ix = make_index("i8", "Cosine", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_i8_filter_x32", ix.stats()
+    srows = stored_rows(vso, rows, "i8", "Cosine")
+    sq = stored_rows(vso, q, "i8", "Cosine")
+    for j in range(0, nq, 13):
+        sc = vso.scan(TYPES["i8"], kernel_metric("i8", "Cosine"), srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l1[j], el.astype(np.int64)) and np.array_equal(d1[j], es), j
 
 
 @pytest.mark.parametrize("typ,metric,dim,n,nq,k", [

@@ -39,30 +39,21 @@ constexpr int X32_QT = 256;           // queries per workgroup
 constexpr int X32_WQ_CAP = 64;         // records per wave-private candidate queue (one ballot's worth always fits)
 constexpr int x32_lds_bytes(int ns) { return ns * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16; }
 
-// VAR bits: 1 = EARLY (rows land one barrier early, fragments prefetched across the barrier), 2 = requests spread over the
-// stream (one piece every 8 MFMAs) instead of behind the first MFMAs, 4 = waves of odd index shift their requests by 4 MFMAs,
-// 8 = two accumulator chains (even / odd k-steps), 16 = s_setprio 1 for the second-dispatched half of the waves
+// VAR bits (the shipped build instantiates 32768 | 1 only; the rest is the tuning build's, profiles/r03_c3_x32.txt):
+// 1 = EARLY (rows land one barrier early, fragments prefetched across the barrier), 2 = requests spread over the stream
+// instead of behind the first MFMAs, 8 = two accumulator chains (even / odd k-steps), 16 = s_setprio 1 for the
+// second-dispatched half of the waves, 16384 = inline-asm fragment reads with counted waits, 32768 = only waves 0-3 request rows
 // X32_NS ring slots, X32_D units requested ahead
 template <int LK, int EPI, int VAR, int X32_NS = 4, int X32_D = 3>
 __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) {
-    static_assert(!((VAR & 32768) && (VAR & 8192)), "ISS4 and WSTAG exclude each other");
     static_assert(X32_D >= 1 && X32_D < X32_NS && (!((VAR & 1) != 0) || X32_D >= 2), "ring geometry");
     static_assert(LK == LP_I8 || LK == LP_U8, "int8 / uint8 rows with 4-byte aux values");
     constexpr bool EARLY = (VAR & 1) != 0;
     constexpr bool SPREAD = (VAR & 2) != 0;
-    constexpr bool STAGGER = (VAR & 4) != 0;
     constexpr bool ACC2 = (VAR & 8) != 0;
     // diagnosis (replies meaningless): 32 = no row requests, 64 = no fragment reads / MFMAs, 128 = no screening, 256 = clocks:
     // wave 0 of every workgroup stores {s_memtime, s_memrealtime} deltas over the kernel into P.tilemin
-    constexpr bool WSTAG = (VAR & 8192) != 0;   // piece j of wave w is requested behind MFMA 8 j + w: one request per MFMA slot on the CU
-    constexpr bool TOP = (VAR & 4096) != 0;   // the refill is requested behind the barrier, before the wave has any LDS read in flight
     constexpr bool STAMPS = (VAR & 512) != 0;   // s_memtime sums per wave: {issue, rest of stream, vmcnt wait, barrier, units}
-    constexpr bool NO_READS = (VAR & 1024) != 0, NO_MFMA = (VAR & 2048) != 0;   // fragment reads off (MFMAs on stale registers) / MFMAs off (reads kept)
-    // 65536: the row requests are plain global loads into scratch registers (HBM traffic and VMEM issue, no LDS write);
-    // 131072: fragments are always read from slot 0, which the requests never write
-    constexpr bool PLAIN_LOADS = (VAR & 65536) != 0, STATIC_READS = (VAR & 131072) != 0;
-    // 262144: requests all land in slot 3, reads rotate over slots 0 .. 2; 524288 (with 131072): reads from slot 0, requests rotate over all four
-    constexpr bool DMA_ONE_SLOT = (VAR & 262144) != 0, STATIC_SHARED = (VAR & 524288) != 0;
     constexpr bool NO_DMA = (VAR & 32) != 0, NO_MMA = (VAR & 64) != 0, NO_SCREEN = (VAR & 128) != 0, CLOCKS = (VAR & 256) != 0;
     // ASMRD: fragment reads in inline asm with counted lgkmcnt waits, 8 in flight (hipcc pairs its own reads with lgkmcnt(0):
     // one LDS round trip per two MFMAs, which is what the stream's time turned out to be made of)
@@ -152,19 +143,13 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         }
     };
     uint32_t ftile = blockIdx.x, fslot = 0, fbuf = 0;
-    i32x4_t sink = {0, 0, 0, 0};
     const uint32_t lane16 = (uint32_t)lane * 16u;
     auto issue_piece = [&](int i) {
         if (NO_DMA || !issuer) return;
         uint32_t row = f_r0 + (uint32_t)(IPWX * wave + i);
         if (row >= P.n_rows) row = P.n_rows - 1;
         const char *rowp = reinterpret_cast<const char *>(cur_sbase) + (size_t)(row & P.slab_mask) * P.row_stride;
-        if (PLAIN_LOADS) {
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(sink) : "v"(rowp + lane16));   // (sink stays reserved: the data lands later)
-            return;
-        }
-        const uint32_t slot = DMA_ONE_SLOT ? 3u : (STATIC_READS && !STATIC_SHARED) ? (fslot == 0 ? 1u : fslot) : fslot;
-        glds16<2>(rowp + lane16, slot * X32_UNIT + lds_wave_off + (uint32_t)i * X32_ROWB, lds);
+        glds16<2>(rowp + lane16, fslot * X32_UNIT + lds_wave_off + (uint32_t)i * X32_ROWB, lds);
     };
     auto issue_aux = [&]() {
         if (wave == 0) {
@@ -201,9 +186,9 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         // row n32, bytes 32 ks + 16 h .. +16 of the row image
         i32x4_t v;
         if (ASMRD) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(frag_lds_off + (STATIC_READS ? 0u : DMA_ONE_SLOT ? (slot == 3 ? 0u : slot) : slot) * X32_UNIT), "n"(ks * 32));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(frag_lds_off + slot * X32_UNIT), "n"(ks * 32));
         } else {
-            v = *reinterpret_cast<const i32x4_t *>(lds + (STATIC_READS ? 0u : DMA_ONE_SLOT ? (slot == 3 ? 0u : slot) : slot) * X32_UNIT + frag_lane_off + ks * 32);
+            v = *reinterpret_cast<const i32x4_t *>(lds + slot * X32_UNIT + frag_lane_off + ks * 32);
             if (LK == LP_U8) v ^= (int)0x80808080;
         }
         return v;
@@ -273,11 +258,6 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         for (int i = 0; i < 16; i++) acc[i] = 0, acc_b[i] = 0;
         stamp(it ? 4 : -1);
         issue_aux();   // (a wave-uniform branch: kept out of the stream's scheduling region)
-        if (TOP) {
-#pragma unroll
-            for (int i = 0; i < IPWX; i++) issue_piece(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (!EARLY) {
 #pragma unroll
             for (int f = 0; f < PF; f++) afr[f] = read_frag(cslot, f);
@@ -285,9 +265,8 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         unsigned long long any = 0, any_g[4] = {0, 0, 0, 0};   // lanes holding a survivor of unit u-1, per group of four accumulator registers (v_cmp + s_or per value)
         // ---- the unit's stream: 32 x {MFMA, next fragment read}, the refill requests for unit u + D (into the slot of unit
         // u - 1, free since the barrier) and the screening of unit u - 1 in between ----
-        auto stream = [&](auto odd_tag) {
-            constexpr bool ODD = decltype(odd_tag)::value;
-            constexpr int PBASE = SPREAD ? (ODD ? 6 : 2) : (ODD ? 17 : 1), PSTEP = SPREAD ? 32 / IPWX : 1;
+        {
+            constexpr int PBASE = SPREAD ? 2 : 1, PSTEP = SPREAD ? 32 / IPWX : 1;
 #pragma unroll
             for (int ks = 0; ks < X32_KS; ks++) {
                 if (!NO_MMA) {
@@ -300,17 +279,13 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
                         if (LK == LP_U8) afr[ks % PF] ^= (int)0x80808080;
                     }
                     const i32x4_t a = afr[ks % PF];
-                    if (NO_MFMA) asm volatile("" ::"v"(a));
-                    else if (ACC2 && (ks & 1)) acc_b = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc_b, 0, 0, 0);
+                    if (ACC2 && (ks & 1)) acc_b = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc_b, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc, 0, 0, 0);
                     const int f = ks + PF;
-                    if (NO_READS) {
-                    } else if (f < X32_KS) afr[ks % PF] = read_frag(cslot, f);
+                    if (f < X32_KS) afr[ks % PF] = read_frag(cslot, f);
                     else if (EARLY) afr[ks % PF] = read_frag(nslot, f - X32_KS);
                 }
-                if (WSTAG) {
-                    if ((ks & 7) == wave) issue_piece(ks >> 3);
-                } else if (!TOP && ks >= PBASE && (ks - PBASE) % PSTEP == 0 && (ks - PBASE) / PSTEP < IPWX) issue_piece((ks - PBASE) / PSTEP);
+                if (ks >= PBASE && (ks - PBASE) % PSTEP == 0 && (ks - PBASE) / PSTEP < IPWX) issue_piece((ks - PBASE) / PSTEP);
                 if (STAMPS && !SPREAD && ks == PBASE + IPWX - 1) stamp(0);
                 // screening of unit u-1, one accumulator register per k-step
                 if (!NO_SCREEN && ks >= 8 && ks < 24) {
@@ -327,16 +302,14 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
             for (int ks = 0; ks < X32_KS; ks++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (!ASMRD && (ks + PF < X32_KS || EARLY)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (!WSTAG && !TOP && ks >= PBASE && (ks - PBASE) % PSTEP == 0 && (ks - PBASE) / PSTEP < IPWX) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (ks >= PBASE && (ks - PBASE) % PSTEP == 0 && (ks - PBASE) / PSTEP < IPWX) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, LK == LP_U8 ? 8 : 4, 0);
             }
-        };
-        if (STAGGER && (wave & 1)) stream(std::true_type{});
-        else stream(std::false_type{});
+        }
         stamp(1);
         // some lane of the wave holds a candidate of unit u-1: queue it (per group of four registers -- usually one group, one value)
         any = any_g[0] | any_g[1] | any_g[2] | any_g[3];
-        if (any != 0 && !(NO_DMA || NO_MMA || NO_SCREEN || NO_READS || NO_MFMA || PLAIN_LOADS || STATIC_READS || DMA_ONE_SLOT)) {
+        if (any != 0 && !(NO_DMA || NO_MMA || NO_SCREEN)) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 if (any_g[g] == 0) continue;
@@ -365,7 +338,7 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
 #pragma unroll
             for (int i = 0; i < 16; i++) acc_prev[i] = acc[i] + acc_b[i];
         } else acc_prev = acc;
-        if (NO_DMA || NO_MMA || NO_SCREEN || NO_READS || NO_MFMA || PLAIN_LOADS || STATIC_READS || DMA_ONE_SLOT) asm volatile("" ::"v"(acc_prev), "s"(any));   // (keeps the diagnosis variants' work alive)
+        if (NO_DMA || NO_MMA || NO_SCREEN) asm volatile("" ::"v"(acc_prev), "s"(any));   // (keeps the diagnosis variants' work alive)
         r0_prev = tile_row0(tile < P.n_tiles ? tile : P.n_tiles - 1);
         nvalid_prev = it < my_tiles ? P.n_rows - r0_prev : 0;
         {
@@ -404,7 +377,6 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         o[1] = r1 - rt0;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (PLAIN_LOADS) asm volatile("" ::"v"(sink));
     if (wq_n) flush_wave_queue();
 }
 

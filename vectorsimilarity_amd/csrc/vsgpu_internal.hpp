@@ -51,7 +51,8 @@ struct vsgpu_ctx {
     long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
-    long opt_lowp_x32 = 0;     // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); value - 1 = VAR bits
+    long opt_lowp_x32 = 32770; // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); 0 = the 16x16x64
+                               // kernel, value - 1 = VAR bits (tuning build; the shipped build has 32769 only)
     long opt_lowp_ksplit = 0;  // int8/uint8 1 KiB rows: K-split filter kernel (mfma_i8ks_kernels.hpp); 2 = with s_setprio
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
     long opt_wg_per_cu = 2;

@@ -275,8 +275,8 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
     }
 }
 
-// 32x32x32 filter for 1 KiB int8 / uint8 rows (mfma_i8x32_kernels.hpp); var = VAR bits of the kernel (+ 1024 x geometry code in the
-// tuning build: 0 = 4 slots / 3 ahead, 1 = 3 / 2, 2 = 4 / 2, 3 = 3 / 1, 4 = 4 / 1)
+// 32x32x32 filter for 1 KiB int8 / uint8 rows (mfma_i8x32_kernels.hpp); var = VAR bits of the kernel (tuning build; the shipped
+// build runs VAR = 32769: requests by waves 0-3, fragments prefetched across the barrier)
 template <int LK, int EPI> static void launch_i8_x32_e(int var, const LowpParams &P, dim3 grid, hipStream_t s) {
     auto go = [&](auto kern, int ns) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, x32_lds_bytes(ns));
@@ -285,19 +285,13 @@ template <int LK, int EPI> static void launch_i8_x32_e(int var, const LowpParams
     switch (var) {
 #ifdef VSGPU_TUNING
 #define X32_CASE(V) case V: go(k_i8_filter_x32<LK, EPI, V>, 4); break;
-    X32_CASE(0) X32_CASE(2) X32_CASE(3) X32_CASE(8) X32_CASE(32) X32_CASE(64) X32_CASE(512) X32_CASE(256) X32_CASE(288)
-    X32_CASE(4096) X32_CASE(4097) X32_CASE(4096 + 512) X32_CASE(4097 + 512) X32_CASE(4096 + 256) X32_CASE(4097 + 256)
-    X32_CASE(8192) X32_CASE(8193) X32_CASE(8192 + 512) X32_CASE(8192 + 16) X32_CASE(8193 + 16)
-    X32_CASE(512 + 32) X32_CASE(512 + 32 + 1024) X32_CASE(512 + 32 + 128) X32_CASE(512 + 32 + 8) X32_CASE(32 + 8) X32_CASE(32 + 8 + 256) X32_CASE(32 + 16) X32_CASE(512 + 32 + 16)
-    X32_CASE(16384) X32_CASE(16385) X32_CASE(16384 + 8192) X32_CASE(16385 + 8192) X32_CASE(16384 + 512) X32_CASE(16384 + 32) X32_CASE(16384 + 256) X32_CASE(16384 + 16) X32_CASE(16384 + 2)
-    X32_CASE(32768) X32_CASE(32769) X32_CASE(32768 + 2) X32_CASE(32769 + 2) X32_CASE(32768 + 16384) X32_CASE(32769 + 16384) X32_CASE(32768 + 16384 + 2) X32_CASE(32769 + 16384 + 2) X32_CASE(32768 + 512) X32_CASE(32768 + 4096)
-    X32_CASE(65536) X32_CASE(131072) X32_CASE(65536 + 256) X32_CASE(131072 + 256) X32_CASE(65536 + 64) X32_CASE(65536 + 32768) X32_CASE(131072 + 32768)
-    X32_CASE(262144) X32_CASE(131072 + 524288)
-    X32_CASE(128) X32_CASE(128 + 256) X32_CASE(128 + 32768) X32_CASE(128 + 16384) X32_CASE(128 + 1)
-    X32_CASE(1024) X32_CASE(2048) X32_CASE(1024 + 32) X32_CASE(2048 + 32) X32_CASE(1024 + 256) X32_CASE(2048 + 256)
+    X32_CASE(0) X32_CASE(1) X32_CASE(2) X32_CASE(3) X32_CASE(8) X32_CASE(16) X32_CASE(32768) X32_CASE(32768 + 2) X32_CASE(32769 + 2)
+    X32_CASE(16384) X32_CASE(16385) X32_CASE(32768 + 16384) X32_CASE(32769 + 16384)
+    X32_CASE(32) X32_CASE(64) X32_CASE(128) X32_CASE(256) X32_CASE(512) X32_CASE(32769 + 128) X32_CASE(32769 + 256) X32_CASE(32769 + 512) X32_CASE(32769 + 32)
+    case 65536 + 32769: go(k_i8_filter_x32<LK, EPI, 32769, 3, 2>, 3); break;
 #undef X32_CASE
 #endif
-    default: go(k_i8_filter_x32<LK, EPI, 1>, 4); break;
+    default: go(k_i8_filter_x32<LK, EPI, 32769>, 4); break;
     }
 }
 static void launch_i8_x32(const vsgpu_table *t, int var, const LowpParams &P, dim3 grid, hipStream_t s) {
@@ -673,7 +667,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512 | 1024 | 2048 | 65536 | 131072 | 262144))) {  // diagnosis variants of the 32x32x32 kernel: time only
+    if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512))) {  // diagnosis variants of the 32x32x32 kernel: time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_i8_filter_x32(dbg)");
         for (size_t q = 0; q < nq; q++) counts[q] = 0;
