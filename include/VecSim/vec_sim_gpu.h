@@ -154,6 +154,12 @@ long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, siz
 int VecSimGpu_SetDevice(int device);
 int VecSimGpu_DeviceCount(void);
 const char *VecSimGpu_LastError(void);
+/* Which reference ISA tier's summation order a new index reproduces on this host: "AVX512" | "AVX512_BF16" | "SCALAR".
+ * Chosen like the reference chooses its kernels -- from the host CPU's features at run time (spaces.h:68-78,
+ * IP_space.cpp:554-615, L2_space.cpp:185-241): avx512f -> the AVX-512 kernels' order, avx512_bf16 && avx512vl on top ->
+ * vdpbf16ps for bf16 IP / Cosine, no avx512f -> the scalar kernels' order.  $VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar
+ * overrides.  An index reports its tier as the last field (DISTANCE_TIER) of VecSimIndex_DebugInfoIterator. */
+const char *VecSimGpu_HostTier(void);
 
 /* HIP-event timing of the dominant scan kernel since the last reset (bench.py roofline leg) */
 typedef struct {

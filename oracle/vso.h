@@ -140,6 +140,14 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
 int vso_flat_topk_batch_fast(int type, int metric, size_t dim, const void *rows, size_t n,
                              size_t stride, const void *queries, size_t nq, size_t qstride,
                              size_t k, int threads, size_t *out_labels, double *out_scores);
+/* the same with the tier spelled out: every (type, metric, tier) of vso_distance has an intrinsics twin in vso_fast.c
+ * (fp64, fp16, bf16 VBMI2, bf16 vdpbf16ps, int8 / uint8 VNNI); vso_fast_available says whether it can run on this host at this dim */
+int vso_flat_topk_batch_fast_tier(int type, int metric, int tier, size_t dim, const void *rows, size_t n,
+                                  size_t stride, const void *queries, size_t nq, size_t qstride,
+                                  size_t k, int threads, size_t *out_labels, double *out_scores);
+int vso_fast_available(int type, int metric, int tier, size_t dim);
+double vso_distance_fast(int type, int metric, size_t dim, const void *a, const void *b);   /* tier AVX512 */
+double vso_distance_fast_tier(int type, int metric, int tier, size_t dim, const void *a, const void *b);
 int vso_has_avx512(void);
 /* fp16 F16C tier (L2_F16C_FP16.h / IP_F16C_FP16.h): the portable restatement at any dim >= 8, and the same
  * algorithm on the host's F16C/FMA units (NaN when absent) -- the tests compare them bit for bit */

@@ -46,6 +46,12 @@ def lib():
         L.vso_distance.argtypes = [i, i, i, sz, vp, vp]
         L.vso_distance_fast.restype = dbl
         L.vso_distance_fast.argtypes = [i, i, sz, vp, vp]
+        L.vso_distance_fast_tier.restype = dbl
+        L.vso_distance_fast_tier.argtypes = [i, i, i, sz, vp, vp]
+        L.vso_fast_available.restype = i
+        L.vso_fast_available.argtypes = [i, i, i, sz]
+        L.vso_flat_topk_batch_fast_tier.restype = i
+        L.vso_flat_topk_batch_fast_tier.argtypes = [i, i, i, sz, vp, sz, sz, vp, sz, sz, sz, i, vp, vp]
         L.vso_uses_scalar.restype = i
         L.vso_uses_scalar.argtypes = [i, i, i, sz]
         L.vso_scan.restype = None
@@ -149,12 +155,17 @@ def distance(vtype, metric, a, b, dim=None, tier=TIER_AVX512):
     return lib().vso_distance(vtype, metric, tier, dim, _ptr(a), _ptr(b))
 
 
-def distance_fast(vtype, metric, a, b, dim=None):
+def distance_fast(vtype, metric, a, b, dim=None, tier=TIER_AVX512):
+    """the intrinsics twin of distance() on the host CPU (vso_fast.c); NaN when the host lacks the tier's instructions"""
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     if dim is None:
         dim = a.size
-    return lib().vso_distance_fast(vtype, metric, dim, _ptr(a), _ptr(b))
+    return lib().vso_distance_fast_tier(vtype, metric, tier, dim, _ptr(a), _ptr(b))
+
+
+def fast_available(vtype, metric, dim, tier=TIER_AVX512):
+    return bool(lib().vso_fast_available(vtype, metric, tier, dim))
 
 
 def scan(vtype, metric, rows, query, dim, tier=TIER_AVX512):
@@ -321,16 +332,16 @@ def flat_topk(vtype, metric, rows, query, k, dim, labels=None, tier=TIER_AVX512)
     return topk_replay(scores, k, labels)
 
 
-def flat_topk_batch_fast(vtype, metric, rows, queries, k, dim, threads=1):
+def flat_topk_batch_fast(vtype, metric, rows, queries, k, dim, threads=1, tier=TIER_AVX512):
     """Timing leg: returns (labels[nq,k] uint64, scores[nq,k] f64, used_intrinsics)."""
     rows = np.ascontiguousarray(rows)
     queries = np.ascontiguousarray(queries)
     nq = queries.shape[0]
     ol = np.empty((nq, k), dtype=np.uint64)
     osc = np.empty((nq, k), dtype=np.float64)
-    fast = lib().vso_flat_topk_batch_fast(vtype, metric, dim, _ptr(rows), rows.shape[0],
-                                          rows.strides[0], _ptr(queries), nq, queries.strides[0],
-                                          k, threads, _ptr(ol), _ptr(osc))
+    fast = lib().vso_flat_topk_batch_fast_tier(vtype, metric, tier, dim, _ptr(rows), rows.shape[0],
+                                               rows.strides[0], _ptr(queries), nq, queries.strides[0],
+                                               k, threads, _ptr(ol), _ptr(osc))
     return ol, osc, bool(fast)
 
 

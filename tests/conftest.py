@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Parity tests compare with the oracle's model of ONE reference tier: pin it (an index otherwise follows the host's CPUID, as the
+# reference does -- tests/test_host_logic.py covers that rule).  Tier-specific tests set the variable themselves.
+os.environ.setdefault("VECSIM_GPU_TIER", "avx512")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -842,11 +842,36 @@ def test_debug_info_iterator_fields_match_reference_layout():
     ix.knn_query(np.ones((1, 24), dtype=np.float32), 3)
     f = ix.debug_info_fields()
     assert [n for n, _ in f] == ["ALGORITHM", "TYPE", "DIMENSION", "METRIC", "IS_MULTI_VALUE", "IS_DISK", "INDEX_SIZE",
-                                 "INDEX_LABEL_COUNT", "MEMORY", "LAST_SEARCH_MODE", "BLOCK_SIZE"]
+                                 "INDEX_LABEL_COUNT", "MEMORY", "LAST_SEARCH_MODE", "BLOCK_SIZE", "DISTANCE_TIER"]
     d = dict(f)
+    assert d["DISTANCE_TIER"] == "AVX512"   # (conftest pins the tier; the extension field sits behind the reference's)
     assert d["ALGORITHM"] == "FLAT" and d["TYPE"] == "FLOAT32" and d["METRIC"] == "COSINE" and d["DIMENSION"] == 24
     assert d["INDEX_SIZE"] == 37 and d["INDEX_LABEL_COUNT"] == 37 and d["IS_MULTI_VALUE"] == 0
     assert d["LAST_SEARCH_MODE"] == "STANDARD_KNN" and d["BLOCK_SIZE"] == 1024
+
+
+@pytest.mark.parametrize("flags,tier,oracle_tier", [
+    ("avx512f,avx512bw,avx512vl,avx512vbmi2,avx512vnni,avx512_bf16", "AVX512_BF16", "avx512_bf16"),
+    ("avx512f,avx512bw,avx512vl,avx512vbmi2,avx512vnni", "AVX512", "avx512"),
+    ("avx,fma3,f16c", "SCALAR", "scalar"),
+])
+def test_tier_follows_the_hosts_cpu_features_like_the_reference_chooser(vso, monkeypatch, flags, tier, oracle_tier):
+    """IP_space.cpp:585-590: avx512_bf16 && avx512vl -> vdpbf16ps first for bf16 IP; avx512f alone -> the VBMI2 order; no AVX-512 ->
+    (of the orders restated here) the scalar kernels.  The index built on such a host reports the tier and scores in its order."""
+    from util import TIERS
+    monkeypatch.delenv("VECSIM_GPU_TIER", raising=False)
+    monkeypatch.setenv("VECSIM_GPU_HOST_FLAGS", flags)
+    rng = np.random.default_rng(77)
+    dim, n = 100, 300
+    rows = random_vectors(rng, n, dim, "bf16", vso)
+    q = random_vectors(rng, 2, dim, "bf16", vso)
+    ix = make_index("bf16", "IP", dim)
+    assert dict(ix.debug_info_fields())["DISTANCE_TIER"] == tier
+    ix.add_vectors(rows, np.arange(n))
+    labels, dists = ix.knn_query(q, n)
+    for j in range(2):
+        el, es = vso.flat_topk(TYPES["bf16"], METRICS["IP"], rows, q[j], n, dim, tier=TIERS[oracle_tier])
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (tier, j)
 
 
 @pytest.mark.parametrize("typ", ["f32", "bf16", "i8"])

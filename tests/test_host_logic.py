@@ -3,6 +3,7 @@ blob sizes, runtime-parameter resolution helpers -- against the oracle."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from util import random_vectors
 from vectorsimilarity_amd import VecSim, _capi
@@ -143,3 +144,41 @@ def test_sq8_mfma_filter_bound_holds(vso):
         assert float(sc) - float(E) <= ref <= float(sc) + float(E), (trial, dim, metric, ref, float(sc), float(E))
         worst = max(worst, abs(ref - float(sc)) / max(float(E), 1e-30))
     assert worst <= 1.0
+
+
+@pytest.mark.parametrize("flags,override,expect", [
+    ("avx512f,avx512bw,avx512vl,avx512vbmi2,avx512vnni,avx512_bf16", None, "AVX512_BF16"),
+    ("avx512f,avx512bw,avx512vbmi2,avx512_bf16", None, "AVX512"),          # avx512_bf16 without avx512vl: IP_space.cpp:585
+    ("avx512f", None, "AVX512"),
+    ("avx,fma3,f16c", None, "SCALAR"),
+    ("", None, "SCALAR"),
+    ("avx512f,avx512vl,avx512_bf16", "avx512", "AVX512"),                  # the override wins
+    ("avx,f16c", "avx512_bf16", "AVX512_BF16"),
+])
+def test_host_tier_rule(monkeypatch, flags, override, expect):
+    """host_tier.h: the tier comes from the host's CPU features the way the reference's choosers pick their kernels
+    (spaces.h:68-78, IP_space.cpp:554-615), $VECSIM_GPU_TIER overrides; no GPU involved"""
+    from vectorsimilarity_amd import _capi
+    lib = _capi.load()
+    monkeypatch.setenv("VECSIM_GPU_HOST_FLAGS", flags)
+    if override is None:
+        monkeypatch.delenv("VECSIM_GPU_TIER", raising=False)
+    else:
+        monkeypatch.setenv("VECSIM_GPU_TIER", override)
+    assert lib.VecSimGpu_HostTier().decode() == expect
+
+
+def test_host_tier_probe_matches_proc_cpuinfo(monkeypatch):
+    """without the test hook the probe is the CPU's own feature list"""
+    from vectorsimilarity_amd import _capi
+    lib = _capi.load()
+    monkeypatch.delenv("VECSIM_GPU_HOST_FLAGS", raising=False)
+    monkeypatch.delenv("VECSIM_GPU_TIER", raising=False)
+    flags = set()
+    with open("/proc/cpuinfo") as f:
+        for line in f:
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                break
+    expect = "SCALAR" if "avx512f" not in flags else ("AVX512_BF16" if {"avx512_bf16", "avx512vl"} <= flags else "AVX512")
+    assert lib.VecSimGpu_HostTier().decode() == expect

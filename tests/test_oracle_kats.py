@@ -121,6 +121,35 @@ def test_lanes_match_avx512_intrinsics(vso):
             assert vso.distance(0, m, a, b) == vso.distance_fast(0, m, a, b), (d, m)
 
 
+@pytest.mark.parametrize("typ,tier", [("f64", "avx512"), ("f16", "avx512"), ("bf16", "avx512"), ("bf16", "avx512_bf16"),
+                                      ("i8", "avx512"), ("u8", "avx512")])
+def test_every_tier_matches_its_intrinsics_twin(vso, typ, tier):
+    """the restatement of each AVX-512 tier (vso.c: lanes, association, reduce tree) against the same published algorithm run
+    on the host CPU's own vector unit (vso_fast.c: vcvtph2ps, vpexpandw / vpunpck, vdpbf16ps, vpdpwssd), bit for bit on random
+    data, every residual class of dim from the tier's minimum up, plus the BASELINE widths.  Order-sensitive: a wrong lane map
+    or reduce tree changes last bits on these inputs (the reference's own v[i] = i tests cannot see that)."""
+    from util import METRICS, TIERS, TYPES, random_vectors, stored_rows
+    t = TYPES[typ]
+    lo = {"f64": 4, "f16": 16, "bf16": 32, "i8": 32, "u8": 32}[typ]
+    step = {"f64": 16, "f16": 32, "bf16": 32, "i8": 64, "u8": 64}[typ]
+    if not vso.fast_available(t, 1, lo + step, TIERS[tier]):
+        pytest.skip("host CPU lacks the instructions of this tier")
+    rng = np.random.default_rng(sum(map(ord, typ + tier)))
+    checked = 0
+    for d in list(range(lo, lo + 2 * step + 1)) + [200, 513, 768, 1000, 1024, 1536]:
+        rows = random_vectors(rng, 4, d, typ, vso)
+        for metric in ("L2", "IP", "Cosine"):
+            if metric == "Cosine" and typ not in ("i8", "u8"):
+                continue   # (fp Cosine is the IP kernel on normalised blobs)
+            st = stored_rows(vso, rows, typ, metric)
+            for j in (1, 2, 3):
+                want = vso.distance(t, METRICS[metric], st[0], st[j], d, TIERS[tier])
+                got = vso.distance_fast(t, METRICS[metric], st[0], st[j], d, TIERS[tier])
+                assert want == got or (np.isnan(want) and np.isnan(got)), (typ, tier, metric, d, want, got)
+                checked += 1
+    assert checked > 100
+
+
 def test_f16c_restatement_matches_the_hosts_f16c_unit(vso):
     """fp16 F16C tier (the reference's kernel for dims 8..15 on an AVX-512 host, L2_space.cpp:404-409): the portable
     restatement equals the same published algorithm run on this host's vcvtph2ps/fmadd units, bit for bit, at every
@@ -433,3 +462,44 @@ def test_topk_replay_follows_libstdcxx_heap_moves_with_nan_scores(vso):
         assert np.array_equal(gs, osc[:c], equal_nan=True)
         cases += bool(np.isnan(sc).any())
     assert cases > 200
+
+
+def test_reference_random_int_vectors_exact_answers(vso):
+    """the reference's own random int8 / uint8 test inputs (tests/unit/test_spaces.cpp:1574-2050: mt19937 seeds 123 / 1234 through
+    tests/utils/tests_utils.h:25-49, regenerated by tests/golden/make_ref_random_kats.py) against answers computed in exact
+    integer arithmetic: every tier the oracle models (scalar, AVX-512 VNNI) and the host's own VNNI unit give exactly those"""
+    import importlib.util
+    import json
+    import os
+    from util import TIERS
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_ref_random_kats", os.path.join(here, "make_ref_random_kats.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(here, "kat_ref_random_ints.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 202
+    for c in cases:
+        signed = c["type"] == "i8"
+        t = 4 if signed else 5
+        dim = c["dim"]
+        a = gen.populate(c["seed_a"], dim, signed).astype(np.int8 if signed else np.uint8)
+        b = gen.populate(c["seed_b"], dim, signed).astype(np.int8 if signed else np.uint8)
+        assert [int(x) for x in a[:4]] == c["head_a"] and [int(x) for x in b[:4]] == c["head_b"]
+        na = np.float32(np.sqrt(np.float64(c["sum_sq_a"])))   # compute_norm.h:18-31: sqrt(uint64) in double, stored as float
+        nb = np.float32(np.sqrt(np.float64(c["sum_sq_b"])))
+        cos = np.float32(1.0) - np.float32(c["dot"]) / (na * nb)   # IP.cpp:264-271, float32 operations
+        sa = np.zeros(dim + 4, dtype=np.uint8)
+        sb = np.zeros(dim + 4, dtype=np.uint8)
+        sa[:dim], sb[:dim] = a.view(np.uint8), b.view(np.uint8)
+        vso.normalize(sa, dim, t)
+        vso.normalize(sb, dim, t)
+        assert sa[dim:].view(np.float32)[0] == na and sb[dim:].view(np.float32)[0] == nb
+        for tier in ("scalar", "avx512"):
+            assert vso.distance(t, 0, a, b, dim, TIERS[tier]) == float(np.float32(c["l2"])), (c["type"], dim, tier)
+            assert vso.distance(t, 1, a, b, dim, TIERS[tier]) == float(np.float32(c["ip"])), (c["type"], dim, tier)
+            assert vso.distance(t, 2, sa, sb, dim, TIERS[tier]) == float(cos), (c["type"], dim, tier)
+        if vso.fast_available(t, 0, dim):
+            assert vso.distance_fast(t, 0, a, b, dim) == float(np.float32(c["l2"]))
+            assert vso.distance_fast(t, 1, a, b, dim) == float(np.float32(c["ip"]))
+            assert vso.distance_fast(t, 2, sa, sb, dim) == float(cos)

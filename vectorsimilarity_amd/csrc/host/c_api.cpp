@@ -19,6 +19,7 @@
 
 #include "blob_prep.h"
 #include "flat_index.h"
+#include "host_tier.h"
 #include "sq8_prep.h"
 #include "hnsw_index.h"
 #include "sharded_index.h"
@@ -302,6 +303,8 @@ VecSim_InfoField f64_field(const char *name, double v) {
     return f;
 }
 }  // namespace
+// the tier a new index would get on this host (VECSIM_GPU_TIER override, else CPUID): "AVX512" | "AVX512_BF16" | "SCALAR"
+extern "C" const char *VecSimGpu_HostTier(void) { return vsa::tier_name(vsa::resolve_tier()); }
 extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
     const VecSimIndexDebugInfo info = index->debugInfo();
     const CommonInfo &ci = info.commonInfo;
@@ -328,6 +331,8 @@ extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *i
         f.push_back(f64_field("EPSILON", info.hnswInfo.epsilon));
         f.push_back(u64_field("NUMBER_OF_MARKED_DELETED", info.hnswInfo.numberOfMarkedDeletedNodes));
     }
+    // extension, behind the reference's fields: which reference ISA tier's summation order the scores reproduce (host_tier.h)
+    f.push_back(str_field("DISTANCE_TIER", vsa::tier_name(index->distanceTier())));
     return it;
 }
 extern "C" size_t VecSimDebugInfoIterator_NumberOfFields(VecSimDebugInfoIterator *it) { return it->fields.size(); }

@@ -1,5 +1,6 @@
 // flat_index.cpp -- see flat_index.h
 #include "flat_index.h"
+#include "host_tier.h"
 
 #include <algorithm>
 #include <cmath>
@@ -55,13 +56,6 @@ static int resolve_device() {
     return 0;
 }
 
-static int resolve_tier() {
-    if (const char *e = std::getenv("VECSIM_GPU_TIER")) {
-        if (!std::strcmp(e, "scalar")) return VSGPU_TIER_SCALAR;
-        if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
-    }
-    return VSGPU_TIER_AVX512;
-}
 
 static size_t reader_lanes() {
     if (const char *e = std::getenv("VECSIM_GPU_READER_LANES")) return (size_t)std::max(1, std::min(8, std::atoi(e)));
@@ -82,7 +76,8 @@ FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
     ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    ix->tier_ = resolve_tier();   // from the host's CPUID, as the reference's choosers do (host_tier.h)
+    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, ix->tier_, p.dim, ix->stored_bytes_);
     if (!ix->table_) {
         vsgpu_ctx_destroy(ctx);
         ix->ctx_ = nullptr;
@@ -133,7 +128,8 @@ FlatIndex *FlatIndex::createSQ8(const BFParams &p, void *logCtx, const float *me
     ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->table_ = vsgpu_table_create(ctx, f16 ? VSGPU_SQ8H : VSGPU_SQ8, (int)p.metric, resolve_tier(), p.dim, ix->stored_bytes_);
+    ix->tier_ = resolve_tier();
+    ix->table_ = vsgpu_table_create(ctx, f16 ? VSGPU_SQ8H : VSGPU_SQ8, (int)p.metric, ix->tier_, p.dim, ix->stored_bytes_);
     if (ix->table_ && mean) vsgpu_table_set_sq8_mean_sum_squares(ix->table_, mean_sum_squares);
     if (!ix->table_) {
         vsgpu_ctx_destroy(ctx);

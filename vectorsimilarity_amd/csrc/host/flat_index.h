@@ -88,6 +88,7 @@ struct VecSimIndexInterface {
     // every GPU context of the index (reader lanes included): options go to all, statistics are summed over them
     virtual std::vector<vsgpu_ctx *> gpus() { return {gpu()}; }
     virtual void setLastMode(VecSearchMode m) = 0;
+    virtual int distanceTier() const { return VSGPU_TIER_AVX512; }   // which reference ISA tier's order the scores follow (host_tier.h)
 };
 
 namespace vsa {
@@ -128,6 +129,7 @@ public:
     long storedVectors(size_t label, void *out, size_t cap_bytes) override;
     size_t storedBlobBytes() const override { return stored_bytes_; }
     vsgpu_ctx *gpu() override { return ctx_; }
+    int distanceTier() const override { return tier_; }
     std::vector<vsgpu_ctx *> gpus() override;
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
@@ -162,6 +164,7 @@ private:
     void removeRow(uint32_t id);
 
     VecSimType type_ = VecSimType_FLOAT32;
+    int tier_ = 0;
     VecSimMetric metric_ = VecSimMetric_L2;
     size_t dim_ = 0, block_size_ = DEFAULT_BLOCK_SIZE;
     size_t stored_bytes_ = 0, query_bytes_ = 0;

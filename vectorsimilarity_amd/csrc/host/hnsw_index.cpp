@@ -1,5 +1,6 @@
 // hnsw_index.cpp -- see hnsw_index.h
 #include "hnsw_index.h"
+#include "host_tier.h"
 
 #include <algorithm>
 #include <cmath>
@@ -52,7 +53,9 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->mult_ = 1.0 / std::log(1.0 * (double)M);                                               // hnsw.h:1646
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, VSGPU_TIER_AVX512, p.dim, ix->blob_bytes_);
+    // (the search kernel scores rows with the lane program of the host's tier as well; the scalar tier is not wired into it)
+    ix->tier_ = resolve_tier() == VSGPU_TIER_AVX512_BF16 ? VSGPU_TIER_AVX512_BF16 : VSGPU_TIER_AVX512;
+    ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, ix->tier_, p.dim, ix->blob_bytes_);
     ix->graph_ = ix->table_ ? vsgpu_graph_create(ix->table_, M) : nullptr;
     if (!ix->table_ || !ix->graph_) {
         delete ix;

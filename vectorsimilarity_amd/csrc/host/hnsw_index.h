@@ -56,6 +56,7 @@ public:
     long storedVectors(size_t label, void *out, size_t cap_bytes) override;
     size_t storedBlobBytes() const override { return blob_bytes_; }
     vsgpu_ctx *gpu() override { return ctx_; }
+    int distanceTier() const override { return tier_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
 
     // test / tooling access to the built graph (VecSimGpu_HnswExport)
@@ -115,6 +116,7 @@ private:
     std::vector<char> raw_;         // stored (preprocessed) blobs in the index's own type: what goes to HBM
     size_t blob_bytes_ = 0, elem_bytes_ = 4;
     vsgpu_ctx *ctx_ = nullptr;
+    int tier_ = 0;
     vsgpu_table *table_ = nullptr;
     vsgpu_graph *graph_ = nullptr;
     size_t uploaded_rows_ = 0;

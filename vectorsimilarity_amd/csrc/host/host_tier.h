@@ -1,0 +1,68 @@
+// host_tier.h -- which reference ISA tier's summation order an index reproduces.
+//
+// The reference picks its distance kernel from the host CPU's features at run time (spaces.h:68-78
+// getCpuOptimizationFeatures; choosers L2_space.cpp:185-516, IP_space.cpp:435-889), so the last bits of a
+// reference reply depend on the machine it runs on.  A drop-in replacement follows the same rule: the tier comes from
+// the host's CPUID --
+//   avx512f                                  -> the AVX-512F / BW / VBMI2 / VNNI kernels' order     (VSGPU_TIER_AVX512)
+//   ... && avx512_bf16 && avx512vl           -> vdpbf16ps first for bf16 IP / Cosine                (VSGPU_TIER_AVX512_BF16;
+//                                               IP_space.cpp:585-590; every other type as AVX512)
+//   no avx512f                               -> the scalar kernels' order                          (VSGPU_TIER_SCALAR)
+// -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar overrides it.  Not restated: the AVX2 / AVX / SSE
+// orders a reference build falls back to on a host without AVX-512 (this library then reproduces the scalar kernels, the
+// reference's own baseline in tests/unit/test_spaces.cpp) and the AVX512-FP16 tier of gcc >= 12 builds (fp16 accumulate).
+// VECSIM_GPU_HOST_FLAGS = comma-separated feature names replaces the CPUID probe (tests).
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "vsgpu.h"
+
+namespace vsa {
+
+struct HostFeatures {
+    bool avx512f = false, avx512bw = false, avx512vl = false, avx512vbmi2 = false, avx512vnni = false, avx512_bf16 = false;
+    bool f16c = false, fma3 = false, avx = false;
+};
+
+inline HostFeatures host_features() {
+    HostFeatures f;
+    if (const char *e = std::getenv("VECSIM_GPU_HOST_FLAGS")) {
+        const std::string s = std::string(",") + e + ",";
+        auto has = [&](const char *n) { return s.find(std::string(",") + n + ",") != std::string::npos; };
+        f.avx512f = has("avx512f"), f.avx512bw = has("avx512bw"), f.avx512vl = has("avx512vl");
+        f.avx512vbmi2 = has("avx512vbmi2"), f.avx512vnni = has("avx512vnni"), f.avx512_bf16 = has("avx512_bf16");
+        f.f16c = has("f16c"), f.fma3 = has("fma3"), f.avx = has("avx");
+        return f;
+    }
+#if defined(__x86_64__)
+    __builtin_cpu_init();
+    f.avx512f = __builtin_cpu_supports("avx512f"), f.avx512bw = __builtin_cpu_supports("avx512bw");
+    f.avx512vl = __builtin_cpu_supports("avx512vl"), f.avx512vbmi2 = __builtin_cpu_supports("avx512vbmi2");
+    f.avx512vnni = __builtin_cpu_supports("avx512vnni"), f.avx512_bf16 = __builtin_cpu_supports("avx512bf16");
+    f.f16c = __builtin_cpu_supports("f16c"), f.fma3 = __builtin_cpu_supports("fma"), f.avx = __builtin_cpu_supports("avx");
+#endif
+    return f;
+}
+
+inline int tier_from_features(const HostFeatures &f) {
+    if (!f.avx512f) return VSGPU_TIER_SCALAR;
+    if (f.avx512_bf16 && f.avx512vl) return VSGPU_TIER_AVX512_BF16;
+    return VSGPU_TIER_AVX512;
+}
+
+inline int resolve_tier() {
+    if (const char *e = std::getenv("VECSIM_GPU_TIER")) {
+        if (!std::strcmp(e, "scalar")) return VSGPU_TIER_SCALAR;
+        if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
+        if (!std::strcmp(e, "avx512")) return VSGPU_TIER_AVX512;
+    }
+    return tier_from_features(host_features());
+}
+
+inline const char *tier_name(int tier) {
+    return tier == VSGPU_TIER_SCALAR ? "SCALAR" : tier == VSGPU_TIER_AVX512_BF16 ? "AVX512_BF16" : "AVX512";
+}
+
+}  // namespace vsa
