@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- Flat top-K over synthetic vectors resident in HBM; one "step" = one query batch answered end to end.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c4] [--rows R] [--dim D] [--batch B] [--topk K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c4|c5] [--rows R] [--dim D] [--batch B] [--topk K]
 
 Configs (BASELINE.json `configs`; default c2 = the one `metric` is quoted on):
     c1  fp32 L2      100 K x 128   1 query    top-10     the reference's own CPU-runnable case
     c2  fp32 L2       10 M x 768   64 queries top-10     headline
     c3  int8 Cosine   50 M x 1024  256 queries top-100   int8 MFMA path
     c4  bf16 IP     12.5 M x 768   128 queries top-10    per GPU: 100 M rows over 8 GPUs, RCCL top-K merge
+    c5  HNSW fp32 L2   1 M x 768   4096 queries top-10   M 16, efC 200, efR 128 (BASELINE: 10 M rows -- --rows 10000000; the graph is built
+                                                          on the host cores first: ~3 min per million rows); --data uniform | lowrank
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (one rank
 per GPU).  Every rank holds its own shard of `rows` vectors (weak scaling), scans it for the same query batch, and the
@@ -48,6 +50,7 @@ CONFIGS = {
     "c2": ("FLOAT32", "L2", 768, 10_000_000, 64, 10, "f32", "rows_f32", 400_000),
     "c3": ("INT8", "Cosine", 1024, 50_000_000, 256, 100, "i8", "rows_i8", 40_000),
     "c4": ("BFLOAT16", "IP", 768, 12_500_000, 128, 10, "bf16", "rows_bf16", 40_000),
+    "c5": ("FLOAT32", "L2", 768, 1_000_000, 4096, 10, "f32", "rows_f32", 0),
 }
 
 
@@ -68,6 +71,10 @@ def parse():
     ap.add_argument("--readers", type=int, default=2,
                     help="threads submitting batches (the reference's readers: bindings.cpp:250-283 knn_parallel); 2 lets one "
                          "batch's upload / probe / re-rank / download / host replay overlap with the next batch's scan kernel")
+    ap.add_argument("--data", default="lowrank", choices=["uniform", "lowrank"],
+                    help="c5 only.  uniform: BASELINE's i.i.d. U[-1,1) rows (intrinsic dimension = d: no graph index finds neighbours "
+                         "there); lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
+    ap.add_argument("--ef", type=int, default=128, help="c5: efRuntime")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning: VecSimGpu_SetOption on the index (e.g. probe_div=64); not used by the default run")
     a = ap.parse_args()
@@ -115,19 +122,23 @@ def cpu_baseline(args, VecSim, synth):
         rows, queries, km = raw, qraw, (vso.L2 if args.metric_name == "L2" else vso.IP)
     nproc = os.cpu_count() or 1
     threads = max(1, min(nproc, args.batch))
-    vso.flat_topk_batch_fast(vt, km, rows[:2000], queries[:1], args.topk, args.dim, 1)
+    # the index follows the host's CPUID like the reference's choosers do (bf16 IP: vdpbf16ps on avx512_bf16 hosts): same tier here
+    from vectorsimilarity_amd import _capi
+    tier_name = _capi.load().VecSimGpu_HostTier().decode()
+    tier = {"AVX512": vso.TIER_AVX512, "SCALAR": vso.TIER_SCALAR, "AVX512_BF16": vso.TIER_AVX512_BF16}[tier_name]
+    vso.flat_topk_batch_fast(vt, km, rows[:2000], queries[:1], args.topk, args.dim, 1, tier)
 
     def best_of(nq, th, reps):
         best, res = None, None
         for _ in range(reps):
             t0 = time.perf_counter()
-            res = vso.flat_topk_batch_fast(vt, km, rows, queries[:nq], args.topk, args.dim, th)
+            res = vso.flat_topk_batch_fast(vt, km, rows, queries[:nq], args.topk, args.dim, th, tier)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         return best, res
     nq1 = max(1, min(args.batch, 4))
-    t1, _ = best_of(nq1, 1, 3)
-    tall, (labels, scores, fast) = best_of(args.batch, threads, 3)
+    t1, _ = best_of(nq1, 1, 5)
+    tall, (labels, scores, fast) = best_of(args.batch, threads, 5)
     # checker: a GPU index over the same n rows must give the same labels, order and scores
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
@@ -140,14 +151,123 @@ def cpu_baseline(args, VecSim, synth):
             "single_thread": {"value": n * nq1 / t1, "unit": "distances/s", "cores": 1,
                               "note": "the reference scans single-threaded (brute_force.h:264-281)"},
             "cpu": cpu_model(), "nproc": nproc,
-            "sample": "first %d of the %d synthetic rows x %d queries (single thread: %d), top-%d, best of 3, %s kernel; "
+            "tier": tier_name,
+            "sample": "first %d of the %d synthetic rows x %d queries (single thread: %d), top-%d, best of 5, %s kernel (tier %s); "
                       "GPU result on the same sample bit-identical: %s" % (
                           n, args.rows, args.batch, nq1, args.topk,
-                          "AVX-512 intrinsics" if fast else "portable reference-order lanes", same)}
+                          "AVX-512 intrinsics (oracle/vso_fast.c twin of the reference kernel)" if fast else "portable reference-order lanes",
+                          tier_name, same)}
+
+
+def run_c5(args):
+    """config 5: HNSW fp32 L2 (graph built on the host cores, queries on the GPU: k_hnsw_search).  One step = one batch of
+    `batch` queries answered end to end.  value = queries/s; roofline = the gathered row bytes (distance evaluations x
+    storedDataSize) over the search kernel's HIP-event time against the HBM peak (the kernel is latency-, not stream-bound);
+    recall@10 against the exact Flat answer computed on the GPU; cpu_baseline = the reference's search loop
+    (hnsw.h:1983-2084, restated in oracle/vso_hnsw.c) on the SAME graph, one thread and all host cores."""
+    from vectorsimilarity_amd import VecSim, synth
+    n, dim, nq, k = args.rows, args.dim, args.batch, args.topk
+    rows = np.empty((n, dim), dtype=np.float32)
+    mix = synth.rows_f32(49, 0, 32, dim)
+
+    def gen(seed, r0, cnt):
+        part = synth.rows_f32(seed, r0, cnt, dim)
+        if args.data == "lowrank":
+            part = (synth.rows_f32(seed, r0, cnt, 32) @ mix + 0.05 * part).astype(np.float32)
+        return part
+    for r0 in range(0, n, 200_000):
+        rows[r0:min(n, r0 + 200_000)] = gen(args.seed, r0, min(n, r0 + 200_000) - r0)
+    nb_distinct = min(args.warmup + args.steps, 4)
+    qsets = [gen(args.seed + 1 + b, 0, nq) for b in range(nb_distinct)]
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2, 16, 200, args.ef
+    ix = VecSim.HNSWIndex(p)
+    t0 = time.perf_counter()
+    ix.add_vectors(rows, np.arange(n))
+    build_s = time.perf_counter() - t0
+    for w in range(max(1, args.warmup)):
+        ix.knn_query(qsets[w % nb_distinct], k)
+    ix.reset_stats()
+    t0 = time.perf_counter()
+    evals, last = 0, None
+    for s in range(args.steps):
+        last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], k)
+        evals += ix.last_distance_evals()
+    dt = time.perf_counter() - t0
+    st = ix.stats()
+    kms = st["scan_ms"] / max(1, st["scan_launches"])
+    # recall@k against the exact answer (Flat index on the same GPU)
+    bp = VecSim.BFParams()
+    bp.type, bp.dim, bp.metric = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2
+    bf = VecSim.BFIndex(bp)
+    bf.add_vectors(rows, np.arange(n))
+    qlast = qsets[(args.warmup + args.steps - 1) % nb_distinct]
+    nx = min(nq, 1024)
+    exact = np.concatenate([bf.knn_query(qlast[i:i + 64], k)[0] for i in range(0, nx, 64)])[:nx]
+    recall = sum(len(set(last[0][i]) & set(exact[i])) for i in range(nx)) / (nx * k)
+    del bf
+    gathered = evals / args.steps * dim * 4
+    out = {
+        "metric": "QPS, HNSW fp32 L2 top-%d, N=%d d=%d M=16 efC=200 efR=%d, batch-%d" % (k, n, dim, args.ef, nq),
+        "value": nq * args.steps / dt, "unit": "queries/s", "qps": nq * args.steps / dt,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c5: hnsw_f32_l2_top%d" % k, "rows_per_gpu": n, "dim": dim, "batch": nq, "k": k, "M": 16,
+                   "efConstruction": 200, "efRuntime": args.ef,
+                   "rows_kind": "i.i.d. U[-1,1) (BASELINE's generator)" if args.data == "uniform" else
+                                "32 latent factors mixed into %d dims + 5%% noise (embedding-like)" % dim,
+                   "note": "BASELINE quotes N = 10 M; the default run builds %d rows (host build %.0f s)" % (n, build_s)},
+        "recall_at_%d" % k: recall, "recall_queries": nx,
+        "dist_evals_per_query": evals / (args.steps * nq), "host_build_s": build_s,
+        "roofline": {"bound": "gather", "achieved": gathered / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (gathered / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0, "traffic": None,
+                     "kernel": st["scan_kernel"], "avg_kernel_ms": kms, "launches": int(st["scan_launches"]),
+                     "algorithmic_bytes_per_launch": gathered,
+                     "note": "random 3 KiB row gathers: latency-bound, the HBM peak is the ceiling of the data path, not a target"},
+    }
+    if not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import vso
+        vso.build()
+        g = ix.graph()
+        nproc = os.cpu_count() or 1
+        nq1, nqa = 64, min(nq, max(256, 8 * nproc))
+
+        def one(j):
+            return vso.hnsw_search(vso.F32, vso.L2, rows, g, qlast[j], k, args.ef, dim)
+        same = True
+        best1 = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = [one(j) for j in range(nq1)]
+            d1 = time.perf_counter() - t0
+            best1 = d1 if best1 is None else min(best1, d1)
+        for j in range(nq1):   # the checker: same graph, same loop -> same reply
+            el, es, _ = res[j]
+            same = same and bool(np.array_equal(last[0][j][:len(el)], el.astype(np.int64)) and np.array_equal(last[1][j][:len(es)], es))
+        with ThreadPoolExecutor(nproc) as pool:
+            besta = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                list(pool.map(one, range(nqa)))
+                da = time.perf_counter() - t0
+                besta = da if besta is None else min(besta, da)
+        out["cpu_baseline"] = {"value": nqa / besta, "unit": "queries/s", "cores": nproc, "kind": "port",
+                               "single_thread": {"value": nq1 / best1, "unit": "queries/s", "cores": 1},
+                               "cpu": cpu_model(), "nproc": nproc,
+                               "sample": "the reference's search loop (oracle/vso_hnsw.c) on the same graph: %d queries on one thread, %d on "
+                                         "%d threads (one query per thread at a time), best of 3; GPU replies on the first %d queries "
+                                         "identical: %s" % (nq1, nqa, nproc, nq1, same)}
+    out["sorted"] = bool(np.all(np.diff(np.where(last[0] >= 0, last[1], np.inf), axis=1) >= 0))
+    print(json.dumps(out))
 
 
 def main():
     args = parse()
+    if args.config == "c5":
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("config 5 (HNSW) is single-GPU: replicas only, graph traversal is global (DESIGN.md 7)")
+        return run_c5(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
