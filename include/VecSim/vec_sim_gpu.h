@@ -93,6 +93,17 @@ int VecSimGpu_ShardedTopKQueryBatch(VecSimShardedIndex *index, const void *query
 int VecSimGpu_ShardedTopKQueryBatchArrays(VecSimShardedIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
                                           size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
                                           int64_t *labels, double *scores, int *codes);
+/* Several reader threads per process: `seq` is the batch's position in the stream of batches EVERY process answers (0, 1, 2 ...,
+ * no gaps; each number used once on each process).  The scans of concurrent batches overlap on the shard's reader lanes, the
+ * exchanges are issued in seq order on every process whatever the threads' relative speed, so batch i's exchange and merge run
+ * under batch i+1's scan.  The plain entry points above are the one-reader form (call order is the order). */
+int VecSimGpu_ShardedTopKQueryBatchArraysSeq(VecSimShardedIndex *index, const void *queryBlobs, size_t nq, size_t queryStride,
+                                             size_t k, VecSimQueryParams *queryParams, VecSimQueryReply_Order order,
+                                             int64_t *labels, double *scores, int *codes, uint64_t seq);
+/* wall time per phase since the last reset, ms: {shard scans, waiting for the exchange turn, exchange, merge + replies},
+ * then {batches answered, bytes this process contributed per exchange, summed} */
+void VecSimGpu_ShardedGetStats(VecSimShardedIndex *index, double out[6]);
+void VecSimGpu_ShardedResetStats(VecSimShardedIndex *index);
 /* the Flat index of a shard held by this process (stats, options); NULL for shards of other processes */
 VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *index, int shard);
 int VecSimGpu_ShardedWorld(VecSimShardedIndex *index);

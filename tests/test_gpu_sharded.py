@@ -163,6 +163,71 @@ def test_rccl_world1_exchange_in_process(vso):
     assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
 
 
+@pytest.mark.parametrize("typ,metric,dim,k", [("f32", "L2", 64, 10), ("f32", "Cosine", 32, 5), ("bf16", "IP", 72, 10), ("i8", "Cosine", 64, 8)])
+def test_nan_score_rows_and_queries_across_shards(vso, typ, metric, dim, k):
+    """brute_force.h:272 lets a NaN-score row into the heap only while it fills (internal ids below k): rows that can score NaN
+    among the first k gids -- on different shards --, NaN / Inf / zero queries, and a tail NaN row: the sharded reply equals
+    the single index's (itself pinned on the oracle's every-row replay in tests/test_gpu_flat_parity.py), NaNs included"""
+    rng = np.random.default_rng(dim + k)
+    n, G, block = 3000, 3, 2          # tiny blocks: gids 0 .. k-1 spread over all three shards
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, 6, dim, typ, vso)
+    if metric == "Cosine":
+        rows[1] = 0
+        rows[4] = 0
+        rows[n - 1] = 0
+        q[3] = 0
+    else:
+        nan = {"f32": np.float32(np.nan), "bf16": np.uint16(0x7FC0)}[typ]
+        inf = {"f32": np.float32(np.inf), "bf16": np.uint16(0x7F80)}[typ]
+        rows[1, 3] = nan
+        rows[4, 0] = nan
+        rows[n - 1, 2] = nan
+        q[3, 1] = nan
+        q[4, 0] = inf
+    labels = np.arange(n) * 3 + 1
+    sx = ShardedFlatIndex(params(typ, metric, dim, block), shards=G)
+    one = VecSim.BFIndex(params(typ, metric, dim, block))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    for kk in (k, 1, 40):
+        gl, gs = sx.knn_query(q, kk)
+        sl, ss = one.knn_query(q, kk)
+        assert np.array_equal(gl, sl) and np.array_equal(gs, ss, equal_nan=True), (typ, metric, kk)
+    # NaN rows only beyond gid k (delete the head ones: the tail row moves into gid 1 first, then goes too): finite queries take
+    # the ordinary candidate path again, NaN queries still the every-row one
+    for lab in (labels[1], labels[4], labels[n - 1]):
+        assert sx.delete_vector(int(lab)) == 1 and one.delete_vector(int(lab)) == 1
+    gl, gs = sx.knn_query(q, k)
+    sl, ss = one.knn_query(q, k)
+    assert np.array_equal(gl, sl) and np.array_equal(gs, ss, equal_nan=True)
+
+
+def test_concurrent_readers_with_sequence_numbers(vso):
+    """two reader threads on one sharded index (VecSimGpu_ShardedTopKQueryBatchArraysSeq): scans overlap on the shards' reader
+    lanes, exchanges go in sequence order; every batch's reply equals the one-reader reply.  Through a real 1-rank RCCL
+    communicator, so the ordered exchange path runs."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(21)
+    dim, n, nq, k = 96, 60_000, 24, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    sx = ShardedFlatIndex(params("f32", "L2", dim, 1024), rank=0, world=1, device=0)
+    sx.add_vectors(rows, np.arange(n))
+    sx.local.set_option("dense_pairs", 0)
+    qsets = [rng.uniform(-1, 1, (nq, dim)).astype(np.float32) for _ in range(12)]
+    want = [sx.knn_query(qs, k) for qs in qsets]
+    sx.reset_stats()
+
+    def reader(t):
+        return [(b, sx.knn_query(qsets[b], k, seq=b)) for b in range(t, 12, 2)]
+    with ThreadPoolExecutor(2) as pool:
+        for part in pool.map(reader, range(2)):
+            for b, (gl, gs) in part:
+                assert np.array_equal(gl, want[b][0]) and np.array_equal(gs, want[b][1]), b
+    st = sx.stats()
+    assert st["batches"] == 12 and st["exchange_ms"] > 0 and st["scan_ms"] > 0, st
+
+
 def test_synthetic_weak_scaling_fill_matches_concatenation(vso):
     """bench.py's fill: shard s holds rows generated from seed + 1000 s; the equivalent single index is their
     concatenation with label = gid"""

@@ -94,6 +94,41 @@ def _worker(rank, world, port, out):
         for qi in range(nq):
             el, es = vso.flat_topk(0, 0, rows, queries[qi], kk, dim, labels.astype(np.uint64))
             ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
+    # two reader threads per process: batch b is answered by thread b % 2 under sequence number b -- the exchanges pair up
+    # across the processes whatever the threads' relative speed (the external shard's scan holds the GIL, so the threads of
+    # the two processes really do run at unrelated paces)
+    from concurrent.futures import ThreadPoolExecutor
+    qsets = [base[(3 * b) % 24:(3 * b) % 24 + nq].copy() for b in range(8)]
+
+    def reader(t):
+        return [(b, ix.knn_query(qsets[b], k, seq=b)) for b in range(t, 8, 2)]
+    ix.reset_stats()
+    with ThreadPoolExecutor(2) as pool:
+        for part in pool.map(reader, range(2)):
+            for b, (got_l, got_s) in part:
+                for qi in range(nq):
+                    el, es = vso.flat_topk(0, 0, rows, qsets[b][qi], k, dim, labels.astype(np.uint64))
+                    ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
+    st = ix.stats()
+    ok &= st["batches"] == 8 and st["exchange_bytes"] > 0
+    # the timeout callback fires on ONE process only: its verdict travels in the exchange, both processes return TimedOut
+    # replies (a process that left before the collective would hang the other)
+    cb = VecSim.set_timeout_callback(lambda ctx: 1 if (ctx == 7 and rank == 1) else 0)
+    qp = VecSim.VecSimQueryParams()
+    qp.timeoutCtx = 7
+    _, _, codes = ix.knn_query(queries, k, query_param=qp, with_codes=True)
+    ok &= bool(np.all(codes == VecSim._capi.VecSim_QueryReply_TimedOut))
+    qp.timeoutCtx = 8
+    got_l, _, codes = ix.knn_query(queries, k, query_param=qp, with_codes=True)
+    ok &= bool(np.all(codes == VecSim._capi.VecSim_QueryReply_OK)) and bool(np.all(got_l >= 0))
+    VecSim.set_timeout_callback(None)
+    del cb
+    # an external (append-only) shard cannot move rows: delete is refused on every process alike, nothing changes
+    ok &= ix.delete_vector(int(labels[5])) == -1 and ix.index_size() == n
+    got_l, got_s = ix.knn_query(queries, k)
+    for qi in range(nq):
+        el, es = vso.flat_topk(0, 0, rows, queries[qi], k, dim, labels.astype(np.uint64))
+        ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
     owned = len(shard.rows)
     dist.barrier()
     dist.destroy_process_group()

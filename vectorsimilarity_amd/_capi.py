@@ -148,6 +148,7 @@ EXPORTS = [
     "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
     "VecSimGpu_ShardedAddVectorsBulk", "VecSimGpu_ShardedAddSyntheticLocal", "VecSimGpu_ShardedDeleteVector",
     "VecSimGpu_ShardedIndexSize", "VecSimGpu_ShardedTopKQueryBatch", "VecSimGpu_ShardedTopKQueryBatchArrays",
+    "VecSimGpu_ShardedTopKQueryBatchArraysSeq", "VecSimGpu_ShardedGetStats", "VecSimGpu_ShardedResetStats",
     "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
@@ -335,6 +336,12 @@ def load():
     L.VecSimGpu_ShardedTopKQueryBatch.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, C.POINTER(vp)]
     L.VecSimGpu_ShardedTopKQueryBatchArrays.restype = i
     L.VecSimGpu_ShardedTopKQueryBatchArrays.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, vp, vp, vp]
+    L.VecSimGpu_ShardedTopKQueryBatchArraysSeq.restype = i
+    L.VecSimGpu_ShardedTopKQueryBatchArraysSeq.argtypes = [vp, vp, sz, sz, sz, C.POINTER(VecSimQueryParams), i, vp, vp, vp, C.c_uint64]
+    L.VecSimGpu_ShardedGetStats.restype = None
+    L.VecSimGpu_ShardedGetStats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.VecSimGpu_ShardedResetStats.restype = None
+    L.VecSimGpu_ShardedResetStats.argtypes = [vp]
     L.VecSimGpu_ShardedLocalIndex.restype = vp
     L.VecSimGpu_ShardedLocalIndex.argtypes = [vp, i]
     L.VecSimGpu_ShardedWorld.restype = i

@@ -437,6 +437,7 @@ struct CallbackExchange final : vsa::Exchange {
     void *user;
     int allgather(const void *send, size_t bytes, void *recv) override { return ag(user, send, bytes, recv); }
     int broadcast(void *buf, size_t bytes, int root) override { return bc ? bc(user, buf, bytes, root) : -1; }
+    bool canBroadcast() const override { return bc != nullptr; }
 };
 struct CallbackShard final : vsa::ShardOps {
     VecSimGpu_ShardAddFn add_fn;
@@ -548,6 +549,27 @@ extern "C" int VecSimGpu_ShardedTopKQueryBatchArrays(VecSimShardedIndex *ix, con
     }
     return 0;
 }
+extern "C" int VecSimGpu_ShardedTopKQueryBatchArraysSeq(VecSimShardedIndex *ix, const void *queryBlobs, size_t nq,
+                                                        size_t queryStride, size_t k, VecSimQueryParams *queryParams,
+                                                        VecSimQueryReply_Order order, int64_t *labels, double *scores, int *codes,
+                                                        uint64_t seq) {
+    if (order != BY_ID && order != BY_SCORE) return -1;
+    std::vector<VecSimQueryReply *> reps(nq, nullptr);
+    int rc = ix->impl->topKQueryBatch(queryBlobs, nq, queryStride, k, queryParams, order, reps.data(), seq);
+    if (rc) return rc;
+    for (size_t q = 0; q < nq; q++) {
+        const auto &r = reps[q]->results;
+        for (size_t j = 0; j < k; j++) {
+            labels[q * k + j] = j < r.size() ? (int64_t)r[j].id : -1;
+            scores[q * k + j] = j < r.size() ? r[j].score : -1.0;
+        }
+        if (codes) codes[q] = (int)reps[q]->code;
+        delete reps[q];
+    }
+    return 0;
+}
+extern "C" void VecSimGpu_ShardedGetStats(VecSimShardedIndex *ix, double out[6]) { ix->impl->stats(out); }
+extern "C" void VecSimGpu_ShardedResetStats(VecSimShardedIndex *ix) { ix->impl->resetStats(); }
 extern "C" VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *ix, int shard) { return ix->impl->localIndex(shard); }
 extern "C" int VecSimGpu_ShardedWorld(VecSimShardedIndex *ix) { return ix->impl->world(); }
 extern "C" int VecSimGpu_ShardedRank(VecSimShardedIndex *ix) { return ix->impl->rank(); }

@@ -581,6 +581,11 @@ size_t FlatIndex::distinctLabels(const uint32_t *ids, size_t n) const {
     return seen.size();
 }
 
+bool FlatIndex::queryMayScoreNaN(const void *raw_query) const {
+    std::vector<char> q = preprocessQuery(raw_query);
+    return mayScoreNaN(q.data());
+}
+
 int FlatIndex::allScores(const void *processed_query, std::vector<double> &scores) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
     if (flush()) return -1;
@@ -671,7 +676,7 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         tbl = lane->view;
     }
     void *tctx = qp ? qp->timeoutCtx : nullptr;
-    last_mode_ = STANDARD_KNN;
+    if (!lane) last_mode_ = STANDARD_KNN;   // (a lane reader holds no lock: the plain member is the lock holder's to write)
     if (nq == 0) return 0;
     std::vector<VecSimQueryReply *> reps(nq);
     for (auto &r : reps) r = new VecSimQueryReply();
@@ -814,17 +819,35 @@ std::vector<char> FlatIndex::packQueries(const void *queries, size_t nq, size_t 
 
 int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, uint32_t *ids,
                               size_t *labels, double *scores, uint32_t *counts) {
-    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
-    last_mode_ = STANDARD_KNN;
+    // concurrent readers (the sharded index's reader threads): the first runs on the index's own context, one that finds it
+    // busy on a reader lane -- as in topKQueryBatch
+    std::unique_lock<std::recursive_mutex> gpu_lock(gpu_mu_, std::defer_lock);
+    Lane *lane = nullptr;
+    if (!gpu_lock.try_lock()) {
+        if (!multi_ && staged_rows_.load(std::memory_order_acquire) == 0) lane = tryLane();
+        if (!lane) gpu_lock.lock();
+    }
+    struct LaneRelease {
+        Lane *l;
+        ~LaneRelease() {
+            if (l) l->mu.unlock();
+        }
+    } lane_release{lane};
+    vsgpu_table *tbl = table_;
+    if (lane) {
+        vsgpu_table_view_sync(lane->view);
+        tbl = lane->view;
+    }
+    if (!lane) last_mode_ = STANDARD_KNN;
     if (multi_) return -1;  // sharded multi-value indexes are not built yet
     if (nq == 0) return 0;
-    if (flush()) return -1;
+    if (!lane && flush()) return -1;
     if (k == 0 || count_ == 0) {
         for (size_t q = 0; q < nq; q++) counts[q] = 0;
         return 0;
     }
     std::vector<char> qbuf = packQueries(queries, nq, stride);
-    int rc = vsgpu_topk(table_, qbuf.data(), nq, query_bytes_, k, cap, ids, scores, counts);
+    int rc = vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids, scores, counts);
     if (rc) return rc;
     for (size_t q = 0; q < nq; q++) {
         if (counts[q] == VSGPU_COUNT_OVERFLOW) continue;

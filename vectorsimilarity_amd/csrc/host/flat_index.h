@@ -141,6 +141,10 @@ public:
     void iteratorDeviceEnd(vsgpu_scorebuf *b) override;
     size_t rowLabel(size_t id) const override { return id_to_label_[id]; }
     int allScores(const void *processed_query, std::vector<double> &scores);
+    // NaN bookkeeping for the sharded index: the smallest id of a row that can score NaN (SIZE_MAX: none) and whether a raw
+    // query can (NaN / Inf elements, a zero vector under Cosine): such replies replay the reference's heap over every row
+    size_t firstNanRow() const { return nan_ids_.empty() ? (size_t)-1 : (size_t)*nan_ids_.begin(); }
+    bool queryMayScoreNaN(const void *raw_query) const;
     // row-level operations for the sharded index (sharded_index.cpp), which replays the equivalent single index's
     // swap-delete (brute_force.h:196-224) across shards: the global last row moves into the hole
     int readRow(uint32_t id, void *stored_blob);                                   // stored (preprocessed) bytes of a row

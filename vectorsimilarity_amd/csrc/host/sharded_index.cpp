@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <queue>
 #include <thread>
@@ -31,6 +33,20 @@ struct FlatShard final : ShardOps {
     }
     size_t size() const override { return ix->indexSize(); }
     size_t storedBytes() const override { return ix->storedBlobBytes(); }
+    bool supportsRowOps() const override { return true; }
+    size_t firstNanRow() const override { return ix->firstNanRow(); }
+    bool queryMayScoreNaN(const void *q) const override { return ix->queryMayScoreNaN(q); }
+    int allScores(const void *query, uint32_t *ids, size_t *labels, double *scores) override {
+        std::vector<char> q = ix->preprocessQuery(query);
+        std::vector<double> sc;
+        if (ix->allScores(q.data(), sc)) return -1;
+        for (size_t i = 0; i < sc.size(); i++) {
+            ids[i] = (uint32_t)i;
+            labels[i] = ix->labelOf(i);
+            scores[i] = sc[i];
+        }
+        return 0;
+    }
     int readRow(uint32_t id, void *out) override { return ix->readRow(id, out); }
     int overwriteRow(uint32_t id, const void *blob, size_t label) override { return ix->overwriteRow(id, blob, label); }
     int dropLastRow() override { return ix->dropLastRow(); }
@@ -51,7 +67,7 @@ std::unique_ptr<ShardOps> make_flat_shard(const BFParams &p, void *logCtx, int d
 }  // namespace
 
 int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
-               const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts) {
+               const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row) {
     struct Cand {
         uint64_t gid;
         size_t label;
@@ -69,7 +85,7 @@ int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const 
             const size_t base = (p * nq + q) * cap;
             for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
         }
-        if (c.size() > k) {
+        if (!every_row && c.size() > k) {   // (every_row: scores may be NaN -- no order to select by; the heap loop below is the reference's)
             tmp.resize(c.size());
             for (size_t i = 0; i < c.size(); i++) tmp[i] = c[i].score;
             std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(k - 1), tmp.end());
@@ -202,22 +218,35 @@ long ShardedIndex::addSyntheticLocal(size_t rows_per_shard, uint64_t seed_base) 
 
 int ShardedIndex::deleteVector(size_t label) {
     if (synthetic_rows_) return -1;
+    // every process takes the same decisions from the same state (SPMD): shards or transports that cannot move rows are
+    // refused before anything changes, and no process leaves between the collectives below on a locally evaluated condition
+    if (!shards_[0]->supportsRowOps() || (ex_ && !ex_->canBroadcast())) return -1;
     auto f = label_to_gid_.find(label);
     if (f == label_to_gid_.end()) return 0;
     const uint64_t hole = f->second, last = n_global_ - 1;
     const size_t s_hole = plan_.owner(hole), s_last = plan_.owner(last);
     const size_t last_label = gid_to_label_[last];
     const size_t bytes = shards_[0]->storedBytes();
+    uint64_t failed = 0;
     if (hole != last) {
-        // the last row of the equivalent single index moves into the hole
-        std::vector<char> row(bytes);
-        if (owns(s_last) && shard(s_last)->readRow((uint32_t)plan_.local(last), row.data())) return -1;
-        if (ex_ && s_hole != s_last && ex_->broadcast(row.data(), bytes, (int)s_last)) return -1;
-        if (owns(s_hole) && shard(s_hole)->overwriteRow((uint32_t)plan_.local(hole), row.data(), last_label)) return -1;
+        // the last row of the equivalent single index moves into the hole; the owner's status travels with the row
+        std::vector<char> row(8 + bytes, 0);
+        if (owns(s_last) && shard(s_last)->readRow((uint32_t)plan_.local(last), row.data() + 8)) row[0] = 1;
+        if (ex_ && s_hole != s_last && ex_->broadcast(row.data(), 8 + bytes, (int)s_last)) return -1;   // (transport failure: fatal everywhere)
+        if (row[0]) failed = 1;
+        else if (owns(s_hole) && shard(s_hole)->overwriteRow((uint32_t)plan_.local(hole), row.data() + 8, last_label)) failed = 1;
+    }
+    if (!failed && owns(s_last) && shard(s_last)->dropLastRow()) failed = 1;
+    if (ex_) {   // agree on the outcome before the maps move
+        std::vector<uint64_t> all(plan_.world, 0);
+        if (ex_->allgather(&failed, 8, all.data())) return -1;
+        for (uint64_t v : all) failed |= v;
+    }
+    if (failed) return -1;
+    if (hole != last) {
         gid_to_label_[hole] = last_label;
         label_to_gid_[last_label] = hole;
     }
-    if (owns(s_last) && shard(s_last)->dropLastRow()) return -1;
     label_to_gid_.erase(label);
     gid_to_label_.pop_back();
     n_global_--;
@@ -225,26 +254,68 @@ int ShardedIndex::deleteVector(size_t label) {
 }
 
 // ---- query ----
-// One pass: candidates of the local shards at capacity `cap`, exchange, merge.  *overflow is set (identically on
-// every process) when some shard had more than `cap` rows tied at or below its local k-th score.
-int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_t k, size_t cap,
-                            std::vector<size_t> &out_labels, std::vector<double> &out_scores,
-                            std::vector<uint32_t> &out_counts, bool *overflow) {
+void ShardedIndex::takeTurn(uint64_t seq) {
+    if (seq == NO_SEQ) return;
+    std::unique_lock<std::mutex> lk(turn_mu_);
+    turn_cv_.wait(lk, [&] { return next_seq_ == seq; });
+}
+void ShardedIndex::passTurn(uint64_t seq) {
+    if (seq == NO_SEQ) return;
+    {
+        std::lock_guard<std::mutex> lk(turn_mu_);
+        next_seq_ = seq + 1;
+    }
+    turn_cv_.notify_all();
+}
+void ShardedIndex::stats(double out[6]) {
+    std::lock_guard<std::mutex> lk(stats_mu_);
+    out[0] = st_scan_, out[1] = st_wait_, out[2] = st_exchange_, out[3] = st_merge_, out[4] = st_batches_, out[5] = st_bytes_;
+}
+void ShardedIndex::resetStats() {
+    std::lock_guard<std::mutex> lk(stats_mu_);
+    st_scan_ = st_wait_ = st_exchange_ = st_merge_ = st_batches_ = st_bytes_ = 0;
+}
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+// One pass: candidates of the local shards at capacity `cap` (all_rows: every row's score, one query), exchange, merge.
+// Record of one shard: header u64 [4] = {flags (1 = shard failed, 2 = timeout callback fired), smallest gid of a row that can
+// score NaN, 0, 0} | counts u64 [nq] | gids u64 [nq][cap] | labels u64 [nq][cap] | scores f64 [nq][cap].  Whatever a process
+// learns locally (a failure, a timeout, NaN-capable rows) travels in the header, so every process takes the same decision
+// AFTER the exchange; nobody leaves before it.
+int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, bool local_timeout, bool all_rows,
+                            const std::function<bool()> &poll_timeout,
+                            const std::function<void(bool)> &turn_hook, std::vector<size_t> &out_labels,
+                            std::vector<double> &out_scores, std::vector<uint32_t> &out_counts, Pass *pass) {
     const size_t G = plan_.world, rec = recordBytes(nq, cap);
     const size_t n_mine = shards_.size();
-    // record of one shard: counts u64 [nq] | gids u64 [nq][cap] | labels u64 [nq][cap] | scores f64 [nq][cap]
     std::vector<char> mine(n_mine * rec, 0);
     std::vector<int> rcs(n_mine, 0);
+    const double t0 = now_ms();
     auto run = [&](size_t i) {
         const size_t s = rank_ < 0 ? i : (size_t)rank_;
         char *r = mine.data() + i * rec;
-        uint64_t *cnt = reinterpret_cast<uint64_t *>(r);
+        uint64_t *hdr = reinterpret_cast<uint64_t *>(r);
+        uint64_t *cnt = hdr + 4;
         uint64_t *gids = cnt + nq;
         size_t *labels = reinterpret_cast<size_t *>(gids + nq * cap);
         double *scores = reinterpret_cast<double *>(labels + nq * cap);
-        std::vector<uint32_t> ids(nq * cap), c32(nq);
-        rcs[i] = shards_[i]->candidates(queries, nq, stride, k, cap, ids.data(), labels, scores, c32.data());
-        if (rcs[i]) return;
+        const size_t fn = shards_[i]->firstNanRow();
+        hdr[1] = fn == (size_t)-1 ? ~0ull : gidOf(fn, s);
+        if (local_timeout) hdr[0] |= 2;
+        std::vector<uint32_t> ids(nq * cap), c32(nq, 0);
+        if (all_rows) {   // nq == 1
+            const size_t n_local = shards_[i]->size();
+            rcs[i] = n_local > cap ? -1 : shards_[i]->allScores(queries, ids.data(), labels, scores);
+            c32[0] = (uint32_t)n_local;
+        } else if (!local_timeout) {
+            rcs[i] = shards_[i]->candidates(queries, nq, stride, k, cap, ids.data(), labels, scores, c32.data());
+        }
+        if (rcs[i]) {
+            hdr[0] |= 1;
+            return;
+        }
         for (size_t q = 0; q < nq; q++) {
             cnt[q] = c32[q];
             if (c32[q] == 0xFFFFFFFFu) continue;
@@ -261,50 +332,89 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
     } else {
         run(0);
     }
-    int rc = 0;
-    for (int r : rcs) rc = rc ? rc : r;
+    if (poll_timeout && poll_timeout()) reinterpret_cast<uint64_t *>(mine.data())[0] |= 2;   // (polled again behind the scan)
+    const double t1 = now_ms();
     const char *all = mine.data();
     std::vector<char> gathered;
+    double t_turn = 0;
     if (ex_) {
-        // a failed shard still takes part in the exchange (a rank that skipped it would hang the others): it
-        // contributes a record flagged as failed
-        if (rc) reinterpret_cast<uint64_t *>(mine.data())[0] = 0xFFFFFFFEull;
+        const double tw = now_ms();
+        turn_hook(true);   // this batch's turn in the stream of exchanges (seq order on every process)
+        t_turn = now_ms() - tw;
         gathered.resize(G * rec);
         if (ex_->allgather(mine.data(), rec, gathered.data())) return -1;
         all = gathered.data();
-        for (size_t p = 0; p < G; p++)
-            if (reinterpret_cast<const uint64_t *>(all + p * rec)[0] == 0xFFFFFFFEull) return -1;
-    } else if (rc) {
-        return rc;
     }
+    const double t2 = now_ms();
     // repack for the merge: [part][nq][cap] arrays
     std::vector<uint32_t> counts(G * nq);
     std::vector<uint64_t> gids(G * nq * cap);
     std::vector<size_t> labels(G * nq * cap);
     std::vector<double> scores(G * nq * cap);
-    *overflow = false;
+    bool failed = false;
+    uint64_t min_nan = ~0ull;
     for (size_t p = 0; p < G; p++) {
         const char *r = all + p * rec;
-        const uint64_t *cnt = reinterpret_cast<const uint64_t *>(r);
+        const uint64_t *hdr = reinterpret_cast<const uint64_t *>(r);
+        const uint64_t *cnt = hdr + 4;
+        if (hdr[0] & 1) failed = true;
+        if (hdr[0] & 2) pass->timed_out = true;
+        min_nan = std::min(min_nan, hdr[1]);
         for (size_t q = 0; q < nq; q++) {
             counts[p * nq + q] = (uint32_t)cnt[q];
-            if ((uint32_t)cnt[q] == 0xFFFFFFFFu) *overflow = true;
+            if ((uint32_t)cnt[q] == 0xFFFFFFFFu) pass->overflow = true;
         }
         std::memcpy(gids.data() + p * nq * cap, cnt + nq, nq * cap * 8);
         std::memcpy(labels.data() + p * nq * cap, cnt + nq + nq * cap, nq * cap * 8);
         std::memcpy(scores.data() + p * nq * cap, cnt + nq + 2 * nq * cap, nq * cap * 8);
     }
-    if (*overflow) return 0;
-    out_labels.assign(nq * k, 0);
-    out_scores.assign(nq * k, 0.0);
-    out_counts.assign(nq, 0);
-    return merge_topk(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k, out_labels.data(),
-                      out_scores.data(), out_counts.data());
+    pass->nan_rows_at_head = !all_rows && min_nan < (uint64_t)k;
+    // every process knows by now whether this batch exchanges again (ties beyond cap, NaN-aware passes): if not, the turn
+    // goes to the next batch before the merge
+    if (failed || pass->timed_out || !(pass->overflow || pass->nan_rows_at_head || pass->more_follows)) turn_hook(false);
+    int rc = 0;
+    if (failed) rc = -1;
+    else if (!pass->timed_out && !pass->overflow) {
+        out_labels.assign(nq * k, 0);
+        out_scores.assign(nq * k, 0.0);
+        out_counts.assign(nq, 0);
+        rc = merge_topk(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k, out_labels.data(),
+                        out_scores.data(), out_counts.data(), all_rows);
+    }
+    const double t3 = now_ms();
+    {
+        std::lock_guard<std::mutex> lk(stats_mu_);
+        st_scan_ += t1 - t0, st_exchange_ += t2 - t1 - t_turn, st_merge_ += t3 - t2, st_bytes_ += ex_ ? (double)rec : 0.0;
+    }
+    return rc;
 }
 
 int ShardedIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
-                                 VecSimQueryReply_Order order, VecSimQueryReply **out) {
+                                 VecSimQueryReply_Order order, VecSimQueryReply **out, uint64_t seq) {
     void *tctx = qp ? qp->timeoutCtx : nullptr;
+    // (a batch with a sequence number takes and passes its turn even when there is nothing to exchange)
+    struct Turn {
+        ShardedIndex *sx;
+        uint64_t seq;
+        bool taken = false;
+        void take() {
+            if (!taken) {
+                const double t0 = now_ms();
+                sx->takeTurn(seq);
+                taken = true;
+                std::lock_guard<std::mutex> lk(sx->stats_mu_);
+                sx->st_wait_ += now_ms() - t0;
+            }
+        }
+        bool passed = false;
+        void release() {   // no further exchange belongs to this batch: the next batch's may go
+            if (passed) return;
+            take();
+            sx->passTurn(seq);
+            passed = true;
+        }
+        ~Turn() { release(); }
+    } turn{this, seq};
     if (nq == 0) return 0;
     std::vector<VecSimQueryReply *> reps(nq);
     for (auto &r : reps) r = new VecSimQueryReply();
@@ -312,40 +422,83 @@ int ShardedIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, 
         for (size_t q = 0; q < nq; q++) out[q] = reps[q];
         return 0;
     };
-    if (k == 0 || n_global_ == 0) return finish();
-    if (timed_out(tctx)) {
-        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+    auto fail_all = [&](int rc) {
+        for (auto *r : reps) delete r;
+        return rc;
+    };
+    auto time_out_all = [&]() {
+        for (auto *r : reps) {
+            r->results.clear();
+            r->code = VecSim_QueryReply_TimedOut;
+        }
         return finish();
-    }
+    };
+    if (k == 0 || n_global_ == 0) return finish();
+    // queries that can score NaN themselves (the same answer on every process: a function of the query alone)
+    std::vector<char> needs_all(nq, 0);
+    bool any_needs_all = false;
+    for (size_t q = 0; q < nq; q++)
+        if (shards_[0]->queryMayScoreNaN(static_cast<const char *>(queries) + q * stride)) needs_all[q] = 1, any_needs_all = true;
     std::vector<size_t> labels;
     std::vector<double> scores;
     std::vector<uint32_t> found;
     size_t cap = std::max<size_t>(2 * k, k + 16);
+    Pass pass;
+    // the timeout callback is polled locally before the scan; its verdict travels in the exchange (a process that left here
+    // on its own would strand the others in the collective)
+    bool local_timeout = timed_out(tctx);
+    const std::function<bool()> poll = [&]() { return timed_out(tctx); };
+    // the scan of a pass runs outside the turn (it overlaps with other batches' exchanges and merges on this process); the turn
+    // is taken right before the exchange and held until the reply is complete
+    // (after_exchange: the merge of the last pass runs outside the turn again)
+    const std::function<void(bool)> turn_hook = [&](bool before) {
+        if (before) turn.take();
+        else turn.release();
+    };
     for (;;) {
-        bool overflow = false;
-        int rc = queryOnce(queries, nq, stride, k, cap, labels, scores, found, &overflow);
-        if (rc) {
-            for (auto *r : reps) delete r;
-            return rc;
-        }
-        if (!overflow) break;
+        pass = Pass();
+        pass.more_follows = any_needs_all;
+        int rc = queryOnce(queries, nq, stride, k, cap, local_timeout, false, poll, turn_hook, labels, scores, found, &pass);
+        if (rc) return fail_all(rc);
+        if (pass.timed_out) return time_out_all();
+        if (!pass.overflow) break;
         // more than `cap` rows tie at some shard's k-th score: again with room for every tie (every process saw
         // the same counts, so all of them come back here together)
         const size_t biggest = synthetic_rows_ ? synthetic_rows_ : (n_global_ / plan_.world + plan_.block);
-        if (cap >= biggest) {
-            for (auto *r : reps) delete r;
-            return -1;
-        }
+        if (cap >= biggest) return fail_all(-1);
         cap = std::min(biggest, cap * 8);
     }
-    if (timed_out(tctx)) {
-        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
-        return finish();
+    // NaN-aware replies (brute_force.h:272: a NaN score enters the heap only while it fills): when a row that can score NaN sits
+    // below gid k, or the query itself can, the reference's reply depends on every row in id order -- those queries are answered
+    // from every shard's full score vector, one query per exchange
+    if (pass.nan_rows_at_head || any_needs_all) {
+        const size_t cap_all = synthetic_rows_ ? synthetic_rows_ : (n_global_ / plan_.world + plan_.block);
+        size_t last_q = 0;
+        for (size_t q = 0; q < nq; q++)
+            if (pass.nan_rows_at_head || needs_all[q]) last_q = q;
+        for (size_t q = 0; q < nq; q++) {
+            if (!pass.nan_rows_at_head && !needs_all[q]) continue;
+            std::vector<size_t> l1;
+            std::vector<double> s1;
+            std::vector<uint32_t> f1;
+            Pass p1;
+            p1.more_follows = q != last_q;
+            int rc = queryOnce(static_cast<const char *>(queries) + q * stride, 1, 0, k, cap_all, false, true, nullptr, turn_hook, l1, s1, f1, &p1);
+            if (rc) return fail_all(rc);
+            found[q] = f1[0];
+            for (size_t j = 0; j < f1[0]; j++) labels[q * k + j] = l1[j], scores[q * k + j] = s1[j];
+        }
     }
+    const double t0 = now_ms();
     for (size_t q = 0; q < nq; q++) {
         auto &res = reps[q]->results;
         for (size_t j = 0; j < found[q]; j++) res.push_back(VecSimQueryResult{labels[q * k + j], scores[q * k + j]});
         if (order == BY_ID) sort_reply(reps[q], BY_ID);
+    }
+    {
+        std::lock_guard<std::mutex> lk(stats_mu_);
+        st_merge_ += now_ms() - t0;
+        st_batches_ += 1;
     }
     return finish();
 }

@@ -165,7 +165,9 @@ class ShardedFlatIndex:
         pass  # every C-API call returns with its streams drained
 
     # ---- query ----
-    def knn_query(self, queries, k, order=VecSim.BY_SCORE):
+    def knn_query(self, queries, k, order=VecSim.BY_SCORE, seq=None, query_param=None, with_codes=False):
+        """seq: the batch's position in the stream of batches every process answers (several reader threads per process:
+        VecSimGpu_ShardedTopKQueryBatchArraysSeq); None = one reader, call order is the order"""
         q = self._blob(queries)
         q = q.reshape(-1, q.shape[-1])
         stride = q.strides[0]
@@ -176,12 +178,25 @@ class ShardedFlatIndex:
         nq = q.shape[0]
         labels = np.empty((nq, k), dtype=np.int64)
         dists = np.empty((nq, k), dtype=np.float64)
-        rc = self._lib.VecSimGpu_ShardedTopKQueryBatchArrays(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k, None,
-                                                            order, labels.ctypes.data_as(C.c_void_p),
-                                                            dists.ctypes.data_as(C.c_void_p), None)
+        codes = np.zeros(nq, dtype=np.int32)
+        qp = C.byref(query_param) if query_param is not None else None
+        rc = self._lib.VecSimGpu_ShardedTopKQueryBatchArraysSeq(self._h, q.ctypes.data_as(C.c_void_p), nq, stride, k, qp,
+                                                               order, labels.ctypes.data_as(C.c_void_p),
+                                                               dists.ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p),
+                                                               0xFFFFFFFFFFFFFFFF if seq is None else int(seq))
         if rc != 0:
             raise RuntimeError("sharded top-k failed: %s" % self._lib.VecSimGpu_LastError().decode())
-        return labels, dists
+        return (labels, dists, codes) if with_codes else (labels, dists)
+
+    def stats(self):
+        """wall ms per phase since reset_stats(): shard scans, waiting for the exchange turn, exchange, merge + replies"""
+        out = (C.c_double * 6)()
+        self._lib.VecSimGpu_ShardedGetStats(self._h, out)
+        return {"scan_ms": out[0], "turn_wait_ms": out[1], "exchange_ms": out[2], "merge_ms": out[3], "batches": int(out[4]),
+                "exchange_bytes": out[5]}
+
+    def reset_stats(self):
+        self._lib.VecSimGpu_ShardedResetStats(self._h)
 
     def __del__(self):
         if getattr(self, "_h", None):
