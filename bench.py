@@ -307,35 +307,63 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # the sharded exchange is a collective: every rank must issue its batches in the same order, so one reader there
-    readers = 1 if distributed else max(1, min(args.readers, args.steps))
-    for w in range(args.warmup):
-        ix.knn_query(qsets[w % nb_distinct], args.topk)
+    # The sharded exchange is a collective, so every rank must pair the same batches: batch b carries sequence number b and is
+    # answered by reader thread b % readers on every rank (the library issues the exchanges in sequence order whatever the
+    # threads' relative speed), so one batch's exchange + merge runs under the next batch's scan, as on a single GPU.
+    readers = max(1, min(args.readers, args.steps))
+    seq = [0]   # next sequence number of this rank's sharded index (same on every rank by construction)
+
+    def answer(b, qs):
+        return ix.knn_query(qs, args.topk, seq=b) if distributed else ix.knn_query(qs, args.topk)
+
+    def run_batches(first_seq, qsel, count):
+        """`count` batches, batch j (sequence number first_seq + j) on thread j % readers; returns the last batch's reply"""
+        if readers == 1:
+            out = None
+            for j in range(count):
+                out = answer(first_seq + j, qsets[qsel(j) % nb_distinct])
+            return out
+        res = list(pool.map(lambda t: [answer(first_seq + j, qsets[qsel(j) % nb_distinct]) for j in range(t, count, readers)][-1:],
+                            range(readers)))
+        return res[(count - 1) % readers][0]
     pool = None
     if readers > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(readers)
-        list(pool.map(lambda w: ix.knn_query(qsets[w % nb_distinct], args.topk), range(2 * readers)))   # lanes warm
+    nwarm = max(args.warmup, 2 * readers if readers > 1 else 0)   # (the reader lanes' scratch is sized on their first batches)
+    run_batches(seq[0], lambda j: j, nwarm)
+    seq[0] += nwarm
     local.reset_stats()
+    if distributed:
+        ix.reset_stats()
     sync()
     t0 = time.perf_counter()
-    last = None
-    if pool is None:
-        for s in range(args.steps):
-            last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk)
-    else:
-        # exactly `steps` batches, each answered end to end by one of the reader threads (ctypes drops the GIL in the call)
-        last = list(pool.map(lambda s: ix.knn_query(qsets[(args.warmup + s) % nb_distinct], args.topk), range(args.steps)))[-1]
+    last = run_batches(seq[0], lambda j: args.warmup + j, args.steps)
+    seq[0] += args.steps
     sync()
     dt = time.perf_counter() - t0
     if pool is not None:
         pool.shutdown()
+    st = local.stats()
+    per_rank = None
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    st = local.stats()
+        # where a rank's time went, per batch: scan kernel (HIP events), shard scan call (wall), waiting for the exchange turn,
+        # exchange, merge + replies -- gathered so that a scaling line can show where non-linearity comes from
+        sst = ix.stats()
+        nb = max(1, sst["batches"])
+        mine = torch.tensor([st["scan_ms"] / max(1, st["scan_launches"]), sst["scan_ms"] / nb, sst["turn_wait_ms"] / nb,
+                             sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h))],
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "scan_kernel_ms": float(t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
+                     "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
+                     "rccl_world": int(t[6])} for r, t in enumerate(allr)]
+        assert all(p["rccl_world"] == world for p in per_rank), per_rank   # every communicator spans all N ranks
 
     if rank == 0:
         total_rows = args.rows * world
@@ -378,9 +406,10 @@ def main():
                        "rows_per_gpu": args.rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
                        "reader_threads": readers,
-                       "exchange": "rccl ncclAllGather of per-shard candidate records + exact host merge (C++ host library)"
-                       if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
+                       "exchange": ("rccl ncclAllGather of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
+                                    "merge (C++ host library)" % world) if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
             "roofline": roof,
+            "per_rank_ms_per_batch": per_rank,
             "candidates_per_query": st["candidates"] / max(1, args.steps * args.batch),
             "fallbacks": int(st["fallbacks"]),
         }
