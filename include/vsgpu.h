@@ -43,7 +43,8 @@ enum {
     VSGPU_ERR_HIP = 2,
     VSGPU_ERR_ARG = 3,
     VSGPU_ERR_UNSUPPORTED = 4,
-    VSGPU_ERR_OOM = 5
+    VSGPU_ERR_OOM = 5,
+    VSGPU_ERR_TIMEOUT = 6      /* the caller's poll function asked to stop (vsgpu_set_poll) */
 };
 
 typedef struct vsgpu_ctx vsgpu_ctx;     /* one per (process, device): stream, scratch, timers */
@@ -181,6 +182,11 @@ typedef struct {
 } vsgpu_stats;
 void vsgpu_stats_reset(vsgpu_ctx *ctx);
 void vsgpu_stats_get(vsgpu_ctx *ctx, vsgpu_stats *out);
+/* poll(user) != 0 stops a top-k call between its launches -- behind the probe + threshold kernels and behind the filter /
+ * scan kernel (the stream is drained there first) -- with VSGPU_ERR_TIMEOUT; NULL (default) = no polling, no drains.  The
+ * reference polls its timeout callback once per scanned vector (brute_force.h:265); a kernel in flight cannot be recalled,
+ * so this is the finest grain the GPU path has. */
+void vsgpu_set_poll(vsgpu_ctx *ctx, int (*poll)(void *user), void *user);
 /* knobs: "mfma" (0/1: allow the MFMA filter stage), "dense_pairs", "probe_div", "cand_cap" */
 int vsgpu_set_option(vsgpu_ctx *ctx, const char *name, long value);
 

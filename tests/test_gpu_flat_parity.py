@@ -37,11 +37,16 @@ CASES = [(t, m, d) for t in ("f32", "f16", "bf16", "f64", "i8", "u8") for m in (
 CASES += [("f16", m, d) for m in ("L2", "IP", "Cosine") for d in (8, 12, 15, 16)]   # F16C tier (dims 8..15) and its upper edge
 
 
+CASES += [("f32", "L2", 4096), ("f32", "IP", 8192), ("f32", "Cosine", 12_000), ("f64", "L2", 6000), ("bf16", "IP", 12_000),
+          ("f16", "L2", 9000), ("i8", "Cosine", 16_000), ("u8", "L2", 18_000)]   # rows far wider than any MFMA filter: the table-driven
+                                                                              # kernels with up to 152 KiB of LDS (the reference takes any dim)
+
+
 @pytest.mark.parametrize("typ,metric,dim", CASES)
 def test_all_scores_bit_exact(vso, typ, metric, dim):
     """k = n returns every row: checks every distance and the full (score,label) order"""
     rng = np.random.default_rng(dim * 7 + len(typ))
-    n = 300
+    n = 300 if dim < 1000 else 120
     rows = random_vectors(rng, n, dim, typ, vso)
     q = random_vectors(rng, 3, dim, typ, vso)
     ix = make_index(typ, metric, dim)
@@ -340,6 +345,38 @@ def test_timeout_callback_at_launch_granularity():
     l, d, code = ix.knn_query_code(q, 5)
     assert code == 0 and np.all(l >= 0)
     del cb
+
+
+def test_timeout_callback_is_polled_between_the_launches_of_a_filtered_scan():
+    """the GPU pass polls a registered callback behind the probe + threshold kernels and behind the scan kernel (vsgpu_set_poll):
+    a callback that fires on its 2nd / 3rd call stops the batch there -- TimedOut, no results -- and the index answers the
+    next batch as if nothing had happened"""
+    dim, n, nq = 128, 60_000, 9
+    rng = np.random.default_rng(3)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    want = ix.knn_query(q, 10)
+    qp = VecSim.VecSimQueryParams()
+    qp.timeoutCtx = 1
+    for fire_at in (2, 3):
+        calls = [0]
+
+        def cb_fn(ctx):
+            calls[0] += 1
+            return 1 if calls[0] >= fire_at else 0
+        cb = VecSim.set_timeout_callback(cb_fn)
+        try:
+            l, d = ix.knn_query(q, 10, qp)
+            assert np.all(l == -1), fire_at
+            assert calls[0] == fire_at, (fire_at, calls)      # entry, behind the probe, behind the scan
+        finally:
+            VecSim.set_timeout_callback(None)
+        del cb
+    got = ix.knn_query(q, 10, qp)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
 def test_synthetic_rows_match_host_generator(vso):

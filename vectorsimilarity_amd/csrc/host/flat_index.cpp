@@ -753,7 +753,19 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     if (!nan_head)
         for (size_t q = 0; q < nq; q++)
             if (mayScoreNaN(qbuf.data() + q * query_bytes_)) every_row[q] = 1, n_every++;
+    // a registered timeout callback is also polled between the launches of the GPU pass (behind the probe and behind the scan)
+    struct PollScope {
+        vsgpu_ctx *c;
+        PollScope(vsgpu_ctx *cc, void *user) : c(cc) {
+            if (globals().timeout_cb && user) vsgpu_set_poll(c, [](void *u) { return timed_out(u) ? 1 : 0; }, user);
+        }
+        ~PollScope() { vsgpu_set_poll(c, nullptr, nullptr); }
+    } poll_scope(lane ? lane->ctx : ctx_, tctx);
     int rc = n_every == nq ? 0 : vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids.data(), sc.data(), counts.data());
+    if (rc == VSGPU_ERR_TIMEOUT) {
+        for (auto *r : reps) r->code = VecSim_QueryReply_TimedOut;
+        return finish();
+    }
     if (n_every)
         for (size_t q = 0; q < nq; q++)
             if (every_row[q]) counts[q] = VSGPU_COUNT_OVERFLOW;

@@ -133,6 +133,10 @@ extern "C" void vsgpu_stats_reset(vsgpu_ctx *c) {
     memcpy(c->stats.scan_kernel, name, sizeof name);
 }
 extern "C" void vsgpu_stats_get(vsgpu_ctx *c, vsgpu_stats *out) { *out = c->stats; }
+extern "C" void vsgpu_set_poll(vsgpu_ctx *c, int (*poll)(void *), void *user) {
+    c->poll = poll;
+    c->poll_user = user;
+}
 extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     std::string n(name);
     if (n == "mfma") c->opt_mfma = value;
@@ -196,17 +200,19 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
     // SQ8 accumulates the code dot product in the IP order whatever the metric (L2 is algebraic: L2.cpp:30-45)
     if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
-    // LDS budget 64 KiB: offs + BT query images
+    // LDS budget: offs + BT query images.  A CU has 160 KiB; up to 152 KiB go to one workgroup when a wide row needs them (the
+    // default 64 KiB held fp32 rows to ~7 K elements and left rows beyond ~1.8 K with one query per pass)
     size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
     size_t q_b = (size_t)t->prog.steps * t->prog.vl * acc_bytes(type);
-    size_t budget = 64 * 1024;
+    size_t budget = VSG_EXACT_LDS_BUDGET;
     if (offs_b + q_b > budget) {
         fail(VSGPU_ERR_UNSUPPORTED, "dim %zu too large for the table-driven kernel's LDS image", dim);
         delete t;
         return nullptr;
     }
+    // as many queries per pass as fit, but an 8-query tile only while two workgroups still share a CU (80 KiB each)
     size_t fit = (budget - offs_b) / q_b;
-    t->bt_max = fit >= 8 ? 8 : (fit >= 4 ? 4 : 1);
+    t->bt_max = (fit >= 8 && offs_b + 8 * q_b <= 80 * 1024) ? 8 : (fit >= 4 ? 4 : 1);
     if (!t->prog.fused || t->opk == OP_IP_DPBF16) t->bt_max = 1;  // these orders are only instantiated for BT=1
     {
         // fp32 MFMA filter: any dim up to 3072.  The kernel instance is the next compiled width (k-steps of 32
@@ -634,6 +640,8 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
 
 // ------------------------------------------------------------------ kernel dispatch
 template <int EK, int OPK, int BT> static void launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024)   // beyond the default dynamic-LDS limit: raised per kernel instance
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan<EK, OPK, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_exact_scan<EK, OPK, BT>), grid, dim3(256), lds, s, P);
 }
 template <int EK, int OPK> static void launch_scan_bt(int bt, const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {

@@ -68,7 +68,17 @@ struct vsgpu_ctx {
     long opt_probe_run = -1;          // probe tiles per contiguous run, as a shift; -1 = about 2 MiB per run (probe_run_shift())
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
+    int (*poll)(void *) = nullptr;   // vsgpu_set_poll
+    void *poll_user = nullptr;
 };
+// between the launches of a top-k call: drain the stream and ask the caller's poll function (no-op without one)
+#define VSG_POLL_POINT(c)                                                          \
+    do {                                                                           \
+        if ((c)->poll) {                                                           \
+            HIPCHK(hipStreamSynchronize((c)->stream));                             \
+            if ((c)->poll((c)->poll_user)) return VSGPU_ERR_TIMEOUT;               \
+        }                                                                          \
+    } while (0)
 
 int poison_byte();
 void poison(void *p, size_t bytes);
@@ -134,6 +144,7 @@ struct vsgpu_table {
 };
 
 static inline size_t acc_bytes(int type) { return type == VSGPU_F64 ? 8 : 4; }
+constexpr size_t VSG_EXACT_LDS_BUDGET = 152 * 1024;   // dynamic LDS of k_exact_scan: lane table + query images
 
 // widen one stored element to the accumulator type (host side of the LDS query image only)
 static inline float widen_f16(uint16_t h) {

@@ -580,6 +580,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
         if (rc) return rc;
     }
+    VSG_POLL_POINT(c);
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {
@@ -667,6 +668,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    VSG_POLL_POINT(c);
     if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512))) {  // diagnosis variants of the 32x32x32 kernel: time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_i8_filter_x32(dbg)");

@@ -248,6 +248,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
         if (rc) return rc;
     }
+    VSG_POLL_POINT(c);
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {   // filter: every tile once
@@ -262,6 +263,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    VSG_POLL_POINT(c);
     wm0.mark("launches");
     rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
