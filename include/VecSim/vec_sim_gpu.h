@@ -181,6 +181,7 @@ typedef struct {
     double other_ms;
     uint64_t candidates;
     uint64_t fallbacks;
+    uint64_t retries;
     char scan_kernel[64];
 } VecSimGpuStats;
 void VecSimGpu_ResetStats(VecSimIndex *index);

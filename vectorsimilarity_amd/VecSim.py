@@ -271,7 +271,7 @@ class VecSimIndex:
         self._lib.VecSimGpu_GetStats(self._h, C.byref(s))
         return {"scan_ms": s.scan_ms, "scan_launches": s.scan_launches, "scan_rows": s.scan_rows,
                 "scan_bytes": s.scan_bytes, "other_ms": s.other_ms, "candidates": s.candidates,
-                "fallbacks": s.fallbacks, "scan_kernel": s.scan_kernel.decode()}
+                "fallbacks": s.fallbacks, "retries": s.retries, "scan_kernel": s.scan_kernel.decode()}
 
     def set_option(self, name, value):
         if self._lib.VecSimGpu_SetOption(self._h, name.encode(), int(value)) != 0:

@@ -91,7 +91,7 @@ class VecSimIndexBasicInfo(C.Structure):
 class VecSimGpuStats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_uint64), ("scan_rows", C.c_uint64),
                 ("scan_bytes", C.c_uint64), ("other_ms", C.c_double), ("candidates", C.c_uint64),
-                ("fallbacks", C.c_uint64), ("scan_kernel", C.c_char * 64)]
+                ("fallbacks", C.c_uint64), ("retries", C.c_uint64), ("scan_kernel", C.c_char * 64)]
 
 
 TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)

@@ -388,6 +388,7 @@ extern "C" void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out) {
         s.other_ms += l.other_ms;
         s.candidates += l.candidates;
         s.fallbacks += l.fallbacks;
+        s.retries += l.retries;
         if (!s.scan_kernel[0]) std::memcpy(s.scan_kernel, l.scan_kernel, sizeof s.scan_kernel);
     }
     std::memcpy(out, &s, sizeof s);

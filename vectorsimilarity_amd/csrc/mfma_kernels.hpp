@@ -537,11 +537,10 @@ static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *can
     __shared__ uint32_t wpos;
     const int q = blockIdx.x;
     const uint32_t raw = counts[q];
-    if (raw > cap) {  // candidate list overflowed: the host falls back to a dense exact pass
-        if (threadIdx.x == 0) out_counts[q] = 0xFFFFFFFFu;
-        return;
-    }
-    const uint32_t n = raw;
+    // (a list that overflowed is selected from all the same: the k-th smallest exact score of the slots that were filled bounds
+    // the true k-th score from above, and the host runs one more filter pass with it -- collect_candidates; it knows from the
+    // raw count that the list is truncated)
+    const uint32_t n = min(raw, cap);
     const uint2 *c = cand + (size_t)q * cap;
     uint32_t T = 0xFFFFFFFFu;
     if (n > k) {

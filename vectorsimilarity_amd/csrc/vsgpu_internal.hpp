@@ -68,6 +68,9 @@ struct vsgpu_ctx {
     long opt_probe_run = -1;          // probe tiles per contiguous run, as a shift; -1 = about 2 MiB per run (probe_run_shift())
     long opt_cand_cap = 8192;         // candidate slots per query
     int n_cu = 256;
+    // second filter pass of queries whose candidate list overflowed (collect_candidates): thresholds handed over instead of probed
+    const float *tau_override = nullptr;
+    bool in_retry = false;
     int (*poll)(void *) = nullptr;   // vsgpu_set_poll
     void *poll_user = nullptr;
 };

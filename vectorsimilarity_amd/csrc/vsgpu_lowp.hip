@@ -515,6 +515,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipMemcpyAsync(c->qfrag2.p, frag32.data(), frag32.size(), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
+    if (have_tau)
+        for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
     HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
 
@@ -563,7 +566,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
 
     ScanChainGuard chain(t);   // behind the other reader lanes' probe + scan (see topk_mfma)
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
-    {
+    if (!have_tau) {
         LowpParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;

@@ -192,6 +192,9 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
+    const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
+    if (have_tau)
+        for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
     HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
     wm0.mark("uploads");
@@ -234,7 +237,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // lane's scan is this lane's query upload before, and its re-rank, selection, download and host replay after
     ScanChainGuard chain(t);
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
-    {   // probe: strided tiles -> per (tile, query) upper bounds
+    if (!have_tau) {   // probe: strided tiles -> per (tile, query) upper bounds
         MfmaParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;
