@@ -543,6 +543,34 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
     assert np.array_equal(replies[0][0][0], el.astype(np.int64)) and np.array_equal(replies[0][1][0], es)
 
 
+@pytest.mark.parametrize("metric,dim,n,nq,k", [
+    ("L2", 4096, 9_000, 64, 10),       # four query tiles of 16
+    ("IP", 3500, 7_001, 20, 5),        # zero query columns past dim, partial last tile
+    ("Cosine", 6144, 5_000, 33, 10),
+    ("L2", 8192, 3_000, 17, 10),
+    ("L2", 5000, 6_000, 70, 100),
+])
+def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
+    """rows beyond 3072 elements: 16 queries per workgroup, the k range split over the waves by ring stage, partial dot products
+    joined in LDS (mfma_wide_kernels.hpp) -- filter + exact re-rank against the exact path and the oracle, 0 ulp"""
+    rng = np.random.default_rng(dim + n)
+    rows = random_vectors(rng, n, dim, "f32", vso)
+    q = random_vectors(rng, nq, dim, "f32", vso)
+    ix = make_index("f32", metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"] == "k_mfma_filter_wide" and st["fallbacks"] == 0, st
+    ix.set_option("mfma", 0)
+    l2, d2 = ix.knn_query(q[:6], k)
+    assert np.array_equal(l1[:6], l2) and np.array_equal(d1[:6], d2)
+    for j in range(0, nq, 7):
+        el, es = oracle_topk(vso, "f32", metric, rows, q[j], k)
+        assert np.array_equal(l1[j], el.astype(np.int64)) and np.array_equal(d1[j], es), (metric, dim, j)
+
+
 def test_mfma_filter_adversarial_near_duplicates(vso):
     """rows within the bf16 error band of each other: the filter cannot separate them, the candidate
     lists overflow and the exact fallback must still give the reference answer (with ties)"""

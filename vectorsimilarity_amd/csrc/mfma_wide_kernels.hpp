@@ -1,0 +1,247 @@
+// mfma_wide_kernels.hpp -- the fp32 MFMA filter for rows wider than k_mfma_filter's registers hold (3072 < dim <= 8192).
+//
+// k_mfma_filter keeps the bf16 fragments of 64 queries in registers (16 per wave); at dim 4096 those alone are the whole
+// register file of a CU.  This variant keeps 16 queries per WORKGROUP and splits the row's k range over the four waves by
+// ring stage: wave w multiplies the stages c with c % 4 == w (one stage = 16 rows x 1 KiB = 256 elements of k), so a wave holds
+// KSTEPS / 4 fragments -- 128 registers at dim 4096, 256 at dim 8192 --, and the four partial dot products of a tile meet in
+// LDS (3 KiB) before the epilogue, which wave 0 runs.  Ring, swizzle, counted vmcnt, candidate queue and the bound E are
+// k_mfma_filter's (mfma_kernels.hpp).  A batch of 64 queries is four query tiles (blockIdx.y): the rows are
+// requested with the default cache policy, not non-temporal, so that the other three tiles' reads of a row hit L2 / the
+// Infinity Cache (workgroups x, x + gridDim.x, ... share an XCD when gridDim.x is a multiple of 8).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mfma_kernels.hpp"
+
+namespace vsg {
+
+constexpr int MFW_QTILE = 16;
+constexpr int MFW_RED_BYTES = 3 * 64 * 16;
+constexpr int mfw_lds_bytes(bool probe) {
+    return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + MFW_RED_BYTES + (probe ? MF_PM_TILES * 64 : 0);
+}
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
+    constexpr int NS = 3, RT = 16;
+    constexpr int KC = (MF_STAGE_BYTES / 4) / RT;    // 256 elements per row per stage
+    constexpr int SEG = KC * 4;                      // 1 KiB
+    constexpr int KSUB = KC / 32;                    // 8 MFMA k-steps per stage
+    static_assert(KSTEPS % (4 * KSUB) == 0, "the row is a whole number of stage quadruples");
+    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
+    constexpr int KMINE = KSTEPS / 4;                // k-steps of one wave
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15;
+    const int kq = lane >> 4;
+    const int qtile = blockIdx.y;
+
+    // this wave's fragments: the k-steps of stages wave, wave + 4, ...
+    bf16x8_t qf[KMINE];
+    {
+        const uint4 *src = P.qfrag + ((size_t)qtile * KSTEPS) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KMINE; i++) {
+            const int s = ((i / KSUB) * 4 + wave) * KSUB + (i % KSUB);
+            uint4 v = src[(size_t)s * 64];
+            qf[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    const int qidx = qtile * MFW_QTILE + m16;
+    float nq2 = P.qn2[qidx];
+    float tau = 0.f;
+    if (MODE == MF_FILTER) tau = P.tau[qidx];
+#pragma unroll
+    for (int i = 0; i < KMINE; i++) asm volatile("" : "+v"(qf[i]));
+    asm volatile("" : "+v"(nq2), "+v"(tau));
+
+    uint32_t st_row[4], st_off[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t L = 1024u * (uint32_t)(4 * wave + t) + 16u * (uint32_t)lane;
+        const uint32_t row = L / SEG, slot = (L % SEG) / 16;
+        st_row[t] = row;
+        st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
+    }
+    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
+    char *norm_lds = lds + NS * MF_STAGE_BYTES;
+    const bool norm_loader = wave == 0;
+    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + 512);
+    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + 512 + 16);
+    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
+    const uint32_t red_off = mf_lds_offset(lds + NS * MF_STAGE_BYTES + 512 + MF_EQ_BYTES);
+    if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
+
+    const uint32_t step = gridDim.x;
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {
+        return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
+    };
+    const char *rp_cur[4], *rp_nxt[4];
+    const float *np_cur, *np_nxt;
+    uint32_t cur_slab = 0xFFFFFFFFu;
+    uint64_t cur_sbase = 0, cur_nbase = 0;
+    auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
+        uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;
+        const uint32_t r0 = tile_row0(tt);
+        const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
+        if (sidx != cur_slab) {   // scalar loads: a vector load here would put a vmcnt(0) into every tile
+            cur_slab = sidx;
+            const char *const *sp = P.slabs + sidx;
+            const float *const *npp = P.norm_slabs + sidx;
+            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(cur_sbase), "=&s"(cur_nbase)
+                         : "s"(sp), "s"(npp)
+                         : "memory");
+        }
+        const char *sbase = reinterpret_cast<const char *>(cur_sbase);
+        const float *nbase = reinterpret_cast<const float *>(cur_nbase);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t row = r0 + st_row[i];
+            if (row >= P.n_rows) row = P.n_rows - 1;
+            rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + st_off[i];
+        }
+        uint32_t nrow = r0 + lane;
+        if (nrow >= P.n_rows) nrow = P.n_rows - 1;
+        np = nbase + (nrow & P.slab_mask);
+    };
+    auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_parity) {
+        const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
+#pragma unroll
+        for (int i = 0; i < 4; i++) glds16<0>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
+        if (with_norm && norm_loader) glds4(np, norm_parity * 256, norm_lds);
+    };
+
+    uint32_t tile = blockIdx.x;
+    make_ptrs(tile, rp_cur, np_cur);
+    make_ptrs(tile + step, rp_nxt, np_nxt);
+    uint32_t slot_c = 0, parity = 0;
+#pragma unroll
+    for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
+
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false) + (uint32_t)m16 * 4u;
+    uint32_t pm_n = 0, pm_tile0 = 0;
+    auto flush_probe_minima = [&]() {   // (wave 0 only)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
+            float v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + it * 64u) : "memory");
+            P.tilemin[(size_t)qidx * P.tilemin_stride + pm_tile0 + it * step] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pm_n = 0;
+    };
+    for (; tile < P.n_tiles; tile += step) {
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            {   // unit (tile, c) landed; one younger unit (4 loads, + the norm load of a unit that opens a tile) may be in flight
+                const bool opens = (c + 1) % KCH == 0;
+                if (opens && norm_loader) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            mf_ring_barrier();
+            if (MODE == MF_FILTER && c == 0) {
+                if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+            }
+            {
+                constexpr int D = NS - 1;
+                uint32_t slot_p = slot_c + D;
+                if (slot_p >= NS) slot_p -= NS;
+                const int cc = c + D;
+                if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
+                else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, parity ^ 1u);
+            }
+            if ((c & 3) == wave) {   // this wave's stage
+                const char *sbase = lds + slot_c * MF_STAGE_BYTES;
+#pragma unroll
+                for (int j = 0; j < KSUB; j++) {
+                    const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
+                    const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
+                    const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
+                    f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+                    f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+                    f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
+                }
+            }
+            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+        }
+        // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS; wave 0 goes on ----
+        if (wave != 0) {
+            const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(red_off + (uint32_t)((wave - 1) * 1024 + lane * 16)), "v"(v) : "memory");
+        }
+        mf_ring_barrier();
+        const uint32_t r0 = tile_row0(tile);
+        bool emitted = false;
+        if (wave == 0) {
+            mf_u32x4 p1, p2, p3;
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                         : "v"(red_off + (uint32_t)(lane * 16))
+                         : "memory");
+            acc += __builtin_bit_cast(f32x4_t, p1);
+            acc += __builtin_bit_cast(f32x4_t, p2);
+            acc += __builtin_bit_cast(f32x4_t, p3);
+            const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * 256);
+            mf_u32x4 nbits;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
+            const f32x4_t n4 = __builtin_bit_cast(f32x4_t, nbits);
+            float tmin = INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t row = r0 + kq * 4 + i;
+                const float ssum = n4[i] + nq2;
+                const float dot = acc[i];
+                const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
+                const float E = P.cE * ssum + P.absE;
+                if (MODE == MF_PROBE) {
+                    const float up = a + E;
+                    if (row < P.n_rows && up < tmin) tmin = up;
+                } else {
+                    const float low = a - E;
+                    if (row < P.n_rows && !(low > tau)) {
+                        const uint32_t pos = mf_queue_reserve(eq_n_off);
+                        if (pos < MF_EQ_CAP) {
+                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));
+                        } else {
+                            uint32_t s = atomicAdd(&P.counts[qidx], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            emitted = true;
+                        }
+                    }
+                }
+            }
+            if (MODE == MF_PROBE) {
+                tmin = fminf(tmin, __shfl_xor(tmin, 16));
+                tmin = fminf(tmin, __shfl_xor(tmin, 32));
+                if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + pm_n * 64u), "v"(tmin) : "memory");
+                if (pm_n == 0) pm_tile0 = tile;
+                if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
+            }
+        }
+        if (MODE == MF_FILTER) {
+            if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) rp_cur[i] = rp_nxt[i];
+        np_cur = np_nxt;
+        make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
+        parity ^= 1u;
+    }
+    if (MODE == MF_PROBE && wave == 0 && pm_n) flush_probe_minima();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (MODE == MF_FILTER) {
+        __builtin_amdgcn_s_barrier();
+        mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+    }
+}
+
+}  // namespace vsg

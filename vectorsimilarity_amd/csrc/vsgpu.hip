@@ -218,7 +218,8 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         // fp32 MFMA filter: any dim up to 3072.  The kernel instance is the next compiled width (k-steps of 32
         // elements); the columns past `dim` hold the start of the next row in LDS and zeros in the query fragments
         // (finite x 0 = 0; a NaN there only makes the filter pass the row on to the exact re-rank).
-        static const int kInst[] = {4, 6, 8, 10, 12, 16, 20, 24, 28, 30, 32, 40, 48, 64, 80, 96};
+        // (widths 128 / 192 / 256 -- dims up to 4096 / 6144 / 8192 -- run on k_mfma_filter_wide, mfma_wide_kernels.hpp)
+        static const int kInst[] = {4, 6, 8, 10, 12, 16, 20, 24, 28, 30, 32, 40, 48, 64, 80, 96, 128, 192, 256};
         size_t ks = 0;
         for (int v : kInst)
             if ((size_t)v * 32 >= dim) {

@@ -1,6 +1,7 @@
 // vsgpu_mfma.hip -- fp32 MFMA filter path of vsgpu_topk (kernels: mfma_kernels.hpp)
 #include "vsgpu_internal.hpp"
 #include "mfma_kernels.hpp"
+#include "mfma_wide_kernels.hpp"
 
 using namespace vsg;
 
@@ -133,12 +134,27 @@ static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t
     }
 }
 
+// rows wider than 3072 elements: 16 queries per workgroup, the k range split over the waves (mfma_wide_kernels.hpp)
+template <int KS, int MODE> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+    auto kern = k_mfma_filter_wide<KS, MODE>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P);
+}
+template <int MODE> static void launch_wide(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    switch (ksteps) {
+    case 128: launch_wide_ks<128, MODE>(P, grid, s); break;
+    case 192: launch_wide_ks<192, MODE>(P, grid, s); break;
+    default: launch_wide_ks<256, MODE>(P, grid, s); break;
+    }
+}
+
 int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                      uint32_t *ids, double *scores, uint32_t *counts) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n, dim = t->dim;
     const int KS = t->ksteps;
-    const size_t q_tiles = (nq + MF_QTILE - 1) / MF_QTILE, nqp = q_tiles * MF_QTILE;
+    const bool wide = KS > 96;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
+    const size_t QT = wide ? (size_t)MFW_QTILE : (size_t)MF_QTILE, TILE_ROWS = wide ? 16 : (size_t)MF_TILE_ROWS;
+    const size_t q_tiles = (nq + QT - 1) / QT, nqp = (nq + MF_QTILE - 1) / MF_QTILE * MF_QTILE;
     const bool l2 = (t->metric == VSGPU_L2);
 
     // (1) bf16 B-operand fragments + |q|^2 for the filter, (2) exact-order query images for the re-rank -- staged behind the
@@ -184,10 +200,10 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     if (rc) return rc;
     rc = ensure(c, c->counts, nqp * 4);
     if (rc) return rc;
-    const uint32_t total_tiles = (uint32_t)((n + MF_TILE_ROWS - 1) / MF_TILE_ROWS);
+    const uint32_t total_tiles = (uint32_t)((n + TILE_ROWS - 1) / TILE_ROWS);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
-    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * MF_TILE_ROWS);
+    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -241,11 +257,12 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         MfmaParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;
-        Q.tile_run_shift = probe_run_shift(c, (size_t)MF_TILE_ROWS * t->row_bytes, probe_tiles);
+        Q.tile_run_shift = probe_run_shift(c, TILE_ROWS * t->row_bytes, probe_tiles);
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        if (wide) launch_wide<MF_PROBE>(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        else if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
@@ -260,7 +277,12 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
         const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_wg_per_cu;
-        if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
+        if (wide) {
+            // one workgroup per CU and query tile in flight at a time per XCD slot: gridDim.x a multiple of 8, so the query
+            // tiles of a row tile (blockIdx.y) land on one XCD and share its L2
+            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            launch_wide<MF_FILTER>(KS, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
+        } else if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         else if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
             launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         HIPCHK(hipGetLastError());
@@ -274,5 +296,5 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     wm0.flush("mfma_pre");
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
-    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_mfma_filter", &chain);
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, wide ? "k_mfma_filter_wide" : "k_mfma_filter", &chain);
 }
