@@ -670,6 +670,17 @@ def test_reply_objects_and_array_entry_points_agree():
     ("u8", "Cosine", 1024, 30_000, 70, 10),     # uint8 Cosine: two aux values per row (sum x', stored norm) in 16-byte records
     ("u8", "Cosine", 768, 20_000, 260, 100),
     ("u8", "Cosine", 300, 40_000, 33, 5),
+    ("i8", "L2", 2048, 12_000, 140, 10),        # rows of 1025 .. 2048 elements: 8 waves x 16 queries, 16-row tiles
+    ("i8", "Cosine", 2000, 9_000, 70, 10),
+    ("u8", "IP", 1500, 10_000, 33, 5),
+    ("u8", "Cosine", 2048, 8_000, 128, 10),
+    ("i8", "IP", 3072, 6_000, 130, 10),
+    ("u8", "L2", 2500, 6_000, 64, 10),
+    ("i8", "Cosine", 4096, 5_000, 70, 10),      # 4 waves x 16 queries, fragments in AGPRs
+    ("u8", "Cosine", 3600, 4_000, 20, 5),
+    ("bf16", "IP", 2048, 9_000, 70, 10),        # 4 waves x 16 queries, fragments in AGPRs
+    ("f16", "L2", 1800, 7_000, 20, 10),
+    ("bf16", "Cosine", 1600, 6_000, 64, 5),
     ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's exact query tile: 256 queries, top-100
     ("bf16", "IP", 768, 40_000, 128, 10),       # BASELINE config 4's exact query tile: 128 queries, top-10
 ])

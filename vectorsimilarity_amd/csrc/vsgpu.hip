@@ -243,17 +243,18 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         // 1536 elements; int8/uint8: 512, 768, 1024) with zero query columns past `dim`
         // (the avx512_bf16 tier rides the same filter: E covers any accumulation order of the exact bf16 products, its
         // absolute term the flushed subnormals; survivors are re-scored in the vdpbf16ps order)
-        if (!t->prog.scalar_tier && t->prog.reduce == 0 && (type == VSGPU_BF16 || type == VSGPU_F16) && dim <= 1536 &&
+        if (!t->prog.scalar_tier && t->prog.reduce == 0 && (type == VSGPU_BF16 || type == VSGPU_F16) && dim <= 2048 &&
             row_bytes == data_bytes) {
-            static const int w16[] = {8, 16, 24, 32, 48};
-            static const int rt16[] = {64, 32, 32, 16, 16};
-            for (int i = 0; i < 5; i++)
+            // (width 2048: 4 waves x 16 queries, the 64 fragments of a wave in AGPRs -- a 64-query tile)
+            static const int w16[] = {8, 16, 24, 32, 48, 64};
+            static const int rt16[] = {64, 32, 32, 16, 16, 16};
+            for (int i = 0; i < 6; i++)
                 if ((size_t)w16[i] * 32 >= dim) {
                     t->lowp_ok = true;
                     t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
                     t->lp_ksteps = w16[i];
                     t->lp_rt = rt16[i];
-                    t->lp_qtile = 128;
+                    t->lp_qtile = w16[i] == 64 ? 64 : 128;
                     break;
                 }
         }
@@ -265,6 +266,16 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_rt = 64;
             t->lp_qtile = 128;
             t->aux_bytes = 16;
+        }
+        if ((type == VSGPU_I8 || type == VSGPU_U8) && dim > 1024 && dim <= 4096) {
+            // widths 2048 / 3072: 8 waves x 16 queries (128 / 192 registers of fragments per wave), 16-row tiles, a 128-query
+            // tile; width 4096: 4 waves x 16 queries, the 64 fragments of a wave in AGPRs, a 64-query tile
+            t->lowp_ok = true;
+            t->lp_kind = type == VSGPU_I8 ? LP_I8 : (metric == VSGPU_COSINE ? LP_U8C : LP_U8);
+            if (t->lp_kind == LP_U8C) t->aux_bytes = 16;
+            t->lp_ksteps = dim <= 2048 ? 32 : (dim <= 3072 ? 48 : 64);
+            t->lp_rt = 16;
+            t->lp_qtile = dim <= 3072 ? 128 : 64;
         }
         if ((type == VSGPU_I8 || type == VSGPU_U8) && dim <= 1024) {
             t->lowp_ok = true;

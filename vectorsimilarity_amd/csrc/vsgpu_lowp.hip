@@ -110,6 +110,10 @@ template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams
     case 16: launch_lowp_t<LK, 16, 32, 1>(mode, P, grid, s); break;
     case 24: launch_lowp_t<LK, 24, 32, 1>(mode, P, grid, s); break;
     case 48: launch_lowp_t<LK, 48, 16, 1>(mode, P, grid, s); break;  // d = 1536: 192 VGPRs of query fragments per wave
+    case 64:   // d = 2048: 4 waves x 16 queries, 256 registers of fragments per wave (AGPRs)
+        if (mode == MF_PROBE) launch_lowp_k<LK, 64, MF_PROBE, 16, 4, 1, 1, 3>(P, grid, s);
+        else launch_lowp_k<LK, 64, MF_FILTER, 16, 4, 1, 1, 3>(P, grid, s);
+        break;
     default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
     }
 }
@@ -224,6 +228,19 @@ template <int LK> static void launch_i8_ksplit(int flavour, const LowpParams &P,
     }
 }
 #endif
+// int8 / uint8 rows of 1025 .. 2048 elements: 8 waves x 16 queries, 16-row tiles of two 16 KiB stages
+template <int LK> static void launch_lowp_w2048(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, 32, MF_PROBE, 16, 8, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, 32, MF_FILTER, 16, 8, 1, 1, 3>(P, grid, s);
+}
+template <int LK> static void launch_lowp_w3072(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (mode == MF_PROBE) launch_lowp_k<LK, 48, MF_PROBE, 16, 8, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, 48, MF_FILTER, 16, 8, 1, 1, 3>(P, grid, s);
+}
+template <int LK> static void launch_lowp_w4096(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {   // 4 waves, fragments in AGPRs
+    if (mode == MF_PROBE) launch_lowp_k<LK, 64, MF_PROBE, 16, 4, 1, 1, 3>(P, grid, s);
+    else launch_lowp_k<LK, 64, MF_FILTER, 16, 4, 1, 1, 3>(P, grid, s);
+}
 static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
 #ifdef VSGPU_TUNING
     // measured, not faster than the 16 x 16 kernel (profiles/r02_i8_ksplit.txt): tuning build only
@@ -238,6 +255,9 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_U8C) {
         switch (t->lp_ksteps) {
+        case 32: launch_lowp_w2048<LP_U8C>(mode, P, grid, s); break;
+        case 48: launch_lowp_w3072<LP_U8C>(mode, P, grid, s); break;
+        case 64: launch_lowp_w4096<LP_U8C>(mode, P, grid, s); break;
         case 8: launch_lowp_i8<8, 64, LP_U8C>(mode, P, grid, s); break;
         case 12: launch_lowp_i8<12, 64, LP_U8C>(mode, P, grid, s); break;
         default:
@@ -253,6 +273,9 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         }
     } else if (t->lp_kind == LP_U8) {
         switch (t->lp_ksteps) {
+        case 32: launch_lowp_w2048<LP_U8>(mode, P, grid, s); break;
+        case 48: launch_lowp_w3072<LP_U8>(mode, P, grid, s); break;
+        case 64: launch_lowp_w4096<LP_U8>(mode, P, grid, s); break;
         case 8: launch_lowp_i8<8, 64, LP_U8>(mode, P, grid, s); break;
         case 12: launch_lowp_i8<12, 64, LP_U8>(mode, P, grid, s); break;
         default:
@@ -265,6 +288,9 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
         // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
         switch (t->lp_ksteps) {
+        case 32: launch_lowp_w2048<LP_I8>(mode, P, grid, s); break;
+        case 48: launch_lowp_w3072<LP_I8>(mode, P, grid, s); break;
+        case 64: launch_lowp_w4096<LP_I8>(mode, P, grid, s); break;
         case 8: launch_lowp_i8<8, 64>(mode, P, grid, s); break;
         case 12: launch_lowp_i8<12, 64>(mode, P, grid, s); break;
         default:
