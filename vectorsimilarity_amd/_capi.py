@@ -163,7 +163,7 @@ GPU_EXPORTS = [
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_table_set_sq8_block_bounds", "vsgpu_stats_reset",
-    "vsgpu_stats_get", "vsgpu_set_option",
+    "vsgpu_stats_get", "vsgpu_set_option", "vsgpu_set_poll",
     "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
     "vsgpu_comm_allgather", "vsgpu_comm_broadcast",
 ]
