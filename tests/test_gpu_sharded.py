@@ -203,6 +203,34 @@ def test_nan_score_rows_and_queries_across_shards(vso, typ, metric, dim, k):
     assert np.array_equal(gl, sl) and np.array_equal(gs, ss, equal_nan=True)
 
 
+@pytest.mark.parametrize("typ,metric,dim,G", [("f32", "L2", 32, 3), ("bf16", "IP", 64, 2), ("i8", "Cosine", 48, 4)])
+def test_multi_value_index_across_shards(vso, typ, metric, dim, G):
+    """BFParams.multi over shards: a label's vectors land on different shards, every shard returns the rows that cover k local
+    labels, the union goes through the reference's label-keyed heap in gid order (brute_force_multi.h:108-277) -- the reply
+    equals the single multi-value index's (pinned on the oracle in tests/test_gpu_flat_parity.py), duplicated rows (ties) included"""
+    rng = np.random.default_rng(dim + G)
+    n, n_labels, nq, block = 4000, 700, 7, 16
+    base = random_vectors(rng, 900, dim, typ, vso)
+    rows = base[rng.integers(0, 900, n)]           # repeated vectors: equal scores under different labels
+    labels = rng.integers(0, n_labels, n)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    pm = params(typ, metric, dim, block)
+    pm.multi = True
+    sx = ShardedFlatIndex(pm, shards=G)
+    one = VecSim.BFIndex(pm)
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    assert sx.index_size() == n
+    for k in (10, 1, 300, 900):                    # 900 > the label count: every label comes back
+        gl, gs = sx.knn_query(q, k)
+        sl, ss = one.knn_query(q, k)
+        assert np.array_equal(gl, sl) and np.array_equal(gs, ss), (typ, metric, k)
+    assert sx.delete_vector(int(labels[0])) == -1   # (label-wise deletes across shards are not built: refused, nothing changes)
+    gl, gs = sx.knn_query(q, 10)
+    sl, ss = one.knn_query(q, 10)
+    assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
+
+
 def test_concurrent_readers_with_sequence_numbers(vso):
     """two reader threads on one sharded index (VecSimGpu_ShardedTopKQueryBatchArraysSeq): scans overlap on the shards' reader
     lanes, exchanges go in sequence order; every batch's reply equals the one-reader reply.  Through a real 1-rank RCCL

@@ -851,7 +851,6 @@ int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, siz
         tbl = lane->view;
     }
     if (!lane) last_mode_ = STANDARD_KNN;
-    if (multi_) return -1;  // sharded multi-value indexes are not built yet
     if (nq == 0) return 0;
     if (!lane && flush()) return -1;
     if (k == 0 || count_ == 0) {
@@ -859,6 +858,38 @@ int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, siz
         return 0;
     }
     std::vector<char> qbuf = packQueries(queries, nq, stride);
+    if (multi_) {
+        // multi-value shard: the rows at or below the k'-th smallest local ROW score, k' grown until they cover k distinct local
+        // labels (or every row).  The local k-th smallest per-label minimum bounds the global one from above (a label's global
+        // minimum is at most its local one), so this is a superset of what the label-keyed replay over the union needs.
+        const size_t n_labels = label_to_ids_.size();
+        std::vector<uint32_t> lid, cnt(1);
+        std::vector<double> lsc;
+        for (size_t q = 0; q < nq; q++) {
+            size_t kr = std::min(count_, std::max<size_t>(k, 1));
+            for (;;) {
+                const size_t c1 = std::max<size_t>(2 * kr, kr + 64);
+                lid.resize(c1);
+                lsc.resize(c1);
+                int rc = vsgpu_topk(tbl, qbuf.data() + q * query_bytes_, 1, query_bytes_, kr, c1, lid.data(), lsc.data(), cnt.data());
+                if (rc) return rc;
+                if (cnt[0] == VSGPU_COUNT_OVERFLOW) break;   // heavy ties: the caller comes back with more room
+                if (kr >= count_ || distinctLabels(lid.data(), cnt[0]) >= std::min(k, n_labels)) break;
+                kr = std::min(count_, kr * 4);
+            }
+            if (cnt[0] == VSGPU_COUNT_OVERFLOW || cnt[0] > cap) {
+                counts[q] = VSGPU_COUNT_OVERFLOW;
+                continue;
+            }
+            counts[q] = cnt[0];
+            for (uint32_t i = 0; i < cnt[0]; i++) {
+                ids[q * cap + i] = lid[i];
+                scores[q * cap + i] = lsc[i];
+                labels[q * cap + i] = id_to_label_[lid[i]];
+            }
+        }
+        return 0;
+    }
     int rc = vsgpu_topk(tbl, qbuf.data(), nq, query_bytes_, k, cap, ids, scores, counts);
     if (rc) return rc;
     for (size_t q = 0; q < nq; q++) {

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <map>
 #include <queue>
 #include <thread>
 
@@ -115,6 +116,66 @@ int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const 
     return 0;
 }
 
+// Multi-value merge (brute_force_multi.h:108-277, utils/updatable_heap.h:20-113): the union of the shards' rows in gid order
+// through the label-keyed updatable heap -- a label keeps its lowest score, the heap keeps the k labels with the lowest,
+// evicting the largest (score, label) on overflow; same procedure as FlatIndex::replayMulti on a single index.
+int merge_topk_multi(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
+                     const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts) {
+    struct Cand {
+        uint64_t gid;
+        size_t label;
+        double score;
+    };
+    for (size_t i = 0; i < parts * nq; i++)
+        if (counts[i] == 0xFFFFFFFFu) return -1;
+    std::vector<Cand> c;
+    for (size_t q = 0; q < nq; q++) {
+        out_counts[q] = 0;
+        if (k == 0) continue;
+        c.clear();
+        for (size_t p = 0; p < parts; p++) {
+            const size_t base = (p * nq + q) * cap;
+            for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
+        }
+        std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
+        std::multimap<double, size_t, std::greater<double>> by_score;
+        std::unordered_map<size_t, std::multimap<double, size_t, std::greater<double>>::iterator> node_of;
+        auto top_it = [&]() {
+            auto rng = by_score.equal_range(by_score.begin()->first);
+            auto best = rng.first;
+            for (auto i = rng.first; i != rng.second; ++i)
+                if (best->second < i->second) best = i;
+            return best;
+        };
+        double upper = std::numeric_limits<double>::lowest();
+        for (const Cand &x : c) {
+            if (x.score < upper || node_of.size() < k) {
+                auto f = node_of.find(x.label);
+                if (f == node_of.end()) node_of.emplace(x.label, by_score.emplace(x.score, x.label));
+                else if (f->second->first > x.score) {
+                    by_score.erase(f->second);
+                    f->second = by_score.emplace(x.score, x.label);
+                }
+                if (node_of.size() > k) {
+                    auto t = top_it();
+                    node_of.erase(t->second);
+                    by_score.erase(t);
+                }
+                upper = top_it()->first;
+            }
+        }
+        out_counts[q] = (uint32_t)node_of.size();
+        for (size_t i = node_of.size(); i-- > 0;) {
+            auto t = top_it();
+            out_labels[q * k + i] = t->second;
+            out_scores[q * k + i] = t->first;
+            node_of.erase(t->second);
+            by_score.erase(t);
+        }
+    }
+    return 0;
+}
+
 std::unique_ptr<Exchange> make_rccl_exchange(vsgpu_ctx *ctx, int rank, int world, const void *id128) {
     vsgpu_comm *c = vsgpu_comm_create(ctx, rank, world, id128);
     if (!c) return nullptr;
@@ -130,7 +191,7 @@ ShardedIndex::~ShardedIndex() {
 
 ShardedIndex *ShardedIndex::createDistributed(const BFParams &p, void *logCtx, int rank, int world, int device,
                                               std::unique_ptr<Exchange> ex, std::unique_ptr<ShardOps> external) {
-    if (world < 1 || rank < 0 || rank >= world || p.multi) return nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return nullptr;
     auto *sx = new ShardedIndex();
     sx->params_ = p;
     sx->plan_.block = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
@@ -147,7 +208,7 @@ ShardedIndex *ShardedIndex::createDistributed(const BFParams &p, void *logCtx, i
 }
 
 ShardedIndex *ShardedIndex::createLocal(const BFParams &p, void *logCtx, int n_shards, const int *devices) {
-    if (n_shards < 1 || p.multi) return nullptr;
+    if (n_shards < 1) return nullptr;
     auto *sx = new ShardedIndex();
     sx->params_ = p;
     sx->plan_.block = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
@@ -172,7 +233,7 @@ VecSimIndexInterface *ShardedIndex::localIndex(int s) {
 // ---- ingest (SPMD: every process makes the same calls in the same order) ----
 int ShardedIndex::addVector(const void *blob, size_t label) {
     if (synthetic_rows_) return -1;  // synthetic fills are append-only through addSyntheticLocal
-    auto f = label_to_gid_.find(label);
+    auto f = params_.multi ? label_to_gid_.end() : label_to_gid_.find(label);   // (multi-value: a label's vectors just accumulate)
     if (f != label_to_gid_.end()) {
         // overwrite in place (brute_force_single.h:139-143): the row keeps its id, so only its owner acts and the
         // global count does not move
@@ -191,7 +252,7 @@ int ShardedIndex::addVector(const void *blob, size_t label) {
         if (shard(s)->add(blob, label) != 1) return -1;
     }
     n_global_++;
-    label_to_gid_.emplace(label, gid);
+    if (!params_.multi) label_to_gid_.emplace(label, gid);
     gid_to_label_.push_back(label);
     return 1;
 }
@@ -221,6 +282,7 @@ int ShardedIndex::deleteVector(size_t label) {
     // every process takes the same decisions from the same state (SPMD): shards or transports that cannot move rows are
     // refused before anything changes, and no process leaves between the collectives below on a locally evaluated condition
     if (!shards_[0]->supportsRowOps() || (ex_ && !ex_->canBroadcast())) return -1;
+    if (params_.multi) return -1;   // (deleting a label's vectors one swap-delete at a time across shards: not built)
     auto f = label_to_gid_.find(label);
     if (f == label_to_gid_.end()) return 0;
     const uint64_t hole = f->second, last = n_global_ - 1;
@@ -368,7 +430,7 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
         std::memcpy(labels.data() + p * nq * cap, cnt + nq + nq * cap, nq * cap * 8);
         std::memcpy(scores.data() + p * nq * cap, cnt + nq + 2 * nq * cap, nq * cap * 8);
     }
-    pass->nan_rows_at_head = !all_rows && min_nan < (uint64_t)k;
+    pass->nan_rows_at_head = !all_rows && !params_.multi && min_nan < (uint64_t)k;   // (multi-value: as on a single index, no NaN-aware replay)
     // every process knows by now whether this batch exchanges again (ties beyond cap, NaN-aware passes): if not, the turn
     // goes to the next batch before the merge
     if (failed || pass->timed_out || !(pass->overflow || pass->nan_rows_at_head || pass->more_follows)) turn_hook(false);
@@ -378,8 +440,10 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
         out_labels.assign(nq * k, 0);
         out_scores.assign(nq * k, 0.0);
         out_counts.assign(nq, 0);
-        rc = merge_topk(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k, out_labels.data(),
-                        out_scores.data(), out_counts.data(), all_rows);
+        rc = params_.multi ? merge_topk_multi(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k,
+                                              out_labels.data(), out_scores.data(), out_counts.data())
+                           : merge_topk(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k, out_labels.data(),
+                                        out_scores.data(), out_counts.data(), all_rows);
     }
     const double t3 = now_ms();
     {
@@ -438,7 +502,7 @@ int ShardedIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, 
     std::vector<char> needs_all(nq, 0);
     bool any_needs_all = false;
     for (size_t q = 0; q < nq; q++)
-        if (shards_[0]->queryMayScoreNaN(static_cast<const char *>(queries) + q * stride)) needs_all[q] = 1, any_needs_all = true;
+        if (!params_.multi && shards_[0]->queryMayScoreNaN(static_cast<const char *>(queries) + q * stride)) needs_all[q] = 1, any_needs_all = true;
     std::vector<size_t> labels;
     std::vector<double> scores;
     std::vector<uint32_t> found;
