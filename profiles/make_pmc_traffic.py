@@ -11,7 +11,7 @@ import sys
 # bench scan-kernel name -> (sub-directory of the profile run, substring of the kernel's name, workload bench.py checks)
 CONFIGS = {
     "k_mfma_filter": ("", "k_mfma_filter<", {"rows": 10_000_000, "dim": 768, "batch": 64}),
-    "k_mfma_filter_lowp(i8)": ("cfg_c3", "k_mfma_filter_lowp<", {"rows": 50_000_000, "dim": 1024, "batch": 256}),
+    "k_i8_filter_x32": ("cfg_c3", "k_i8_filter_x32<", {"rows": 50_000_000, "dim": 1024, "batch": 256}),
     "k_mfma_filter_lowp(h16)": ("cfg_c4", "k_mfma_filter_lowp<", {"rows": 12_500_000, "dim": 768, "batch": 128}),
 }
 

@@ -18,6 +18,9 @@ if [ "$ALL" = "all" ]; then
   for c in c1 c3 c4; do
     timeout 600 python $R/bench.py --config $c --steps 20 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
   done
+  # config 5: the graph is built on the host cores first (~3 min per million rows); both row distributions
+  timeout 900 python $R/bench.py --config c5 --steps 5 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+  timeout 600 python $R/bench.py --config c5 --rows 200000 --data uniform --steps 5 --warmup 1 > $OUT/bench_c5_uniform.json 2> $OUT/bench_c5_uniform.err
   for c in c3 c4; do
     mkdir -p $OUT/cfg_$c
     rocprofv3 --kernel-trace --stats -d $OUT/cfg_$c/trace -o r1 -- python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > $OUT/cfg_$c/trace.log 2>&1

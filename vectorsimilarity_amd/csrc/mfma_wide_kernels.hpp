@@ -22,7 +22,7 @@ constexpr int mfw_lds_bytes(bool probe) {
     return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + MFW_RED_BYTES + (probe ? MF_PM_TILES * 64 : 0);
 }
 
-template <int KSTEPS, int MODE>
+template <int KSTEPS, int MODE, int AUX = 0>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int NS = 3, RT = 16;
     constexpr int KC = (MF_STAGE_BYTES / 4) / RT;    // 256 elements per row per stage
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_parity) {
         const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
 #pragma unroll
-        for (int i = 0; i < 4; i++) glds16<0>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
+        for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
         if (with_norm && norm_loader) glds4(np, norm_parity * 256, norm_lds);
     };
 

@@ -136,6 +136,12 @@ static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t
 
 // rows wider than 3072 elements: 16 queries per workgroup, the k range split over the waves (mfma_wide_kernels.hpp)
 template <int KS, int MODE> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+#ifdef VSGPU_TUNING
+    if (getenv("VSGPU_WIDE_NT")) {
+        hipLaunchKernelGGL((k_mfma_filter_wide<KS, MODE, 2>), grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P);
+        return;
+    }
+#endif
     auto kern = k_mfma_filter_wide<KS, MODE>;
     hipLaunchKernelGGL(kern, grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P);
 }
@@ -280,7 +286,10 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (wide) {
             // one workgroup per CU and query tile in flight at a time per XCD slot: gridDim.x a multiple of 8, so the query
             // tiles of a row tile (blockIdx.y) land on one XCD and share its L2
-            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+#ifdef VSGPU_TUNING
+            if (const char *e = getenv("VSGPU_WIDE_GX")) gx = (uint32_t)atoi(e);
+#endif
             launch_wide<MF_FILTER>(KS, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         else if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
