@@ -68,15 +68,18 @@ template <> struct Elem<EK_U8> {
     static constexpr int VL = 32;
     __device__ static inline int load(const char *p) { return (int)(*reinterpret_cast<const uint8_t *>(p)); }
 };
+// SQ8 tables keep every code as code ^ 0x80 in HBM, i.e. code - 128 as int8 -- the operand the int8 MFMA of the filter wants
+// (vsgpu.hip: sq8_flip_codes on the way in, undone on the way out); code = stored + 128, exact in fp32.
+__device__ inline float sq8_code(const char *p) { return (float)((int)(*reinterpret_cast<const int8_t *>(p)) + 128); }
 template <> struct Elem<EK_SQ8H> {   // SQ8 rows against fp16 queries: four 16-lane accumulators = 64 virtual lanes
     using acc_t = float; using score_t = float;
     static constexpr int VL = 64;
-    __device__ static inline float load(const char *p) { return (float)(*reinterpret_cast<const uint8_t *>(p)); }
+    __device__ static inline float load(const char *p) { return sq8_code(p); }
 };
 template <> struct Elem<EK_SQ8> {   // uint8 code widened exactly to float; the query side is fp32
     using acc_t = float; using score_t = float;
     static constexpr int VL = 32;
-    __device__ static inline float load(const char *p) { return (float)(*reinterpret_cast<const uint8_t *>(p)); }
+    __device__ static inline float load(const char *p) { return sq8_code(p); }
 };
 
 // vdpbf16ps treats subnormal inputs as zero and flushes subnormal results (IP_AVX512_BF16_VL_BF16.h:14-47; the

@@ -97,6 +97,10 @@ struct LowpParams {
     // min min, max |c'|_2, min sum_squares}; sq8_blk_on = 0 switches the test off
     float sq8_blk[8];   // (+ max sum_squares, pad)
     int sq8_blk_on;
+    // SQ8 filter, per-value screen: {max delta, max |min|, max sum_squares} over the table (float bits, k_row_aux_sq8) and
+    // the largest |code dot + K| / |c - 128|_2 any row of this width can have
+    const uint32_t *sq8_max;
+    float sq8_fmax, sq8_ncmax;
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
     const float *qmeta;                  // LP_SQ8: [queries][8] = {s, bits(int 128 sum Y), y_sum, y_sum_squares, Wref, 128 sum e, |e|_2, 0}
@@ -158,6 +162,9 @@ template <typename T> __device__ static inline void lowp_wait_lgkmcnt(int n, T &
 #ifndef LOWP_PF
 #define LOWP_PF 4
 #endif
+#ifndef EXP_PF
+#define EXP_PF 2
+#endif
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
           bool SKEW = false, int DIST = 0, int DLATE = 0, bool DIAG = false, int ISS = 0>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
@@ -166,7 +173,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     constexpr bool U8C = (LK == LP_U8C);
     constexpr bool SQ8 = (LK == LP_SQ8) || U8C;   // (the 16-byte aux record path; the name stuck)
     constexpr int AUXBUF = SQ8 ? 1024 : 256;   // bytes of per-tile aux values: 4 B per row, 16 B per row for SQ8 / uint8 Cosine
+    // UADDR: request addresses as a wave-uniform 64-bit base (SGPRs) + one constant 32-bit offset per lane and piece (the
+    // scalar-base form of global_load_lds) instead of a 64-bit address per lane and piece.  Rows past the table's end are not
+    // clamped: a tile never leaves its slab, whose allocation is whole, and the epilogues mask such rows (nvalid).
+    constexpr bool UADDR = (LK == LP_SQ8);
     static_assert(!SQ8 || (!SKEW && NQW == 1 && RT * 16 <= AUXBUF && NWAVES * 256 >= AUXBUF), "SQ8 aux geometry");
+    static_assert(LK != LP_SQ8 || RT == 64, "SQ8 aux arrays are laid out per 64 rows (k_row_aux_sq8)");
     // units requested ahead.  DIST = NS-2 leaves one slot of slack: the slot refilled after a barrier was last read
     // a whole unit earlier, so the plain s_barrier is enough and hipcc may keep pipelining LDS reads across it
     constexpr int D = DIST ? DIST : NS - 1;
@@ -227,6 +239,30 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
         for (int j = 0; j < 7; j++) asm volatile("" : "+v"(qm_r[j]));
     }
+    // SQ8: per-query constants, kept as few registers as the screen allows (the kernel runs at 128 VGPRs, two workgroups per CU):
+    // with g = 2 (L2) or 1 (IP)   sq_a = {-g s, -g 128 sum e}   sq_b = {-g y_sum, -g |e|_2}   sq_c = {y_sq | shift, Wref}
+    // (exact scalings, so the per-value pass gets s, y_sum ... back from them), sq_T = the screen's threshold, sq_K = 128 sum Y.
+    f32x2_t sq_a = {0, 0}, sq_b = {0, 0}, sq_c = {0, 0};
+    float sq_T = 0.f;
+    int sq_K = 0;
+    if (LK == LP_SQ8) {
+        const bool l2 = P.epi == LE_FP_L2;
+        const float G = l2 ? 2.0f : 1.0f;
+        const float qs = qm_r[0], ysum = qm_r[2], ysq = qm_r[3], Wref = qm_r[4], ce = qm_r[5], ne = qm_r[6];
+        sq_K = (int)__float_as_uint(qm_r[1]);
+        sq_a = f32x2_t{-G * qs, -G * ce};
+        sq_b = f32x2_t{-G * ysum, -G * ne};
+        sq_c = f32x2_t{ysq, Wref};
+        if (MODE == MF_FILTER) {
+            const float dl_hi = __uint_as_float(P.sq8_max[0]), mn_hi = __uint_as_float(P.sq8_max[1]), xsq_hi = __uint_as_float(P.sq8_max[2]);
+            // every magnitude a rounding of the screen, of `bounds` or of the reference can be relative to, from table-wide maxima
+            const float tmax = fabsf(qs) * P.sq8_fmax + fabsf(ce);
+            const float mag = G * (mn_hi * fabsf(ysum) + dl_hi * (tmax + P.sq8_ncmax * ne)) + (l2 ? xsq_hi : 1.0f) + fabsf(ysq) + fabsf(tau[0]);
+            const float slack = (G * dl_hi * Wref) * 1.0001f + (192.0f / 16777216.0f) * mag;
+            sq_T = l2 ? (tau[0] - ysq) + slack : tau[0] + slack;
+        }
+        asm volatile("" : "+v"(sq_a), "+v"(sq_b), "+v"(sq_c), "+v"(sq_T), "+v"(sq_K));
+    }
     // pin the ordinary loads before the first DMA (see k_mfma_filter)
 #pragma unroll
     for (int nt = 0; nt < NQW; nt++) {
@@ -252,12 +288,15 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 
     // staging geometry: instruction g = wave*IPW + t fills LDS bytes [1024 g, 1024 g + 1024)
     uint32_t st_row[IPW], st_off[IPW];
+    uint32_t st_row0[IPW], st_lane[IPW];   // UADDR: the piece's first row (uniform) and the lane's byte offset from that row's start
 #pragma unroll
     for (int t = 0; t < IPW; t++) {
         const uint32_t L = 1024u * (uint32_t)(IPW * wave + t) + 16u * (uint32_t)lane;
         const uint32_t row = L / SEG, slot = (L % SEG) / 16;
         st_row[t] = row;
         st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
+        st_row0[t] = (1024u * (uint32_t)(IPW * wave + t)) / SEG;
+        st_lane[t] = (row - st_row0[t]) * P.row_stride + st_off[t];
     }
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * IPW * 1024);
     const bool issuer = !ISS || wave < NISS;
@@ -311,7 +350,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     auto make_ptrs = [&](uint32_t t, const char *(&rp)[IPW], const uint32_t *&ap) {
         if (!issuer) return;
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;
-        const uint32_t r0 = tile_row0(tt);
+        const uint32_t r0 = UADDR ? (uint32_t)__builtin_amdgcn_readfirstlane(tile_row0(tt)) : tile_row0(tt);
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
         if (sidx != cur_slab) {
             // asm scalar loads: left to hipcc these become vector loads, and the vmcnt(0) it then needs on the
@@ -326,6 +365,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         }
         const char *sbase = reinterpret_cast<const char *>(cur_sbase);
         const uint32_t *abase = reinterpret_cast<const uint32_t *>(cur_abase);
+        if (UADDR) {
+            // rp[0] = the tile's first row (uniform); the pieces add their row and lane offsets when they are issued
+            rp[0] = sbase + (size_t)(r0 & P.slab_mask) * P.row_stride;
+            ap = abase + (size_t)(r0 & P.slab_mask) * (SQ8 ? 4 : 1);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < IPW; i++) {
             uint32_t row = r0 + st_row[i];
@@ -333,7 +378,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + st_off[i];
         }
         uint32_t arow = r0 + lane;
-        if (arow >= P.n_rows) arow = P.n_rows - 1;
+        // (LP_SQ8: lane l fetches 16 bytes of the tile's four aux arrays, not row l's record: no clamp -- aux slabs are whole groups)
+        if (LK != LP_SQ8 && arow >= P.n_rows) arow = P.n_rows - 1;
         ap = abase + (size_t)(arow & P.slab_mask) * (SQ8 ? 4 : 1);
     };
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
@@ -343,13 +389,30 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         if (!(dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < IPW; i++) {
+                if (UADDR) {
+                    const uint64_t pb = reinterpret_cast<uint64_t>(rpt[0]) + (uint64_t)st_row0[i] * P.row_stride + (uint64_t)kc * SEG;
+                    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);   // (uniform already: keeps it in SGPRs)
+                    uint32_t lo32 = st_lane[i];
+                    asm volatile("" : "+v"(lo32));   // (keeps the zero-extension in this block: hoisted, the scalar-base form is not selected)
+                    glds16<2>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
+                    continue;
+                }
                 // paired query tiles want the row to stay in L2 for the partner: default cache policy there
                 if (pair_map) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
                 else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
             }
         }
         if (with_aux && aux_loader) {
-            if (SQ8) glds16<0>(apt, abuf_i * AUXBUF, aux_lds);
+            if (UADDR) {
+                const uint64_t ab = reinterpret_cast<uint64_t>(apt);
+                const uint64_t au = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ab >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ab);
+                uint32_t lo32 = (uint32_t)lane * (SQ8 ? 16u : 4u);
+                asm volatile("" : "+v"(lo32));
+                glds16<0>(reinterpret_cast<const char *>(au) + lo32, abuf_i * AUXBUF, aux_lds);
+            }
+            else if (SQ8) glds16<0>(apt, abuf_i * AUXBUF, aux_lds);
             else glds4(apt, abuf_i * 256, aux_lds);
         }
     };
@@ -412,7 +475,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int nt = 0; nt < NQW; nt++) acc[mt][nt] = acc_t{0, 0, 0, 0};
+            for (int nt = 0; nt < NQW; nt++) {
+                if constexpr (LK == LP_SQ8) acc[mt][nt] = acc_t{sq_K, sq_K, sq_K, sq_K};   // the epilogue wants D + K, K = 128 sum Y (LowpOps<LP_SQ8>)
+                else acc[mt][nt] = acc_t{0, 0, 0, 0};
+            }
 
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
@@ -455,7 +521,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             constexpr int NFRAG = KSUB * MT;
             auto do_frags = [&](auto f0_tag, auto f1_tag) {
                 constexpr int F0 = decltype(f0_tag)::value, F1 = decltype(f1_tag)::value, N = F1 - F0;
-                constexpr int PF = N < LOWP_PF ? N : LOWP_PF;  // 8 in flight measured no better (8-wave kernels)
+                constexpr int PFW = (LK == LP_SQ8 && MINW >= 4) ? EXP_PF : LOWP_PF;   // (the 128-register SQ8 kernel: fewer fragments in flight)
+                constexpr int PF = N < PFW ? N : PFW;  // 8 in flight measured no better (8-wave kernels)
                 u32x4_t afr[N];
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
@@ -463,7 +530,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                     const char *rowp = sbase + (mt * 16 + m16) * SEG + (j / 4) * 256;
                     const int p = (4 * (j % 4) + kq) ^ m16;
                     afr[f - F0] = *reinterpret_cast<const u32x4_t *>(rowp + p * 16);
-                    if (LK == LP_U8 || LK == LP_SQ8 || LK == LP_U8C) afr[f - F0] ^= 0x80808080u;
+                    if (LK == LP_U8 || LK == LP_U8C) afr[f - F0] ^= 0x80808080u;   // (SQ8 codes are stored re-centred)
                 }
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
@@ -645,100 +712,89 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             }
         };
         // SQ8: bounds on the reference's score from the exact code dot product (LowpOps<LP_SQ8>).  With A = |min y_sum|,
-        // B = |delta (s (D + K) + 128 sum e)|:  |score_ref - score| <= g delta (|c'| |e| + Wref) + kU (2A + 2B + C), g = 1 (IP) or 2 (L2: the score carries 2 ip), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
+        // B = |delta (s (D + K) + 128 sum e)|:  |score_ref - score| <= g (delta |c'| |e| + delta Wref) + kU (2A + 2B + C), g = 1 (IP) or 2 (L2: the score carries 2 ip), C = 1 (IP) or x_sq + y_sq (L2); kU = 64 ulp
         // covers every fp32 rounding on either side (a dozen at most, each relative to one of those magnitudes).
+        // The tile's aux values sit in LDS as four arrays of 64 floats {min, delta, sum_squares, delta |c'|} (k_row_aux_sq8);
+        // the accumulators hold D + K.
         auto epilogue_sq8 = [&](auto l2_tag) {
             constexpr bool L2 = decltype(l2_tag)::value;
             constexpr float kU = 64.0f / 16777216.0f;
-            const float qs = qm_r[0], ysum = qm_r[2], ysq = qm_r[3], Wref = qm_r[4], ce = qm_r[5], ne = qm_r[6];
-            const int K = (int)__float_as_uint(qm_r[1]);
+            constexpr float rG = L2 ? -0.5f : -1.0f;
+            const float ysq = sq_c[0], Wref = sq_c[1];
             const float tq = tau[0];
-            const uint32_t arow_off = aux_lds_off + abuf * AUXBUF;
-            // score and bound of one (row, query) value from the row's aux record {min, delta, sum_squares, |c'|_2}
-            auto bounds = [&](const u32x4_t a, int d, float &low, float &up) {
-                const float mn = __uint_as_float(a[0]), dl = __uint_as_float(a[1]), xsq = __uint_as_float(a[2]);
-                const float nc = __uint_as_float(a[3]);
-                const float f = (float)(d + K);
+            const uint32_t arow_off = aux_lds_off + abuf * AUXBUF + (uint32_t)kq * 16u;
+            // the four aux arrays' entries for rows mt*16 + kq*4 .. +3
+            auto read_aux = [&](int mt, f32x4_t &mn, f32x4_t &dl, f32x4_t &xs, f32x4_t &pp) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(mn) : "v"(arow_off), "n"(mt * 64));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dl) : "v"(arow_off), "n"(256 + mt * 64));
+                if (L2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xs) : "v"(arow_off), "n"(512 + mt * 64));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pp) : "v"(arow_off), "n"(768 + mt * 64));
+                if (L2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(xs), "+v"(pp));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(pp));
+            };
+            // score and bound of one (row, query) value
+            auto bounds = [&](float mn, float dl, float xsq, float p, int d, float &low, float &up) {
+                const float qs = rG * sq_a[0], ce = rG * sq_a[1], ysum = rG * sq_b[0], ne = rG * sq_b[1];
+                const float f = (float)d;
                 const float dq = dl * (qs * f + ce);
                 const float my = mn * ysum;
                 const float ip = my + dq;
                 const float C = L2 ? (xsq + ysq) : 1.0f;
                 const float sc = L2 ? (C - 2.0f * ip) : ((1.0f - ip) - ysq);   // IP: ysq holds the shift (y_mean_ip or 0, exact_kernels.hpp sq8_score)
-                const float E = (L2 ? 2.0f : 1.0f) * dl * (nc * ne + Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C + (L2 ? 0.0f : fabsf(ysq)));   // L2 carries 2 ip
+                const float E = (L2 ? 2.0f : 1.0f) * (p * ne + dl * Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C + (L2 ? 0.0f : fabsf(ysq)));   // L2 carries 2 ip
                 low = sc - E;
                 up = sc + E;
             };
             if (MODE == MF_FILTER) {
-                // Block pre-screen: one bound for the lane's 4 MT values (one query, 4 MT rows) from the largest and the
-                // smallest of its dots and the extremes of the table's aux values (P.sq8_blk, kept by the host index: max / min
-                // delta, max / min min, max |c'|, min sum_squares over every row ever stored -- widened, never narrowed).
-                // A value passes the per-value test only if
-                //   g ip + E >= R,   R = (1 - shift) - tau (IP)  or  (x_sq + y_sq)(1 - kU) - tau (L2, kU C moved over),
-                // and over the block  g ip + E <= g (max my + max dq) + g dl_hi (nc_hi ne + Wref) + kU 2 (max|my| + max|dq|) (+ kU (1 + |shift|)),
-                // with dq = delta (qs f + ce) between the products of the extreme deltas and the extreme f.  2 kU more on every
-                // magnitude covers the roundings of both evaluations.  On rows of one scale the k-th score sits far outside
-                // what 16 rows reach, so almost every block ends here: ~55 VALU operations instead of 18 per value.  The host
-                // switches the test off (sq8_blk_on = 0) for tables whose rows differ much in scale, where it cannot reject,
-                // and for L2 tables: measured on 10 M x 768 uniform rows, batch 128, IP 2.52 -> 2.13 ms, L2 2.57 -> 2.70 ms
-                // (the table-wide minimum of x_sq -- or the lane's own 16 rows' -- leaves the L2 bound too little room; a
-                // bound that keeps x_sq and the dot paired per value, h_i = x_sq_i - 2 delta_i qs f_i, rejected well but its
-                // extra code pushed this 256-VGPR kernel into 118-190 spilled registers: DESIGN.md 9).
-                if (P.sq8_blk_on) {
-                    int dmax = (int)acc[0][0][0], dmin = dmax;
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            dmax = max(dmax, (int)acc[mt][0][i]);
-                            dmin = min(dmin, (int)acc[mt][0][i]);
-                        }
-                    const float dl_hi = P.sq8_blk[0], dl_lo = P.sq8_blk[1], mn_hi = P.sq8_blk[2], mn_lo = P.sq8_blk[3];
-                    const float nc_hi = P.sq8_blk[4], xsq_lo = P.sq8_blk[5];
-                    const float v_hi = qs * (float)(dmax + K) + ce, v_lo = qs * (float)(dmin + K) + ce;
-                    const float D_hi = (v_hi >= 0.0f ? dl_hi : dl_lo) * v_hi;
-                    const float D_abs = dl_hi * fmaxf(fabsf(v_hi), fabsf(v_lo));
-                    const float M_hi = fmaxf(mn_hi * ysum, mn_lo * ysum);
-                    const float M_abs = fmaxf(fabsf(mn_hi), fabsf(mn_lo)) * fabsf(ysum);
-                    const float W_hi = (L2 ? 2.0f : 1.0f) * dl_hi * (nc_hi * ne + Wref);
-                    const float R = L2 ? ((xsq_lo + ysq) * (1.0f - kU) - tq) : ((1.0f - ysq) - tq);
-                    const float mag = M_abs + D_abs;
-                    const float U = (L2 ? 2.0f : 1.0f) * (M_hi + D_hi) + W_hi +
-                                    kU * (2.0f * mag + (L2 ? 0.0f : 1.0f + fabsf(ysq))) +
-                                    2.0f * kU * (2.0f * mag + W_hi + fabsf(R) + fabsf(tq) + (L2 ? (fabsf(xsq_lo) + fabsf(ysq)) : 1.0f + fabsf(ysq)));
-                    if (!__any(!(U < R))) return;   // (a NaN anywhere keeps the block: the per-value test decides)
-                }
-                // survivors are rare: one branch-free pass over the lane's 4 MT values decides whether any lane of the wave has
-                // one (the per-value emission branches below cost an exec-mask save and a jump each, 16 of them per tile)
+                // Screen: survivors are rare, so one branch-free pass decides whether any lane of the wave has a value that may
+                // pass; only then does the per-value loop below run.  With g = 2 (L2) or 1 (IP) the screen evaluates
+                //     lowS = [x_sq | 1 - shift] + min (-g y_sum) + delta (-g (s f + 128 sum e)) - g delta |c'| |e|
+                // in four fused operations on pairs of rows (v_pk_fma_f32: 4 + a conversion + a compare per value, against ~18 for
+                // `bounds`) and rejects when lowS > sc_T = tau [- y_sq] + slack.  slack (per query, kernel prologue) holds what
+                // the screen leaves out of `bounds`' E with the table-wide maxima in place of the row's values: g max(delta) Wref
+                // and 192 ulp of every magnitude involved (64 for E's own term, the rest for the screen's roundings) -- the
+                // Cauchy-Schwarz term, which dominates E by orders of magnitude, stays per row.  A NaN anywhere rejects nothing.
                 bool any = false;
+                const f32x2_t x0 = {1.0f - ysq, 0.0f};   // IP: the score's constant part (ysq holds the shift)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    u32x4_t am[4];
+                    f32x4_t mn, dl, xs, pp;
+                    read_aux(mt, mn, dl, xs, pp);
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(am[i]) : "v"(arow_off + (uint32_t)((mt * 16 + kq * 4 + i) * 16)));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]));
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float low, up;
-                        bounds(am[i], (int)acc[mt][0][i], low, up);
-                        any |= !(low > tq);
+                    for (int h = 0; h < 2; h++) {
+                        const f32x2_t f = {(float)(int)acc[mt][0][2 * h], (float)(int)acc[mt][0][2 * h + 1]};
+                        const f32x2_t mn2 = {mn[2 * h], mn[2 * h + 1]}, dl2 = {dl[2 * h], dl[2 * h + 1]}, pp2 = {pp[2 * h], pp[2 * h + 1]};
+                        f32x2_t t, s1, s2, lo;
+                        // (op_sel picks the dword of a register pair each half of the result reads: the constants are broadcast)
+                        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(sq_a), "v"(f));
+                        if (L2) {
+                            const f32x2_t x2 = {xs[2 * h], xs[2 * h + 1]};
+                            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(s1) : "v"(dl2), "v"(t), "v"(x2));
+                        } else {
+                            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(s1) : "v"(dl2), "v"(t), "v"(x0));
+                        }
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(s2) : "v"(mn2), "v"(sq_b), "v"(s1));
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(lo) : "v"(pp2), "v"(sq_b), "v"(s2));
+                        any |= !(lo[0] > sq_T) | !(lo[1] > sq_T);
                     }
-                    __builtin_amdgcn_sched_barrier(0);   // one M-block at a time: 16 values in flight at once spilled
                 }
                 if (!__any(any)) return;
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                u32x4_t am[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(am[i]) : "v"(arow_off + (uint32_t)((mt * 16 + kq * 4 + i) * 16)));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]));
+            // The per-value pass: rolled over the M-blocks in the filter (a rare path: its registers would otherwise set the
+            // kernel's allocation), the block's accumulators picked by compares on the uniform counter.
+            auto value_pass = [&](int mt, const acc_t a4) {
+                f32x4_t mn, dl, xs = {0, 0, 0, 0}, pp;
+                const uint32_t ao = arow_off + (uint32_t)mt * 64u;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(mn) : "v"(ao));
+                asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dl) : "v"(ao));
+                if (L2) asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(xs) : "v"(ao));
+                asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(pp) : "v"(ao));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(xs), "+v"(pp));
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t lrow = mt * 16 + kq * 4 + i;
+                    const uint32_t lrow = (uint32_t)mt * 16u + kq * 4 + i;
                     float low, up;
-                    bounds(am[i], (int)acc[mt][0][i], low, up);
+                    bounds(mn[i], dl[i], xs[i], pp[i], (int)a4[i], low, up);
                     if (MODE == MF_PROBE) {
                         if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
                     } else if (lrow < nvalid && !(low > tq)) {   // (a NaN bound goes on to the exact re-rank)
@@ -752,6 +808,20 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                             emitted = true;
                         }
                     }
+                }
+            };
+            if (MODE == MF_FILTER) {
+                static_assert(MT == 4, "SQ8 tiles are 64 rows");
+#pragma unroll 1
+                for (int mt = 0; mt < MT; mt++) {
+                    const acc_t lo = mt & 1 ? acc[1][0] : acc[0][0], hi = mt & 1 ? acc[3][0] : acc[2][0];
+                    value_pass(mt, mt & 2 ? hi : lo);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    value_pass(mt, acc[mt][0]);
+                    __builtin_amdgcn_sched_barrier(0);   // one M-block at a time
                 }
             }
         };
@@ -872,10 +942,14 @@ static __global__ __launch_bounds__(256) void k_row_norms_h16(const char *rows, 
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) out[row] = __float_as_uint((float)s);
 }
-// SQ8: {min, delta, sum_squares, 0} of every row, copied out of the (unaligned) metadata behind the codes into 16-byte
-// aux records (sum_squares only exists in L2 blobs)
+// SQ8: {min, delta, sum_squares, delta |c - 128|_2} of every row, taken out of the (unaligned) metadata behind the codes
+// (sum_squares only exists in L2 blobs).  Layout: per group of 64 rows four arrays of 64 floats (1 KiB, fetched by ONE
+// LDS-DMA piece of the filter like 16-byte records would be), so that a lane's ds_read_b128 returns the same field of its
+// four rows -- operands of v_pk_fma_f32 as they land.  `first` = the in-slab index of rows[0], `out` = the slab's aux base.
+// tmax: {max delta, max |min|, max sum_squares} over every row ever stored (float bits; all values >= 0, so unsigned
+// order = float order and a NaN wins): the filter's screen takes its table-wide slack terms from them.
 static __global__ __launch_bounds__(256) void k_row_aux_sq8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
-                                                     int is_l2, uint4 *out) {
+                                                     int is_l2, uint32_t first, uint32_t *out, uint32_t *tmax) {
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     const unsigned char *cd = reinterpret_cast<const unsigned char *>(rows + (size_t)row * row_stride);
@@ -883,11 +957,20 @@ static __global__ __launch_bounds__(256) void k_row_aux_sq8(const char *rows, ui
     auto ld = [&](int o) { return (uint32_t)m[o] | ((uint32_t)m[o + 1] << 8) | ((uint32_t)m[o + 2] << 16) | ((uint32_t)m[o + 3] << 24); };
     unsigned long long ss = 0;   // |c - 128|_2, rounded up: the row's factor of the Cauchy-Schwarz term of the filter bound
     for (uint32_t i = 0; i < dim; i++) {
-        const int v = (int)cd[i] - 128;
+        const int v = (int)(signed char)cd[i];   // (stored as code ^ 0x80 = code - 128: vsgpu.hip sq8_flip_codes)
         ss += (unsigned long long)(v * v);
     }
-    const float nc = (float)(sqrt((double)ss) * 1.000001);   // (the factor dwarfs the two roundings)
-    out[row] = make_uint4(ld(0), ld(4), is_l2 ? ld(12) : 0u, __float_as_uint(nc));
+    const float nc = (float)(sqrt((double)ss) * 1.000001);   // (the factor dwarfs the roundings, the product's below too)
+    const uint32_t mn = ld(0), dl = ld(4), xsq = is_l2 ? ld(12) : 0u;
+    const uint32_t r = first + row;
+    uint32_t *g = out + (size_t)(r >> 6) * 256 + (r & 63u);
+    g[0] = mn;
+    g[64] = dl;
+    g[128] = xsq;
+    g[192] = __float_as_uint(fabsf(__uint_as_float(dl)) * nc);
+    atomicMax(&tmax[0], dl & 0x7FFFFFFFu);
+    atomicMax(&tmax[1], mn & 0x7FFFFFFFu);
+    atomicMax(&tmax[2], xsq & 0x7FFFFFFFu);
 }
 // uint8 Cosine: {stored float norm, sum (x - 128), 0, 0} per row
 static __global__ __launch_bounds__(256) void k_row_aux_u8c(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n, uint4 *out) {

@@ -301,6 +301,12 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         delete t;
         return nullptr;
     }
+    if (t->lowp_ok && t->lp_kind == LP_SQ8 &&
+        (hipMalloc((void **)&t->d_sq8_max, 16) != hipSuccess || hipMemset(t->d_sq8_max, 0, 16) != hipSuccess)) {
+        fail(VSGPU_ERR_HIP, "SQ8 aux allocation failed");
+        delete t;
+        return nullptr;
+    }
     return t;
 }
 
@@ -335,6 +341,7 @@ extern "C" int vsgpu_table_view_sync(vsgpu_table *v) {
     v->d_slabs_cap = p->d_slabs_cap;
     v->norm_slabs = p->norm_slabs;
     v->d_norm_slabs = p->d_norm_slabs;
+    v->d_sq8_max = p->d_sq8_max;
     v->n = p->n;
     for (int i = 0; i < 8; i++) v->sq8_blk[i] = p->sq8_blk[i];
     v->sq8_blk_set = p->sq8_blk_set;
@@ -356,6 +363,7 @@ extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
     if (t->d_slabs) (void)hipFree(t->d_slabs);
     if (t->d_norm_slabs) (void)hipFree(t->d_norm_slabs);
     if (t->d_offs) (void)hipFree(t->d_offs);
+    if (t->d_sq8_max) (void)hipFree(t->d_sq8_max);
     delete t;
 }
 extern "C" size_t vsgpu_table_size(const vsgpu_table *t) { return t->n; }
@@ -410,6 +418,33 @@ static inline char *row_ptr(const vsgpu_table *t, size_t id) {
     return t->slabs[id >> t->slab_shift] + (id & mask) * t->row_bytes;
 }
 
+// SQ8 tables hold code ^ 0x80 (= code - 128 as int8, the filter's MFMA operand; exact_kernels.hpp sq8_code): flip the codes of
+// rows [first, first+n) that just arrived from the host.  The metadata behind the codes stays as it is.
+static __global__ __launch_bounds__(256) void k_sq8_flip_codes(char *rows, uint32_t row_stride, uint32_t dim, uint32_t n) {
+    const uint32_t per_row = (dim + 3) / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < (uint64_t)n * per_row; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t row = (uint32_t)(i / per_row), e = (uint32_t)(i % per_row) * 4;
+        unsigned char *p = reinterpret_cast<unsigned char *>(rows) + (size_t)row * row_stride + e;
+        for (uint32_t j = 0; j < 4 && e + j < dim; j++) p[j] ^= 0x80u;
+    }
+}
+static int sq8_flip_codes(vsgpu_table *t, size_t first, size_t n) {
+    if ((t->type != VSGPU_SQ8 && t->type != VSGPU_SQ8H) || n == 0) return VSGPU_OK;
+    const size_t slab_rows = (size_t)1 << t->slab_shift;
+    size_t id = first, left = n;
+    while (left) {
+        const size_t in_slab = std::min(left, slab_rows - (id & (slab_rows - 1)));
+        const uint64_t work = (uint64_t)in_slab * ((t->dim + 3) / 4);
+        hipLaunchKernelGGL(k_sq8_flip_codes, dim3((unsigned)std::min<uint64_t>((work + 255) / 256, 65536)), dim3(256), 0, t->ctx->stream,
+                           row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab);
+        id += in_slab;
+        left -= in_slab;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));   // (reader lanes query on their own streams)
+    return VSGPU_OK;
+}
+
 // recompute |x|^2 of rows [first, first+n) (fp32 tables on the MFMA path only)
 static int update_norms(vsgpu_table *t, size_t first, size_t n) {
     if (!(t->mfma_ok || t->lowp_ok) || n == 0) return VSGPU_OK;
@@ -425,7 +460,8 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
         else if (t->lowp_ok && t->lp_kind == LP_SQ8)
             hipLaunchKernelGGL(k_row_aux_sq8, dim3((unsigned)((in_slab + 255) / 256)), dim3(256), 0, t->ctx->stream,
                                (const char *)row_ptr(t, id), (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
-                               t->epi == EPI_SQ8_L2 ? 1 : 0, (uint4 *)np);
+                               t->epi == EPI_SQ8_L2 ? 1 : 0, (uint32_t)(id & (slab_rows - 1)),
+                               (uint32_t *)t->norm_slabs[id >> t->slab_shift], t->d_sq8_max);
         else if (t->mfma_ok && t->type == VSGPU_F64)
             hipLaunchKernelGGL(k_row_norms_f64, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, np);
@@ -465,6 +501,8 @@ extern "C" int vsgpu_table_append(vsgpu_table *t, const void *host_rows, size_t 
         left -= in_slab;
     }
     HIPCHK(hipStreamSynchronize(t->ctx->stream));  // the caller's buffer is borrowed for this call only
+    rc = sq8_flip_codes(t, t->n, n);
+    if (rc) return rc;
     rc = update_norms(t, t->n, n);
     if (rc) return rc;
     t->n += n;
@@ -476,6 +514,8 @@ extern "C" int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row
     // same stream as the norm kernel and the queries (the ctx stream does not synchronise with the legacy stream)
     HIPCHK(hipMemcpyAsync(row_ptr(t, id), host_row, t->row_bytes, hipMemcpyHostToDevice, t->ctx->stream));
     HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    const int rc = sq8_flip_codes(t, id, 1);
+    if (rc) return rc;
     return update_norms(t, id, 1);
 }
 extern "C" int vsgpu_table_move(vsgpu_table *t, size_t dst, size_t src) {
@@ -495,6 +535,8 @@ extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
     HIPCHK(hipSetDevice(t->ctx->device));
     HIPCHK(hipMemcpyAsync(host_row, row_ptr(t, id), t->row_bytes, hipMemcpyDeviceToHost, t->ctx->stream));
     HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    if (t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H)   // (the device keeps code ^ 0x80: sq8_flip_codes)
+        for (size_t i = 0; i < t->dim; i++) reinterpret_cast<unsigned char *>(host_row)[i] ^= 0x80u;
     return VSGPU_OK;
 }
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
@@ -986,11 +1028,11 @@ static __global__ __launch_bounds__(256) void k_sq8_pairs(const char *const *sla
     if (mode == 2) {
         float product = 0.f;
         if (lane == 0)
-            for (uint32_t i = 0; i < dim; i++) product = __fadd_rn(product, (float)((int)a[i] * (int)b[i]));
+            for (uint32_t i = 0; i < dim; i++) product = __fadd_rn(product, (float)((int)(a[i] ^ 0x80u) * (int)(b[i] ^ 0x80u)));   // (codes are stored ^ 0x80)
         fdot = product;
     } else {
         int dot = 0;
-        for (uint32_t i = lane; i < dim; i += 64) dot += (int)a[i] * (int)b[i];
+        for (uint32_t i = lane; i < dim; i += 64) dot += (int)(a[i] ^ 0x80u) * (int)(b[i] ^ 0x80u);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
         fdot = (float)dot;

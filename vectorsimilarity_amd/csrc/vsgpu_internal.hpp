@@ -141,7 +141,8 @@ struct vsgpu_table {
     float sq8_mss = 0.f;        // sum mean_i^2, the symmetric IP correction constant
     float sq8_blk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)
     bool sq8_blk_set = false;
-    size_t aux_bytes = 4;   // per-row aux record of the MFMA filters: 4 B, or 16 B {min, delta, sum_squares, 0} for SQ8 rows
+    size_t aux_bytes = 4;   // per-row aux of the MFMA filters: 4 B, or 16 B for SQ8 rows (k_row_aux_sq8: four arrays per 64 rows)
+    uint32_t *d_sq8_max = nullptr;   // SQ8: {max delta, max |min|, max sum_squares} over the rows ever stored (k_row_aux_sq8)
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;
 };

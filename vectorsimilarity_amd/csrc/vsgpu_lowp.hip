@@ -22,7 +22,11 @@ static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
     };
     // the diagnosis build (run-time dbg switches, paired query tiles) exists for the plain 3-slot filter kernels only
+#ifdef VSGPU_TUNING
+    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 12 && ISS == 0;
+#else
     constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16 && ISS == 0;
+#endif
     if constexpr (has_diag) {
         if (P.dbg || P.pair_map) return go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, true>);
     }
@@ -205,6 +209,19 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
         case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
         case 24: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 6>);
+        }
+    }
+    if (t->lp_kind == LP_SQ8 && t->lp_ksteps == 12) {
+        switch (variant) {
+        case 1: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4>);
+        case 2: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
+        case 3: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 4, 3>);                   // 128 VGPRs: two workgroups per CU
+        case 4: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 24576>);            // 64 rows x 384 B per unit
+        case 5: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 2, 49152>);            // whole rows, 2 slots
+        case 6: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 4>);      // refill after 4 fragments
+        case 7: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 16384, 2>);         // 4 slots, 2 ahead: plain barrier
+        case 8: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 24576>);
+        case 9: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 4, 1, 2, 3>);                   // the 4-wave kernel of narrow batches
         }
     }
     return false;
@@ -562,6 +579,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         // block pre-screen: worth its ~55 operations per lane and tile only where it can reject, i.e. rows of one scale
         for (int i = 0; i < 8; i++) P.sq8_blk[i] = t->sq8_blk[i];
         const float dh = t->sq8_blk[0], dlw = t->sq8_blk[1];
+        P.sq8_max = t->d_sq8_max;
+        P.sq8_fmax = (float)(2.0 * 128.0 * 127.0 * (double)kdim * (1.0 + 1e-6));   // |D| <= 128 * 127 * width, |K| likewise
+        P.sq8_ncmax = (float)(128.0 * std::sqrt((double)kdim) * 1.00001);
         P.sq8_blk_on = (t->sq8_blk_set && c->opt_sq8_block && t->metric != VSGPU_L2 && dlw > 0.0f && std::isfinite(dh) && dh <= 2.0f * dlw) ? 1 : 0;
     } else if (is_int) {
         P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
