@@ -1,8 +1,4 @@
-set -x
-timeout 900 python tools/bench_sq8.py --metric L2 --batches 128 --steps 10 --sweep lowp_variant=0,1,2,4,5,6,7,8,9 2>&1 | grep "mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt lowp_dbg=8 2>&1 | grep -i "phases\|mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt lowp_dbg=1 2>&1 | grep -i "mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt lowp_dbg=2 2>&1 | grep -i "mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt lowp_dbg=3 2>&1 | grep -i "mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt lowp_dbg=4 2>&1 | grep -i "mfma 1"
-timeout 300 python tools/bench_sq8.py --metric L2 --batches 128 --steps 4 --rows 5000000 --opt wg_per_cu=2 --sweep lowp_variant=0,3 2>&1 | grep -i "mfma 1"
+# SQ8 filter variants (make TUNING=1 build): tools/tuning_tests/sq8_sweep.sh
+timeout 900 python tools/bench_sq8.py --metric L2 --batches 128 --steps 10 --sweep lowp_variant=0,3,10,1,2 2>&1 | grep "mfma 1"
+timeout 600 python tools/bench_sq8.py --metric IP --batches 64,128 --steps 10 2>&1 | grep "mfma 1"
+timeout 600 python -m pytest tests/test_gpu_sq8.py tests/test_gpu_sq8_centred.py -m gpu -x -q 2>&1 | tail -3

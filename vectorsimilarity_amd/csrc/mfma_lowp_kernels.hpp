@@ -162,9 +162,7 @@ template <typename T> __device__ static inline void lowp_wait_lgkmcnt(int n, T &
 #ifndef LOWP_PF
 #define LOWP_PF 4
 #endif
-#ifndef EXP_PF
-#define EXP_PF 2
-#endif
+
 template <int LK, int KSTEPS, int MODE, int RT, int NWAVES, int NQW, int MINW = 1, int NS = 3, int STAGE = MF_STAGE_BYTES,
           bool SKEW = false, int DIST = 0, int DLATE = 0, bool DIAG = false, int ISS = 0>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpParams P) {
@@ -521,8 +519,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
             constexpr int NFRAG = KSUB * MT;
             auto do_frags = [&](auto f0_tag, auto f1_tag) {
                 constexpr int F0 = decltype(f0_tag)::value, F1 = decltype(f1_tag)::value, N = F1 - F0;
-                constexpr int PFW = (LK == LP_SQ8 && MINW >= 4) ? EXP_PF : LOWP_PF;   // (the 128-register SQ8 kernel: fewer fragments in flight)
-                constexpr int PF = N < PFW ? N : PFW;  // 8 in flight measured no better (8-wave kernels)
+                constexpr int PF = N < LOWP_PF ? N : LOWP_PF;  // 8 in flight measured no better (8-wave kernels)
                 u32x4_t afr[N];
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
@@ -718,10 +715,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         // the accumulators hold D + K.
         auto epilogue_sq8 = [&](auto l2_tag) {
             constexpr bool L2 = decltype(l2_tag)::value;
-            constexpr float kU = 64.0f / 16777216.0f;
             constexpr float rG = L2 ? -0.5f : -1.0f;
-            const float ysq = sq_c[0], Wref = sq_c[1];
-            const float tq = tau[0];
+            const float ysq = sq_c[0];
             const uint32_t arow_off = aux_lds_off + abuf * AUXBUF + (uint32_t)kq * 16u;
             // the four aux arrays' entries for rows mt*16 + kq*4 .. +3
             auto read_aux = [&](int mt, f32x4_t &mn, f32x4_t &dl, f32x4_t &xs, f32x4_t &pp) {
@@ -731,19 +726,6 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pp) : "v"(arow_off), "n"(768 + mt * 64));
                 if (L2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(xs), "+v"(pp));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(pp));
-            };
-            // score and bound of one (row, query) value
-            auto bounds = [&](float mn, float dl, float xsq, float p, int d, float &low, float &up) {
-                const float qs = rG * sq_a[0], ce = rG * sq_a[1], ysum = rG * sq_b[0], ne = rG * sq_b[1];
-                const float f = (float)d;
-                const float dq = dl * (qs * f + ce);
-                const float my = mn * ysum;
-                const float ip = my + dq;
-                const float C = L2 ? (xsq + ysq) : 1.0f;
-                const float sc = L2 ? (C - 2.0f * ip) : ((1.0f - ip) - ysq);   // IP: ysq holds the shift (y_mean_ip or 0, exact_kernels.hpp sq8_score)
-                const float E = (L2 ? 2.0f : 1.0f) * (p * ne + dl * Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C + (L2 ? 0.0f : fabsf(ysq)));   // L2 carries 2 ip
-                low = sc - E;
-                up = sc + E;
             };
             if (MODE == MF_FILTER) {
                 // Screen: survivors are rare, so one branch-free pass decides whether any lane of the wave has a value that may
@@ -780,47 +762,67 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 }
                 if (!__any(any)) return;
             }
-            // The per-value pass: rolled over the M-blocks in the filter (a rare path: its registers would otherwise set the
-            // kernel's allocation), the block's accumulators picked by compares on the uniform counter.
-            auto value_pass = [&](int mt, const acc_t a4) {
-                f32x4_t mn, dl, xs = {0, 0, 0, 0}, pp;
-                const uint32_t ao = arow_off + (uint32_t)mt * 64u;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(mn) : "v"(ao));
-                asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dl) : "v"(ao));
-                if (L2) asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(xs) : "v"(ao));
-                asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(pp) : "v"(ao));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(xs), "+v"(pp));
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t lrow = (uint32_t)mt * 16u + kq * 4 + i;
-                    float low, up;
-                    bounds(mn[i], dl[i], xs[i], pp[i], (int)a4[i], low, up);
-                    if (MODE == MF_PROBE) {
-                        if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
-                    } else if (lrow < nvalid && !(low > tq)) {   // (a NaN bound goes on to the exact re-rank)
+            if constexpr (MODE == MF_FILTER) {
+                // Some lane holds a value the screen did not reject: the same test again value by value, rolled (a rare path --
+                // unrolled, its registers would set the allocation of the whole kernel), the value's accumulator picked by
+                // compares on the uniform counter.  Every value that passes goes to the exact re-rank; the record's score field
+                // is overwritten there (k_exact_pairs).
+                static_assert(MT == 4, "SQ8 tiles are 64 rows");
+                const float x0s = 1.0f - ysq;
+#pragma unroll 1
+                for (int v = 0; v < 16; v++) {
+                    const int mt = v >> 2, i = v & 3;
+                    const acc_t lo4 = mt & 1 ? acc[1][0] : acc[0][0], hi4 = mt & 1 ? acc[3][0] : acc[2][0];
+                    const acc_t a4 = mt & 2 ? hi4 : lo4;
+                    const int dlo = i & 1 ? a4[1] : a4[0], dhi = i & 1 ? a4[3] : a4[2];
+                    const float f = (float)(i & 2 ? dhi : dlo);
+                    const uint32_t ao = arow_off + (uint32_t)(mt * 64 + i * 4);
+                    float mn, dl, xs = x0s, pp;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(mn) : "v"(ao));
+                    asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(dl) : "v"(ao));
+                    if (L2) asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(xs) : "v"(ao));
+                    asm volatile("ds_read_b32 %0, %1 offset:768" : "=v"(pp) : "v"(ao));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mn), "+v"(dl), "+v"(xs), "+v"(pp));
+                    const float t = __fmaf_rn(sq_a[0], f, sq_a[1]);
+                    const float s1 = __fmaf_rn(dl, t, xs);
+                    const float s2 = __fmaf_rn(mn, sq_b[0], s1);
+                    const float lo = __fmaf_rn(pp, sq_b[1], s2);
+                    const uint32_t lrow = (uint32_t)(mt * 16 + i) + (uint32_t)kq * 4u;
+                    if (lrow < nvalid && !(lo > sq_T)) {   // (a NaN goes on to the exact re-rank)
                         const uint32_t row = r0 + lrow;
                         const uint32_t pos = mf_queue_reserve(q_cnt_off);
                         if (pos < Q_CAP) {
-                            mf_queue_write(q_rec_off + pos * 16, row, (uint32_t)qidx[0], __float_as_uint(low));
+                            mf_queue_write(q_rec_off + pos * 16, row, (uint32_t)qidx[0], __float_as_uint(lo));
                         } else {
                             uint32_t s = atomicAdd(&P.counts[qidx[0]], 1u);
-                            if (s < P.cap) P.cand[(size_t)qidx[0] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            if (s < P.cap) P.cand[(size_t)qidx[0] * P.cap + s] = make_uint2(row, __float_as_uint(lo));
                             emitted = true;
                         }
                     }
                 }
-            };
-            if (MODE == MF_FILTER) {
-                static_assert(MT == 4, "SQ8 tiles are 64 rows");
-#pragma unroll 1
-                for (int mt = 0; mt < MT; mt++) {
-                    const acc_t lo = mt & 1 ? acc[1][0] : acc[0][0], hi = mt & 1 ? acc[3][0] : acc[2][0];
-                    value_pass(mt, mt & 2 ? hi : lo);
-                }
             } else {
+                // Probe: the upper end of every value's bound
+                constexpr float kU = 64.0f / 16777216.0f;
+                const float Wref = sq_c[1];
+                const float qs = rG * sq_a[0], ce = rG * sq_a[1], ysum = rG * sq_b[0], ne = rG * sq_b[1];
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    value_pass(mt, acc[mt][0]);
+                    f32x4_t mn4, dl4, xs4 = {0, 0, 0, 0}, pp4;
+                    read_aux(mt, mn4, dl4, xs4, pp4);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t lrow = mt * 16 + kq * 4 + i;
+                        const float mn = mn4[i], dl = dl4[i], xsq = xs4[i], p = pp4[i];
+                        const float f = (float)(int)acc[mt][0][i];
+                        const float dq = dl * (qs * f + ce);
+                        const float my = mn * ysum;
+                        const float ip = my + dq;
+                        const float C = L2 ? (xsq + ysq) : 1.0f;
+                        const float sc = L2 ? (C - 2.0f * ip) : ((1.0f - ip) - ysq);   // IP: ysq holds the shift (y_mean_ip or 0, exact_kernels.hpp sq8_score)
+                        const float E = (L2 ? 2.0f : 1.0f) * (p * ne + dl * Wref) + kU * (2.0f * (fabsf(my) + fabsf(dq)) + C + (L2 ? 0.0f : fabsf(ysq)));   // L2 carries 2 ip
+                        const float up = sc + E;
+                        if (lrow < nvalid && up < tmin[0]) tmin[0] = up;
+                    }
                     __builtin_amdgcn_sched_barrier(0);   // one M-block at a time
                 }
             }

@@ -215,13 +215,13 @@ static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P,
         switch (variant) {
         case 1: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4>);
         case 2: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
-        case 3: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 4, 3>);                   // 128 VGPRs: two workgroups per CU
+        case 3: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3>);                   // 256 VGPRs: one workgroup per CU
+        case 10: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 4, 3>);                  // 128 VGPRs, 3 slots
         case 4: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 24576>);            // 64 rows x 384 B per unit
         case 5: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 2, 49152>);            // whole rows, 2 slots
         case 6: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 4>);      // refill after 4 fragments
         case 7: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 16384, 2>);         // 4 slots, 2 ahead: plain barrier
         case 8: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 24576>);
-        case 9: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 4, 1, 2, 3>);                   // the 4-wave kernel of narrow batches
         }
     }
     return false;
@@ -283,9 +283,17 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
             break;
         }
     } else if (t->lp_kind == LP_SQ8) {
+        // filter, widths 512 / 768: 128 registers and a 4-slot ring, two workgroups per CU -- one's epilogue and refill requests
+        // run under the other's MFMA stream (10 M x 768 L2, batch 128: 1.83 ms at one workgroup per CU, 1.68 with two, 1.63 with 4 slots)
         switch (t->lp_ksteps) {
-        case 8: launch_lowp_t<LP_SQ8, 8, 64, 1>(mode, P, grid, s); break;
-        case 12: launch_lowp_t<LP_SQ8, 12, 64, 1>(mode, P, grid, s); break;
+        case 8:
+            if (mode == MF_FILTER) launch_lowp_k<LP_SQ8, 8, MF_FILTER, 64, 8, 1, 4, 4>(P, grid, s);
+            else launch_lowp_t<LP_SQ8, 8, 64, 1>(mode, P, grid, s);
+            break;
+        case 12:
+            if (mode == MF_FILTER) launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 4, 4>(P, grid, s);
+            else launch_lowp_t<LP_SQ8, 12, 64, 1>(mode, P, grid, s);
+            break;
         default: launch_lowp_t<LP_SQ8, 16, 64, 1>(mode, P, grid, s); break;
         }
     } else if (t->lp_kind == LP_U8) {
@@ -637,7 +645,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tile_first = 0;
         Q.tile_step = 1;
         Q.n_tiles = total_tiles;
-        const uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_lowp_wg_per_cu;
+        uint32_t fw = (uint32_t)c->n_cu * (uint32_t)c->opt_lowp_wg_per_cu;
+        if (is_sq8 && !narrow && t->lp_ksteps < 16) fw = std::max(fw, (uint32_t)c->n_cu * 2u);   // (launch_lowp: the 128-register SQ8 filter)
         Q.dbg = (int)c->opt_lowp_dbg;
         uint32_t *d_ph = nullptr;
         const size_t ph_words = (size_t)fw * q_tiles * 16 * 8;
