@@ -122,11 +122,10 @@ int vsgpu_sq8_pair_scores(vsgpu_table *t, const uint32_t *ids_a, const uint32_t 
  * holds rows {codes, min, delta, sum, x_mean_ip}; its query blobs are {y[dim], y_sum, y_mean_ip} and every score is
  * base - y_mean_ip; pair scores are base - x_mean_ip - y_mean_ip + mean_sum_squares with the constant set here. */
 int vsgpu_table_set_sq8_mean_sum_squares(vsgpu_table *t, float mean_sum_squares);
-/* Optional, SQ8 tables: extremes of the stored rows' metadata -- {max delta, min delta, max min, min min, max |codes - 128|_2,
- * min sum_squares, max sum_squares (L2 blobs; 0 otherwise), 0} over every row the table holds or ever held (the caller widens them as rows arrive
- * and never narrows them).  With them the MFMA filter rejects whole blocks of (row, query) values by one bound before it
- * evaluates per-value bounds (mfma_lowp_kernels.hpp epilogue_sq8); they only steer work, the results do not depend on them as
- * long as they do cover the rows.  NULL clears them.  The FlatSQ8 index maintains them (csrc/host/flat_index.cpp). */
+/* SQ8 tables: extremes of the stored rows' metadata {max delta, min delta, max min, min min, max |codes - 128|_2, min sum_squares,
+ * max sum_squares, 0}.  Rounds 1-2 used them for a block pre-screen in the MFMA filter; since round 3 the filter's per-value
+ * screen (mfma_lowp_kernels.hpp epilogue_sq8) takes the table-wide maxima it needs from the device-side aux pass
+ * (k_row_aux_sq8), so the call is accepted, kept with the table and has no effect on any result or kernel. */
 int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[8]);
 
 /* ---- HNSW query loops (algorithms/hnsw/hnsw.h:530-613, 1210-1258, 1967-2084) ----

@@ -93,10 +93,6 @@ struct LowpParams {
     uint32_t n_rows;
     uint32_t tile_first, tile_step, n_tiles;   // tile t covers rows (tile_first + t*tile_step)*RT ...
     uint32_t tile_run_shift;                   // ... probe: in runs of 2^shift consecutive tiles (see MfmaParams)
-    // SQ8 filter, block pre-screen (epilogue_sq8): extremes of the aux values over the table {max delta, min delta, max min,
-    // min min, max |c'|_2, min sum_squares}; sq8_blk_on = 0 switches the test off
-    float sq8_blk[8];   // (+ max sum_squares, pad)
-    int sq8_blk_on;
     // SQ8 filter, per-value screen: {max delta, max |min|, max sum_squares} over the table (float bits, k_row_aux_sq8) and
     // the largest |code dot + K| / |c - 128|_2 any row of this width can have
     const uint32_t *sq8_max;

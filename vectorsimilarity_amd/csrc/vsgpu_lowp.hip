@@ -584,13 +584,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     P.qmeta = (const float *)c->qmeta.p;
     if (is_sq8) {
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
-        // block pre-screen: worth its ~55 operations per lane and tile only where it can reject, i.e. rows of one scale
-        for (int i = 0; i < 8; i++) P.sq8_blk[i] = t->sq8_blk[i];
-        const float dh = t->sq8_blk[0], dlw = t->sq8_blk[1];
         P.sq8_max = t->d_sq8_max;
         P.sq8_fmax = (float)(2.0 * 128.0 * 127.0 * (double)kdim * (1.0 + 1e-6));   // |D| <= 128 * 127 * width, |K| likewise
         P.sq8_ncmax = (float)(128.0 * std::sqrt((double)kdim) * 1.00001);
-        P.sq8_blk_on = (t->sq8_blk_set && c->opt_sq8_block && t->metric != VSGPU_L2 && dlw > 0.0f && std::isfinite(dh) && dh <= 2.0f * dlw) ? 1 : 0;
     } else if (is_int) {
         P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
     } else {
