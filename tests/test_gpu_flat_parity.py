@@ -681,6 +681,14 @@ def test_reply_objects_and_array_entry_points_agree():
     ("bf16", "IP", 2048, 9_000, 70, 10),        # 4 waves x 16 queries, fragments in AGPRs
     ("f16", "L2", 1800, 7_000, 20, 10),
     ("bf16", "Cosine", 1600, 6_000, 64, 5),
+    # bf16 / fp16 rows of 2049 .. 8192 elements: k split over the four waves (k_mfma_filter_wide<.., EK = 1 | 2>), widths
+    # 3072 / 4096 / 6144 / 8192
+    ("bf16", "IP", 3072, 5_003, 20, 10),
+    ("bf16", "L2", 2049, 4_000, 7, 10),
+    ("f16", "IP", 4096, 4_001, 17, 10),
+    ("bf16", "Cosine", 5000, 3_001, 33, 10),
+    ("f16", "L2", 8192, 2_500, 9, 10),
+    ("bf16", "L2", 8191, 2_100, 16, 5),
     ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's exact query tile: 256 queries, top-100
     ("bf16", "IP", 768, 40_000, 128, 10),       # BASELINE config 4's exact query tile: 128 queries, top-10
 ])
@@ -694,7 +702,8 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)
     st = ix.stats()
-    assert st["scan_kernel"].startswith(("k_mfma_filter_lowp", "k_i8_filter_x32")), st
+    assert st["scan_kernel"].startswith(("k_mfma_filter_wide(h16)",) if typ in ("bf16", "f16") and dim > 2048
+                                        else ("k_mfma_filter_lowp", "k_i8_filter_x32")), st
     # ints are heavy on exact ties (integer scores): the candidate lists may legitimately overflow
     if typ not in ("i8", "u8"):
         assert st["fallbacks"] == 0, st

@@ -29,6 +29,7 @@
 namespace vsg {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x8_t __attribute__((ext_vector_type(8)));

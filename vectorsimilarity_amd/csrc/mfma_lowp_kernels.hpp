@@ -27,7 +27,6 @@ namespace vsg {
 enum LowpKind { LP_BF16 = 0, LP_F16 = 1, LP_I8 = 2, LP_U8 = 3, LP_SQ8 = 4, LP_U8C = 5 };
 enum LowpEpi { LE_FP_L2 = 0, LE_FP_IP = 1, LE_I8_L2 = 2, LE_I8_IP = 3, LE_I8_COS = 4, LE_U8_IP = 5 };
 
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -170,7 +169,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     // UADDR: request addresses as a wave-uniform 64-bit base (SGPRs) + one constant 32-bit offset per lane and piece (the
     // scalar-base form of global_load_lds) instead of a 64-bit address per lane and piece.  Rows past the table's end are not
     // clamped: a tile never leaves its slab, whose allocation is whole, and the epilogues mask such rows (nvalid).
-    constexpr bool UADDR = (LK == LP_SQ8);
+#ifndef LOWP_UADDR_ALL
+#define LOWP_UADDR_ALL 0
+#endif
+    constexpr bool UADDR = (LK == LP_SQ8) || (LOWP_UADDR_ALL && !SKEW);
     static_assert(!SQ8 || (!SKEW && NQW == 1 && RT * 16 <= AUXBUF && NWAVES * 256 >= AUXBUF), "SQ8 aux geometry");
     static_assert(LK != LP_SQ8 || RT == 64, "SQ8 aux arrays are laid out per 64 rows (k_row_aux_sq8)");
     // units requested ahead.  DIST = NS-2 leaves one slot of slack: the slot refilled after a barrier was last read
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);   // (uniform already: keeps it in SGPRs)
                     uint32_t lo32 = st_lane[i];
                     asm volatile("" : "+v"(lo32));   // (keeps the zero-extension in this block: hoisted, the scalar-base form is not selected)
-                    glds16<2>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
+                    if (pair_map) glds16<0>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
+                    else glds16<2>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
                     continue;
                 }
                 // paired query tiles want the row to stay in L2 for the partner: default cache policy there
@@ -402,9 +405,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                 const uint64_t ab = reinterpret_cast<uint64_t>(apt);
                 const uint64_t au = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ab >> 32)) << 32) |
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ab);
-                uint32_t lo32 = (uint32_t)lane * (SQ8 ? 16u : 4u);
+                // (lanes past the tile's RT rows re-read its first rows: the tile's aux values end where the slab's may)
+                uint32_t lo32 = (uint32_t)(RT < 64 ? lane & (RT - 1) : lane) * (SQ8 ? 16u : 4u);
                 asm volatile("" : "+v"(lo32));
-                glds16<0>(reinterpret_cast<const char *>(au) + lo32, abuf_i * AUXBUF, aux_lds);
+                if (SQ8) glds16<0>(reinterpret_cast<const char *>(au) + lo32, abuf_i * AUXBUF, aux_lds);
+                else glds4(reinterpret_cast<const char *>(au) + lo32, abuf_i * 256, aux_lds);
             }
             else if (SQ8) glds16<0>(apt, abuf_i * AUXBUF, aux_lds);
             else glds4(apt, abuf_i * 256, aux_lds);

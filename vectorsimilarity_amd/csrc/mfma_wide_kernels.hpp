@@ -1,4 +1,5 @@
-// mfma_wide_kernels.hpp -- the fp32 MFMA filter for rows wider than k_mfma_filter's registers hold (3072 < dim <= 8192).
+// mfma_wide_kernels.hpp -- the MFMA filter for rows wider than the other filters' registers hold: fp32 3072 < dim <= 8192
+// (EK = 0), bf16 / fp16 2048 < dim <= 8192 (EK = 1 / 2: the stored elements are the MFMA operands, a stage holds 512 of them).
 //
 // k_mfma_filter keeps the bf16 fragments of 64 queries in registers (16 per wave); at dim 4096 those alone are the whole
 // register file of a CU.  This variant keeps 16 queries per WORKGROUP and splits the row's k range over the four waves by
@@ -22,15 +23,16 @@ constexpr int mfw_lds_bytes(bool probe) {
     return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + MFW_RED_BYTES + (probe ? MF_PM_TILES * 64 : 0);
 }
 
-template <int KSTEPS, int MODE, int AUX = 0>
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int NS = 3, RT = 16;
-    constexpr int KC = (MF_STAGE_BYTES / 4) / RT;    // 256 elements per row per stage
-    constexpr int SEG = KC * 4;                      // 1 KiB
-    constexpr int KSUB = KC / 32;                    // 8 MFMA k-steps per stage
-    static_assert(KSTEPS % (4 * KSUB) == 0, "the row is a whole number of stage quadruples");
-    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
-    constexpr int KMINE = KSTEPS / 4;                // k-steps of one wave
+    constexpr int EB = EK == 0 ? 4 : 2;              // bytes per stored element
+    constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) elements per row per stage
+    constexpr int SEG = KC * EB;                     // 1 KiB
+    constexpr int KSUB = KC / 32;                    // 8 / 16 MFMA k-steps per stage
+    static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
+    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile (wave w takes stages w, w + 4, ...)
+    constexpr int KMINE = ((KCH + 3) / 4) * KSUB;    // k-steps of one wave (the last quadruple may be short)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         const uint4 *src = P.qfrag + ((size_t)qtile * KSTEPS) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
-            const int s = ((i / KSUB) * 4 + wave) * KSUB + (i % KSUB);
+            const int st = (i / KSUB) * 4 + wave;   // (a stage past the row's last: never multiplied)
+            const int s = (st < KCH ? st : 0) * KSUB + (i % KSUB);
             uint4 v = src[(size_t)s * 64];
             qf[i] = __builtin_bit_cast(bf16x8_t, v);
         }
@@ -160,14 +163,26 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                 const char *sbase = lds + slot_c * MF_STAGE_BYTES;
 #pragma unroll
                 for (int j = 0; j < KSUB; j++) {
-                    const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
-                    const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
-                    const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
-                    f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
-                    f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
-                    f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
+                    if constexpr (EK == 0) {
+                        const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
+                        const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
+                        const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
+                        f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+                        f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+                        f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
+                    } else {
+                        // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
+                        // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
+                        const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
+                        const int p = (4 * (j % 4) + kq) ^ m16;
+                        const mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+                        if constexpr (EK == 1)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
+                        else
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[(c / 4) * KSUB + j]), acc, 0, 0, 0);
+                    }
                 }
             }
             slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;

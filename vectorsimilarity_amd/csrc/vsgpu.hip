@@ -258,6 +258,21 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
                     break;
                 }
         }
+        if (!t->prog.scalar_tier && t->prog.reduce == 0 && (type == VSGPU_BF16 || type == VSGPU_F16) && dim > 2048 && dim <= 8192 &&
+            row_bytes == data_bytes) {
+            // 16 queries per workgroup, the row's k range split over the four waves by ring stage (mfma_wide_kernels.hpp)
+            static const int ww[] = {96, 128, 192, 256};
+            for (int i = 0; i < 4; i++)
+                if ((size_t)ww[i] * 32 >= dim) {
+                    t->lowp_ok = true;
+                    t->lp_wide = true;
+                    t->lp_kind = type == VSGPU_BF16 ? LP_BF16 : LP_F16;
+                    t->lp_ksteps = ww[i];
+                    t->lp_rt = 16;
+                    t->lp_qtile = 16;
+                    break;
+                }
+        }
         if ((type == VSGPU_SQ8 || type == VSGPU_SQ8H) && !t->prog.scalar_tier && dim <= 1024) {
             // SQ8 x FP32 on the int8 MFMA filter (mfma_lowp_kernels.hpp LP_SQ8): 8 waves x 16 queries, 64-row tiles
             t->lowp_ok = true;

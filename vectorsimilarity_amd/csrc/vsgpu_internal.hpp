@@ -137,6 +137,7 @@ struct vsgpu_table {
     // low-precision MFMA filter (bf16/fp16/int8 rows): kernel shape picked at create time
     bool lowp_ok = false;
     int lp_kind = 0, lp_ksteps = 0, lp_rt = 0, lp_qtile = 0;
+    bool lp_wide = false;   // bf16 / fp16 rows of 2049 .. 8192 elements: k_mfma_filter_wide<.., EK = 1 | 2> (16 queries per workgroup)
     bool sq8_centred = false;   // mean-centred IP rows (dim + 16 bytes: x_mean_ip behind the three base slots), queries carry y_mean_ip
     float sq8_mss = 0.f;        // sum mean_i^2, the symmetric IP correction constant
     float sq8_blk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)

@@ -2,6 +2,7 @@
 #include "vsgpu_internal.hpp"
 #include "mfma_lowp_kernels.hpp"
 #include "mfma_i8x32_kernels.hpp"
+#include "mfma_wide_kernels.hpp"
 #ifdef VSGPU_TUNING
 #include "mfma_free_kernels.hpp"
 #include "mfma_i8ks_kernels.hpp"
@@ -391,6 +392,48 @@ template <int LK> static void launch_lowp_h16_split(int mode, const LowpParams &
 template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim3, hipStream_t) {}
 #endif
 
+// bf16 / fp16 rows of 2049 .. 8192 elements on k_mfma_filter_wide (mfma_wide_kernels.hpp): same records, same bound
+template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P); };
+    switch (ksteps) {
+    case 96: go(k_mfma_filter_wide<96, MODE, 0, EK>); break;
+    case 128: go(k_mfma_filter_wide<128, MODE, 0, EK>); break;
+    case 192: go(k_mfma_filter_wide<192, MODE, 0, EK>); break;
+    default: go(k_mfma_filter_wide<256, MODE, 0, EK>); break;
+    }
+}
+static void launch_wide_h16(const vsgpu_table *t, int mode, const LowpParams &L, dim3 grid, hipStream_t s) {
+    MfmaParams P{};
+    P.slabs = L.slabs;
+    P.norm_slabs = reinterpret_cast<const float *const *>(L.aux_slabs);
+    P.slab_shift = L.slab_shift;
+    P.slab_mask = L.slab_mask;
+    P.row_stride = L.row_stride;
+    P.n_rows = L.n_rows;
+    P.tile_first = L.tile_first;
+    P.tile_step = L.tile_step;
+    P.n_tiles = L.n_tiles;
+    P.tile_run_shift = L.tile_run_shift;
+    P.qfrag = L.qfrag;
+    P.qn2 = reinterpret_cast<const float *>(L.qaux);
+    P.cE = L.cE;
+    P.absE = L.absE;
+    P.is_l2 = L.epi == LE_FP_L2 ? 1 : 0;
+    P.tilemin = L.tilemin;
+    P.tilemin_stride = L.tilemin_stride;
+    P.tau = L.tau;
+    P.counts = L.counts;
+    P.cand = L.cand;
+    P.cap = L.cap;
+    if (t->lp_kind == LP_BF16) {
+        if (mode == MF_PROBE) launch_wide_h16_m<1, MF_PROBE>(t->lp_ksteps, P, grid, s);
+        else launch_wide_h16_m<1, MF_FILTER>(t->lp_ksteps, P, grid, s);
+    } else {
+        if (mode == MF_PROBE) launch_wide_h16_m<2, MF_PROBE>(t->lp_ksteps, P, grid, s);
+        else launch_wide_h16_m<2, MF_FILTER>(t->lp_ksteps, P, grid, s);
+    }
+}
+
 int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                      uint32_t *ids, double *scores, uint32_t *counts) {
     vsgpu_ctx *c = t->ctx;
@@ -624,7 +667,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
+        if (t->lp_wide) launch_wide_h16(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs * 2), (unsigned)q_tiles), c->stream);
+        else if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (narrow) launch_lowp_narrow_any(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs * 2), (unsigned)q_tiles), c->stream);
@@ -697,6 +741,10 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 if (!h.empty()) fprintf(stderr, "x32 clocks: %.0f shader ticks / %.0f ref ticks per workgroup = %.3f GHz (ref 100 MHz), %.3f ms\n",
                         sc / (h.size() / 2), sr / (h.size() / 2), sc / sr * 0.1, sr / (h.size() / 2) * 1e-5);
             }
+        } else if (t->lp_wide) {
+            // gridDim.x a multiple of 8: the query tiles of a row tile (blockIdx.y) land on one XCD and share its L2 (vsgpu_mfma.hip)
+            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            launch_wide_h16(t, MF_FILTER, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
@@ -742,7 +790,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
-                              is_sq8 ? "k_mfma_filter_lowp(sq8)" : !is_int ? "k_mfma_filter_lowp(h16)"
+                              is_sq8 ? "k_mfma_filter_lowp(sq8)" : t->lp_wide ? "k_mfma_filter_wide(h16)" : !is_int ? "k_mfma_filter_lowp(h16)"
 #ifdef VSGPU_TUNING
                               : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
 #endif
