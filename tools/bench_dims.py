@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--type", default="f32")
 ap.add_argument("--metric", default="L2")
 ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE index option (repeatable)")
 ap.add_argument("dims", nargs="*", type=int, default=[768, 1536, 2048, 3072])
 a = ap.parse_args()
 T = {"f32": (VecSim.VecSimType_FLOAT32, 4, synth.rows_f32), "bf16": (VecSim.VecSimType_BFLOAT16, 2, synth.rows_bf16),
@@ -24,6 +25,8 @@ for dim in a.dims:
     p.type, p.dim, p.metric = T[0], dim, getattr(VecSim, "VecSimMetric_" + a.metric)
     ix = VecSim.BFIndex(p)
     ix.add_synthetic(n, 47)
+    for o in a.opt:
+        ix.set_option(o.split("=")[0], int(o.split("=")[1]))
     q = T[2](48, 0, a.batch, dim)
     ix.knn_query(q, 10)
     ix.reset_stats()

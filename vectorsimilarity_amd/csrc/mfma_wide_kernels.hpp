@@ -17,13 +17,15 @@
 
 namespace vsg {
 
-constexpr int MFW_QTILE = 16;
-constexpr int MFW_RED_BYTES = 3 * 64 * 16;
-constexpr int mfw_lds_bytes(bool probe) {
-    return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + MFW_RED_BYTES + (probe ? MF_PM_TILES * 64 : 0);
+constexpr int MFW_QTILE = 16;               // queries per column block; a workgroup holds NQ of them (1 or 2)
+constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block
+constexpr int mfw_lds_bytes(bool probe, int nq = 1) {
+    return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
 }
 
-template <int KSTEPS, int MODE, int AUX = 0, int EK = 0>
+// NQ = 2: 32 queries per workgroup -- every fragment read from LDS feeds two MFMAs and a batch needs half the query tiles, i.e.
+// half the passes over the rows (the tiles of a row tile share it through L2 only in part); 2 x KMINE fragments per wave.
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int NS = 3, RT = 16;
     constexpr int EB = EK == 0 ? 4 : 2;              // bytes per stored element
@@ -43,24 +45,29 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     const int qtile = blockIdx.y;
 
     // this wave's fragments: the k-steps of stages wave, wave + 4, ...
-    bf16x8_t qf[KMINE];
-    {
-        const uint4 *src = P.qfrag + ((size_t)qtile * KSTEPS) * 64 + lane;
+    bf16x8_t qf[NQ][KMINE];
+    int qidx[NQ];
+    float nq2[NQ], tau[NQ];
+#pragma unroll
+    for (int nt = 0; nt < NQ; nt++) {
+        const uint4 *src = P.qfrag + ((size_t)(qtile * NQ + nt) * KSTEPS) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
             const int st = (i / KSUB) * 4 + wave;   // (a stage past the row's last: never multiplied)
             const int s = (st < KCH ? st : 0) * KSUB + (i % KSUB);
             uint4 v = src[(size_t)s * 64];
-            qf[i] = __builtin_bit_cast(bf16x8_t, v);
+            qf[nt][i] = __builtin_bit_cast(bf16x8_t, v);
         }
+        qidx[nt] = (qtile * NQ + nt) * MFW_QTILE + m16;
+        nq2[nt] = P.qn2[qidx[nt]];
+        tau[nt] = MODE == MF_FILTER ? P.tau[qidx[nt]] : 0.f;
     }
-    const int qidx = qtile * MFW_QTILE + m16;
-    float nq2 = P.qn2[qidx];
-    float tau = 0.f;
-    if (MODE == MF_FILTER) tau = P.tau[qidx];
 #pragma unroll
-    for (int i = 0; i < KMINE; i++) asm volatile("" : "+v"(qf[i]));
-    asm volatile("" : "+v"(nq2), "+v"(tau));
+    for (int nt = 0; nt < NQ; nt++) {
+#pragma unroll
+        for (int i = 0; i < KMINE; i++) asm volatile("" : "+v"(qf[nt][i]));
+        asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]));
+    }
 
     uint32_t st_row[4], st_off[4];
 #pragma unroll
@@ -126,20 +133,25 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
     for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
 
-    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false) + (uint32_t)m16 * 4u;
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
     auto flush_probe_minima = [&]() {   // (wave 0 only)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
-            float v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + it * 64u) : "memory");
-            P.tilemin[(size_t)qidx * P.tilemin_stride + pm_tile0 + it * step] = v;
+#pragma unroll
+            for (int nt = 0; nt < NQ; nt++) {
+                float v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (it * NQ + nt) * 64u) : "memory");
+                P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pm_n = 0;
     };
     for (; tile < P.n_tiles; tile += step) {
-        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        f32x4_t acc[NQ];
+#pragma unroll
+        for (int nt = 0; nt < NQ; nt++) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
             {   // unit (tile, c) landed; one younger unit (4 loads, + the norm load of a unit that opens a tile) may be in flight
@@ -171,17 +183,22 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                         f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
                         f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                         bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NQ; nt++)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][(c / 4) * KSUB + j], acc[nt], 0, 0, 0);
                     } else {
                         // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
                         // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
                         const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
                         const int p = (4 * (j % 4) + kq) ^ m16;
                         const mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-                        if constexpr (EK == 1)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[(c / 4) * KSUB + j], acc, 0, 0, 0);
-                        else
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[(c / 4) * KSUB + j]), acc, 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NQ; nt++) {
+                            if constexpr (EK == 1)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][(c / 4) * KSUB + j], acc[nt], 0, 0, 0);
+                            else
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][(c / 4) * KSUB + j]), acc[nt], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -189,54 +206,63 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         }
         // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS; wave 0 goes on ----
         if (wave != 0) {
-            const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc);
-            asm volatile("ds_write_b128 %0, %1" ::"v"(red_off + (uint32_t)((wave - 1) * 1024 + lane * 16)), "v"(v) : "memory");
+#pragma unroll
+            for (int nt = 0; nt < NQ; nt++) {
+                const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc[nt]);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(red_off + (uint32_t)(nt * MFW_RED_BYTES + (wave - 1) * 1024 + lane * 16)), "v"(v) : "memory");
+            }
         }
         mf_ring_barrier();
         const uint32_t r0 = tile_row0(tile);
         bool emitted = false;
         if (wave == 0) {
-            mf_u32x4 p1, p2, p3;
-            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(p1), "=&v"(p2), "=&v"(p3)
-                         : "v"(red_off + (uint32_t)(lane * 16))
-                         : "memory");
-            acc += __builtin_bit_cast(f32x4_t, p1);
-            acc += __builtin_bit_cast(f32x4_t, p2);
-            acc += __builtin_bit_cast(f32x4_t, p3);
             const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * 256);
             mf_u32x4 nbits;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
             const f32x4_t n4 = __builtin_bit_cast(f32x4_t, nbits);
-            float tmin = INFINITY;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t row = r0 + kq * 4 + i;
-                const float ssum = n4[i] + nq2;
-                const float dot = acc[i];
-                const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
-                const float E = P.cE * ssum + P.absE;
-                if (MODE == MF_PROBE) {
-                    const float up = a + E;
-                    if (row < P.n_rows && up < tmin) tmin = up;
-                } else {
-                    const float low = a - E;
-                    if (row < P.n_rows && !(low > tau)) {
-                        const uint32_t pos = mf_queue_reserve(eq_n_off);
-                        if (pos < MF_EQ_CAP) {
-                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));
-                        } else {
-                            uint32_t s = atomicAdd(&P.counts[qidx], 1u);
-                            if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                            emitted = true;
+            for (int nt = 0; nt < NQ; nt++) {
+                mf_u32x4 p1, p2, p3;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                             : "v"(red_off + (uint32_t)(nt * MFW_RED_BYTES + lane * 16))
+                             : "memory");
+                f32x4_t a4 = acc[nt];
+                a4 += __builtin_bit_cast(f32x4_t, p1);
+                a4 += __builtin_bit_cast(f32x4_t, p2);
+                a4 += __builtin_bit_cast(f32x4_t, p3);
+                float tmin = INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t row = r0 + kq * 4 + i;
+                    const float ssum = n4[i] + nq2[nt];
+                    const float dot = a4[i];
+                    const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
+                    const float E = P.cE * ssum + P.absE;
+                    if (MODE == MF_PROBE) {
+                        const float up = a + E;
+                        if (row < P.n_rows && up < tmin) tmin = up;
+                    } else {
+                        const float low = a - E;
+                        if (row < P.n_rows && !(low > tau[nt])) {
+                            const uint32_t pos = mf_queue_reserve(eq_n_off);
+                            if (pos < MF_EQ_CAP) {
+                                mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                            } else {
+                                uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
+                                if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                                emitted = true;
+                            }
                         }
                     }
                 }
+                if (MODE == MF_PROBE) {
+                    tmin = fminf(tmin, __shfl_xor(tmin, 16));
+                    tmin = fminf(tmin, __shfl_xor(tmin, 32));
+                    if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + (pm_n * NQ + nt) * 64u), "v"(tmin) : "memory");
+                }
             }
             if (MODE == MF_PROBE) {
-                tmin = fminf(tmin, __shfl_xor(tmin, 16));
-                tmin = fminf(tmin, __shfl_xor(tmin, 32));
-                if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + pm_n * 64u), "v"(tmin) : "memory");
                 if (pm_n == 0) pm_tile0 = tile;
                 if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
             }

@@ -393,16 +393,22 @@ template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim
 #endif
 
 // bf16 / fp16 rows of 2049 .. 8192 elements on k_mfma_filter_wide (mfma_wide_kernels.hpp): same records, same bound
-template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P); };
+template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kern, int nqb) {
+        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb);
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
+    };
+    // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave)
     switch (ksteps) {
-    case 96: go(k_mfma_filter_wide<96, MODE, 0, EK>); break;
-    case 128: go(k_mfma_filter_wide<128, MODE, 0, EK>); break;
-    case 192: go(k_mfma_filter_wide<192, MODE, 0, EK>); break;
-    default: go(k_mfma_filter_wide<256, MODE, 0, EK>); break;
+    case 96: nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1>, 1); break;
+    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1>, 1); break;
+    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1>, 1); break;
+    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1>, 1); break;
     }
 }
-static void launch_wide_h16(const vsgpu_table *t, int mode, const LowpParams &L, dim3 grid, hipStream_t s) {
+static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const LowpParams &L, dim3 grid, hipStream_t s) {
     MfmaParams P{};
     P.slabs = L.slabs;
     P.norm_slabs = reinterpret_cast<const float *const *>(L.aux_slabs);
@@ -426,11 +432,11 @@ static void launch_wide_h16(const vsgpu_table *t, int mode, const LowpParams &L,
     P.cand = L.cand;
     P.cap = L.cap;
     if (t->lp_kind == LP_BF16) {
-        if (mode == MF_PROBE) launch_wide_h16_m<1, MF_PROBE>(t->lp_ksteps, P, grid, s);
-        else launch_wide_h16_m<1, MF_FILTER>(t->lp_ksteps, P, grid, s);
+        if (mode == MF_PROBE) launch_wide_h16_m<1, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
+        else launch_wide_h16_m<1, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
     } else {
-        if (mode == MF_PROBE) launch_wide_h16_m<2, MF_PROBE>(t->lp_ksteps, P, grid, s);
-        else launch_wide_h16_m<2, MF_FILTER>(t->lp_ksteps, P, grid, s);
+        if (mode == MF_PROBE) launch_wide_h16_m<2, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
+        else launch_wide_h16_m<2, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
     }
 }
 
@@ -455,7 +461,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                      && !c->opt_lowp_ksplit
 #endif
         ;
-    const size_t QT = hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
+    // k_mfma_filter_wide: 32 queries per workgroup at width 6144 (6 GB of bf16 rows, batch 64: 3.04 -> 2.03 ms); at widths 3072 / 4096
+    // four 16-query tiles sharing the rows through L2 measured faster than two 32-query tiles (1.90 against 2.16 ms); option
+    // wide_blocks: 1 = 16 everywhere, 2 = 32 wherever the registers allow
+    const int wide_blocks = (t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && (KS == 192 || (c->opt_wide_blocks == 2 && KS < 192))) ? 2 : 1;
+    const size_t QT = t->lp_wide ? (size_t)16 * wide_blocks : hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
     const bool is_u8c = (t->lp_kind == LP_U8C);
@@ -667,7 +677,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        if (t->lp_wide) launch_wide_h16(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs * 2), (unsigned)q_tiles), c->stream);
+        if (t->lp_wide) launch_wide_h16(t, MF_PROBE, wide_blocks, Q, dim3(std::min(probe_tiles, wgs * 2), (unsigned)q_tiles), c->stream);
         else if (qsplit) launch_lowp_i8_split(t, MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_PROBE, Q, dim3(std::min(probe_tiles, wgs), (unsigned)q_tiles), c->stream);
@@ -743,8 +753,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             }
         } else if (t->lp_wide) {
             // gridDim.x a multiple of 8: the query tiles of a row tile (blockIdx.y) land on one XCD and share its L2 (vsgpu_mfma.hip)
-            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
-            launch_wide_h16(t, MF_FILTER, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
+            const uint32_t per_cu = (wide_blocks == 2 || KS > 192) ? 1u : 2u;   // (workgroups resident per CU)
+            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            launch_wide_h16(t, MF_FILTER, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit) launch_lowp_h16_split<LP_F16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);

@@ -135,21 +135,31 @@ static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t
 }
 
 // rows wider than 3072 elements: 16 queries per workgroup, the k range split over the waves (mfma_wide_kernels.hpp)
-template <int KS, int MODE> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+template <int KS, int MODE, int NQ> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, NQ);
 #ifdef VSGPU_TUNING
     if (getenv("VSGPU_WIDE_NT")) {
-        hipLaunchKernelGGL((k_mfma_filter_wide<KS, MODE, 2>), grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P);
+        hipLaunchKernelGGL((k_mfma_filter_wide<KS, MODE, 2, 0, NQ>), grid, dim3(256), lds_bytes, s, P);
         return;
     }
 #endif
-    auto kern = k_mfma_filter_wide<KS, MODE>;
-    hipLaunchKernelGGL(kern, grid, dim3(256), mfw_lds_bytes(MODE == MF_PROBE), s, P);
+    auto kern = k_mfma_filter_wide<KS, MODE, 0, 0, NQ>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
 }
-template <int MODE> static void launch_wide(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+// nq_blocks: 16-query column blocks per workgroup (2 up to width 6144: the fragments of 32 queries fit the registers of a wave)
+template <int MODE> static void launch_wide(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     switch (ksteps) {
-    case 128: launch_wide_ks<128, MODE>(P, grid, s); break;
-    case 192: launch_wide_ks<192, MODE>(P, grid, s); break;
-    default: launch_wide_ks<256, MODE>(P, grid, s); break;
+    case 128:
+        if (nq_blocks == 2) launch_wide_ks<128, MODE, 2>(P, grid, s);
+        else launch_wide_ks<128, MODE, 1>(P, grid, s);
+        break;
+    case 192:
+        if (nq_blocks == 2) launch_wide_ks<192, MODE, 2>(P, grid, s);
+        else launch_wide_ks<192, MODE, 1>(P, grid, s);
+        break;
+    default: launch_wide_ks<256, MODE, 1>(P, grid, s); break;
     }
 }
 
@@ -159,7 +169,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t n = t->n, dim = t->dim;
     const int KS = t->ksteps;
     const bool wide = KS > 96;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
-    const size_t QT = wide ? (size_t)MFW_QTILE : (size_t)MF_QTILE, TILE_ROWS = wide ? 16 : (size_t)MF_TILE_ROWS;
+    const int wide_blocks = (wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1;
+    const size_t QT = wide ? (size_t)MFW_QTILE * wide_blocks : (size_t)MF_QTILE, TILE_ROWS = wide ? 16 : (size_t)MF_TILE_ROWS;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = (nq + MF_QTILE - 1) / MF_QTILE * MF_QTILE;
     const bool l2 = (t->metric == VSGPU_L2);
 
@@ -267,7 +278,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
-        if (wide) launch_wide<MF_PROBE>(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        if (wide) launch_wide<MF_PROBE>(KS, wide_blocks, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         else if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
         HIPCHK(hipGetLastError());
@@ -286,11 +297,14 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (wide) {
             // one workgroup per CU and query tile in flight at a time per XCD slot: gridDim.x a multiple of 8, so the query
             // tiles of a row tile (blockIdx.y) land on one XCD and share its L2
-            uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * 2 / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            // (as many workgroups as are resident at once -- two per CU while a wave's fragments leave room for it, else one --
+            // so that the query tiles of a row tile run at the same time)
+            const uint32_t per_cu = (wide_blocks == 2 || KS > 192) ? 1u : 2u;
+            uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
 #ifdef VSGPU_TUNING
             if (const char *e = getenv("VSGPU_WIDE_GX")) gx = (uint32_t)atoi(e);
 #endif
-            launch_wide<MF_FILTER>(KS, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
+            launch_wide<MF_FILTER>(KS, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         else if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
             launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
