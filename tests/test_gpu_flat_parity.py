@@ -549,6 +549,7 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
     ("Cosine", 6144, 5_000, 33, 10),
     ("L2", 8192, 3_000, 17, 10),
     ("L2", 5000, 6_000, 70, 100),
+    ("IP", 4096, 4_000, 9, 10),        # at most 16 queries: one column block per workgroup
 ])
 def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
     """rows beyond 3072 elements: 16 queries per workgroup, the k range split over the waves by ring stage, partial dot products
@@ -569,6 +570,28 @@ def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
     for j in range(0, nq, 7):
         el, es = oracle_topk(vso, "f32", metric, rows, q[j], k)
         assert np.array_equal(l1[j], el.astype(np.int64)) and np.array_equal(d1[j], es), (metric, dim, j)
+
+
+@pytest.mark.parametrize("typ,dim,blocks", [("bf16", 3072, 2), ("f16", 4096, 2), ("bf16", 6144, 1), ("f32", 4096, 1), ("f32", 6144, 1)])
+def test_wide_rows_both_workgroup_shapes(vso, typ, dim, blocks):
+    """k_mfma_filter_wide with 16 and with 32 queries per workgroup (option wide_blocks) where production picks the other one"""
+    rng = np.random.default_rng(dim + blocks)
+    n, nq, k = 3_001, 40, 10
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    l0, d0 = ix.knn_query(q, k)
+    ix.set_option("wide_blocks", blocks)
+    ix.reset_stats()
+    l1, d1 = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"].startswith("k_mfma_filter_wide") and st["fallbacks"] == 0, st
+    assert np.array_equal(l0, l1) and np.array_equal(d0, d1)
+    ix.set_option("mfma", 0)
+    l2, d2 = ix.knn_query(q[:5], k)
+    assert np.array_equal(l1[:5], l2) and np.array_equal(d1[:5], d2)
 
 
 def test_mfma_filter_adversarial_near_duplicates(vso):
@@ -689,6 +712,7 @@ def test_reply_objects_and_array_entry_points_agree():
     ("bf16", "Cosine", 5000, 3_001, 33, 10),
     ("f16", "L2", 8192, 2_500, 9, 10),
     ("bf16", "L2", 8191, 2_100, 16, 5),
+    ("bf16", "IP", 6000, 2_000, 12, 10),        # width 6144 with one 16-query block (a batch of at most 16)
     ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's exact query tile: 256 queries, top-100
     ("bf16", "IP", 768, 40_000, 128, 10),       # BASELINE config 4's exact query tile: 128 queries, top-10
 ])
