@@ -232,25 +232,7 @@ void FlatIndex::noteRow(uint32_t id, const void *stored) {
     bool w;
     if (sq8_) {
         w = values_may_nan(b + dim_, VecSimType_FLOAT32, metric_ == VecSimMetric_L2 ? 4 : 3);
-        // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h: vsgpu_table_set_sq8_block_bounds):
-        // widened with every stored blob, never narrowed
-        float meta[4] = {0, 0, 0, 0};
-        std::memcpy(meta, b + dim_, (metric_ == VecSimMetric_L2 ? 4 : 3) * sizeof(float));
-        uint64_t ss = 0;
-        for (size_t i = 0; i < dim_; i++) {
-            const int c = (int)(unsigned char)b[i] - 128;
-            ss += (uint64_t)(c * c);
-        }
-        const float nc = std::nextafter((float)(std::sqrt((double)ss) * 1.000001), std::numeric_limits<float>::infinity());
-        const float xsq = metric_ == VecSimMetric_L2 ? meta[3] : 0.0f;
-        float nb[8] = {std::max(sq8_blk_[0], meta[1]), std::min(sq8_blk_[1], meta[1]), std::max(sq8_blk_[2], meta[0]),
-                       std::min(sq8_blk_[3], meta[0]), std::max(sq8_blk_[4], nc), std::min(sq8_blk_[5], xsq),
-                       std::max(sq8_blk_[6], xsq), 0.0f};
-        if (w) nb[0] = std::numeric_limits<float>::infinity();   // a row with non-finite metadata: no block test on this table
-        if (std::memcmp(nb, sq8_blk_, sizeof nb) != 0) {   // (at once: the bounds must cover a row before a query can see it)
-            std::memcpy(sq8_blk_, nb, sizeof nb);
-            vsgpu_table_set_sq8_block_bounds(table_, sq8_blk_);
-        }
+        // (the filter's table-wide maxima are kept on the device: k_row_aux_sq8)
     } else {
         w = mayScoreNaN(b);
     }

@@ -185,10 +185,6 @@ private:
     bool sq8_ = false;
     std::vector<float> sq8_mean_;   // empty: plain SQ8
     float sq8_mss_ = 0.0f;
-    // {max delta, min delta, max min, min min, max |codes - 128|_2, min sum_squares, max sum_squares, 0} over every blob stored so far
-    float sq8_blk_[8] = {-std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(),
-                         -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(),
-                         0.0f, std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(), 0.0f};
     // fp32 vector (dim_ floats) -> stored blob / query blob of this index (Cosine: normalised first; SQ8: quantised)
     void toStored(const void *blob, char *out) const;
     void toQuery(const void *query, char *out) const;
