@@ -19,15 +19,27 @@ namespace vsg {
 
 constexpr int MFW_QTILE = 16;               // queries per column block; a workgroup holds NQ of them (1 or 2)
 constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block
-constexpr int mfw_lds_bytes(bool probe, int nq = 1) {
-    return 3 * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
+constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3) {
+    return ns * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
+}
+// s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
+__device__ static inline void mfw_wait_vmcnt(int n) {
+    switch (n) {
+#define VSG_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    VSG_W(0) VSG_W(1) VSG_W(2) VSG_W(3) VSG_W(4) VSG_W(5) VSG_W(6) VSG_W(7) VSG_W(8) VSG_W(9) VSG_W(10) VSG_W(11)
+    VSG_W(12) VSG_W(13) VSG_W(14) VSG_W(15) VSG_W(16) VSG_W(17) VSG_W(18) VSG_W(19) VSG_W(20) VSG_W(21) VSG_W(22)
+    VSG_W(23) VSG_W(24) VSG_W(25) VSG_W(26) VSG_W(27) VSG_W(28) VSG_W(29) VSG_W(30) VSG_W(31) VSG_W(32) VSG_W(33)
+#undef VSG_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
 // NQ = 2: 32 queries per workgroup -- every fragment read from LDS feeds two MFMAs and a batch needs half the query tiles, i.e.
 // half the passes over the rows (the tiles of a row tile share it through L2 only in part); 2 x KMINE fragments per wave.
-template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1>
+// NS = ring slots (3 in production: 6 slots for a workgroup alone on its CU measured no faster, profiles/r03_wide_dims.txt).
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
-    constexpr int NS = 3, RT = 16;
+    constexpr int RT = 16;
     constexpr int EB = EK == 0 ? 4 : 2;              // bytes per stored element
     constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) elements per row per stage
     constexpr int SEG = KC * EB;                     // 1 KiB
@@ -35,6 +47,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
     constexpr int KCH = KSTEPS / KSUB;               // stages per row tile (wave w takes stages w, w + 4, ...)
     constexpr int KMINE = ((KCH + 3) / 4) * KSUB;    // k-steps of one wave (the last quadruple may be short)
+    static_assert(NS - 1 <= KCH && (NS - 2) * 4 + 2 <= 33, "requests reach into the next tile at most");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
     for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
 
-    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ) + (uint32_t)m16 * 4u;
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
     auto flush_probe_minima = [&]() {   // (wave 0 only)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -154,10 +167,12 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         for (int nt = 0; nt < NQ; nt++) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
-            {   // unit (tile, c) landed; one younger unit (4 loads, + the norm load of a unit that opens a tile) may be in flight
-                const bool opens = (c + 1) % KCH == 0;
-                if (opens && norm_loader) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            {   // unit (tile, c) landed; the NS - 2 younger units (4 loads each, + the norm load of a unit that opens a tile) may be in flight
+                int n_norm = 0;
+#pragma unroll
+                for (int j = 1; j < NS - 1; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
+                if (norm_loader) mfw_wait_vmcnt((NS - 2) * 4 + n_norm);
+                else mfw_wait_vmcnt((NS - 2) * 4);
             }
             mf_ring_barrier();
             if (MODE == MF_FILTER && c == 0) {

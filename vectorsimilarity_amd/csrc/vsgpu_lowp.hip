@@ -393,19 +393,24 @@ template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim
 #endif
 
 // bf16 / fp16 rows of 2049 .. 8192 elements on k_mfma_filter_wide (mfma_wide_kernels.hpp): same records, same bound
+#ifndef WIDE_NS_ALONE
+#define WIDE_NS_ALONE 3
+#endif
 template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
-    auto go = [&](auto kern, int nqb) {
-        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb);
+    auto go = [&](auto kern, int nqb, int ns) {
+        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns);
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
     };
-    // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave)
+    // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave);
+    // WIDE_NS_ALONE: see vsgpu_mfma.hip (a deeper ring for a workgroup alone on its CU measured no faster)
+    constexpr int NA = WIDE_NS_ALONE;
     switch (ksteps) {
-    case 96: nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1>, 1); break;
-    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1>, 1); break;
-    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2>, 2) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1>, 1); break;
-    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1>, 1); break;
+    case 96: nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
+    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA>, 1, NA); break;
     }
 }
 static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const LowpParams &L, dim3 grid, hipStream_t s) {
