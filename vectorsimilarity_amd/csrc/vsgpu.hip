@@ -150,6 +150,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "hnsw_slots") c->opt_hnsw_slots = std::max(1L, std::min(64L, value));
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;
+    else if (n == "chain_early") c->opt_chain_early = value;
     else if (n == "sq8_block") c->opt_sq8_block = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);

@@ -50,6 +50,7 @@ struct vsgpu_ctx {
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_wide_blocks = 0;  // k_mfma_filter_wide: 0 = 32 queries per workgroup where measured faster, 1 = always 16, 2 = 32 wherever the registers allow
     long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
+    long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1) instead of its select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
     long opt_lowp_x32 = 32770; // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); 0 = the 16x16x64

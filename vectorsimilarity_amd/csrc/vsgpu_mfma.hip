@@ -319,6 +319,9 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    // the scan is in the stream: the next reader lane's probe may follow it and run beside this lane's re-rank and select
+    // kernels (small grids both) instead of behind them -- its scan then starts about when they end
+    if (c->opt_chain_early) chain.submitted();
     VSG_POLL_POINT(c);
     wm0.mark("launches");
     rc = stage_queries(t, queries, nq, qstride);
