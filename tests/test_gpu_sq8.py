@@ -201,8 +201,8 @@ def test_sq8_mfma_filter_hard_inputs(vso, metric):
 @pytest.mark.parametrize("nq", [64, 128])
 @pytest.mark.parametrize("shape", ["offset", "uniform", "constant_rows"])
 def test_sq8_block_prescreen_tight_cases(vso, metric, nq, shape):
-    """the filter's block pre-screen (one bound per lane and 64-row tile from the extreme dots and the tile's aux summary) is
-    tightest on homogeneous rows: vectors far from the origin with a small spread (min * y_sum dominates, delta tiny),
+    """the filter's screen (round 3: per value, 4 fused operations against a per-query slack from table-wide maxima; rounds 1-2:
+    a block pre-screen) is tightest on homogeneous rows: vectors far from the origin with a small spread (min * y_sum dominates, delta tiny),
     plain uniform rows at a size where the k-th score is deep in the tail, and tiles holding constant vectors (delta = 1,
     all codes 0) next to ordinary ones; 4-wave (nq 64) and 8-wave (nq 128) kernels"""
     rng = np.random.default_rng(len(shape) + nq)
@@ -228,6 +228,35 @@ def test_sq8_block_prescreen_tight_cases(vso, metric, nq, shape):
         el, es = vso.topk_replay(sc, k)
         assert np.array_equal(labels[j], el.astype(np.int64)), (metric, shape, j, labels[j], el)
         assert np.array_equal(dists[j], es), (metric, shape, j)
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+@pytest.mark.parametrize("nq", [40, 128])
+def test_sq8_screen_with_rows_of_very_different_scale(vso, metric, nq):
+    """the screen's slack comes from TABLE-WIDE maxima of {delta, |min|, sum_squares}: a few rows hundreds of times larger
+    than the rest (and, for L2 / IP, one with astronomically large values) blow it up for every row -- the screen then rejects
+    little, the exact re-rank decides, the reply stays the reference's"""
+    rng = np.random.default_rng(77 + nq)
+    dim, n, k = 96, 50_000, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    big = rng.choice(n, 400, replace=False)
+    rows[big] *= rng.uniform(100, 800, (400, 1)).astype(np.float32)
+    if metric != "Cosine":
+        rows[big[0]] = rng.uniform(-1, 1, dim).astype(np.float32) * np.float32(1e18)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    q[::7] *= np.float32(300)
+    ix = make(metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(sq8)"
+    st, qb = oracle_blobs(vso, rows, q, metric)
+    for j in range(0, nq, 3):
+        sc = vso.sq8_fp32_scan(MET[metric], st, qb[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(labels[j], el.astype(np.int64)), (metric, j, labels[j], el)
+        assert np.array_equal(dists[j], es, equal_nan=True), (metric, j)
 
 
 # ---------------------------------------------------------------- fp16 vectors / queries (QuantPreprocessor<float16>, SQ8_FP16_*)
