@@ -539,6 +539,7 @@ static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *can
     __shared__ uint32_t wpos;
     const int q = blockIdx.x;
     const uint32_t raw = counts[q];
+    if (threadIdx.x == 0) out_counts[gridDim.x + q] = raw;   // the raw count rides along (statistics, "fewer than k" check)
     // (a list that overflowed is selected from all the same: the k-th smallest exact score of the slots that were filled bounds
     // the true k-th score from above, and the host runs one more filter pass with it -- collect_candidates; it knows from the
     // raw count that the list is truncated)
@@ -640,6 +641,7 @@ static __global__ __launch_bounds__(256) void k_select_upto_kth_f64(const uint2 
     __shared__ uint32_t wpos;
     const int q = blockIdx.x;
     const uint32_t raw = counts[q];
+    if (threadIdx.x == 0) out_counts[gridDim.x + q] = raw;
     if (raw > cap) {
         if (threadIdx.x == 0) out_counts[q] = 0xFFFFFFFFu;
         return;

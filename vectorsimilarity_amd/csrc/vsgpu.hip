@@ -53,14 +53,35 @@ void poison(void *p, size_t bytes) {
 }
 int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return VSGPU_OK;
-    if (b.p) HIPCHK(hipFree(b.p));
+    if (b.p && !b.alias) HIPCHK(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
+    b.alias = false;
     size_t want = std::max(bytes, (size_t)4096);
     want = (want + 0xFFFF) & ~(size_t)0xFFFF;
     HIPCHK(hipMalloc(&b.p, want));
     poison(b.p, want);
     b.cap = want;
+    return VSGPU_OK;
+}
+// b becomes a region of another buffer (its own memory, if any, is released: every call ends with a stream sync, nothing reads it)
+void alias_into(DevBuf &b, void *p, size_t bytes) {
+    if (b.p && !b.alias) (void)hipFree(b.p);
+    b.p = p;
+    b.cap = bytes;
+    b.alias = true;
+}
+int ensure_pin_up(vsgpu_ctx *c, size_t bytes) {
+    if (bytes <= c->pin_up_cap) return VSGPU_OK;
+    if (c->pin_up) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipHostFree(c->pin_up));
+    }
+    c->pin_up = nullptr;
+    c->pin_up_cap = 0;
+    const size_t want = (std::max(bytes, (size_t)1 << 18) + 0xFFFF) & ~(size_t)0xFFFF;
+    HIPCHK(hipHostMalloc(&c->pin_up, want, hipHostMallocDefault));
+    c->pin_up_cap = want;
     return VSGPU_OK;
 }
 int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
@@ -110,9 +131,10 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta})
-        if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock})
+        if (b->p && !b->alias) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pin_up) (void)hipHostFree(c->pin_up);
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);
     (void)hipEventDestroy(c->ev_c);
@@ -1159,21 +1181,22 @@ static int collect_candidates_f64(vsgpu_table *t, const void *queries, size_t nq
                                   ScanChainGuard *chain) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n, ocap = cap;
-    int rc = ensure(c, c->sel, nq * ocap * sizeof(SelRec64));
-    if (rc) return rc;
-    rc = ensure(c, c->selcnt, nq * 8);
+    // one block {selected counts [nq], raw counts [nq], records [nq][ocap]}: one download
+    const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
+    int rc = ensure(c, c->sel, hdr + nq * ocap * sizeof(SelRec64));
     if (rc) return rc;
     hipLaunchKernelGGL(k_select_upto_kth_f64, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
                        (const double *)c->dense.p, (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n),
-                       (SelRec64 *)c->sel.p, (uint32_t *)c->selcnt.p, (uint32_t)ocap);
+                       (SelRec64 *)((char *)c->sel.p + hdr), (uint32_t *)c->sel.p, (uint32_t)ocap);
     HIPCHK(hipGetLastError());
     if (chain) chain->submitted();
-    HIPCHK(hipMemcpyAsync((uint32_t *)c->selcnt.p + nq, c->counts.p, nq * 4, hipMemcpyDeviceToDevice, c->stream));
-    std::vector<uint32_t> hsel(2 * nq);
-    std::vector<SelRec64> hrec(nq * ocap);
-    HIPCHK(hipMemcpyAsync(hsel.data(), c->selcnt.p, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hrec.data(), c->sel.p, nq * ocap * sizeof(SelRec64), hipMemcpyDeviceToHost, c->stream));
+    rc = ensure_pinned(c, hdr + nq * ocap * sizeof(SelRec64));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->pinned, c->sel.p, hdr + nq * ocap * sizeof(SelRec64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    // (copied out of the pinned staging area: the dense fallback below reuses it)
+    std::vector<uint32_t> hsel((const uint32_t *)c->pinned, (const uint32_t *)c->pinned + 2 * nq);
+    std::vector<SelRec64> hrec((const SelRec64 *)((const char *)c->pinned + hdr), (const SelRec64 *)((const char *)c->pinned + hdr) + nq * ocap);
     {
         account_scan(c, t, n, 1, scan_name);
         float ms = 0;
@@ -1213,26 +1236,23 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     const size_t n = t->n;
     // GPU: keep, per query, the candidates with exact score <= T_k; only those travel to the host
     const size_t ocap = cap;
-    int rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
-    if (rc) return rc;
-    rc = ensure(c, c->selcnt, nq * 8);
+    // one block {selected counts [nq], raw counts [nq], records [nq][ocap]}: one download
+    const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
+    int rc = ensure(c, c->sel, hdr + nq * ocap * sizeof(uint2));
     if (rc) return rc;
     hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
-                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)c->sel.p,
-                       (uint32_t *)c->selcnt.p, (uint32_t)ocap);
+                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
+                       (uint32_t *)c->sel.p, (uint32_t)ocap);
     HIPCHK(hipGetLastError());
     // the last kernel of this batch is in the stream: the next reader lane's kernels may follow (its probe and scan then
     // overlap with this lane's downloads and host replay, not with its kernels -- a re-rank or select kernel sharing the
     // CUs with another lane's scan cost that scan more than the overlap saved: bf16 config 4, 3.18 -> 3.33 ms)
     if (chain) chain->submitted();
-    // raw candidate counts ride along (statistics + "fewer than k" sanity check)
-    HIPCHK(hipMemcpyAsync((uint32_t *)c->selcnt.p + nq, c->counts.p, nq * 4, hipMemcpyDeviceToDevice, c->stream));
-    rc = ensure_pinned(c, nq * 8 + nq * ocap * sizeof(uint2));
+    rc = ensure_pinned(c, hdr + nq * ocap * sizeof(uint2));
     if (rc) return rc;
     uint32_t *hsel = (uint32_t *)c->pinned;
-    uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 8);
-    HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    uint2 *hrec = (uint2 *)((char *)c->pinned + hdr);
+    HIPCHK(hipMemcpyAsync(c->pinned, c->sel.p, hdr + nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     WallMarks wm;
     HIPCHK(hipStreamSynchronize(c->stream));
     wm.mark("wait_gpu");
@@ -1501,7 +1521,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
             const size_t ocap = cap;
             rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
             if (rc) return rc;
-            rc = ensure(c, c->selcnt, nq * 4);
+            rc = ensure(c, c->selcnt, nq * 8);   // (selected counts, then the raw counts the kernel passes on)
             if (rc) return rc;
             hipLaunchKernelGGL(k_select_dense_upto_kth, dim3((unsigned)nq), dim3(1024), 0, c->stream, (const float *)c->dense.p,
                                n, (uint32_t)n, (uint32_t)std::min(k, n), (uint2 *)c->sel.p, (uint32_t *)c->selcnt.p,
@@ -1540,7 +1560,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
             if (rc) return rc;
             rc = ensure(c, c->sel, group * ocap * sizeof(SelRec64));
             if (rc) return rc;
-            rc = ensure(c, c->selcnt, group * 4);
+            rc = ensure(c, c->selcnt, group * 8);
             if (rc) return rc;
             std::vector<uint32_t> hcnt(group);
             std::vector<SelRec64> hrec(group * ocap);

@@ -33,6 +33,7 @@ int vsg_fail(int code, const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool alias = false;   // p points into another buffer (vsgpu_ctx::qblock): never freed through this handle
 };
 
 struct vsgpu_ctx {
@@ -40,6 +41,10 @@ struct vsgpu_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qfrag2, qn2, sel, selcnt, qmeta;
+    // one upload per batch: {query fragments, |q|^2, thresholds, zeroed counters} are regions of qblock, staged in pin_up
+    DevBuf qblock;
+    void *pin_up = nullptr;
+    size_t pin_up_cap = 0;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     vsgpu_stats stats{};
@@ -194,6 +199,8 @@ struct ScanChainGuard {
     }
 };
 int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride);
+int ensure_pin_up(vsgpu_ctx *c, size_t bytes);
+void alias_into(DevBuf &b, void *p, size_t bytes);
 int tile_rows_of(int ek);
 int run_scan(vsgpu_table *t, vsg::ScanParams &P, size_t nq, bool timed);
 void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name);

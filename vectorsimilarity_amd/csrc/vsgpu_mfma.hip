@@ -187,8 +187,19 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     int rc = VSGPU_OK;
     WallMarks wm0;
     const size_t kdim = (size_t)KS * 32;       // kernel width >= dim
-    std::vector<uint16_t> frag(nqp * kdim, 0);  // [q_tile][wave][kstep][lane][8]
-    std::vector<float> qn2(nqp, 0.f), tau0(nqp, -INFINITY);
+    // ONE upload per batch: {fragments [q_tile][wave][kstep][lane][8], |q|^2, thresholds, zeroed candidate counters} are built in a
+    // pinned staging block and land in regions of ctx->qblock (three copies and a fill were four operations on the stream -- 4-7 us
+    // of blit kernel each -- in front of every batch; a single query's whole GPU time is 31 us)
+    const size_t fb = (nqp * kdim * 2 + 255) & ~(size_t)255, ab = (nqp * 4 + 255) & ~(size_t)255;
+    rc = ensure(c, c->qblock, fb + 3 * ab);
+    if (rc) return rc;
+    rc = ensure_pin_up(c, fb + 3 * ab);
+    if (rc) return rc;
+    uint16_t *frag = reinterpret_cast<uint16_t *>(c->pin_up);
+    float *qn2 = reinterpret_cast<float *>((char *)c->pin_up + fb), *tau0 = reinterpret_cast<float *>((char *)c->pin_up + fb + ab);
+    memset(c->pin_up, 0, fb + ab);
+    for (size_t q = 0; q < nqp; q++) tau0[q] = -INFINITY;
+    memset((char *)c->pin_up + fb + 2 * ab, 0, ab);
     const bool f64 = t->type == VSGPU_F64;
     std::vector<float> narrow(f64 ? dim : 0);
     for (size_t q = 0; q < nq; q++) {
@@ -217,27 +228,20 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             }
     }
     wm0.mark("frag_build");
-    rc = ensure(c, c->qfrag, frag.size() * 2);
-    if (rc) return rc;
-    rc = ensure(c, c->qn2, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->tau, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->counts, nqp * 4);
-    if (rc) return rc;
+    alias_into(c->qfrag, c->qblock.p, fb);
+    alias_into(c->qn2, (char *)c->qblock.p + fb, ab);
+    alias_into(c->tau, (char *)c->qblock.p + fb + ab, ab);
+    alias_into(c->counts, (char *)c->qblock.p + fb + 2 * ab, ab);
     const uint32_t total_tiles = (uint32_t)((n + TILE_ROWS - 1) / TILE_ROWS);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size() * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->qn2.p, qn2.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
     if (have_tau)
         for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
-    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
+    HIPCHK(hipMemcpyAsync(c->qblock.p, c->pin_up, fb + 3 * ab, hipMemcpyHostToDevice, c->stream));
     wm0.mark("uploads");
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
