@@ -597,14 +597,6 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             memcpy(&qaux[q], &f, 4);
         }
     }
-    rc = ensure(c, c->qfrag, frag.size());
-    if (rc) return rc;
-    rc = ensure(c, c->qn2, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->tau, nqp * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->counts, nqp * 4);
-    if (rc) return rc;
     const uint32_t total_tiles = (uint32_t)((n + RT - 1) / RT);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, !is_int), (uint32_t)(4 * k));
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
@@ -612,24 +604,33 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * RT) * (is_sq8 ? 6 : 1);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
-    if (is_sq8 || is_u8c) {
-        rc = ensure(c, c->qmeta, qmeta.size() * 4);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->qmeta.p, qmeta.data(), qmeta.size() * 4, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(hipMemcpyAsync(c->qfrag.p, frag.data(), frag.size(), hipMemcpyHostToDevice, c->stream));
-    if (x32) {
-        rc = ensure(c, c->qfrag2, frag32.size());
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->qfrag2.p, frag32.data(), frag32.size(), hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(hipMemcpyAsync(c->qn2.p, qaux.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
     const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
     if (have_tau)
         for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
-    HIPCHK(hipMemcpyAsync(c->tau.p, tau0.data(), nqp * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->counts.p, 0, nqp * 4, c->stream));
-
+    {
+        // ONE upload per batch (vsgpu_mfma.hip): every per-query input of the filter is a region of ctx->qblock, staged in pinned memory
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_f2 = al(frag.size()), o_aux = o_f2 + al(frag32.size()), o_tau = o_aux + al(nqp * 4), o_cnt = o_tau + al(nqp * 4),
+                     o_meta = o_cnt + al(nqp * 4), total = o_meta + al(qmeta.size() * 4);
+        rc = ensure(c, c->qblock, total);
+        if (rc) return rc;
+        rc = ensure_pin_up(c, total);
+        if (rc) return rc;
+        char *hb = (char *)c->pin_up, *db = (char *)c->qblock.p;
+        memcpy(hb, frag.data(), frag.size());
+        if (!frag32.empty()) memcpy(hb + o_f2, frag32.data(), frag32.size());
+        memcpy(hb + o_aux, qaux.data(), nqp * 4);
+        memcpy(hb + o_tau, tau0.data(), nqp * 4);
+        memset(hb + o_cnt, 0, nqp * 4);
+        if (!qmeta.empty()) memcpy(hb + o_meta, qmeta.data(), qmeta.size() * 4);
+        alias_into(c->qfrag, db, al(frag.size()));
+        alias_into(c->qfrag2, db + o_f2, al(frag32.size()));
+        alias_into(c->qn2, db + o_aux, al(nqp * 4));
+        alias_into(c->tau, db + o_tau, al(nqp * 4));
+        alias_into(c->counts, db + o_cnt, al(nqp * 4));
+        alias_into(c->qmeta, db + o_meta, al(qmeta.size() * 4));
+        HIPCHK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
+    }
     LowpParams P{};
     P.slabs = t->d_slabs;
     P.aux_slabs = (const uint32_t *const *)t->d_norm_slabs;
