@@ -20,6 +20,7 @@ ap.add_argument("--metric", default="L2")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--readers", type=int, default=1, help="threads submitting the batches (2: the steady state bench.py measures)")
 ap.add_argument("--sweep", default="", help="NAME=V1,V2: repeat every MFMA measurement with this index option at each value")
 a = ap.parse_args()
 p = VecSim.BFParams()
@@ -44,10 +45,19 @@ for b in [int(x) for x in a.batches.split(",")]:
         ix.knn_query(qs[0], a.k)
         ix.reset_stats()
         steps = a.steps if mf else 2
-        t0 = time.perf_counter()
-        for s in range(steps):
-            ix.knn_query(qs[s % 3], a.k)
-        dt = (time.perf_counter() - t0) / steps
+        if a.readers > 1 and mf:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(a.readers) as pool:
+                list(pool.map(lambda t: [ix.knn_query(qs[j % 3], a.k) for j in range(t, 2 * a.readers, a.readers)], range(a.readers)))   # lanes' scratch
+                ix.reset_stats()
+                t0 = time.perf_counter()
+                list(pool.map(lambda t: [ix.knn_query(qs[j % 3], a.k) for j in range(t, steps, a.readers)], range(a.readers)))
+                dt = (time.perf_counter() - t0) / steps
+        else:
+            t0 = time.perf_counter()
+            for s in range(steps):
+                ix.knn_query(qs[s % 3], a.k)
+            dt = (time.perf_counter() - t0) / steps
         st = ix.stats()
         kms = st["scan_ms"] / max(1, st["scan_launches"])
         print("batch %d mfma %d: %.2f ms per batch = %.1f G distances/s; %s %.3f ms per launch, %d launches per batch = %.0f GB/s "

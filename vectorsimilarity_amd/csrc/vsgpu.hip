@@ -359,13 +359,17 @@ extern "C" vsgpu_table *vsgpu_table_view_create(vsgpu_table *parent, vsgpu_ctx *
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     if (!parent->chain) {
         parent->chain = new ScanChain();
-        if (hipEventCreateWithFlags(&parent->chain_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&parent->chain_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&parent->scan_ev, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
     }
     vsgpu_table *v = new vsgpu_table(*parent);
     v->ctx = ctx;
     v->parent = parent;
     v->chain_ev = nullptr;
-    if (hipEventCreateWithFlags(&v->chain_ev, hipEventDisableTiming) != hipSuccess) {
+    v->scan_ev = nullptr;
+    if (hipEventCreateWithFlags(&v->chain_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->scan_ev, hipEventDisableTiming) != hipSuccess) {
         delete v;
         return nullptr;
     }
@@ -392,6 +396,7 @@ extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
     if (t->chain_ev) (void)hipEventDestroy(t->chain_ev);
+    if (t->scan_ev) (void)hipEventDestroy(t->scan_ev);
     if (t->chain && --t->chain->users == 0) delete t->chain;
     if (t->parent) {   // a view owns nothing else
         delete t;

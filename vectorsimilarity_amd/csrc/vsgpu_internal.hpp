@@ -55,7 +55,7 @@ struct vsgpu_ctx {
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_wide_blocks = 0;  // k_mfma_filter_wide: 0 = 32 queries per workgroup where measured faster, 1 = always 16, 2 = 32 wherever the registers allow
     long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
-    long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1) instead of its select kernel (0)
+    long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
     long opt_lowp_x32 = 32770; // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); 0 = the 16x16x64
@@ -117,8 +117,14 @@ int ensure_pinned(vsgpu_ctx *c, size_t bytes);
 // one recorded), so they run one after the other at full bandwidth while a lane's small kernels, copies and host work
 // overlap with another lane's scan.
 struct ScanChain {
-    std::mutex mu;
-    hipEvent_t last = nullptr;   // recorded behind the most recently submitted scan kernel (owned by that lane's table)
+    // two gates, always taken in this order.  mu_scan / last_scan: from a lane's probe to its scan kernel -- the next lane's PROBE
+    // waits for last_scan (recorded behind the scan).  mu_batch / last_batch: from a lane's scan to its select kernel -- the next
+    // lane's SCAN waits for last_batch (recorded behind the select kernel).  So a lane's probe runs beside the other lane's re-rank
+    // and select (small grids), but nothing ever runs beside a scan: the scans deal their tiles statically over the workgroups
+    // resident at launch, and a kernel still holding CUs when a scan starts leaves late workgroups that finish late
+    // (SQ8 10 M x 768, batch 128, two readers: scan 1.74 -> 2.67 ms when the other lane's re-rank overlapped its start).
+    std::mutex mu_scan, mu_batch;
+    hipEvent_t last_scan = nullptr, last_batch = nullptr;   // (owned by the recording lane's table)
     int users = 1;
 };
 
@@ -126,7 +132,7 @@ struct vsgpu_table {
     vsgpu_ctx *ctx = nullptr;
     vsgpu_table *parent = nullptr;   // non-null: a view (shares the parent's slabs, lane table and aux arrays)
     ScanChain *chain = nullptr;
-    hipEvent_t chain_ev = nullptr;
+    hipEvent_t chain_ev = nullptr, scan_ev = nullptr;
     int type = 0, metric = 0, tier = 0;
     size_t dim = 0, row_bytes = 0;
     vsg::LaneProgram prog;
@@ -180,22 +186,43 @@ static inline uint16_t bf16_rne(float f) {
 // around the launch of a table-wide scan kernel (between the timing events): orders it behind the other lanes' scans
 struct ScanChainGuard {
     vsgpu_table *t;
-    bool held = false;
-    explicit ScanChainGuard(vsgpu_table *tt) : t(tt) {
+    bool early;                      // option chain_early: the two gates apart (else both from the start to the select kernel)
+    bool held_scan = false, held_batch = false;
+    explicit ScanChainGuard(vsgpu_table *tt) : t(tt), early(tt->ctx->opt_chain_early != 0) {
         if (!t->chain) return;
-        t->chain->mu.lock();
-        held = true;
-        if (t->chain->last && t->chain->last != t->chain_ev) (void)hipStreamWaitEvent(t->ctx->stream, t->chain->last, 0);
+        t->chain->mu_scan.lock();
+        held_scan = true;
+        if (t->chain->last_scan && t->chain->last_scan != t->scan_ev) (void)hipStreamWaitEvent(t->ctx->stream, t->chain->last_scan, 0);
+        if (!early) before_scan();
     }
-    void submitted() {   // the scan is in the stream
-        if (!held) return;
+    void before_scan() {   // in front of the scan kernel's launch
+        if (!t->chain || held_batch) return;
+        t->chain->mu_batch.lock();
+        held_batch = true;
+        if (t->chain->last_batch && t->chain->last_batch != t->chain_ev) (void)hipStreamWaitEvent(t->ctx->stream, t->chain->last_batch, 0);
+    }
+    void scan_submitted() {   // the scan is in the stream
+        if (!held_scan) return;
+        (void)hipEventRecord(t->scan_ev, t->ctx->stream);
+        t->chain->last_scan = t->scan_ev;
+        t->chain->mu_scan.unlock();
+        held_scan = false;
+    }
+    void scan_submitted_if_early() {
+        if (early) scan_submitted();
+    }
+    void submitted() {   // the batch's last kernel is in the stream
+        if (!t->chain) return;
+        scan_submitted();
+        if (!held_batch) return;
         (void)hipEventRecord(t->chain_ev, t->ctx->stream);
-        t->chain->last = t->chain_ev;
-        t->chain->mu.unlock();
-        held = false;
+        t->chain->last_batch = t->chain_ev;
+        t->chain->mu_batch.unlock();
+        held_batch = false;
     }
     ~ScanChainGuard() {
-        if (held) t->chain->mu.unlock();
+        if (held_scan) t->chain->mu_scan.unlock();
+        if (held_batch) t->chain->mu_batch.unlock();
     }
 };
 int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride);

@@ -695,6 +695,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     }
     VSG_POLL_POINT(c);
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    chain.before_scan();   // behind the other lane's select kernel (ScanChain)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {
         LowpParams Q = P;
@@ -788,8 +789,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     // the scan is in the stream: the next reader lane's probe may follow it and run beside this lane's re-rank and select
-    // kernels (small grids both) instead of behind them -- its scan then starts about when they end
-    if (c->opt_chain_early) chain.submitted();
+    // kernels (small grids both); its SCAN waits for them (ScanChain)
+    chain.scan_submitted_if_early();
     VSG_POLL_POINT(c);
     if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512))) {  // diagnosis variants of the 32x32x32 kernel: time only
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -299,6 +299,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     }
     VSG_POLL_POINT(c);
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    chain.before_scan();   // behind the other lane's select kernel (ScanChain)
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {   // filter: every tile once
         MfmaParams Q = P;
@@ -324,8 +325,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     // the scan is in the stream: the next reader lane's probe may follow it and run beside this lane's re-rank and select
-    // kernels (small grids both) instead of behind them -- its scan then starts about when they end
-    if (c->opt_chain_early) chain.submitted();
+    // kernels (small grids both); its SCAN waits for them (ScanChain)
+    chain.scan_submitted_if_early();
     VSG_POLL_POINT(c);
     wm0.mark("launches");
     rc = stage_queries(t, queries, nq, qstride);
