@@ -303,7 +303,15 @@ def main():
     nb_distinct = min(n_batches, 8)                       # host-side query sets, cycled
     qsets = [gen(args.seed + 1 + b, 0, args.batch, args.dim) for b in range(nb_distinct)]
 
+    from vectorsimilarity_amd import _capi
+
     def sync():
+        # the timed region is bracketed by a barrier and a device-wide synchronisation on both sides (the query calls are
+        # synchronous, so the device is idle here anyway; hipDeviceSynchronize through the product's library covers every stream
+        # of this process on its GPU, torch's included, without initialising a second HIP context through torch.cuda)
+        if dist is not None:
+            dist.barrier()
+        _capi.load().VecSimGpu_DeviceSynchronize()
         if dist is not None:
             dist.barrier()
 

@@ -164,6 +164,9 @@ long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, siz
 /* device selection for indexes created afterwards on this thread/process (default: $VECSIM_GPU_DEVICE or 0) */
 int VecSimGpu_SetDevice(int device);
 int VecSimGpu_DeviceCount(void);
+/* waits for everything this process has queued on the device it uses (VECSIM_GPU_DEVICE / VecSimGpu_SetDevice): the query calls
+ * are synchronous, so this only matters to timing brackets (bench.py) */
+int VecSimGpu_DeviceSynchronize(void);
 const char *VecSimGpu_LastError(void);
 /* Which reference ISA tier's summation order a new index reproduces on this host: "AVX512" | "AVX512_BF16" | "SCALAR".
  * Chosen like the reference chooses its kernels -- from the host CPU's features at run time (spaces.h:68-78,

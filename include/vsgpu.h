@@ -52,6 +52,7 @@ typedef struct vsgpu_table vsgpu_table; /* device-resident rows of one Flat inde
 
 /* ---- runtime ---- */
 int vsgpu_device_count(void);                 /* 0 when no GPU is visible */
+int vsgpu_device_synchronize(int device);     /* hipDeviceSynchronize on `device`: every stream of every context (bench brackets) */
 const char *vsgpu_last_error(void);           /* thread-local message of the last failure */
 vsgpu_ctx *vsgpu_ctx_create(int device);      /* NULL on failure (see vsgpu_last_error) */
 void vsgpu_ctx_destroy(vsgpu_ctx *ctx);

@@ -142,7 +142,7 @@ EXPORTS = [
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
-    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_ResetStats",
+    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
     "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
@@ -154,7 +154,7 @@ EXPORTS = [
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
 ]
 GPU_EXPORTS = [
-    "vsgpu_device_count", "vsgpu_last_error", "vsgpu_ctx_create", "vsgpu_ctx_destroy",
+    "vsgpu_device_count", "vsgpu_device_synchronize", "vsgpu_last_error", "vsgpu_ctx_create", "vsgpu_ctx_destroy",
     "vsgpu_ctx_device", "vsgpu_ctx_sync", "vsgpu_table_create", "vsgpu_table_destroy",
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
     "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_append_synthetic",
@@ -302,6 +302,8 @@ def load():
     L.VecSimGpu_SetDevice.restype = i
     L.VecSimGpu_SetDevice.argtypes = [i]
     L.VecSimGpu_DeviceCount.restype = i
+    L.VecSimGpu_DeviceSynchronize.restype = i
+    L.VecSimGpu_DeviceSynchronize.argtypes = []
     L.VecSimGpu_LastError.restype = C.c_char_p
     L.VecSimGpu_HostTier.restype = C.c_char_p
     L.VecSimGpu_ResetStats.restype = None

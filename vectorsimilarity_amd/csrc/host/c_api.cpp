@@ -365,6 +365,17 @@ extern "C" int VecSimGpu_SetDevice(int device) {
     return 0;
 }
 extern "C" int VecSimGpu_DeviceCount(void) { return vsgpu_device_count(); }
+extern "C" int VecSimGpu_DeviceSynchronize(void) {
+    const int n = vsgpu_device_count();
+    if (n <= 0) return -1;
+    int d = vsa::globals().device;   // (as FlatIndex resolves it)
+    if (d < 0) {
+        if (const char *e = std::getenv("VECSIM_GPU_DEVICE")) d = std::atoi(e);
+        else if (const char *e2 = std::getenv("LOCAL_RANK")) d = std::atoi(e2) % n;
+        else d = 0;
+    }
+    return vsgpu_device_synchronize(d) == VSGPU_OK ? 0 : -1;
+}
 extern "C" const char *VecSimGpu_LastError(void) { return vsgpu_last_error(); }
 extern "C" void VecSimGpu_ResetStats(VecSimIndex *index) {
     for (vsgpu_ctx *c : index->gpus()) vsgpu_stats_reset(c);

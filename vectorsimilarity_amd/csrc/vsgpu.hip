@@ -26,6 +26,11 @@ int vsg_fail(int code, const char *fmt, ...) {
 
 extern "C" const char *vsgpu_last_error(void) { return g_err.c_str(); }
 
+extern "C" int vsgpu_device_synchronize(int device) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return VSGPU_OK;
+}
 extern "C" int vsgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
