@@ -200,7 +200,7 @@ def test_sq8_mfma_filter_hard_inputs(vso, metric):
 @pytest.mark.parametrize("metric", ["L2", "IP"])
 @pytest.mark.parametrize("nq", [64, 128])
 @pytest.mark.parametrize("shape", ["offset", "uniform", "constant_rows"])
-def test_sq8_block_prescreen_tight_cases(vso, metric, nq, shape):
+def test_sq8_screen_tight_cases(vso, metric, nq, shape):
     """the filter's screen (round 3: per value, 4 fused operations against a per-query slack from table-wide maxima; rounds 1-2:
     a block pre-screen) is tightest on homogeneous rows: vectors far from the origin with a small spread (min * y_sum dominates, delta tiny),
     plain uniform rows at a size where the k-th score is deep in the tail, and tiles holding constant vectors (delta = 1,

@@ -54,7 +54,7 @@ struct vsgpu_ctx {
     long opt_lowp_variant = 0;
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_wide_blocks = 0;  // k_mfma_filter_wide: 0 = 32 queries per workgroup where measured faster, 1 = always 16, 2 = 32 wherever the registers allow
-    long opt_sq8_block = 1;    // SQ8 filter: block pre-screen from the table-wide metadata extremes (when the index supplies them)
+    long opt_sq8_block = 1;    // (rounds 1-2: the SQ8 filter's block pre-screen; accepted, without effect since round 3)
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
