@@ -631,6 +631,10 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         alias_into(c->qmeta, db + o_meta, al(qmeta.size() * 4));
         HIPCHK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
     }
+    if (!is_int) {   // exact-order images for the re-rank, uploaded ahead of the scan (vsgpu_mfma.hip)
+        rc = stage_queries(t, queries, nq, qstride);
+        if (rc) return rc;
+    }
     LowpParams P{};
     P.slabs = t->d_slabs;
     P.aux_slabs = (const uint32_t *const *)t->d_norm_slabs;
@@ -805,8 +809,6 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         return VSGPU_OK;
     }
     if (!is_int) {
-        rc = stage_queries(t, queries, nq, qstride);   // exact-order images for the re-rank
-        if (rc) return rc;
         rc = launch_exact_pairs(t, nq, ccap);
         if (rc) return rc;
     }

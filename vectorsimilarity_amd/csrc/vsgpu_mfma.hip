@@ -243,6 +243,11 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
     HIPCHK(hipMemcpyAsync(c->qblock.p, c->pin_up, fb + 3 * ab, hipMemcpyHostToDevice, c->stream));
     wm0.mark("uploads");
+    // the exact-order query images of the re-rank go up now too: queued behind the scan, their copy sat between the scan and the
+    // re-rank kernel, which then started after the other reader lane's probe had taken the CUs (155 us beside it, 54 us ahead of it)
+    rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
+    wm0.mark("stage_queries");
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
     const double u = std::ldexp(1.0, -24);
@@ -329,9 +334,6 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     chain.scan_submitted_if_early();
     VSG_POLL_POINT(c);
     wm0.mark("launches");
-    rc = stage_queries(t, queries, nq, qstride);
-    if (rc) return rc;
-    wm0.mark("stage_queries");
     wm0.flush("mfma_pre");
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
