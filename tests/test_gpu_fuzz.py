@@ -10,9 +10,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [3, 11])
-def test_random_shapes_filter_path_equals_exact_path(seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seconds", "12", "--seed", str(seed)],
+@pytest.mark.parametrize("seed,readers", [(3, 0), (11, 2)])
+def test_random_shapes_filter_path_equals_exact_path(seed, readers):
+    """(readers 2: every shape is also queried by two threads at once -- reader lanes, scan chain; the soaks with 2 and 3 readers:
+    798 + 288 shapes, no mismatch)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seconds", "12", "--seed", str(seed),
+                        "--readers", str(readers)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout, r.stdout[-2000:]

@@ -16,6 +16,7 @@ from vectorsimilarity_amd import VecSim  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--readers", type=int, default=0, help="> 1: every shape is also queried by this many threads at once (reader lanes)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 T = {"f32": VecSim.VecSimType_FLOAT32, "f64": VecSim.VecSimType_FLOAT64, "bf16": VecSim.VecSimType_BFLOAT16,
@@ -66,6 +67,16 @@ while time.time() < t_end:
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)
     kern = ix.stats()["scan_kernel"]
+    if a.readers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(a.readers) as pool:
+            outs = list(pool.map(lambda t: [ix.knn_query(q, k) for _ in range(3)], range(a.readers)))
+        for o in outs:
+            for (lc, dc) in o:
+                if not (np.array_equal(lc, l1) and np.array_equal(dc, d1, equal_nan=True)):
+                    bad += 1
+                    print("MISMATCH (concurrent readers)", typ, metric, "dim", dim, "n", n, "nq", nq, "k", k, "kernel", kern, flush=True)
+                    break
     kernels[kern] = kernels.get(kern, 0) + 1
     ix.set_option("mfma", 0)
     nchk = min(nq, 6)
