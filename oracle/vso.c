@@ -69,6 +69,12 @@ uint16_t vso_f32_to_f16(float f) {
     return (uint16_t)((uint32_t)o | (sign >> 16));
 }
 
+/* array forms (NaN payloads survive: a float never crosses the ctypes boundary by value) */
+void vso_f32_to_bf16_n(const float *in, size_t n, uint16_t *out) { for (size_t i = 0; i < n; i++) out[i] = vso_f32_to_bf16(in[i]); }
+void vso_f32_to_f16_n(const float *in, size_t n, uint16_t *out) { for (size_t i = 0; i < n; i++) out[i] = vso_f32_to_f16(in[i]); }
+void vso_bf16_to_f32_n(const uint16_t *in, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = vso_bf16_to_f32(in[i]); }
+void vso_f16_to_f32_n(const uint16_t *in, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = vso_f16_to_f32(in[i]); }
+
 size_t vso_elem_size(int type) {
     switch (type) {
     case VSO_F32: return 4;
@@ -600,15 +606,20 @@ typedef struct {
     double score;
     size_t label;
 } heap_item;
-/* std::less<pair<score,label>> : lexicographic, NaN-unordered on the score */
+/* std::less<pair<score,label>> AS THE REFERENCE'S BUILD HAS IT: gnu++20 (src/VecSim/CMakeLists.txt:15), where pair's `<` is
+ * synthesised from operator<=> -- lexicographic on ordinary scores, and on a NaN score the pairs are UNORDERED (neither is
+ * less; `first <=> first` is partial_ordering::unordered and the comparison stops there).  C++17's operator< fell through to
+ * the labels instead; rounds 1-3 restated that and were wrong on NaN inputs -- found in round 4 by running the reference's
+ * own container (oracle/_ref, tests/golden/ref_scalar_random.json section `topk`). */
 static int item_less(const heap_item *x, const heap_item *y) {
     if (x->score < y->score) return 1;
     if (y->score < x->score) return 0;
-    return x->label < y->label;
+    if (x->score == y->score) return x->label < y->label;
+    return 0; /* unordered */
 }
 /* std::priority_queue<pair<DistType, labelType>> (utils/vecsim_stl.h:66-72) is std::push_heap / std::pop_heap over a
  * vector.  Under a strict weak order any correct heap pops the same items, but a NaN score is unordered (item_less
- * falls through to the labels), and then WHICH item sits where depends on the heap algorithm itself.  The reference's
+ * says neither is less), and then WHICH item sits where depends on the heap algorithm itself.  The reference's
  * platform is gcc/libstdc++, so the two routines below follow libstdc++'s published algorithm (bits/stl_heap.h,
  * GCC 11: __push_heap, __adjust_heap, __pop_heap) move for move; tests/test_oracle_kats.py checks them against the
  * real std::priority_queue on inputs with NaNs (tests/helpers/heap_probe.cpp). */

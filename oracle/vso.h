@@ -63,6 +63,10 @@ uint16_t vso_f32_to_bf16(float f);
 float vso_bf16_to_f32(uint16_t h);
 uint16_t vso_f32_to_f16(float f);
 float vso_f16_to_f32(uint16_t h);
+void vso_f32_to_bf16_n(const float *in, size_t n, uint16_t *out);
+void vso_f32_to_f16_n(const float *in, size_t n, uint16_t *out);
+void vso_bf16_to_f32_n(const uint16_t *in, size_t n, float *out);
+void vso_f16_to_f32_n(const uint16_t *in, size_t n, float *out);
 
 /* Flat top-K with the reference's sequential heap semantics (brute_force.h:257-288).
  * scores[i] belongs to internal id i, labels[i] is its label (NULL => label == id).

@@ -351,16 +351,30 @@ def synth_rows_f32(seed, first_row, nrows, dim):
     return out
 
 
+def _conv(name, a, src, dst):
+    a = np.ascontiguousarray(a, dtype=src)
+    out = np.empty(a.shape, dtype=dst)
+    f = getattr(lib(), name)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    f(_ptr(a), a.size, _ptr(out))
+    return out
+
+
 def f32_to_bf16(a):
-    a = np.asarray(a, dtype=np.float32)
-    f = lib().vso_f32_to_bf16
-    return np.array([f(float(x)) for x in a.ravel()], dtype=np.uint16).reshape(a.shape)
+    return _conv("vso_f32_to_bf16_n", a, np.float32, np.uint16)
 
 
 def f32_to_f16(a):
-    a = np.asarray(a, dtype=np.float32)
-    f = lib().vso_f32_to_f16
-    return np.array([f(float(x)) for x in a.ravel()], dtype=np.uint16).reshape(a.shape)
+    return _conv("vso_f32_to_f16_n", a, np.float32, np.uint16)
+
+
+def bf16_to_f32(a):
+    return _conv("vso_bf16_to_f32_n", a, np.uint16, np.float32)
+
+
+def f16_to_f32(a):
+    return _conv("vso_f16_to_f32_n", a, np.uint16, np.float32)
 
 
 def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512):

@@ -1,6 +1,7 @@
 // heap_probe.cpp -- test helper: the sequential top-k loop of brute_force.h:257-288 over a score array, on the REAL
 // std::priority_queue<std::pair<score, label>> of this toolchain's libstdc++ (what utils/vecsim_stl.h:66-72 wraps).
-// tests/test_oracle_kats.py uses it to pin oracle/vso.c's restated heap moves, which matter once scores hold NaNs.
+// Compiled as gnu++20 LIKE THE REFERENCE (src/VecSim/CMakeLists.txt:15): pair's `<` comes from operator<=> there and treats NaN
+// scores as unordered, where C++17 compared the labels.  tests/test_oracle_kats.py uses it to pin oracle/vso.c's restated heap moves, which matter once scores hold NaNs.
 #include <cstddef>
 #include <limits>
 #include <queue>

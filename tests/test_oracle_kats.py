@@ -441,7 +441,7 @@ def test_topk_replay_follows_libstdcxx_heap_moves_with_nan_scores(vso):
     helpers = os.path.join(os.path.dirname(__file__), "helpers")
     so, src = os.path.join(helpers, "libheap_probe.so"), os.path.join(helpers, "heap_probe.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, src], check=True)
+        subprocess.run(["g++", "-O1", "-std=gnu++20", "-fPIC", "-shared", "-o", so, src], check=True)
     L = C.CDLL(so)
     L.heap_probe_topk.restype = C.c_size_t
     L.heap_probe_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -1,0 +1,109 @@
+"""CPU: the oracle's scalar tier against tests/golden/ref_scalar_random.json -- numbers the REFERENCE'S OWN compiled code
+produced on seeded random inputs (tests/golden/make_ref_scalar_random.py over oracle/_ref, built by oracle/build_ref.sh
+from the reference's L2.cpp / IP.cpp / vecsim_malloc.cpp with plain g++).  Random inputs are summation-order sensitive,
+so unlike the reference's `v[i] = i` known answers these pin the order as well.  Tolerance: none (bit patterns).
+
+Which parts of the oracle this makes reference-executed: the scalar kernels (A3), normalisation (A9), the bf16 / fp16
+conversions (every fp16 / bf16 input), scalar SQ8, and the sequential top-k containers (A10, multi-value included).
+The AVX-512 tiers stay twin-checked (tests/test_oracle_kats.py: vso.c against intrinsics on the host's vector unit).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+import refgen  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    with open(os.path.join(GOLD, "ref_scalar_random.json")) as f:
+        return json.load(f)
+
+
+class OracleScalar:
+    """refgen backend over oracle/vso.py, scalar tier"""
+
+    def __init__(self, vso):
+        self.vso = vso
+        self.f32_to_bf16, self.f32_to_f16 = vso.f32_to_bf16, vso.f32_to_f16
+        self.bf16_to_f32, self.f16_to_f32 = vso.bf16_to_f32, vso.f16_to_f32
+
+    def distance(self, t, m, a, b, dim):
+        return self.vso.distance(t, m, a, b, dim, tier=self.vso.TIER_SCALAR)
+
+    def normalize(self, blob, dim, t):
+        return self.vso.normalize(blob, dim, t)
+
+    def sq8_distance(self, kind, m, storage, query, dim):
+        f = {"fp32": self.vso.sq8_fp32_distance, "fp16": self.vso.sq8_fp16_distance, "sq8": self.vso.sq8_sq8_distance}[kind]
+        return f(m, storage, query, dim, tier=self.vso.TIER_SCALAR)
+
+    def topk(self, scores, k, labels, multi, wide):
+        if not wide:
+            scores = np.asarray(scores, dtype=np.float64).astype(np.float32).astype(np.float64)
+        return self.vso.topk_replay_multi(scores, k, labels) if multi else self.vso.topk_replay(scores, k, labels)
+
+
+def _diff(name, got, want, key=lambda e: e):
+    bad = [(key(w), g, w) for g, w in zip(got, want) if g != w]
+    assert len(got) == len(want) and not bad, "%s: %d of %d differ, first: %r" % (name, len(bad), len(want), bad[:3])
+
+
+def test_scalar_distance_kernels_equal_the_compiled_reference(vso, fixture):
+    got = refgen.compute_distances(OracleScalar(vso))
+    _diff("distances", got, fixture["distances"], key=lambda e: (e["type"], e["metric"], e["dim"]))
+    assert len(got) == len(refgen.TYPES) * len(refgen.METRICS) * len(refgen.DIMS)
+
+
+def test_conversions_equal_the_compiled_reference(vso, fixture):
+    assert refgen.compute_conversions(OracleScalar(vso)) == fixture["conversions"]
+
+
+def test_normalisation_equals_the_compiled_reference(vso, fixture):
+    _diff("normalize", refgen.compute_normalize(OracleScalar(vso)), fixture["normalize"], key=lambda e: (e["type"], e["dim"]))
+
+
+def test_scalar_sq8_kernels_equal_the_compiled_reference(vso, fixture):
+    _diff("sq8", refgen.compute_sq8(OracleScalar(vso)), fixture["sq8"], key=lambda e: (e["kind"], e["metric"], e["dim"]))
+
+
+def test_topk_replay_equals_the_reference_containers(vso, fixture):
+    """brute_force.h:257-288 over vecsim_stl::max_priority_queue / updatable_max_heap, ties and NaNs included"""
+    _diff("topk", refgen.compute_topk(OracleScalar(vso)), fixture["topk"], key=lambda e: e["case"])
+
+
+def test_fixture_is_what_the_reference_build_produces_here(fixture):
+    """where oracle/_ref exists (the build container; the .so also travels to the GPU box), re-run the reference's code on
+    the seeds: the committed fixture must be reproducible, and a wider random sweep must agree with the oracle too"""
+    from oracle import vsref
+    if not vsref.available():
+        pytest.skip("oracle/_ref/libvsref.so not built (needs /root/reference; sh oracle/build_ref.sh)")
+    try:
+        vsref.lib()
+    except OSError as e:     # a library built against another libstdc++
+        pytest.skip("oracle/_ref/libvsref.so does not load here: %s" % e)
+    live = refgen.compute_all(vsref)
+    for section in ("distances", "conversions", "normalize", "sq8", "topk"):
+        assert live[section] == fixture[section], section
+
+
+def test_oracle_scalar_tier_equals_the_live_reference_on_more_dims(vso):
+    from oracle import vsref
+    if not vsref.available():
+        pytest.skip("oracle/_ref/libvsref.so not built")
+    try:
+        vsref.lib()
+    except OSError as e:
+        pytest.skip(str(e))
+    dims = (41, 63, 64, 65, 100, 255, 256, 257, 513, 1000, 1536, 2048, 4099)
+    a = refgen.compute_distances(vsref, dims)
+    b = refgen.compute_distances(OracleScalar(vso), dims)
+    _diff("live distances", b, a, key=lambda e: (e["type"], e["metric"], e["dim"]))
+    a = refgen.compute_sq8(vsref, (9, 100, 257, 1536))
+    b = refgen.compute_sq8(OracleScalar(vso), (9, 100, 257, 1536))
+    _diff("live sq8", b, a, key=lambda e: (e["kind"], e["metric"], e["dim"]))

@@ -18,6 +18,7 @@
 #include <unordered_map>
 
 #include "blob_prep.h"
+#include "ref_heap.h"
 #include "flat_index.h"
 #include "host_tier.h"
 #include "sq8_prep.h"
@@ -618,7 +619,7 @@ using ScoredLabel = std::pair<double, size_t>;
 static VecSimQueryReply *next_by_heap(VecSimBatchIterator *it, size_t n_res) {
     auto *rep = new VecSimQueryReply();
     auto &sc = it->scores;
-    std::priority_queue<ScoredLabel> best;             // max-heap on (score, label)
+    vsa::RefMaxHeap<ScoredLabel> best;                 // max-heap on (score, label)
     std::unordered_map<size_t, size_t> slot_of_label;  // label -> position in sc
     double upper = std::numeric_limits<double>::lowest();
     for (size_t i = it->valid_start; i < sc.size(); i++) {
@@ -695,7 +696,7 @@ static bool sparse_next_by_heap(VecSimBatchIterator *it, size_t n_res, VecSimQue
     std::sort(live.begin(), live.end(), [](const Ent &a, const Ent &b) { return a.pos < b.pos; });
     // the reference's loop over the live range, restricted to the entries at or below the n_res-th smallest score
     using Item = std::pair<ScoredLabel, size_t>;  // ((score, label), index into live)
-    std::priority_queue<Item> best;
+    vsa::RefMaxHeap<Item> best;
     double upper = std::numeric_limits<double>::lowest();
     for (size_t i = 0; i < live.size(); i++) {
         if (best.size() >= n_res) {

@@ -17,6 +17,7 @@
 #include <unordered_set>
 
 #include "blob_prep.h"
+#include "ref_heap.h"
 #include "sq8_prep.h"
 
 namespace vsa {
@@ -496,7 +497,7 @@ std::vector<char> FlatIndex::preprocessQuery(const void *query) const {
 // largest (score,label).  SURVEY.md §8a row A10 proves this equals the full scan.
 void FlatIndex::replay(const uint32_t *ids, const double *scores, size_t n, size_t k, VecSimQueryReply *rep) const {
     using Item = std::pair<double, size_t>;
-    std::priority_queue<Item> heap;  // std::less<pair>: max-heap on (score, label)
+    RefMaxHeap<Item> heap;  // the reference's max-heap on (score, label), gnu++20 pair order (ref_heap.h)
     double upper = std::numeric_limits<double>::lowest();
     for (size_t i = 0; i < n; i++) {
         const double s = scores[i];

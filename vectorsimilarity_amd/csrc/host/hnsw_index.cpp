@@ -1,6 +1,7 @@
 // hnsw_index.cpp -- see hnsw_index.h
 #include "hnsw_index.h"
 #include "host_tier.h"
+#include "ref_heap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -637,7 +638,7 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
                 rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
             }
             if (rc) break;
-            std::priority_queue<Item> heap;
+            RefMaxHeap<Item> heap;
             double upper = std::numeric_limits<double>::lowest();
             const size_t m = all.empty() ? c1[0] : n_;
             for (size_t i = 0; i < m; i++) {

@@ -1,0 +1,39 @@
+// ref_heap.h -- the order of the reference's top-k containers, spelled out.
+//
+// vecsim_stl::max_priority_queue (utils/vecsim_stl.h:63-83) is std::priority_queue over std::less<std::pair<DistType,
+// labelType>>, and the reference is built as gnu++20 (src/VecSim/CMakeLists.txt:15): pair's `<` is synthesised from
+// operator<=> there.  On ordinary scores that is the familiar lexicographic order.  On a NaN score it is not what C++17's
+// operator< did: `a.first <=> b.first` is partial_ordering::unordered, the pair comparison stops there, and NEITHER pair
+// is less than the other -- C++17 fell through to the labels.  Which rows a reply holds once NaN scores sit in the heap
+// depends on exactly this (oracle/_ref runs the reference's own container: tests/golden/ref_scalar_random.json, section
+// `topk`).  This library is built as C++17, so the rule is written out instead of inherited from the standard in force.
+#pragma once
+#include <cstddef>
+#include <queue>
+#include <utility>
+#include <vector>
+
+namespace vsa {
+
+// -1 less, 0 equivalent, +1 greater, 2 unordered (a NaN on either side)
+inline int score_cmp3(double a, double b) { return a < b ? -1 : (b < a ? 1 : (a == b ? 0 : 2)); }
+
+struct RefPairLess {
+    bool operator()(const std::pair<double, size_t> &a, const std::pair<double, size_t> &b) const {
+        const int c = score_cmp3(a.first, b.first);
+        return c != 0 ? c < 0 : a.second < b.second;
+    }
+    // ((score, label), tag): the batch iterator keeps an index beside the reference's pair
+    bool operator()(const std::pair<std::pair<double, size_t>, size_t> &a,
+                    const std::pair<std::pair<double, size_t>, size_t> &b) const {
+        const int c = score_cmp3(a.first.first, b.first.first);
+        if (c != 0) return c < 0;
+        if (a.first.second != b.first.second) return a.first.second < b.first.second;
+        return a.second < b.second;
+    }
+};
+
+template <typename Item = std::pair<double, size_t>>
+using RefMaxHeap = std::priority_queue<Item, std::vector<Item>, RefPairLess>;
+
+}  // namespace vsa

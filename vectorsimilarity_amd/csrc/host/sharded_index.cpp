@@ -12,6 +12,7 @@
 #include <thread>
 
 #include "blob_prep.h"
+#include "ref_heap.h"
 
 namespace vsa {
 
@@ -97,7 +98,7 @@ int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const 
             c.resize(w);
         }
         std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
-        std::priority_queue<std::pair<double, size_t>> heap;
+        RefMaxHeap<> heap;
         double upper = std::numeric_limits<double>::lowest();
         for (const Cand &x : c) {
             if (x.score < upper || heap.size() < k) {
