@@ -104,6 +104,9 @@ int VecSimGpu_ShardedTopKQueryBatchArraysSeq(VecSimShardedIndex *index, const vo
  * then {batches answered, bytes this process contributed per exchange, summed} */
 void VecSimGpu_ShardedGetStats(VecSimShardedIndex *index, double out[6]);
 void VecSimGpu_ShardedResetStats(VecSimShardedIndex *index);
+/* Starts a new stream of numbered batches at 0 (every process, with no batch in flight).  A ...Seq call whose number has
+ * already been answered returns -1 instead of waiting for ever. */
+void VecSimGpu_ShardedResetSeq(VecSimShardedIndex *index);
 /* the Flat index of a shard held by this process (stats, options); NULL for shards of other processes */
 VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *index, int shard);
 int VecSimGpu_ShardedWorld(VecSimShardedIndex *index);
@@ -171,9 +174,12 @@ const char *VecSimGpu_LastError(void);
 /* Which reference ISA tier's summation order a new index reproduces on this host: "AVX512" | "AVX512_BF16" | "SCALAR".
  * Chosen like the reference chooses its kernels -- from the host CPU's features at run time (spaces.h:68-78,
  * IP_space.cpp:554-615, L2_space.cpp:185-241): avx512f -> the AVX-512 kernels' order, avx512_bf16 && avx512vl on top ->
- * vdpbf16ps for bf16 IP / Cosine, no avx512f -> the scalar kernels' order.  $VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar
- * overrides.  An index reports its tier as the last field (DISTANCE_TIER) of VecSimIndex_DebugInfoIterator. */
+ * vdpbf16ps for bf16 IP / Cosine.  A host without AVX-512 also gets "AVX512" (its reference build would run AVX2 / SSE
+ * kernels, whose orders are not restated; one line on stderr says so).  $VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar
+ * overrides.  VecSimGpu_IndexTier: the tier an existing index answers in (VecSimIndex_DebugInfoIterator carries exactly the
+ * reference's fields). */
 const char *VecSimGpu_HostTier(void);
+const char *VecSimGpu_IndexTier(VecSimIndex *index);
 
 /* HIP-event timing of the dominant scan kernel since the last reset (bench.py roofline leg) */
 typedef struct {
@@ -184,8 +190,8 @@ typedef struct {
     double other_ms;
     uint64_t candidates;
     uint64_t fallbacks;
-    uint64_t retries;
     char scan_kernel[64];
+    uint64_t retries;   /* (new fields go at the end: the layout in front is what earlier callers compiled against) */
 } VecSimGpuStats;
 void VecSimGpu_ResetStats(VecSimIndex *index);
 void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out);

@@ -178,8 +178,8 @@ typedef struct {
     double other_ms;       /* probe + select + rerank kernels */
     uint64_t candidates;   /* candidate pairs that reached the exact re-rank */
     uint64_t fallbacks;    /* queries answered by a dense exact pass (candidate list overflowed twice, or fewer than k candidates) */
-    uint64_t retries;      /* queries whose candidate list overflowed and that a second filter pass with a tighter threshold answered */    /* queries answered through the dense fallback */
     char scan_kernel[64];  /* name of the kernel timed as "scan" */
+    uint64_t retries;      /* queries whose candidate list overflowed and that a second filter pass with a tighter threshold answered */
 } vsgpu_stats;
 void vsgpu_stats_reset(vsgpu_ctx *ctx);
 void vsgpu_stats_get(vsgpu_ctx *ctx, vsgpu_stats *out);

@@ -290,6 +290,34 @@ def compute_topk(backend):
     return out
 
 
+# uint8 rows beyond 33 025 elements: the choosers return the scalar kernel there (spaces.h:57-66, L2_space.cpp:474-476,
+# IP_space.cpp:788,843), whose 64-bit total is exact where a 32-bit one overflows.  "max": every element 255 against 255
+# (IP, Cosine) or against 0 (L2) -- the worst case the bound is derived from; "rand": seeded bytes.
+WIDE_U8 = [(33025, "max"), (33026, "max"), (33026, "rand"), (40000, "max"), (50001, "rand")]
+
+
+def wide_u8_inputs(dim, kind, metric):
+    if kind == "max":
+        a = np.full((1, dim), 255, dtype=np.uint8)
+        b = np.full(dim, 0 if metric == "L2" else 255, dtype=np.uint8)
+        return a, b
+    v = vectors(case_seed("wide_u8", dim, metric), 2, dim, "u8")
+    return v[:1], v[1]
+
+
+def compute_wide_u8(backend):
+    out = []
+    for dim, kind in WIDE_U8:
+        for metric in METRICS:
+            a, b = wide_u8_inputs(dim, kind, metric)
+            st = stored_form(backend, a, "u8", metric)
+            qq = stored_form(backend, b[None, :], "u8", metric)[0]
+            sc = backend.distance(TYPE_ID["u8"], METRIC_ID[metric], st[0], qq, dim)
+            out.append({"dim": dim, "kind": kind, "metric": metric, "score": _score_hex("f32", [sc])[0]})
+    return out
+
+
 def compute_all(backend):
     return {"distances": compute_distances(backend), "conversions": compute_conversions(backend),
-            "normalize": compute_normalize(backend), "sq8": compute_sq8(backend), "topk": compute_topk(backend)}
+            "normalize": compute_normalize(backend), "sq8": compute_sq8(backend), "topk": compute_topk(backend),
+            "wide_u8": compute_wide_u8(backend)}

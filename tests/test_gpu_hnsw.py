@@ -131,8 +131,7 @@ def test_hnsw_debug_info_iterator_fields():
     f = ix.debug_info_fields()
     names = [n for n, _ in f]
     assert names[0] == "ALGORITHM" and names[10] == "BLOCK_SIZE"
-    assert names[11:] == ["M", "EF_CONSTRUCTION", "EF_RUNTIME", "MAX_LEVEL", "ENTRYPOINT", "EPSILON", "NUMBER_OF_MARKED_DELETED",
-                          "DISTANCE_TIER"]   # (extension field behind the reference's)
+    assert names[11:] == ["M", "EF_CONSTRUCTION", "EF_RUNTIME", "MAX_LEVEL", "ENTRYPOINT", "EPSILON", "NUMBER_OF_MARKED_DELETED"]   # exactly the reference's fields
     d = dict(f)
     assert d["ALGORITHM"] == "HNSW" and d["M"] == 8 and d["EF_CONSTRUCTION"] == 40 and d["EF_RUNTIME"] == 17
     assert d["INDEX_SIZE"] == 300 and d["NUMBER_OF_MARKED_DELETED"] == 0

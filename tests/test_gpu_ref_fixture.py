@@ -20,9 +20,14 @@ import refgen  # noqa: E402
 
 
 @pytest.fixture(scope="module")
-def distances():
+def fixture():
     with open(os.path.join(GOLD, "ref_scalar_random.json")) as f:
-        return json.load(f)["distances"]
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def distances(fixture):
+    return fixture["distances"]
 
 
 @pytest.mark.parametrize("typ", refgen.TYPES)
@@ -50,3 +55,24 @@ def test_scalar_tier_scores_equal_the_compiled_reference(monkeypatch, distances,
         if h0 != e["scores"][0]:
             bad.append((metric, dim, "get_distance_from", h0, e["scores"][0]))
     assert not bad, "%s: %d cases differ, first %r" % (typ, len(bad), bad[:3])
+
+
+@pytest.mark.parametrize("tier", ["avx512", "scalar"])
+def test_uint8_rows_beyond_33025_elements_equal_the_compiled_reference(monkeypatch, fixture, tier):
+    """above the 32-bit bound every reference chooser returns the scalar kernel and its 64-bit total (spaces.h:57-66,
+    L2_space.cpp:474-476, IP_space.cpp:788,843) -- whatever the host's tier; 255 x 255 x 33 026 no longer fits an int32"""
+    monkeypatch.setenv("VECSIM_GPU_TIER", tier)
+    bad = []
+    for e in fixture["wide_u8"]:
+        if tier == "scalar" and e["dim"] > 40000:
+            continue
+        a, b = refgen.wide_u8_inputs(e["dim"], e["kind"], e["metric"])
+        p = VecSim.BFParams()
+        p.type, p.dim, p.metric = TYPES["u8"], e["dim"], METRICS[e["metric"]]
+        ix = VecSim.BFIndex(p)
+        ix.add_vectors(a, np.arange(1))
+        labels, dists = ix.knn_query(b[None, :], 1)
+        got = refgen.hexbits(np.float32(dists[0][0]))[0]
+        if got != e["score"]:
+            bad.append((e, got))
+    assert not bad, bad[:3]

@@ -231,6 +231,30 @@ def test_multi_value_index_across_shards(vso, typ, metric, dim, G):
     assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
 
 
+def test_multi_value_shard_with_hundreds_of_identical_rows_under_distinct_labels(vso):
+    """round-3 advisor finding: more than max(k, 64) rows of ONE shard tie at the k-th row score (one vector stored under many
+    labels).  The shard's candidate call used to report overflow whatever room the caller offered, so the sharded query failed;
+    it now grows its own room.  Reply == the single multi-value index's."""
+    rng = np.random.default_rng(8)
+    dim, G, block = 24, 2, 16
+    base = rng.integers(-3, 4, (40, dim)).astype(np.float32)
+    rows = np.concatenate([np.repeat(base[:1], 400, axis=0), base[rng.integers(1, 40, 1200)]])   # 400 copies of one vector
+    labels = np.concatenate([np.arange(400) + 1000, rng.integers(0, 300, 1200)])
+    perm = rng.permutation(len(rows))
+    rows, labels = rows[perm], labels[perm]
+    pm = params("f32", "L2", dim, block)
+    pm.multi = True
+    sx = ShardedFlatIndex(pm, shards=G)
+    one = VecSim.BFIndex(pm)
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    q = np.concatenate([base[:1], base[5:8]])          # the first query IS the duplicated vector: 400 rows at score 0
+    for k in (5, 10, 150):
+        gl, gs = sx.knn_query(q, k)
+        sl, ss = one.knn_query(q, k)
+        assert np.array_equal(gl, sl) and np.array_equal(gs, ss), k
+
+
 def test_concurrent_readers_with_sequence_numbers(vso):
     """two reader threads on one sharded index (VecSimGpu_ShardedTopKQueryBatchArraysSeq): scans overlap on the shards' reader
     lanes, exchanges go in sequence order; every batch's reply equals the one-reader reply.  Through a real 1-rank RCCL

@@ -150,8 +150,9 @@ def test_sq8_mfma_filter_bound_holds(vso):
     ("avx512f,avx512bw,avx512vl,avx512vbmi2,avx512vnni,avx512_bf16", None, "AVX512_BF16"),
     ("avx512f,avx512bw,avx512vbmi2,avx512_bf16", None, "AVX512"),          # avx512_bf16 without avx512vl: IP_space.cpp:585
     ("avx512f", None, "AVX512"),
-    ("avx,fma3,f16c", None, "SCALAR"),
-    ("", None, "SCALAR"),
+    ("avx,fma3,f16c", None, "AVX512"),                                     # no AVX-512: still the AVX-512 order (host_tier.h says why)
+    ("", None, "AVX512"),
+    ("avx,fma3,f16c", "scalar", "SCALAR"),                                 # the scalar order is an explicit choice
     ("avx512f,avx512vl,avx512_bf16", "avx512", "AVX512"),                  # the override wins
     ("avx,f16c", "avx512_bf16", "AVX512_BF16"),
 ])
@@ -180,5 +181,5 @@ def test_host_tier_probe_matches_proc_cpuinfo(monkeypatch):
             if line.startswith("flags"):
                 flags = set(line.split(":", 1)[1].split())
                 break
-    expect = "SCALAR" if "avx512f" not in flags else ("AVX512_BF16" if {"avx512_bf16", "avx512vl"} <= flags else "AVX512")
+    expect = "AVX512_BF16" if {"avx512f", "avx512_bf16", "avx512vl"} <= flags else "AVX512"
     assert lib.VecSimGpu_HostTier().decode() == expect

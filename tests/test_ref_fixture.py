@@ -77,6 +77,16 @@ def test_topk_replay_equals_the_reference_containers(vso, fixture):
     _diff("topk", refgen.compute_topk(OracleScalar(vso)), fixture["topk"], key=lambda e: e["case"])
 
 
+def test_uint8_beyond_the_32_bit_bound_equals_the_compiled_reference(vso, fixture):
+    """dim > 33 025: the reference's choosers hand back the scalar kernel with its 64-bit total (spaces.h:57-66)"""
+    _diff("wide_u8", refgen.compute_wide_u8(OracleScalar(vso)), fixture["wide_u8"], key=lambda e: (e["dim"], e["kind"], e["metric"]))
+    # the oracle's default tier resolves to the same exact integer there
+    class Avx(OracleScalar):
+        def distance(self, t, m, a, b, dim):
+            return self.vso.distance(t, m, a, b, dim, tier=self.vso.TIER_AVX512)
+    _diff("wide_u8 (avx512 tier)", refgen.compute_wide_u8(Avx(vso)), fixture["wide_u8"], key=lambda e: (e["dim"], e["kind"], e["metric"]))
+
+
 def test_fixture_is_what_the_reference_build_produces_here(fixture):
     """where oracle/_ref exists (the build container; the .so also travels to the GPU box), re-run the reference's code on
     the seeds: the committed fixture must be reproducible, and a wider random sweep must agree with the oracle too"""
@@ -88,7 +98,7 @@ def test_fixture_is_what_the_reference_build_produces_here(fixture):
     except OSError as e:     # a library built against another libstdc++
         pytest.skip("oracle/_ref/libvsref.so does not load here: %s" % e)
     live = refgen.compute_all(vsref)
-    for section in ("distances", "conversions", "normalize", "sq8", "topk"):
+    for section in ("distances", "conversions", "normalize", "sq8", "topk", "wide_u8"):
         assert live[section] == fixture[section], section
 
 

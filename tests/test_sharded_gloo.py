@@ -111,6 +111,18 @@ def _worker(rank, world, port, out):
                     ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
     st = ix.stats()
     ok &= st["batches"] == 8 and st["exchange_bytes"] > 0
+    # a sequence number that has already been answered is an error on every process (it used to wait for ever and strand the
+    # peers in their collective); reset_seq starts a new stream at 0
+    try:
+        ix.knn_query(qsets[0], k, seq=3)
+        ok = False
+    except RuntimeError:
+        pass
+    ix.reset_seq()
+    got_l, got_s = ix.knn_query(qsets[1], k, seq=0)
+    for qi in range(nq):
+        el, es = vso.flat_topk(0, 0, rows, qsets[1][qi], k, dim, labels.astype(np.uint64))
+        ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
     # the timeout callback fires on ONE process only: its verdict travels in the exchange, both processes return TimedOut
     # replies (a process that left before the collective would hang the other)
     cb = VecSim.set_timeout_callback(lambda ctx: 1 if (ctx == 7 and rank == 1) else 0)

@@ -250,6 +250,10 @@ class VecSimIndex:
             self._lib.VecSimDebugInfoIterator_Free(it)
         return out
 
+    def distance_tier(self):
+        """which reference ISA tier's summation order this index answers in: 'AVX512' | 'AVX512_BF16' | 'SCALAR'"""
+        return self._lib.VecSimGpu_IndexTier(self._h).decode()
+
     def index_type(self):
         return self._type
 

@@ -91,7 +91,7 @@ class VecSimIndexBasicInfo(C.Structure):
 class VecSimGpuStats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_uint64), ("scan_rows", C.c_uint64),
                 ("scan_bytes", C.c_uint64), ("other_ms", C.c_double), ("candidates", C.c_uint64),
-                ("fallbacks", C.c_uint64), ("retries", C.c_uint64), ("scan_kernel", C.c_char * 64)]
+                ("fallbacks", C.c_uint64), ("scan_kernel", C.c_char * 64), ("retries", C.c_uint64)]
 
 
 TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -142,13 +142,13 @@ EXPORTS = [
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
-    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_ResetStats",
+    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_IndexTier", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
     "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
     "VecSimGpu_ShardedAddVectorsBulk", "VecSimGpu_ShardedAddSyntheticLocal", "VecSimGpu_ShardedDeleteVector",
     "VecSimGpu_ShardedIndexSize", "VecSimGpu_ShardedTopKQueryBatch", "VecSimGpu_ShardedTopKQueryBatchArrays",
-    "VecSimGpu_ShardedTopKQueryBatchArraysSeq", "VecSimGpu_ShardedGetStats", "VecSimGpu_ShardedResetStats",
+    "VecSimGpu_ShardedTopKQueryBatchArraysSeq", "VecSimGpu_ShardedGetStats", "VecSimGpu_ShardedResetStats", "VecSimGpu_ShardedResetSeq",
     "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
@@ -306,6 +306,8 @@ def load():
     L.VecSimGpu_DeviceSynchronize.argtypes = []
     L.VecSimGpu_LastError.restype = C.c_char_p
     L.VecSimGpu_HostTier.restype = C.c_char_p
+    L.VecSimGpu_IndexTier.restype = C.c_char_p
+    L.VecSimGpu_IndexTier.argtypes = [C.c_void_p]
     L.VecSimGpu_ResetStats.restype = None
     L.VecSimGpu_ResetStats.argtypes = [vp]
     L.VecSimGpu_GetStats.restype = None
@@ -344,6 +346,8 @@ def load():
     L.VecSimGpu_ShardedGetStats.argtypes = [vp, C.POINTER(C.c_double)]
     L.VecSimGpu_ShardedResetStats.restype = None
     L.VecSimGpu_ShardedResetStats.argtypes = [vp]
+    L.VecSimGpu_ShardedResetSeq.restype = None
+    L.VecSimGpu_ShardedResetSeq.argtypes = [vp]
     L.VecSimGpu_ShardedLocalIndex.restype = vp
     L.VecSimGpu_ShardedLocalIndex.argtypes = [vp, i]
     L.VecSimGpu_ShardedWorld.restype = i

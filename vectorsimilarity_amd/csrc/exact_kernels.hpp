@@ -111,6 +111,13 @@ template <int OPK> __device__ inline int acc_step(int x, int q, int acc) {
 __device__ inline float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ inline double add_rn(double a, double b) { return __dadd_rn(a, b); }
 __device__ inline int add_rn(int a, int b) { return a + b; }
+__device__ inline long long add_rn(long long a, long long b) { return a + b; }
+// what the lanes' accumulators are reduced in: integer rows widen to 64 bits there.  A lane's own int32 sum is safe up to
+// ~1 M elements (255^2 * dim / 32), the cross-lane total is not: uint8 rows beyond 33 025 elements are the reference's
+// 64-bit scalar kernel (spaces.h:57-66, L2_space.cpp:474-476, IP.cpp:240-262: `long long` total, then float) -- an exact
+// integer in any order, so the striding lanes + a 64-bit tree give that number.
+template <typename A> struct Reduced { using type = A; };
+template <> struct Reduced<int> { using type = long long; };
 
 // Horizontal add of a VL-lane accumulator group; the result is valid in the group's lane 0.
 //   kind 0: halving tree, offsets VL/2 .. 1 (sum0 + sum1, then gcc 11's _mm512_reduce_add order)
@@ -163,10 +170,10 @@ struct ScanParams {
     uint32_t cap;
 };
 
-template <typename S> __device__ inline S epilogue_score(int acc, int epi, float nrow, float nq) {
-    if (epi == EPI_INT_L2) return (S)(float)acc;
-    if (epi == EPI_INT_IP) return (S)(float)(1 - acc);
-    float ip = (float)acc;
+template <typename S> __device__ inline S epilogue_score(long long acc, int epi, float nrow, float nq) {
+    if (epi == EPI_INT_L2) return (S)__ll2float_rn(acc);          // float(long long): L2.cpp:164-174
+    if (epi == EPI_INT_IP) return (S)__ll2float_rn(1ll - acc);    // IP.cpp:258-262
+    float ip = __ll2float_rn(acc);
     return (S)__fsub_rn(1.0f, __fdiv_rn(ip, __fmul_rn(nrow, nq)));
 }
 template <typename S> __device__ inline S epilogue_score(float acc, int epi, float, float) {
@@ -199,10 +206,15 @@ template <int EK> struct ScanShape {
     static constexpr int TILE_ROWS = GROUPS * R;
 };
 
-template <int EK, int OPK, int BT>
+// GT = true: the lane table and the query image are read from global memory (L1 / L2 hits) instead of an LDS copy -- the
+// path of rows whose table + one query image exceed the CU's LDS (any dim is accepted, as the reference does:
+// spaces/L2_space.cpp:185-241); one query per pass.
+template <int EK, int OPK, int BT, bool GT = false>
 __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
+    static_assert(!GT || BT == 1, "global-table variant: one query per pass");
     using E = Elem<EK>;
     using acc_t = typename E::acc_t;
+    using red_t = typename Reduced<acc_t>::type;
     using score_t = typename E::score_t;
     constexpr int VL = E::VL;
     constexpr int R = ScanShape<EK>::R;
@@ -210,19 +222,25 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
     constexpr int TILE_ROWS = ScanShape<EK>::TILE_ROWS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *offs_s = reinterpret_cast<int32_t *>(smem);
-    acc_t *q_s = reinterpret_cast<acc_t *>(smem + (((size_t)P.steps * VL * 4 + 15) & ~(size_t)15));
-
     const int steps = P.steps;
     const int q0 = blockIdx.y * BT;  // first query of this block's tile
     const int nqt = min(BT, P.nq - q0);
-    for (int i = threadIdx.x; i < steps * VL; i += 256) offs_s[i] = P.offs[i];
-    {
+    const int32_t *offs_s;
+    const acc_t *q_s;
+    if constexpr (GT) {
+        offs_s = P.offs;
+        q_s = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q0 * steps * VL;
+    } else {
+        int32_t *offs_l = reinterpret_cast<int32_t *>(smem);
+        acc_t *q_l = reinterpret_cast<acc_t *>(smem + (((size_t)P.steps * VL * 4 + 15) & ~(size_t)15));
+        for (int i = threadIdx.x; i < steps * VL; i += 256) offs_l[i] = P.offs[i];
         const acc_t *qg = reinterpret_cast<const acc_t *>(P.qperm) + (size_t)q0 * steps * VL;
         for (int i = threadIdx.x; i < BT * steps * VL; i += 256)
-            q_s[i] = (i < nqt * steps * VL) ? qg[i] : (acc_t)0;
+            q_l[i] = (i < nqt * steps * VL) ? qg[i] : (acc_t)0;
+        __syncthreads();
+        offs_s = offs_l;
+        q_s = q_l;
     }
-    __syncthreads();
 
     const int lane = threadIdx.x % VL;
     const int grp = threadIdx.x / VL;
@@ -306,48 +324,34 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
             }
         }
 
-        // halving tree: offsets VL/2 .. 1 (== sum0+sum1, then _mm512_reduce_add order)
+        // halving tree: offsets VL/2 .. 1 (== sum0+sum1, then _mm512_reduce_add order); integer rows in 64 bits
 #pragma unroll
-        for (int r = 0; r < R; r++)
+        for (int r = 0; r < R; r++) {
+            float nrow = 0.f;
+            if (lane == 0 && valid[r] && P.epilogue == EPI_INT_COS) nrow = load_f32_unaligned(rp[r] + P.norm_off);
 #pragma unroll
             for (int b = 0; b < BT; b++) {
-                acc[r][b] = lane_reduce<VL>(acc[r][b], P.reduce);
-            }
-
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (!valid[r]) continue;
-                float nrow = 0.f;
-                if (P.epilogue == EPI_INT_COS) {
-                    const unsigned char *np = reinterpret_cast<const unsigned char *>(rp[r] + P.norm_off);
-                    uint32_t u = (uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) |
-                                 ((uint32_t)np[3] << 24);
-                    nrow = __uint_as_float(u);
+                const red_t tot = lane_reduce<VL>((red_t)acc[r][b], P.reduce);
+                if (lane != 0 || !valid[r] || b >= nqt) continue;
+                const int q = q0 + b;
+                const float nq = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
+                score_t sc;
+                if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) {
+                    sc = sq8_score(tot, P.epilogue, P.sq8_fused, rp[r] + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
+                } else {
+                    sc = epilogue_score<score_t>(tot, P.epilogue, nrow, nq);
                 }
-#pragma unroll
-                for (int b = 0; b < BT; b++) {
-                    if (b >= nqt) break;
-                    const int q = q0 + b;
-                    const float nq = (P.epilogue == EPI_INT_COS) ? P.qnorm[q] : 0.f;
-                    score_t sc;
-                    if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) {
-                        sc = sq8_score(acc[r][b], P.epilogue, P.sq8_fused, rp[r] + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
-                    } else {
-                        sc = epilogue_score<score_t>(acc[r][b], P.epilogue, nrow, nq);
-                    }
-                    if (P.mode == MODE_DENSE) {
-                        reinterpret_cast<score_t *>(P.out)[(size_t)q * P.out_stride + comp[r]] = sc;
-                    } else {
-                        const score_t t = reinterpret_cast<const score_t *>(P.tau)[q];
-                        if (sc <= t) {
-                            uint32_t slot = atomicAdd(&P.counts[q], 1u);
-                            if (slot < P.cap) {
-                                uint2 rec;
-                                rec.x = rowid[r];
-                                rec.y = __float_as_uint((float)sc);
-                                P.cand[(size_t)q * P.cap + slot] = rec;
-                            }
+                if (P.mode == MODE_DENSE) {
+                    reinterpret_cast<score_t *>(P.out)[(size_t)q * P.out_stride + comp[r]] = sc;
+                } else {
+                    const score_t t = reinterpret_cast<const score_t *>(P.tau)[q];
+                    if (sc <= t) {
+                        uint32_t slot = atomicAdd(&P.counts[q], 1u);
+                        if (slot < P.cap) {
+                            uint2 rec;
+                            rec.x = rowid[r];
+                            rec.y = __float_as_uint((float)sc);
+                            P.cand[(size_t)q * P.cap + slot] = rec;
                         }
                     }
                 }

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const acc_t a = lane_reduce<VL>(acc[u], P.reduce);
+            const typename Reduced<acc_t>::type a = lane_reduce<VL>((typename Reduced<acc_t>::type)acc[u], P.reduce);   // (integer rows: 64-bit total)
             if (vl == 0 && act[u]) {
                 float nrow = 0.f;
                 if (P.epilogue == EPI_INT_COS) {

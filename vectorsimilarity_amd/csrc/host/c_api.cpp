@@ -306,6 +306,7 @@ VecSim_InfoField f64_field(const char *name, double v) {
 }  // namespace
 // the tier a new index would get on this host (VECSIM_GPU_TIER override, else CPUID): "AVX512" | "AVX512_BF16" | "SCALAR"
 extern "C" const char *VecSimGpu_HostTier(void) { return vsa::tier_name(vsa::resolve_tier()); }
+extern "C" const char *VecSimGpu_IndexTier(VecSimIndex *index) { return index ? vsa::tier_name(index->distanceTier()) : ""; }
 extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
     const VecSimIndexDebugInfo info = index->debugInfo();
     const CommonInfo &ci = info.commonInfo;
@@ -332,8 +333,8 @@ extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *i
         f.push_back(f64_field("EPSILON", info.hnswInfo.epsilon));
         f.push_back(u64_field("NUMBER_OF_MARKED_DELETED", info.hnswInfo.numberOfMarkedDeletedNodes));
     }
-    // extension, behind the reference's fields: which reference ISA tier's summation order the scores reproduce (host_tier.h)
-    f.push_back(str_field("DISTANCE_TIER", vsa::tier_name(index->distanceTier())));
+    // (exactly the reference's fields, info_iterator / vec_sim_index.h debugInfoIterator: consumers count them.  The tier an
+    // index answers in is VecSimGpu_IndexTier.)
     return it;
 }
 extern "C" size_t VecSimDebugInfoIterator_NumberOfFields(VecSimDebugInfoIterator *it) { return it->fields.size(); }
@@ -583,6 +584,7 @@ extern "C" int VecSimGpu_ShardedTopKQueryBatchArraysSeq(VecSimShardedIndex *ix, 
 }
 extern "C" void VecSimGpu_ShardedGetStats(VecSimShardedIndex *ix, double out[6]) { ix->impl->stats(out); }
 extern "C" void VecSimGpu_ShardedResetStats(VecSimShardedIndex *ix) { ix->impl->resetStats(); }
+extern "C" void VecSimGpu_ShardedResetSeq(VecSimShardedIndex *ix) { ix->impl->resetSeq(); }
 extern "C" VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *ix, int shard) { return ix->impl->localIndex(shard); }
 extern "C" int VecSimGpu_ShardedWorld(VecSimShardedIndex *ix) { return ix->impl->world(); }
 extern "C" int VecSimGpu_ShardedRank(VecSimShardedIndex *ix) { return ix->impl->rank(); }

@@ -740,7 +740,8 @@ int FlatIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     struct PollScope {
         vsgpu_ctx *c;
         PollScope(vsgpu_ctx *cc, void *user) : c(cc) {
-            if (globals().timeout_cb && user) vsgpu_set_poll(c, [](void *u) { return timed_out(u) ? 1 : 0; }, user);
+            // (whenever a callback is registered: the reference calls it with a NULL context as well, brute_force.h:265)
+            if (globals().timeout_cb) vsgpu_set_poll(c, [](void *u) { return timed_out(u) ? 1 : 0; }, user);
         }
         ~PollScope() { vsgpu_set_poll(c, nullptr, nullptr); }
     } poll_scope(lane ? lane->ctx : ctx_, tctx);
@@ -850,13 +851,21 @@ int FlatIndex::topKCandidates(const void *queries, size_t nq, size_t stride, siz
         std::vector<double> lsc;
         for (size_t q = 0; q < nq; q++) {
             size_t kr = std::min(count_, std::max<size_t>(k, 1));
+            size_t c1 = std::max<size_t>(2 * kr, kr + 64);
             for (;;) {
-                const size_t c1 = std::max<size_t>(2 * kr, kr + 64);
+                c1 = std::min(count_, std::max(c1, std::max<size_t>(2 * kr, kr + 64)));
                 lid.resize(c1);
                 lsc.resize(c1);
                 int rc = vsgpu_topk(tbl, qbuf.data() + q * query_bytes_, 1, query_bytes_, kr, c1, lid.data(), lsc.data(), cnt.data());
                 if (rc) return rc;
-                if (cnt[0] == VSGPU_COUNT_OVERFLOW) break;   // heavy ties: the caller comes back with more room
+                if (cnt[0] == VSGPU_COUNT_OVERFLOW) {
+                    // more rows tie at the kr-th score than c1 holds (duplicated vectors under distinct labels, low-dim int8): the
+                    // room has to grow HERE -- it does not depend on the caller's `cap`, so a caller retrying with a larger cap
+                    // would meet the same overflow for ever (round-3 advisor finding)
+                    if (c1 >= count_) break;
+                    c1 = std::min(count_, c1 * 8);
+                    continue;
+                }
                 if (kr >= count_ || distinctLabels(lid.data(), cnt[0]) >= std::min(k, n_labels)) break;
                 kr = std::min(count_, kr * 4);
             }

@@ -7,12 +7,20 @@
 //   avx512f                                  -> the AVX-512F / BW / VBMI2 / VNNI kernels' order     (VSGPU_TIER_AVX512)
 //   ... && avx512_bf16 && avx512vl           -> vdpbf16ps first for bf16 IP / Cosine                (VSGPU_TIER_AVX512_BF16;
 //                                               IP_space.cpp:585-590; every other type as AVX512)
-//   no avx512f                               -> the scalar kernels' order                          (VSGPU_TIER_SCALAR)
-// -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar overrides it.  Not restated: the AVX2 / AVX / SSE
-// orders a reference build falls back to on a host without AVX-512 (this library then reproduces the scalar kernels, the
-// reference's own baseline in tests/unit/test_spaces.cpp) and the AVX512-FP16 tier of gcc >= 12 builds (fp16 accumulate).
+//   no avx512f                               -> ALSO the AVX-512 kernels' order, with one line on stderr: a reference build
+//                                               there runs its AVX2 / AVX / SSE kernels, whose orders are not restated
+//                                               (DESIGN.md 3), so no tier this library has equals it; AVX512 keeps the MFMA
+//                                               filters (the scalar order turns them off: 10-50x slower) and is the order
+//                                               the same index gives on any AVX-512 host.  The scalar kernels' order
+//                                               (VSGPU_TIER_SCALAR) is an explicit choice only.
+// -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar overrides it.  Also not restated: the AVX512-FP16 tier of gcc >= 12
+// builds (fp16 accumulate).  The reference asks for more than avx512f per type (bf16: avx512bw && avx512vbmi2,
+// L2_space.cpp:332-337; int8 / uint8: avx512bw && avx512vl && avx512vnni, L2_space.cpp:451-455; fp16: avx512bw && avx512vl):
+// reference_order_modelled() says whether the host's own reference build would run the order this library restates for
+// a type, and the one-line note names what is missing.
 // VECSIM_GPU_HOST_FLAGS = comma-separated feature names replaces the CPUID probe (tests).
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -47,9 +55,20 @@ inline HostFeatures host_features() {
 }
 
 inline int tier_from_features(const HostFeatures &f) {
-    if (!f.avx512f) return VSGPU_TIER_SCALAR;
-    if (f.avx512_bf16 && f.avx512vl) return VSGPU_TIER_AVX512_BF16;
+    if (f.avx512f && f.avx512_bf16 && f.avx512vl) return VSGPU_TIER_AVX512_BF16;
     return VSGPU_TIER_AVX512;
+}
+
+// would a reference build on this host run the kernel order restated for `type` (VSGPU_F32 ...)?
+inline bool reference_order_modelled(const HostFeatures &f, int type) {
+    if (!f.avx512f) return false;
+    switch (type) {
+    case VSGPU_BF16: return f.avx512bw && f.avx512vbmi2;
+    case VSGPU_F16: return f.avx512bw && f.avx512vl;
+    case VSGPU_I8:
+    case VSGPU_U8: return true;   // exact integers: every tier gives the same number
+    default: return true;
+    }
 }
 
 inline int resolve_tier() {
@@ -58,7 +77,16 @@ inline int resolve_tier() {
         if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
         if (!std::strcmp(e, "avx512")) return VSGPU_TIER_AVX512;
     }
-    return tier_from_features(host_features());
+    const HostFeatures f = host_features();
+    if (!f.avx512f) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            std::fprintf(stderr, "vecsim_amd: host CPU has no AVX-512: scores follow the reference's AVX-512 kernel order (its AVX2 / SSE "
+                                 "orders are not restated); set VECSIM_GPU_TIER=scalar for the scalar kernels' order\n");
+        }
+    }
+    return tier_from_features(f);
 }
 
 inline const char *tier_name(int tier) {

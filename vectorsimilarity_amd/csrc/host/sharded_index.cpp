@@ -317,16 +317,35 @@ int ShardedIndex::deleteVector(size_t label) {
 }
 
 // ---- query ----
-void ShardedIndex::takeTurn(uint64_t seq) {
-    if (seq == NO_SEQ) return;
+// A numbered batch waits for its number; a batch WITHOUT a number takes the exchange section as a plain critical section, so its
+// collectives never interleave with a numbered batch's on this process (mixing the two modes across processes is still the
+// caller's to keep consistent, like the order of the calls themselves).  A number that has already passed is an error, not a
+// wait for ever: next_seq_ only grows (resetSeq starts a new stream of batches at 0).
+bool ShardedIndex::takeTurn(uint64_t seq) {
     std::unique_lock<std::mutex> lk(turn_mu_);
-    turn_cv_.wait(lk, [&] { return next_seq_ == seq; });
+    if (seq == NO_SEQ) {
+        turn_cv_.wait(lk, [&] { return !turn_held_; });
+        turn_held_ = true;
+        return true;
+    }
+    if (seq < next_seq_) return false;
+    turn_cv_.wait(lk, [&] { return (next_seq_ == seq && !turn_held_) || seq < next_seq_; });
+    if (seq < next_seq_) return false;   // (a resetSeq / an earlier duplicate overtook this call)
+    turn_held_ = true;
+    return true;
 }
 void ShardedIndex::passTurn(uint64_t seq) {
-    if (seq == NO_SEQ) return;
     {
         std::lock_guard<std::mutex> lk(turn_mu_);
-        next_seq_ = seq + 1;
+        turn_held_ = false;
+        if (seq != NO_SEQ) next_seq_ = seq + 1;
+    }
+    turn_cv_.notify_all();
+}
+void ShardedIndex::resetSeq() {
+    {
+        std::lock_guard<std::mutex> lk(turn_mu_);
+        next_seq_ = 0;
     }
     turn_cv_.notify_all();
 }
@@ -461,11 +480,14 @@ int ShardedIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, 
     struct Turn {
         ShardedIndex *sx;
         uint64_t seq;
-        bool taken = false;
+        bool taken = false, stale = false;
         void take() {
-            if (!taken) {
+            if (!taken && !stale) {
                 const double t0 = now_ms();
-                sx->takeTurn(seq);
+                if (!sx->takeTurn(seq)) {
+                    stale = true;
+                    return;
+                }
                 taken = true;
                 std::lock_guard<std::mutex> lk(sx->stats_mu_);
                 sx->st_wait_ += now_ms() - t0;
@@ -475,11 +497,20 @@ int ShardedIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, 
         void release() {   // no further exchange belongs to this batch: the next batch's may go
             if (passed) return;
             take();
-            sx->passTurn(seq);
+            if (taken) sx->passTurn(seq);
             passed = true;
         }
         ~Turn() { release(); }
     } turn{this, seq};
+    if (seq != NO_SEQ) {   // a number that already passed would wait for ever (and strand the peers in their collective)
+        std::lock_guard<std::mutex> lk(turn_mu_);
+        if (seq < next_seq_) {
+            turn.stale = turn.passed = true;
+            std::fprintf(stderr, "vecsim_amd: sharded batch with sequence number %llu after %llu was answered (VecSimGpu_ShardedResetSeq starts a new stream)\n",
+                         (unsigned long long)seq, (unsigned long long)next_seq_);
+            return -1;
+        }
+    }
     if (nq == 0) return 0;
     std::vector<VecSimQueryReply *> reps(nq);
     for (auto &r : reps) r = new VecSimQueryReply();

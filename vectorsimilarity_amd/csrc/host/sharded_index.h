@@ -88,6 +88,7 @@ public:
     // exchange, merge + replies, batches, exchanged bytes per rank}
     void stats(double out[6]);
     void resetStats();
+    void resetSeq();   // the next numbered batch is 0 again (no batch may be in flight)
     VecSimIndexInterface *localIndex(int shard);
     void setExchange(std::unique_ptr<Exchange> ex) { ex_ = std::move(ex); }
     int world() const { return (int)plan_.world; }
@@ -110,7 +111,7 @@ private:
     int queryOnce(const void *queries, size_t nq, size_t stride, size_t k, size_t cap, bool local_timeout, bool all_rows,
                   const std::function<bool()> &poll_timeout, const std::function<void(bool)> &turn_hook,
                   std::vector<size_t> &out_labels, std::vector<double> &out_scores, std::vector<uint32_t> &out_counts, Pass *pass);
-    void takeTurn(uint64_t seq);
+    bool takeTurn(uint64_t seq);   // false: the number has already passed
     void passTurn(uint64_t seq);
 
     BFParams params_{};
@@ -126,6 +127,7 @@ private:
     std::mutex turn_mu_;
     std::condition_variable turn_cv_;
     uint64_t next_seq_ = 0;
+    bool turn_held_ = false;
     std::mutex stats_mu_;
     double st_scan_ = 0, st_wait_ = 0, st_exchange_ = 0, st_merge_ = 0, st_batches_ = 0, st_bytes_ = 0;
 };

@@ -504,14 +504,14 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
                 acc = off[j] >= 0 ? t : acc;
             }
         }
-        acc = lane_reduce<VL>(acc, P.reduce);
+        const typename Reduced<acc_t>::type tot = lane_reduce<VL>((typename Reduced<acc_t>::type)acc, P.reduce);
         if (lane == 0) {
             if constexpr (EK == EK_F64) {   // double scores live beside the candidate list: P.out[q][slot]
-                reinterpret_cast<double *>(P.out)[(size_t)q * P.cap + s] = epilogue_score<double>(acc, P.epilogue, 0.f, 0.f);
+                reinterpret_cast<double *>(P.out)[(size_t)q * P.cap + s] = epilogue_score<double>(tot, P.epilogue, 0.f, 0.f);
             } else {
                 float sc;
-                if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) sc = sq8_score(acc, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
-                else sc = epilogue_score<float>(acc, P.epilogue, 0.f, 0.f);
+                if constexpr (EK == EK_SQ8 || EK == EK_SQ8H) sc = sq8_score(tot, P.epilogue, P.sq8_fused, rp + P.norm_off, P.qnorm[2 * q], P.qnorm[2 * q + 1]);
+                else sc = epilogue_score<float>(tot, P.epilogue, 0.f, 0.f);
                 rec.y = __float_as_uint(sc);
                 P.cand[(size_t)q * P.cap + s] = rec;
             }

@@ -234,13 +234,11 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
     size_t q_b = (size_t)t->prog.steps * t->prog.vl * acc_bytes(type);
     size_t budget = VSG_EXACT_LDS_BUDGET;
-    if (offs_b + q_b > budget) {
-        fail(VSGPU_ERR_UNSUPPORTED, "dim %zu too large for the table-driven kernel's LDS image", dim);
-        delete t;
-        return nullptr;
-    }
+    // The reference takes any dim (spaces/L2_space.cpp:185-241, spaces.h:57-66): rows whose lane table + one query image do
+    // not fit the LDS run on the global-table variant of the exact kernels, one query per pass (slow, correct).
+    t->gtab = offs_b + q_b > budget;
     // as many queries per pass as fit, but an 8-query tile only while two workgroups still share a CU (80 KiB each)
-    size_t fit = (budget - offs_b) / q_b;
+    size_t fit = t->gtab ? 1 : (budget - offs_b) / q_b;
     t->bt_max = (fit >= 8 && offs_b + 8 * q_b <= 80 * 1024) ? 8 : (fit >= 4 ? 4 : 1);
     if (!t->prog.fused || t->opk == OP_IP_DPBF16) t->bt_max = 1;  // these orders are only instantiated for BT=1
     {
@@ -743,6 +741,10 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
 
 // ------------------------------------------------------------------ kernel dispatch
 template <int EK, int OPK, int BT> static void launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t s) {
+    if (lds == 0) {   // tables from global memory (vsgpu_table::gtab); callers pass one query per pass
+        if constexpr (BT == 1) hipLaunchKernelGGL((k_exact_scan<EK, OPK, 1, true>), grid, dim3(256), 0, s, P);
+        return;
+    }
     if (lds > 64 * 1024)   // beyond the default dynamic-LDS limit: raised per kernel instance
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan<EK, OPK, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_exact_scan<EK, OPK, BT>), grid, dim3(256), lds, s, P);
@@ -809,12 +811,12 @@ int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     P.norm_off = (uint32_t)t->dim;
     P.qnorm = (const float *)c->qnorm.p;
     P.sq8_fused = t->prog.fused ? 1 : 0;
-    const int bt = pick_bt(t, nq);
+    const int bt = t->gtab ? 1 : pick_bt(t, nq);
     const int tile_rows = tile_rows_of(t->ek);
     const uint32_t n_tiles = (P.n_compact + tile_rows - 1) / tile_rows;
     if (n_tiles == 0) return VSGPU_OK;
     const size_t offs_b = ((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15;
-    const size_t lds = offs_b + (size_t)bt * t->prog.steps * t->prog.vl * acc_bytes(t->type);
+    const size_t lds = t->gtab ? 0 : offs_b + (size_t)bt * t->prog.steps * t->prog.vl * acc_bytes(t->type);
     const uint32_t q_tiles = (uint32_t)((nq + bt - 1) / bt);
     uint32_t gx = std::min<uint32_t>(n_tiles, (uint32_t)c->n_cu * 8);
     if (timed) HIPCHK(hipEventRecord(c->ev_a, c->stream));

@@ -144,6 +144,7 @@ struct vsgpu_table {
     size_t n = 0;
     int ek = 0, opk = 0, epi = 0;
     int bt_max = 1;  // largest query tile whose LDS image fits
+    bool gtab = false;   // lane table + one query image exceed the LDS budget: k_exact_scan<..., GT = true> reads both from global memory
     // MFMA filter path (fp32, AVX-512-order tier, dim a multiple of 64): |x|^2 per row, slab-parallel
     bool mfma_ok = false;
     int ksteps = 0;

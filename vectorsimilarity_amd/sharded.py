@@ -198,6 +198,10 @@ class ShardedFlatIndex:
     def reset_stats(self):
         self._lib.VecSimGpu_ShardedResetStats(self._h)
 
+    def reset_seq(self):
+        """start a new stream of numbered batches at 0 (every process, nothing in flight)"""
+        self._lib.VecSimGpu_ShardedResetSeq(self._h)
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._lib.VecSimGpu_ShardedFree(self._h)
