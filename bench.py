@@ -12,7 +12,8 @@ Configs (BASELINE.json `configs`; default c2 = the one `metric` is quoted on):
                                                           on the host cores first: ~3 min per million rows); --data uniform | lowrank
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (one rank
-per GPU).  Every rank holds its own shard of `rows` vectors (weak scaling), scans it for the same query batch, and the
+per GPU).  Every rank holds its own shard of `rows` vectors (weak scaling; --scaling strong: rows / N of them, the job's
+total stays `rows`), scans it for the same query batch, and the
 per-shard candidate records are exchanged by ONE ncclAllGather per batch -- RCCL over xGMI, issued by the C++ host
 library (csrc/vsgpu_comm.hip behind VecSimGpu_Sharded*, include/VecSim/vec_sim_gpu.h) -- and merged into the exact
 single-index reply on every rank.  torch.distributed is the control plane only (gloo: rank 0's RCCL id, barriers, the
@@ -47,9 +48,9 @@ I8_MFMA_PEAK_TOPS = 3944  # same guide, 16x16x64 int8 ubench ceiling
 # name: (type, metric, dim, rows per GPU, batch, k, dtype tag, generator, CPU sample rows)
 CONFIGS = {
     "c1": ("FLOAT32", "L2", 128, 100_000, 1, 10, "f32", "rows_f32", 100_000),
-    "c2": ("FLOAT32", "L2", 768, 10_000_000, 64, 10, "f32", "rows_f32", 400_000),
-    "c3": ("INT8", "Cosine", 1024, 50_000_000, 256, 100, "i8", "rows_i8", 40_000),
-    "c4": ("BFLOAT16", "IP", 768, 12_500_000, 128, 10, "bf16", "rows_bf16", 40_000),
+    "c2": ("FLOAT32", "L2", 768, 10_000_000, 64, 10, "f32", "rows_f32", 1_000_000),    # CPU sample = N / 10
+    "c3": ("INT8", "Cosine", 1024, 50_000_000, 256, 100, "i8", "rows_i8", 1_000_000),
+    "c4": ("BFLOAT16", "IP", 768, 12_500_000, 128, 10, "bf16", "rows_bf16", 1_250_000),
     "c5": ("FLOAT32", "L2", 768, 1_000_000, 4096, 10, "f32", "rows_f32", 0),
 }
 
@@ -75,6 +76,10 @@ def parse():
                     help="c5 only.  uniform: BASELINE's i.i.d. U[-1,1) rows (intrinsic dimension = d: no graph index finds neighbours "
                          "there); lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
     ap.add_argument("--ef", type=int, default=128, help="c5: efRuntime")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1.  weak (default, what the driver's plain --gpus N run measures): every rank holds --rows vectors, the "
+                         "job holds N x rows (config 4 is defined that way: 100 M rows over 8 GPUs).  strong: the job holds --rows "
+                         "vectors, rank r holds its share of them (BASELINE's headline reads N = 10 M at 1 / 2 / 4 / 8 GPUs)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning: VecSimGpu_SetOption on the index (e.g. probe_div=64); not used by the default run")
     a = ap.parse_args()
@@ -108,7 +113,18 @@ def cpu_baseline(args, VecSim, synth):
     n = min(args.cpu_sample_rows, args.rows)
     vt = getattr(vso, {"FLOAT32": "F32", "INT8": "I8", "BFLOAT16": "BF16"}[args.type_name])
     gen = getattr(synth, args.gen)
-    raw = gen(args.seed, 0, n, args.dim)                    # same generator, same seed: rows 0..n-1
+    # the sample = rows 0..n-1 of the same generator and seed.  They are generated ON THE GPU into a small index (the device twin
+    # of the host generator, csrc/exact_kernels.hpp k_fill_*; tests/test_gpu_flat_parity.py pins the twins on each other) and read
+    # back as stored blobs -- the host generator takes minutes per million rows.  The same index is the checker's GPU side below.
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
+    small = VecSim.BFIndex(p)
+    small.add_synthetic(n, args.seed)
+    small.set_option("mfma", args.mfma)
+    rows = small.stored_rows(0, n)
+    head = gen(args.seed, 0, min(n, 64), args.dim)              # host twin on the first rows: same bytes
+    assert np.array_equal(rows[:len(head), :head.view(np.uint8).reshape(len(head), -1).shape[1]], head.view(np.uint8).reshape(len(head), -1)) \
+        or args.metric_name == "Cosine", "device and host generators disagree"
     qraw = gen(args.seed + 1, 0, args.batch, args.dim)
     if args.metric_name == "Cosine":                         # int8 Cosine: stored blob = elements + float norm
         def with_norm(a):
@@ -117,10 +133,14 @@ def cpu_baseline(args, VecSim, synth):
             for i in range(a.shape[0]):
                 vso.normalize(out[i], args.dim, vt)
             return out
-        rows, queries, km = with_norm(raw), with_norm(qraw), vso.COSINE
+        assert np.array_equal(rows[:len(head)], with_norm(head)), "device and host generators disagree"
+        queries, km = with_norm(qraw), vso.COSINE
     else:
-        rows, queries, km = raw, qraw, (vso.L2 if args.metric_name == "L2" else vso.IP)
+        rows = rows.view({"FLOAT32": np.float32, "INT8": np.int8, "BFLOAT16": np.uint16}[args.type_name])
+        queries, km = qraw, (vso.L2 if args.metric_name == "L2" else vso.IP)
     nproc = os.cpu_count() or 1
+    # one query per thread at a time, as the reference's own parallel mode does (bindings.cpp:250-283 knn_parallel): a batch of B
+    # queries keeps at most B threads busy, whatever the core count
     threads = max(1, min(nproc, args.batch))
     # the index follows the host's CPUID like the reference's choosers do (bf16 IP: vdpbf16ps on avx512_bf16 hosts): same tier here
     from vectorsimilarity_amd import _capi
@@ -139,12 +159,7 @@ def cpu_baseline(args, VecSim, synth):
     nq1 = max(1, min(args.batch, 4))
     t1, _ = best_of(nq1, 1, 5)
     tall, (labels, scores, fast) = best_of(args.batch, threads, 5)
-    # checker: a GPU index over the same n rows must give the same labels, order and scores
-    p = VecSim.BFParams()
-    p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
-    small = VecSim.BFIndex(p)
-    small.add_synthetic(n, args.seed)
-    small.set_option("mfma", args.mfma)
+    # checker: the GPU index over the same n rows must give the same labels, order and scores
     gl, gs = small.knn_query(qraw, args.topk)
     same = bool(np.array_equal(gl, labels.astype(np.int64)) and np.array_equal(gs, scores))
     return {"value": n * args.batch / tall, "unit": "distances/s", "cores": threads, "kind": "port",
@@ -286,9 +301,12 @@ def main():
 
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
+    # rows this rank holds.  weak: --rows each.  strong: the job's --rows dealt evenly (the first rows % N ranks hold one more).
+    my_rows = args.rows if args.scaling == "weak" else args.rows // world + (1 if rank < args.rows % world else 0)
+    total_rows = args.rows * world if args.scaling == "weak" else args.rows
     if distributed:
         ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)   # RCCL exchange
-        ix.add_synthetic_local(args.rows, args.seed)     # weak scaling: shard r holds `rows` vectors of seed + 1000 r
+        ix.add_synthetic_local(my_rows, args.seed)     # shard r holds its vectors of seed + 1000 r
         local = ix.local
     else:
         ix = local = VecSim.BFIndex(p)
@@ -354,6 +372,7 @@ def main():
         pool.shutdown()
     st = local.stats()
     per_rank = None
+    my_dt = dt
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -364,17 +383,20 @@ def main():
         sst = ix.stats()
         nb = max(1, sst["batches"])
         mine = torch.tensor([st["scan_ms"] / max(1, st["scan_launches"]), sst["scan_ms"] / nb, sst["turn_wait_ms"] / nb,
-                             sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h))],
+                             sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h)),
+                             my_dt / args.steps * 1e3, float(my_rows)],
                             dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "scan_kernel_ms": float(t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
+        # fixed_ms_per_batch: what a batch costs this rank beyond its scan kernel (probe, threshold, re-rank, select, exchange,
+        # merge, launch gaps) -- the part that does NOT shrink with rows / N under strong scaling
+        per_rank = [{"rank": r, "rows": int(t[8]), "ms_per_batch": float(t[7]), "scan_kernel_ms": float(t[0]),
+                     "fixed_ms_per_batch": float(t[7] - t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
                      "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
                      "rccl_world": int(t[6])} for r, t in enumerate(allr)]
         assert all(p["rccl_world"] == world for p in per_rank), per_rank   # every communicator spans all N ranks
 
     if rank == 0:
-        total_rows = args.rows * world
         dists = total_rows * args.batch * args.steps
         launches = max(1, st["scan_launches"])
         avg_ms = st["scan_ms"] / launches
@@ -408,19 +430,31 @@ def main():
             "qps": args.batch * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: flat_%s_%s_top%d" % (args.config, args.dtype, args.metric_name.lower(), args.topk),
-                       "rows_per_gpu": args.rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
+                       "rows_per_gpu": my_rows, "rows_total": total_rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
                        "reader_threads": readers,
                        "exchange": ("rccl ncclAllGather of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
                                     "merge (C++ host library)" % world) if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
             "roofline": roof,
+            # step time beyond the scan kernel (probe, threshold, re-rank, select, copies, host replay not hidden, launch gaps)
+            "fixed_ms_per_batch": dt / args.steps * 1e3 - avg_ms,
             "per_rank_ms_per_batch": per_rank,
             "candidates_per_query": st["candidates"] / max(1, args.steps * args.batch),
             "fallbacks": int(st["fallbacks"]),
         }
+        if world == 1:
+            # A PREDICTION, not a measurement (no run on more than one GPU exists): strong scaling of this workload from the
+            # pieces measured above -- the scan kernel shrinks with rows / G, the fixed part does not, and the exchange is priced
+            # at what a 1-rank RCCL communicator cost on this box (README).  efficiency = t_1 / (G * t_G).
+            fixed = dt / args.steps * 1e3 - avg_ms
+            exch = 0.10
+            out["predicted_strong_scaling"] = {
+                "note": "prediction from 1-GPU pieces: t_G = scan_kernel / G + fixed + exchange (%.2f ms assumed); unmeasured" % exch,
+                "t_ms": {str(g): avg_ms / g + fixed + (exch if g > 1 else 0.0) for g in (1, 2, 4, 8)},
+                "efficiency": {str(g): (avg_ms + fixed) / (g * (avg_ms / g + fixed + exch)) for g in (2, 4, 8)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, VecSim, synth)
         # size-independent property at full size: replies are ascending in score

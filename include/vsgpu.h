@@ -72,6 +72,7 @@ int vsgpu_table_write(vsgpu_table *t, size_t id, const void *host_row);   /* upd
 int vsgpu_table_move(vsgpu_table *t, size_t dst_id, size_t src_id);       /* swap-delete copy */
 int vsgpu_table_truncate(vsgpu_table *t, size_t new_size);
 int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row);          /* getElement */
+int vsgpu_table_read_range(vsgpu_table *t, size_t first, size_t n, void *host_rows);   /* rows [first, first + n) as stored */
 /* Reader lanes: a view shares the parent's rows but runs its queries on another context (own stream and scratch), so
  * concurrent readers -- which the reference allows on one index (vec_sim.h, bindings.cpp:250-283 knn_parallel) -- overlap
  * one reader's small kernels, copies and host work with another reader's scan kernel.  The table-wide scan kernels of all

@@ -49,7 +49,10 @@ def test_scalar_tier_scores_equal_the_compiled_reference(monkeypatch, distances,
             got[int(lab)] = refgen.hexbits(np.float64(d) if typ == "f64" else np.float32(d))[0]
         if got != e["scores"]:
             bad.append((metric, dim, got, e["scores"]))
-        # the same numbers through getDistanceFrom (brute_force_single.h:202-212)
+        # the same numbers through getDistanceFrom (brute_force_single.h:202-212; it takes the blob as it is -- no query
+        # preprocessing -- so Cosine, whose queries are normalised by the top-k path, is left to the check above)
+        if metric == "Cosine":
+            continue
         d0 = ix.get_distance_from(0, q)
         h0 = refgen.hexbits(np.float64(d0) if typ == "f64" else np.float32(d0))[0]
         if h0 != e["scores"][0]:

@@ -138,7 +138,7 @@ EXPORTS = [
     "VecSimBatchIterator_HasNext", "VecSimBatchIterator_Free", "VecSimBatchIterator_Reset",
     "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
-    "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors",
+    "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors", "VecSimGpu_ReadStoredRows",
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
@@ -157,7 +157,7 @@ GPU_EXPORTS = [
     "vsgpu_device_count", "vsgpu_device_synchronize", "vsgpu_last_error", "vsgpu_ctx_create", "vsgpu_ctx_destroy",
     "vsgpu_ctx_device", "vsgpu_ctx_sync", "vsgpu_table_create", "vsgpu_table_destroy",
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
-    "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_append_synthetic",
+    "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_read_range", "vsgpu_table_append_synthetic",
     "vsgpu_table_view_create", "vsgpu_table_view_sync",
     "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
@@ -244,6 +244,8 @@ def load():
     L.VecSimGpu_SQ8_QueryBlobCentered.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     L.VecSimGpu_GetStoredVectors.restype = C.c_long
     L.VecSimGpu_GetStoredVectors.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.VecSimGpu_ReadStoredRows.restype = C.c_long
+    L.VecSimGpu_ReadStoredRows.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.VecSimIndex_StatsInfo.restype = VecSimIndexStatsInfo
     L.VecSimIndex_StatsInfo.argtypes = [vp]
     L.VecSimIndex_BasicInfo.restype = VecSimIndexBasicInfo

@@ -438,6 +438,11 @@ extern "C" long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, voi
     if (blob_bytes) *blob_bytes = index->storedBlobBytes();
     return out ? index->storedVectors(label, out, cap_bytes) : 0;
 }
+extern "C" long VecSimGpu_ReadStoredRows(VecSimIndex *index, size_t first_id, size_t n, void *out, size_t cap_bytes) {
+    auto *f = dynamic_cast<vsa::FlatIndex *>(index);
+    if (!f || !out || cap_bytes < n * f->storedBlobBytes()) return -1;
+    return f->readRows((uint32_t)first_id, n, out) ? -1 : (long)n;
+}
 extern "C" uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index) {
     auto *h = dynamic_cast<vsa::HnswIndex *>(index);
     return h ? h->lastDistanceEvals() : 0;

@@ -451,6 +451,11 @@ int FlatIndex::readRow(uint32_t id, void *stored_blob) {
     if (id >= count_ || flush()) return -1;
     return vsgpu_table_read(table_, id, stored_blob);
 }
+int FlatIndex::readRows(uint32_t first, size_t n, void *stored_blobs) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if ((size_t)first + n > count_ || flush()) return -1;
+    return vsgpu_table_read_range(table_, first, n, stored_blobs);
+}
 int FlatIndex::overwriteRow(uint32_t id, const void *stored_blob, size_t new_label) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
     if (multi_ || id >= count_ || flush()) return -1;

@@ -586,6 +586,25 @@ extern "C" int vsgpu_table_read(vsgpu_table *t, size_t id, void *host_row) {
         for (size_t i = 0; i < t->dim; i++) reinterpret_cast<unsigned char *>(host_row)[i] ^= 0x80u;
     return VSGPU_OK;
 }
+// rows [first, first + n) as stored, one D2H copy per slab segment (measurement / test hook: the CPU baseline of bench.py
+// reads the synthetic rows back instead of regenerating them on the host)
+extern "C" int vsgpu_table_read_range(vsgpu_table *t, size_t first, size_t n, void *host_rows) {
+    if (first + n > t->n) return fail(VSGPU_ERR_ARG, "rows [%zu, %zu) out of range", first, first + n);
+    HIPCHK(hipSetDevice(t->ctx->device));
+    const size_t per_slab = (size_t)1 << t->slab_shift;
+    char *dst = static_cast<char *>(host_rows);
+    for (size_t r = first; r < first + n;) {
+        const size_t run = std::min(first + n - r, per_slab - (r & (per_slab - 1)));
+        HIPCHK(hipMemcpyAsync(dst, row_ptr(t, r), run * t->row_bytes, hipMemcpyDeviceToHost, t->ctx->stream));
+        dst += run * t->row_bytes;
+        r += run;
+    }
+    HIPCHK(hipStreamSynchronize(t->ctx->stream));
+    if (t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H)   // (the device keeps code ^ 0x80: sq8_flip_codes)
+        for (size_t i = 0; i < n; i++)
+            for (size_t j = 0; j < t->dim; j++) static_cast<unsigned char *>(host_rows)[i * t->row_bytes + j] ^= 0x80u;
+    return VSGPU_OK;
+}
 extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t seed) {
     if (t->type == VSGPU_F64 || t->type == VSGPU_U8 || t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H)
         return fail(VSGPU_ERR_UNSUPPORTED, "synthetic fill: fp32/bf16/fp16/int8 only");
