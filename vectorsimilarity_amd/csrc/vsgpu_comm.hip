@@ -57,8 +57,12 @@ struct vsgpu_comm {
     int rank = 0, world = 1;
     RcclComm comm = nullptr;
     hipStream_t stream = nullptr;
-    void *d_send = nullptr, *d_recv = nullptr, *h_stage = nullptr;
-    size_t send_cap = 0, recv_cap = 0, stage_cap = 0;
+    // send / receive buffers are host memory mapped into the device (hipHostMalloc): the caller's record is written where the
+    // collective reads it and read where the collective wrote it.  Round 3 staged through device buffers -- host -> pinned -> H2D
+    // -> ncclAllGather -> D2H -> host -- and every one of those copies queued behind the scan another reader had running; the
+    // records are tens of KB, so the PCIe hop inside the collective costs nothing next to that.
+    void *h_send = nullptr, *h_recv = nullptr;
+    size_t send_cap = 0, recv_cap = 0;
 };
 
 #define RCCLCHK(expr)                                                                                  \
@@ -102,7 +106,10 @@ extern "C" vsgpu_comm *vsgpu_comm_create(vsgpu_ctx *ctx, int rank, int world, co
         delete c;
         return nullptr;
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    // highest priority the device offers: the collective's kernel is dispatched ahead of whatever else is waiting for a CU
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
         fail(VSGPU_ERR_HIP, "stream creation failed");
         r->CommDestroy(c->comm);
         delete c;
@@ -116,9 +123,8 @@ extern "C" void vsgpu_comm_destroy(vsgpu_comm *c) {
     (void)hipSetDevice(c->ctx->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) rccl()->CommDestroy(c->comm);
-    if (c->d_send) (void)hipFree(c->d_send);
-    if (c->d_recv) (void)hipFree(c->d_recv);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -128,25 +134,16 @@ extern "C" int vsgpu_comm_world(const vsgpu_comm *c) { return c->world; }
 static int comm_reserve(vsgpu_comm *c, size_t send_bytes, size_t recv_bytes) {
     auto grow = [](void *&p, size_t &cap, size_t need) -> hipError_t {
         if (need <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
         const size_t want = (need + 0xFFFF) & ~(size_t)0xFFFF;
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
         if (e == hipSuccess) cap = want;
         return e;
     };
-    HIPCHK(grow(c->d_send, c->send_cap, send_bytes));
-    HIPCHK(grow(c->d_recv, c->recv_cap, recv_bytes));
-    const size_t stage = send_bytes + recv_bytes;
-    if (stage > c->stage_cap) {
-        if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
-        c->h_stage = nullptr;
-        c->stage_cap = 0;
-        const size_t want = (stage + 0xFFFF) & ~(size_t)0xFFFF;
-        HIPCHK(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
-        c->stage_cap = want;
-    }
+    HIPCHK(grow(c->h_send, c->send_cap, send_bytes));
+    HIPCHK(grow(c->h_recv, c->recv_cap, recv_bytes));
     return VSGPU_OK;
 }
 
@@ -156,13 +153,10 @@ extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t byte
     const size_t total = bytes * (size_t)c->world;
     int rc = comm_reserve(c, bytes, total);
     if (rc) return rc;
-    char *hs = (char *)c->h_stage, *hr = hs + bytes;
-    memcpy(hs, send, bytes);
-    HIPCHK(hipMemcpyAsync(c->d_send, hs, bytes, hipMemcpyHostToDevice, c->stream));
-    RCCLCHK(rccl()->AllGather(c->d_send, c->d_recv, bytes, kRcclInt8, c->comm, c->stream));
-    HIPCHK(hipMemcpyAsync(hr, c->d_recv, total, hipMemcpyDeviceToHost, c->stream));
+    memcpy(c->h_send, send, bytes);
+    RCCLCHK(rccl()->AllGather(c->h_send, c->h_recv, bytes, kRcclInt8, c->comm, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    memcpy(recv, hr, total);
+    memcpy(recv, c->h_recv, total);
     return VSGPU_OK;
 }
 
@@ -172,18 +166,9 @@ extern "C" int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int 
     HIPCHK(hipSetDevice(c->ctx->device));
     int rc = comm_reserve(c, bytes, bytes);
     if (rc) return rc;
-    char *hs = (char *)c->h_stage;
-    if (c->rank == root) {
-        memcpy(hs, buf, bytes);
-        HIPCHK(hipMemcpyAsync(c->d_send, hs, bytes, hipMemcpyHostToDevice, c->stream));
-    }
-    RCCLCHK(rccl()->Broadcast(c->d_send, c->d_send, bytes, kRcclInt8, root, c->comm, c->stream));
-    if (c->rank != root) {
-        HIPCHK(hipMemcpyAsync(hs, c->d_send, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        memcpy(buf, hs, bytes);
-    } else {
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
+    if (c->rank == root) memcpy(c->h_send, buf, bytes);
+    RCCLCHK(rccl()->Broadcast(c->h_send, c->h_send, bytes, kRcclInt8, root, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->rank != root) memcpy(buf, c->h_send, bytes);
     return VSGPU_OK;
 }
