@@ -3,9 +3,11 @@
 #include "mfma_lowp_kernels.hpp"
 #include "mfma_i8x32_kernels.hpp"
 #include "mfma_wide_kernels.hpp"
+// (the diagnosis build of the filter kernels -- run-time dbg switches -- covers narrower widths in a tuning build)
 #ifdef VSGPU_TUNING
-#include "mfma_free_kernels.hpp"
-#include "mfma_i8ks_kernels.hpp"
+constexpr int LOWP_DIAG_MIN_KS = 12;
+#else
+constexpr int LOWP_DIAG_MIN_KS = 16;
 #endif
 
 using namespace vsg;
@@ -23,38 +25,13 @@ static void launch_lowp_k(const LowpParams &P, dim3 grid, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
     };
     // the diagnosis build (run-time dbg switches, paired query tiles) exists for the plain 3-slot filter kernels only
-#ifdef VSGPU_TUNING
-    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 12 && ISS == 0;
-#else
-    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= 16 && ISS == 0;
-#endif
+    constexpr bool has_diag = MODE == MF_FILTER && NS == 3 && DIST == 0 && DLATE == 0 && KS >= LOWP_DIAG_MIN_KS && ISS == 0;
     if constexpr (has_diag) {
         if (P.dbg || P.pair_map) return go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, true>);
     }
     // (no diagnosis build of this variant: the switches are compiled out, the production kernel runs)
     go(k_mfma_filter_lowp<LK, KS, MODE, RT, NW, NQW, MINW, NS, STAGE, false, DIST, DLATE, false, ISS>);
 }
-#ifdef VSGPU_TUNING
-// barrier-free variant (mfma_free_kernels.hpp): NS slots, D units requested ahead, landed signalled L units early
-template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE, int D, int L>
-static void launch_lowp_free(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = free_lds_bytes(NW, KS, RT, NS, STAGE, D);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto kern = k_mfma_filter_free<LK, KS, RT, NW, NQW, NS, STAGE, D, L>;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
-}
-template <int LK, int KS, int RT, int NW, int NQW, int NS, int STAGE = MF_STAGE_BYTES>
-static void launch_lowp_skew(const LowpParams &P, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = lowp_lds_bytes(NW, KS, RT, NS, STAGE, true);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    auto kern = k_mfma_filter_lowp<LK, KS, MF_FILTER, RT, NW, NQW, 1, NS, STAGE, true>;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, P);
-}
-#endif
 template <int LK, int KS, int RT, int NQW>
 static void launch_lowp_t(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
     if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, RT, 8, NQW, 1, 3>(P, grid, s);
@@ -122,129 +99,17 @@ template <int LK> static void launch_lowp_h16(int ks, int mode, const LowpParams
     default: launch_lowp_t<LK, 32, 16, 1>(mode, P, grid, s); break;
     }
 }
+// Measured-slower variants of these kernels (barrier-free ring, K-split int8 kernel, query-split bf16 tiles, ring-depth sweeps)
+// live in tools/tuning_kernels/ and are compiled only by `make TUNING=1`: lowp_tuning.inc defines the hooks, the shipped build
+// has these stubs.
 #ifdef VSGPU_TUNING
-// tuning variants (option "lowp_variant") for the two BASELINE shapes: bf16 d=768 and int8 d=1024.  A variant
-// picks its own tile height, so it sizes the tile count and the grid itself.
-static bool launch_lowp_variant(const vsgpu_table *t, int variant, LowpParams P, uint32_t max_wgs, unsigned q_tiles,
-                                hipStream_t s) {
-    if (variant == 0) return false;
-    auto go = [&](int rt, auto launcher) {
-        P.tile_first = 0;
-        P.tile_step = 1;
-        P.n_tiles = (uint32_t)((t->n + rt - 1) / rt);
-        launcher(P, dim3(std::min(P.n_tiles, max_wgs), q_tiles), s);
-        return true;
-    };
-    if (t->lp_kind == LP_BF16 && t->lp_ksteps == 24) {
-        switch (variant) {
-        case 1: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4>);
-        case 2: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 6>);
-        case 3: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 8>);
-        case 4: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 2, 4>);
-        case 5: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 24576>);   // 32 rows x 768 B
-        case 6: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 49152>);   // 32 whole rows
-        case 7: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 8, 1, 1, 5, 24576>);   // 16 whole rows
-        case 8: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 2>);  // 4 slots, 2 ahead: plain barrier
-        case 9: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 5, 16384, 3>);
-        case 10: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 2>);  // refill requested after 2 / 4 / 8 fragments
-        case 11: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 4>);
-        case 12: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 8>);
-        case 60: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
-        // two independent 4-wave workgroups per CU, 32 queries per wave (192 registers of query fragments, 2 waves per SIMD)
-        case 70: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 3>);
-        case 71: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 4>);
-        case 72: return go(16, launch_lowp_k<LP_BF16, 24, MF_FILTER, 16, 4, 2, 2, 4, 24576>);   // 16 whole rows per unit
-        case 73: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 4, 2, 2, 3, 24576>);   // 32 rows x 768 B per unit
-        case 50: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 3, 16384, 0, -1>);   // staggered refill
-        case 51: return go(32, launch_lowp_k<LP_BF16, 24, MF_FILTER, 32, 8, 1, 1, 4, 16384, 0, -1>);
-        case 40: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 5, 2>);   // barrier-free ring
-        case 41: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 4, 2>);
-        case 42: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 8, 16384, 6, 3>);
-        case 43: return go(32, launch_lowp_free<LP_BF16, 24, 32, 8, 1, 6, 16384, 4, 2>);
-        case 20: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 3>);                      // phase-skewed halves
-        case 21: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 4>);
-        case 22: return go(32, launch_lowp_skew<LP_BF16, 24, 32, 8, 1, 6>);
-        }
-    }
-    if (t->lp_kind == LP_I8 && t->lp_ksteps == 16) {
-        switch (variant) {
-        case 1: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4>);
-        case 2: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 6>);
-        case 3: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 8>);
-        case 4: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 4>);           // 16 whole rows
-        case 5: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 16, 1, 1, 6>);
-        case 6: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768>);    // 32 whole rows
-        case 7: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768>);
-        case 8: return go(64, launch_lowp_k<LP_I8, 16, MF_FILTER, 64, 16, 1, 1, 4, 32768>);    // 64 rows x 512 B
-        case 9: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3>);            // 8 waves x 32 queries
-        case 10: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4>);
-        case 11: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3>);           // 4 waves x 64 queries
-        case 12: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4>);
-        case 17: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 3, 32768>);    // 4 waves x 64 queries, whole rows
-        case 18: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 4, 4, 1, 4, 32768>);
-        case 19: return go(16, launch_lowp_k<LP_I8, 16, MF_FILTER, 16, 4, 4, 1, 4>);           // 16 whole rows per unit
-        case 60: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 8>);   // 8 of the 16 waves request rows
-        case 61: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 0, 4>);   // one per SIMD
-        case 62: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 0, 8>);
-        case 50: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, -1>);   // staggered refill
-        case 51: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, -1>);
-        case 52: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 0, -1>);
-        case 40: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 5, 2>);   // barrier-free ring
-        case 41: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 4, 2>);
-        case 42: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 8, 16384, 6, 3>);
-        case 43: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 4, 32768, 2, 1>);
-        case 44: return go(32, launch_lowp_free<LP_I8, 16, 32, 16, 1, 6, 16384, 4, 2>);
-        case 30: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 4>);   // refill requested after 4 / 8 / 16 / all fragments
-        case 35: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 2>);
-        case 36: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 4>);
-        case 31: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 8>);
-        case 32: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 3, 32768, 0, 16>);
-        case 33: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 8>);
-        case 34: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 0, 32>);
-        case 15: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 32768, 2>);  // 4 slots, 2 ahead: plain barrier
-        case 16: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 16, 1, 1, 4, 16384, 2>);
-        // (64 whole rows per unit with 2 slots -- half the barriers per row -- spills 76 VGPRs at the 128-register budget: not built)
-        case 13: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 3, 32768>);    // 8 waves x 32 queries, whole rows
-        case 14: return go(32, launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 2, 1, 4, 32768>);
-        case 20: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3, 32768>);                // phase-skewed halves
-        case 21: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 4>);
-        case 22: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 3>);
-        case 24: return go(32, launch_lowp_skew<LP_I8, 16, 32, 16, 1, 6>);
-        }
-    }
-    if (t->lp_kind == LP_SQ8 && t->lp_ksteps == 12) {
-        switch (variant) {
-        case 1: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4>);
-        case 2: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 0, 4>);   // 4 of the 8 waves request rows
-        case 3: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3>);                   // 256 VGPRs: one workgroup per CU
-        case 10: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 4, 3>);                  // 128 VGPRs, 3 slots
-        case 4: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 24576>);            // 64 rows x 384 B per unit
-        case 5: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 2, 49152>);            // whole rows, 2 slots
-        case 6: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 3, 16384, 0, 4>);      // refill after 4 fragments
-        case 7: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 16384, 2>);         // 4 slots, 2 ahead: plain barrier
-        case 8: return go(64, launch_lowp_k<LP_SQ8, 12, MF_FILTER, 64, 8, 1, 1, 4, 24576>);
-        }
-    }
-    return false;
-}
+#include "lowp_tuning.inc"
 #else
 static bool launch_lowp_variant(const vsgpu_table *, int, LowpParams, uint32_t, unsigned, hipStream_t) { return false; }
-#endif
-#ifdef VSGPU_TUNING
-// K-split filter for 1 KiB int8 / uint8 rows (mfma_i8ks_kernels.hpp); option lowp_ksplit: 1 = on, 2 = + s_setprio
-template <int LK> static void launch_i8_ksplit(int flavour, const LowpParams &P, dim3 grid, hipStream_t s) {
-    auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS_BYTES);
-        hipLaunchKernelGGL(kern, grid, dim3(KS_NW * 64), KS_LDS_BYTES, s, P);
-    };
-    // flavour - 1 = MODE bits of the kernel (setprio, refill placement); P.dbg selects the diagnosis build
-    if (P.dbg) return flavour == 3 ? go(k_i8_filter_ksplit<LK, 10>) : go(k_i8_filter_ksplit<LK, 8>);
-    switch (flavour - 1) {
-    case 1: go(k_i8_filter_ksplit<LK, 1>); break;
-    case 2: go(k_i8_filter_ksplit<LK, 2>); break;
-    default: go(k_i8_filter_ksplit<LK, 0>); break;
-    }
-}
+static bool tuning_launch_lowp(const vsgpu_table *, int, const LowpParams &, dim3, hipStream_t) { return false; }
+static bool tuning_ksplit_on(const vsgpu_ctx *) { return false; }
+static bool tuning_hsplit(const vsgpu_table *, const vsgpu_ctx *, size_t) { return false; }
+template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim3, hipStream_t) {}
 #endif
 // int8 / uint8 rows of 1025 .. 2048 elements: 8 waves x 16 queries, 16-row tiles of two 16 KiB stages
 template <int LK> static void launch_lowp_w2048(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
@@ -260,15 +125,7 @@ template <int LK> static void launch_lowp_w4096(int mode, const LowpParams &P, d
     else launch_lowp_k<LK, 64, MF_FILTER, 16, 4, 1, 1, 3>(P, grid, s);
 }
 static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-#ifdef VSGPU_TUNING
-    // measured, not faster than the 16 x 16 kernel (profiles/r02_i8_ksplit.txt): tuning build only
-    const long ksplit = t->ctx->opt_lowp_ksplit;
-    if (ksplit && mode == MF_FILTER && t->lp_ksteps == 16 && t->lp_rt == 32 && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8)) {
-        if (t->lp_kind == LP_I8) launch_i8_ksplit<LP_I8>((int)ksplit, P, grid, s);
-        else launch_i8_ksplit<LP_U8>((int)ksplit, P, grid, s);
-        return;
-    }
-#endif
+    if (tuning_launch_lowp(t, mode, P, grid, s)) return;   // (tuning build only)
     if (t->lp_kind == LP_BF16) launch_lowp_h16<LP_BF16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_U8C) {
@@ -375,22 +232,6 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
     }
 }
 
-// bf16 / fp16 rows of up to 768 elements with the batch split into 64-query tiles: 4 waves x 16 queries per workgroup, two
-// workgroups per CU (the fp32 filter's shape).  Both query tiles of a 128-query batch walk the same row tiles from the same
-// XCD (pair_map), so the rows cross HBM once and the partner's copy comes from L2.  Measured on config 4 (12.5 M x 768 bf16,
-// batch 128): bit-identical, 4.02 ms against 3.31 ms for the one 8-wave workgroup -- tuning build only (option lowp_qsplit).
-#ifdef VSGPU_TUNING
-template <int LK> static void launch_lowp_h16_split(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
-    if (mode == MF_PROBE) launch_lowp_k<LK, 24, MF_PROBE, 32, 4, 1, 2, 3>(P, grid, s);
-    else if (grid.y == 2 && grid.x % 8 == 0) {
-        LowpParams Q = P;
-        Q.pair_map = 1;
-        launch_lowp_k<LK, 24, MF_FILTER, 32, 4, 1, 2, 3>(Q, dim3(grid.x * 2), s);
-    } else launch_lowp_k<LK, 24, MF_FILTER, 32, 4, 1, 2, 3>(P, grid, s);
-}
-#else
-template <int LK> static void launch_lowp_h16_split(int, const LowpParams &, dim3, hipStream_t) {}
-#endif
 
 // bf16 / fp16 rows of 2049 .. 8192 elements on k_mfma_filter_wide (mfma_wide_kernels.hpp): same records, same bound
 #ifndef WIDE_NS_ALONE
@@ -451,20 +292,12 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t n = t->n, dim = t->dim;
     const int KS = t->lp_ksteps, RT = t->lp_rt;
     const bool qsplit = t->lp_kind == LP_I8 && c->opt_lowp_qsplit;
-    // bf16 / fp16, kernel width 768: 64-query tiles when the batch fills exactly two of them (option lowp_qsplit)
-#ifdef VSGPU_TUNING
-    const bool hsplit = (t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && c->opt_lowp_qsplit && t->lp_ksteps == 24 &&
-                        t->lp_rt == 32 && nq > 64 && nq <= 128;
-#else
-    const bool hsplit = false;
-#endif
+    const bool hsplit = tuning_hsplit(t, c, nq);   // (tuning build only: 64-query bf16 tiles, measured slower)
     const bool narrow = !hsplit && !qsplit && lowp_narrow_qtile(t) && nq <= lowp_narrow_qtile(t) && c->opt_lowp_narrow;
     // int8 / uint8 rows of kernel width 1024, more than 128 queries: the filter pass runs on the 32 x 32 x 32 kernel
     const bool x32 = c->opt_lowp_x32 && !narrow && !qsplit && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 &&
                      t->lp_rt == 32 && t->lp_qtile == X32_QT && !c->opt_lowp_variant && !c->opt_lowp_dbg
-#ifdef VSGPU_TUNING
-                     && !c->opt_lowp_ksplit
-#endif
+                     && !tuning_ksplit_on(c)
         ;
     // k_mfma_filter_wide: 32 queries per workgroup at width 6144 (6 GB of bf16 rows, batch 64: 3.04 -> 2.03 ms); at widths 3072 / 4096
     // four 16-query tiles sharing the rows through L2 measured faster than two 32-query tiles (1.90 against 2.16 ms); option
@@ -814,8 +647,6 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
                               is_sq8 ? "k_mfma_filter_lowp(sq8)" : t->lp_wide ? "k_mfma_filter_wide(h16)" : !is_int ? "k_mfma_filter_lowp(h16)"
-#ifdef VSGPU_TUNING
-                              : (c->opt_lowp_ksplit && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
-#endif
+                              : (tuning_ksplit_on(c) && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
                               : x32 ? "k_i8_filter_x32" : "k_mfma_filter_lowp(i8)", &chain);
 }
