@@ -138,6 +138,8 @@ int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[8]);
 typedef struct vsgpu_graph vsgpu_graph;
 vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M);
 void vsgpu_graph_destroy(vsgpu_graph *g);
+/* multi-value index (hnsw_multi.h): labels repeat across nodes, top_candidates keeps one entry per label (its lowest distance) */
+void vsgpu_graph_set_multi(vsgpu_graph *g, int multi);
 /* upper_off[i]: index (in blocks of 1+M words) of node i's level-1 block inside `upper`, 0xFFFFFFFF
  * for level-0-only nodes; block l-1 of a node holds {count, links[M]} of level l. */
 int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *links0, const uint16_t *cnt0,

@@ -129,6 +129,12 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
                        const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
                        uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
                        double *out_scores, uint64_t *dist_evals);
+/* the same over a multi-value index (labels repeat): top_candidates is the label-keyed heap of hnsw_multi.h:108-112 */
+size_t vso_hnsw_search_multi(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                       const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                       uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
+                       double *out_scores, uint64_t *dist_evals);
 /* range search (hnsw.h:616-680, 2087-2187): results in discovery order, returns their number (may exceed
  * out_cap, only out_cap are stored) */
 size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,

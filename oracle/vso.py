@@ -79,6 +79,8 @@ def lib():
         L.vso_hnsw_search.restype = sz
         L.vso_hnsw_search.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
                                       C.c_uint32, i, vp, sz, sz, vp, vp, vp]
+        L.vso_hnsw_search_multi.restype = sz
+        L.vso_hnsw_search_multi.argtypes = L.vso_hnsw_search.argtypes
         L.vso_hnsw_range.restype = sz
         L.vso_hnsw_range.argtypes = [i, i, i, sz, vp, sz, C.c_uint32, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp,
                                      C.c_uint32, i, vp, dbl, dbl, vp, vp, sz, vp]
@@ -377,15 +379,17 @@ def f16_to_f32(a):
     return _conv("vso_f16_to_f32_n", a, np.uint16, np.float32)
 
 
-def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512):
-    """graph: dict from vectorsimilarity_amd.VecSim.HNSWIndex.graph(); rows: stored (preprocessed) blobs by id"""
+def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512, multi=False):
+    """graph: dict from vectorsimilarity_amd.VecSim.HNSWIndex.graph(); rows: stored (preprocessed) blobs by id;
+    multi: the graph's labels repeat (multi-value index), results are per label"""
     rows = np.ascontiguousarray(rows)
     query = np.ascontiguousarray(query)
     ol = np.zeros(max(k, 1), dtype=np.uint64)
     osc = np.zeros(max(k, 1), dtype=np.float64)
     ev = C.c_uint64(0)
     g = graph
-    c = lib().vso_hnsw_search(vtype, metric, tier, dim, _ptr(rows), rows.strides[0], g["n"], _ptr(g["links0"]),
+    fn = lib().vso_hnsw_search_multi if multi else lib().vso_hnsw_search
+    c = fn(vtype, metric, tier, dim, _ptr(rows), rows.strides[0], g["n"], _ptr(g["links0"]),
                               _ptr(g["cnt0"]), g["M0"], _ptr(g["upper_off"]), _ptr(g["upper"]), g["M"],
                               _ptr(g["deleted"]), _ptr(g["labels"]), g["entry"], g["max_level"], _ptr(query), k, ef,
                               _ptr(ol), _ptr(osc), C.byref(ev))

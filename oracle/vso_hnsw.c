@@ -24,8 +24,11 @@
 
 #include "vso.h"
 
-typedef struct { float d; uint32_t id; } cand_t;
-typedef struct { float d; uint64_t label; } top_t;
+/* distances are kept as doubles: a float score widens exactly and orders the same; fp64 indexes have DistType = double
+ * (index_factories/hnsw_factory.cpp:47) and keep every bit */
+typedef struct { double d; uint32_t id; } cand_t;
+typedef struct { double d; uint64_t label; } top_t;
+#define NARROW(type, v) ((type) == VSO_F64 ? (double)(v) : (double)(float)(v))
 
 static const uint32_t *links_at(uint32_t node, int level, const uint32_t *links0, const uint16_t *cnt0, uint32_t M0,
                                 const uint32_t *upper_off, const uint32_t *upper, uint32_t M, uint32_t *cnt) {
@@ -38,18 +41,20 @@ static const uint32_t *links_at(uint32_t node, int level, const uint32_t *links0
     return blk + 1;
 }
 
-size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+/* multi != 0: top_candidates is the label-keyed updatable_max_heap of a multi-value index (hnsw_multi.h:108-112,
+ * utils/updatable_heap.h:93-113): a label that is already in keeps the lower of its two distances, the size counts labels */
+static size_t hnsw_search_impl(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
                        const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
                        const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
                        uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
-                       double *out_scores, uint64_t *dist_evals) {
+                       double *out_scores, uint64_t *dist_evals, int multi) {
     if (n == 0 || k == 0 || entry == 0xFFFFFFFFu) return 0;
     if (ef < k) ef = k;
     const char *base = rows;
     uint64_t evals = 0;
-#define DIST(node) (evals++, (float)vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query))
+#define DIST(node) (evals++, NARROW(type, vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query)))
     uint32_t cur = entry;
-    float curd = DIST(cur);
+    double curd = DIST(cur);
     for (int level = max_level; level > 0; level--) {
         int changed = 1;
         while (changed) {
@@ -57,7 +62,7 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
             uint32_t cnt;
             const uint32_t *lk = links_at(cur, level, links0, cnt0, M0, upper_off, upper, M, &cnt);
             for (uint32_t i = 0; i < cnt; i++) {   /* walks the ORIGINAL node's list to its end */
-                float d = DIST(lk[i]);
+                double d = DIST(lk[i]);
                 if (d < curd) { curd = d; cur = lk[i]; changed = 1; }
             }
         }
@@ -66,14 +71,14 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
     cand_t *cand = malloc(((size_t)n + 1) * sizeof(cand_t));
     top_t *top = malloc((ef + 2) * sizeof(top_t));
     size_t nc = 0, nt = 0;
-    float lower;
+    double lower;
     if (!deleted[cur]) {
-        float d = DIST(cur);   /* the reference re-evaluates dist(ep) here */
+        double d = DIST(cur);   /* the reference re-evaluates dist(ep) here */
         lower = d;
         top[nt].d = d; top[nt].label = labels[cur]; nt++;
         cand[nc].d = d; cand[nc].id = cur; nc++;
     } else {
-        lower = 3.402823466e+38f;
+        lower = type == VSO_F64 ? 1.7976931348623157e308 : 3.402823466e+38f;   /* numeric_limits<DistType>::max() */
         cand[nc].d = lower; cand[nc].id = cur; nc++;
     }
     visited[cur] = 1;
@@ -91,10 +96,17 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
             uint32_t nb = lk[j];
             if (visited[nb]) continue;
             visited[nb] = 1;
-            float d = DIST(nb);
+            double d = DIST(nb);
             if (lower > d || nt < ef) {
                 cand[nc].d = d; cand[nc].id = nb; nc++;
-                if (!deleted[nb]) { top[nt].d = d; top[nt].label = labels[nb]; nt++; }
+                if (!deleted[nb]) {
+                    size_t f = nt;
+                    if (multi)
+                        for (size_t i = 0; i < nt; i++)
+                            if (top[i].label == labels[nb]) { f = i; break; }
+                    if (f == nt) { top[nt].d = d; top[nt].label = labels[nb]; nt++; }
+                    else if (top[f].d > d) top[f].d = d;
+                }
                 if (nt > ef) {   /* pop the max (d, label) */
                     size_t mi = 0;
                     for (size_t i = 1; i < nt; i++)
@@ -102,7 +114,7 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
                     top[mi] = top[--nt];
                 }
                 if (nt) {
-                    float mx = top[0].d;
+                    double mx = top[0].d;
                     for (size_t i = 1; i < nt; i++) if (top[i].d > mx) mx = top[i].d;
                     lower = mx;
                 }
@@ -125,6 +137,22 @@ size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *r
     free(visited); free(cand); free(top);
     return nt;
 }
+size_t vso_hnsw_search(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                       const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                       uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
+                       double *out_scores, uint64_t *dist_evals) {
+    return hnsw_search_impl(type, metric, tier, dim, rows, stride, n, links0, cnt0, M0, upper_off, upper, M, deleted, labels, entry,
+                            max_level, query, k, ef, out_labels, out_scores, dist_evals, 0);
+}
+size_t vso_hnsw_search_multi(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                       const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                       uint32_t entry, int max_level, const void *query, size_t k, size_t ef, uint64_t *out_labels,
+                       double *out_scores, uint64_t *dist_evals) {
+    return hnsw_search_impl(type, metric, tier, dim, rows, stride, n, links0, cnt0, M0, upper_off, upper, M, deleted, labels, entry,
+                            max_level, query, k, ef, out_labels, out_scores, dist_evals, 1);
+}
 
 /*
  * Range search: rangeQuery (hnsw.h:2153-2187) -> searchBottomLayerEP -> searchRangeBottomLayer_WithTimeout
@@ -141,11 +169,11 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
                       uint64_t *out_labels, double *out_scores, size_t out_cap, uint64_t *dist_evals) {
     if (n == 0 || entry == 0xFFFFFFFFu) return 0;
     const char *base = rows;
-    const float radius = (float)radius_d;
+    const double radius = NARROW(type, radius_d);
     uint64_t evals = 0;
-#define RDIST(node) (evals++, (float)vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query))
+#define RDIST(node) (evals++, NARROW(type, vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query)))
     uint32_t cur = entry;
-    float curd = RDIST(cur);
+    double curd = RDIST(cur);
     for (int level = max_level; level > 0; level--) {
         int changed = 1;
         while (changed) {
@@ -153,7 +181,7 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
             uint32_t cnt;
             const uint32_t *lk = links_at(cur, level, links0, cnt0, M0, upper_off, upper, M, &cnt);
             for (uint32_t i = 0; i < cnt; i++) {
-                float d = RDIST(lk[i]);
+                double d = RDIST(lk[i]);
                 if (d < curd) { curd = d; cur = lk[i]; changed = 1; }
             }
         }
@@ -161,9 +189,9 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
     uint8_t *visited = calloc(n, 1);
     cand_t *cand = malloc(((size_t)n + 1) * sizeof(cand_t));
     size_t nc = 0, nres = 0;
-    float ep_dist, dyn, bound;
+    double ep_dist, dyn, bound;
     if (deleted[cur]) {
-        ep_dist = 3.402823466e+38f;
+        ep_dist = type == VSO_F64 ? 1.7976931348623157e308 : 3.402823466e+38f;
         dyn = bound = ep_dist;
     } else {
         ep_dist = RDIST(cur);
@@ -173,7 +201,7 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
             nres++;
             dyn = radius;
         }
-        bound = (float)((double)dyn * (1.0 + epsilon));
+        bound = NARROW(type, (double)dyn * (1.0 + epsilon));
     }
     cand[nc].d = ep_dist; cand[nc].id = cur; nc++;
     visited[cur] = 1;
@@ -187,7 +215,7 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
         cand[b] = cand[--nc];
         if (c.d < dyn && c.d >= radius) {
             dyn = c.d;
-            bound = (float)((double)dyn * (1.0 + epsilon));
+            bound = NARROW(type, (double)dyn * (1.0 + epsilon));
         }
         uint32_t cnt;
         const uint32_t *lk = links_at(c.id, 0, links0, cnt0, M0, upper_off, upper, M, &cnt);
@@ -195,7 +223,7 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
             const uint32_t id = lk[j];
             if (visited[id]) continue;
             visited[id] = 1;
-            const float d = RDIST(id);
+            const double d = RDIST(id);
             if (d < bound) {
                 cand[nc].d = d; cand[nc].id = id; nc++;
                 if (d <= radius && !deleted[id]) {

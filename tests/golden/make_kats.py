@@ -259,7 +259,33 @@ def hnsw():
               radius=4.0 * 5 ** 2, expect_count=11, expect_scores_by_score=[4.0 * ((r + 1) // 2) ** 2 for r in range(11)],
               expect_abs_diff_by_score=[(r + 1) // 2 for r in range(11)], expect_labels_by_id=[2500 - 5 + r for r in range(11)],
               epsilons=[0.01, 1.0])
-    return dict(topk=cases, range=rq)
+    # multi-value HNSW (tests/unit/test_hnsw_multi.cpp): labels own several vectors, a label is reported once with its best score
+    multi = []
+    multi.append(dict(name="multi_vector_search_test", src="test_hnsw_multi.cpp:106-132", dim=4, metric="L2",
+                      vectors=[[float(i)] * 4 for i in range(1000)], labels=[i % 100 for i in range(1000)], n_labels=100,
+                      query=[50.0] * 4, k=11, expect_abs_diff_from=50, expect_abs_diff=[(r + 1) // 2 for r in range(11)],
+                      expect_scores=[4.0 * ((r + 1) // 2) ** 2 for r in range(11)]))
+    n, nl = 100, 10
+    els = [((n - i - 1) % nl) + ((n - i - 1) // nl) for i in range(n)]
+    best = {i // nl: float(els[i] * els[i] * 4) for i in range(n) if i % nl == nl - 1}
+    multi.append(dict(name="multi_find_better_score", src="test_hnsw_multi.cpp:217-259", dim=4, metric="L2",
+                      vectors=[[float(e)] * 4 for e in els], labels=[i // nl for i in range(n)], n_labels=nl, query=[0.0] * 4, k=10,
+                      expect_labels=[10 - r - 1 for r in range(10)], expect_scores=[best[10 - r - 1] for r in range(10)]))
+    multi.append(dict(name="multi_find_better_score_after_pop", src="test_hnsw_multi.cpp:261-287", dim=4, metric="L2",
+                      vectors=[[float(12 - i)] * 4 for i in range(12)], labels=[i % 3 for i in range(12)], n_labels=3, query=[0.0] * 4,
+                      k=3, expect_labels=[3 - r - 1 for r in range(3)]))
+    vecs, labs = [], []
+    for i in range(1000):
+        vecs.append([float(i)] * 4)
+        labs.append(i)
+        for _ in range(4):
+            vecs.append([float(i + 5000)] * 4)
+            labs.append(i)
+    mrq = dict(name="multi_rangeQuery", src="test_hnsw_multi.cpp:1461-1510", dim=4, metric="L2", n_labels=1000, per_label=5, pivot=500,
+               radius=4.0 * 5 ** 2, expect_count=11, expect_scores_by_score=[4.0 * ((r + 1) // 2) ** 2 for r in range(11)],
+               expect_abs_diff_by_score=[(r + 1) // 2 for r in range(11)], expect_labels_by_id=[500 - 5 + r for r in range(11)],
+               epsilons=[0.01, 1.0])
+    return dict(topk=cases, range=rq, multi=multi, multi_range=mrq)
 
 
 if __name__ == "__main__":

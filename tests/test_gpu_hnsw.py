@@ -401,3 +401,108 @@ def test_reference_hnsw_range_known_answers(vso):
         assert list(l[0]) == c["expect_labels_by_id"]
         ol, od, _ = vso.hnsw_range(0, 0, rows, g, q, c["radius"], eps, dim)
         assert sorted(int(x) for x in ol) == c["expect_labels_by_id"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-value HNSW (hnsw_multi.h:16-247): a label owns several vectors, the search keeps one entry per label
+def build_multi(dim, rows, labels, metric=VecSim.VecSimMetric_L2, M=16, efc=200, ef=10, typ=VecSim.VecSimType_FLOAT32):
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime, p.multi = typ, dim, metric, M, efc, ef, True
+    ix = VecSim.HNSWIndex(p)
+    for v, lab in zip(rows, labels):          # one at a time: the sequential insert path, repeated labels welcome
+        assert ix.add_vector(v, int(lab)) == 1   # "we always add the vector, no overrides" (hnsw_multi.h:213-218)
+    return ix
+
+
+def test_multi_value_reference_known_answers(vso):
+    """tests/unit/test_hnsw_multi.cpp closed forms (tests/golden/kat_hnsw.json, sections multi / multi_range) on the product (host-built
+    graph, GPU search, C API) and on the oracle's multi-value search over the graph the index exports"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat_hnsw.json")) as f:
+        kat = json.load(f)
+    for c in kat["multi"]:
+        rows = np.array(c["vectors"], dtype=np.float32)
+        ix = build_multi(c["dim"], rows, c["labels"])
+        assert ix.index_size() == len(rows) and dict(ix.debug_info_fields())["INDEX_LABEL_COUNT"] == c["n_labels"]
+        q = np.array(c["query"], dtype=np.float32)
+        labels, dists = ix.knn_query(q, c["k"])
+        el, es, _ = vso.hnsw_search(0, 0, rows, ix.graph(), q, c["k"], max(10, c["k"]), c["dim"], multi=True)
+        for got_l, got_s in ((labels[0], dists[0]), (el.astype(np.int64), es)):
+            assert len(set(got_l.tolist())) == len(got_l), c["name"]          # a label comes back once
+            if "expect_labels" in c:
+                assert got_l.tolist() == c["expect_labels"], c["name"]
+            if "expect_abs_diff" in c:
+                assert [abs(int(x) - c["expect_abs_diff_from"]) for x in got_l] == c["expect_abs_diff"], c["name"]
+            if "expect_scores" in c:
+                assert got_s.tolist() == c["expect_scores"], c["name"]
+        assert np.array_equal(labels[0], el.astype(np.int64)) and np.array_equal(dists[0], es)
+    r = kat["multi_range"]
+    vecs, labs = [], []
+    for i in range(r["n_labels"]):
+        vecs.append([float(i)] * 4)
+        labs.append(i)
+        for _ in range(r["per_label"] - 1):
+            vecs.append([float(i + r["n_labels"] * r["per_label"])] * 4)
+            labs.append(i)
+    ix = build_multi(4, np.array(vecs, dtype=np.float32), labs)
+    q = np.full(4, float(r["pivot"]), dtype=np.float32)
+    for eps in r["epsilons"]:
+        qp = VecSim.VecSimQueryParams()
+        qp.hnswRuntimeParams.epsilon = eps
+        l, d = ix.range_query(q, r["radius"], qp)
+        assert l.shape[1] == r["expect_count"]
+        assert d[0].tolist() == r["expect_scores_by_score"]
+        assert [abs(int(x) - r["pivot"]) for x in l[0]] == r["expect_abs_diff_by_score"]
+    l, d = ix.range_query(q, r["radius"], order=VecSim.BY_ID)
+    assert l[0].tolist() == r["expect_labels_by_id"]
+
+
+@pytest.mark.parametrize("metric,dim,n,n_labels,ef,k", [
+    (VecSim.VecSimMetric_L2, 32, 4000, 600, 60, 10),
+    (VecSim.VecSimMetric_IP, 64, 3000, 200, 100, 20),
+    (VecSim.VecSimMetric_Cosine, 48, 3000, 1000, 40, 10),
+])
+def test_multi_value_gpu_search_equals_reference_loops(vso, metric, dim, n, n_labels, ef, k):
+    """random vectors, repeated vectors under different labels and repeated labels: labels, order, scores and the number of distance
+    evaluations equal the oracle's label-keyed search (updatable_max_heap semantics) on the same graph"""
+    rng = np.random.default_rng(n_labels)
+    base = rng.uniform(-1, 1, (n // 2, dim)).astype(np.float32)
+    rows = base[rng.integers(0, len(base), n)]
+    labels = rng.integers(0, n_labels, n)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime, p.multi = VecSim.VecSimType_FLOAT32, dim, metric, 12, 80, ef, True
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(rows, labels)                 # bulk path: repeated labels in one batch
+    assert ix.index_size() == n
+    g = ix.graph()
+    q = rng.uniform(-1, 1, (40, dim)).astype(np.float32)
+    got_l, got_s = ix.knn_query(q, k)
+    evals = ix.last_distance_evals()
+    srows, sq = stored(vso, rows, metric), stored(vso, q, metric)
+    km = 0 if metric == VecSim.VecSimMetric_L2 else 1
+    total = 0
+    for j in range(len(q)):
+        el, es, ev = vso.hnsw_search(0, km, srows, g, sq[j], k, ef, dim, multi=True)
+        total += ev
+        assert np.array_equal(got_l[j][:len(el)], el.astype(np.int64)), (j, got_l[j], el)
+        assert np.array_equal(got_s[j][:len(es)], es), j
+        assert len(set(el.tolist())) == len(el)
+    assert evals == total - len(q)
+    # get_distance_from = the minimum over the label's vectors (hnsw_multi.h:138-162); delete removes all of them
+    lab = int(labels[0])
+    mine = np.nonzero(labels == lab)[0]
+    want = min(vso.distance(0, km, srows[i], sq[0], dim) for i in mine)
+    assert ix.get_distance_from(lab, sq[0]) == want
+    assert ix.delete_vector(lab) == len(mine) and ix.index_size() == n - len(mine)
+    got_l, _ = ix.knn_query(q, k)
+    assert lab not in set(got_l.ravel().tolist())
+    # batch iterator: every label once, ascending, the first batch = the exact best labels
+    it = ix.create_batch_iterator(q[0])
+    seen, last = [], -np.inf
+    while it.has_next():
+        l, d = it.get_next_results(50)
+        assert np.all(np.diff(d[0]) >= 0) and d[0][0] >= last
+        last = d[0][-1]
+        seen += l[0].tolist()
+    assert len(seen) == len(set(seen)) == len(set(labels.tolist()) - {lab})

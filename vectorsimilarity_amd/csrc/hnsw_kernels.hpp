@@ -61,6 +61,9 @@ struct HnswParams {
     uint32_t *next_query;  // work queue head (zeroed before the launch): waves draw queries one at a time
     // range mode (hnsw.h:616-680, 2087-2150): every result within `radius`, discovery order, up to rcap per query;
     // out_counts[q] = number found (bit 31: the candidate window overflowed, the caller must not trust the list)
+    // multi-value index (hnsw_multi.h:108-112): top_candidates is the label-keyed updatable heap (utils/updatable_heap.h:20-113) --
+    // a label keeps its lowest distance, the heap's size counts labels
+    int multi;
     int range;
     float radius;
     double epsilon;
@@ -95,6 +98,33 @@ __device__ __forceinline__ uint32_t top_insert(float *D, uint64_t *L, uint32_t n
     }
     if (lane == 0) { D[pos] = d; L[pos] = lab; }
     return n + 1;
+}
+// updatable_max_heap::emplace (updatable_heap.h:93-113): a new label is inserted; a label already present keeps the lower of its
+// two distances (and its place in the order moves with it)
+__device__ __forceinline__ uint32_t top_emplace_label(float *D, uint64_t *L, uint32_t n, float d, uint64_t lab, int lane) {
+    uint32_t at = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const unsigned long long hit = __ballot(i < n && L[i] == lab);
+        if (hit) at = base + (uint32_t)__ffsll((long long)hit) - 1u;   // (a label sits in the array at most once)
+    }
+    if (at != 0xFFFFFFFFu) {
+        if (!(D[at] > d)) return n;   // "else if (existing priority > p)": only a strictly lower distance replaces
+        __syncthreads();
+        // close the gap at `at`: shift (at, n) left by one, lowest chunk first; within a chunk every read precedes every write
+        for (uint32_t base = at + 1; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            float vd = 0.f;
+            uint64_t vl = 0;
+            const bool act = i < n;
+            if (act) { vd = D[i]; vl = L[i]; }
+            __syncthreads();
+            if (act) { D[i - 1] = vd; L[i - 1] = vl; }
+            __syncthreads();
+        }
+        n--;
+    }
+    return top_insert(D, L, n, d, lab, lane);
 }
 __device__ __forceinline__ uint32_t cand_insert(float *D, uint32_t *I, uint32_t head, uint32_t tail, float d, uint32_t id,
                                                 int lane) {
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         if (!P.deleted[cur]) {
             // (the reference recomputes dist(ep): same value as curd)
             lower = curd;
-            top_n = top_insert(top_d, top_l, top_n, curd, P.labels[cur], lane);
+            top_n = top_insert(top_d, top_l, top_n, curd, P.labels[cur], lane);   // (the heap is empty: multi or not, one insert)
             ctail = cand_insert(cand_d, cand_i, chead, ctail, curd, cur, lane);
         } else {
             lower = 3.402823466e+38f;
@@ -418,7 +448,11 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                         }
                         ctail = cand_insert(cand_d, cand_i, chead, ctail, d, id, lane);
                     }
-                    if (!P.deleted[id]) top_n = top_insert(top_d, top_l, top_n, d, P.labels[id], lane);
+                    if (!P.deleted[id]) {
+                        __syncthreads();
+                        top_n = P.multi ? top_emplace_label(top_d, top_l, top_n, d, P.labels[id], lane)
+                                        : top_insert(top_d, top_l, top_n, d, P.labels[id], lane);
+                    }
                     if (top_n > P.ef) top_n--;  // pop the largest (dist, label)
                     __syncthreads();
                     if (top_n > 0) lower = top_d[top_n - 1];

@@ -19,10 +19,6 @@ static constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     if (p.dim == 0 || p.metric > VecSimMetric_Cosine) return nullptr;
-    if (p.multi) {
-        std::fprintf(stderr, "vecsim_amd: multi-value HNSW indexes are not built yet\n");
-        return nullptr;
-    }
     if ((unsigned)p.type > (unsigned)VecSimType_UINT8 || p.type == VecSimType_FLOAT64) {
         std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/bf16/fp16/int8/uint8 (L2, IP, Cosine)\n");
         return nullptr;
@@ -62,6 +58,8 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
         delete ix;
         return nullptr;
     }
+    ix->multi_ = p.multi;
+    vsgpu_graph_set_multi(ix->graph_, p.multi ? 1 : 0);
     return ix;
 }
 
@@ -392,7 +390,8 @@ uint32_t HnswIndex::allocNode(const char *stored_blob, size_t label, int level) 
     upper_off_.push_back(NONE);
     deleted_.push_back(0);
     labels_.push_back((uint64_t)label);
-    label_to_id_[label] = id;
+    if (multi_) label_to_ids_[label].push_back(id);
+    else label_to_id_[label] = id;
     if (level > 0) {
         upper_off_[id] = (uint32_t)(upper_.size() / (M_ + 1));
         upper_.resize(upper_.size() + (size_t)level * (M_ + 1), 0u);
@@ -453,7 +452,7 @@ void HnswIndex::insertNode(uint32_t id, const float *v, BuildCtx &bc) {
 
 int HnswIndex::addVector(const void *blob, size_t label) {
     int is_new = 1;
-    auto it = label_to_id_.find(label);
+    auto it = multi_ ? label_to_id_.end() : label_to_id_.find(label);   // multi: "we always add the vector, no overrides" (hnsw_multi.h:213-218)
     if (it != label_to_id_.end()) {  // overwrite = mark the old vector deleted + insert (hnsw_single.h)
         deleted_[it->second] = 1;
         n_deleted_++;
@@ -472,6 +471,14 @@ int HnswIndex::addVector(const void *blob, size_t label) {
 // linking runs on VECSIM_HNSW_BUILD_THREADS host threads (default: all cores, at most 64) with per-node
 // link-list locks, the way the reference's parallel insert path does (hnsw.h:436-445, bindings.cpp:383-426).
 long HnswIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
+    if (multi_) {
+        auto f = label_to_ids_.find(label);
+        if (f == label_to_ids_.end()) return 0;
+        if (cap_bytes < f->second.size() * blob_bytes_) return -1;
+        for (size_t i = 0; i < f->second.size(); i++)
+            std::memcpy((char *)out + i * blob_bytes_, raw_.data() + (size_t)f->second[i] * blob_bytes_, blob_bytes_);
+        return (long)f->second.size();
+    }
     auto f = label_to_id_.find(label);
     if (f == label_to_id_.end()) return 0;
     if (cap_bytes < blob_bytes_) return -1;
@@ -480,9 +487,9 @@ long HnswIndex::storedVectors(size_t label, void *out, size_t cap_bytes) {
 }
 
 long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
-    for (size_t i = 0; i < n; i++)
+    for (size_t i = 0; i < n && !multi_; i++)
         if (label_to_id_.count(labels[i])) return -1;
-    {   // a label may appear once per batch (the sequential path would overwrite; the parallel one would keep both alive)
+    if (!multi_) {   // a label may appear once per batch (the sequential path would overwrite; the parallel one would keep both alive)
         std::unordered_map<size_t, char> seen;
         seen.reserve(n * 2);
         for (size_t i = 0; i < n; i++)
@@ -535,6 +542,18 @@ long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
 }
 
 int HnswIndex::deleteVector(size_t label) {
+    if (multi_) {   // hnsw_multi.h:197-211: every node of the label, the number removed is returned
+        auto f = label_to_ids_.find(label);
+        if (f == label_to_ids_.end()) return 0;
+        const int removed = (int)f->second.size();
+        for (uint32_t id : f->second) {
+            deleted_[id] = 1;
+            n_deleted_++;
+        }
+        label_to_ids_.erase(f);
+        graph_dirty_ = true;
+        return removed;
+    }
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end()) return 0;
     deleted_[it->second] = 1;  // mark only: the node stays traversable (hnsw.h:572-573), never returned
@@ -600,7 +619,8 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     // (the admission test `size < ef` then never fails): clamp before sizing the kernel's LDS heaps
     const size_t live = n_ - n_deleted_;
     if (live == 0) return finish();
-    const size_t k_eff = std::min(k, live);
+    // (multi-value: the heap holds labels, hnsw_multi.h:108-112 -- no more than there are)
+    const size_t k_eff = std::min(k, multi_ ? label_to_ids_.size() : live);
     ef = std::min(ef, live);
     // only Cosine needs a private (normalised) copy of the queries
     std::vector<char> qbuf;
@@ -638,7 +658,32 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
                 rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
             }
             if (rc) break;
+            if (multi_ && all.empty()) {   // the k best LABELS need every row's score (a label's best row may rank anywhere)
+                all.resize(n_);
+                rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
+                if (rc) break;
+            }
             RefMaxHeap<Item> heap;
+            std::unordered_map<size_t, double> best_of;   // multi: per-label minimum first, then the plain heap over labels
+            if (multi_) {
+                for (size_t i = 0; i < n_; i++) {
+                    if (deleted_[i]) continue;
+                    auto f = best_of.find((size_t)labels_[i]);
+                    if (f == best_of.end()) best_of.emplace((size_t)labels_[i], all[i]);
+                    else if (all[i] < f->second) f->second = all[i];
+                }
+                for (auto &e : best_of) {
+                    heap.emplace(e.second, e.first);
+                    if (heap.size() > k_eff) heap.pop();
+                }
+                cnt[q] = (uint32_t)heap.size();
+                for (size_t i = heap.size(); i-- > 0;) {
+                    labs[q * k_eff + i] = heap.top().second;
+                    sc[q * k_eff + i] = heap.top().first;
+                    heap.pop();
+                }
+                continue;
+            }
             double upper = std::numeric_limits<double>::lowest();
             const size_t m = all.empty() ? c1[0] : n_;
             for (size_t i = 0; i < m; i++) {
@@ -743,6 +788,20 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
             rep->results[i].score = sc[i];
         }
     }
+    if (multi_) {   // unique_results_container (vecsim_results_container.h:33-62): one result per label, its lowest score
+        std::unordered_map<size_t, size_t> at;
+        size_t w = 0;
+        for (size_t i = 0; i < rep->results.size(); i++) {
+            auto f = at.find(rep->results[i].id);
+            if (f == at.end()) {
+                at.emplace(rep->results[i].id, w);
+                rep->results[w++] = rep->results[i];
+            } else if (rep->results[i].score < rep->results[f->second].score) {
+                rep->results[f->second].score = rep->results[i].score;
+            }
+        }
+        rep->results.resize(w);
+    }
     sort_reply(rep, order);
     return rep;
 }
@@ -774,6 +833,7 @@ int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair
 // device-resident iterator state: the same score buffer as the Flat index, deleted nodes retired up front
 vsgpu_scorebuf *HnswIndex::iteratorDeviceBegin(const void *processed_query) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    if (multi_) return nullptr;   // (a label's best vector has to win: the host array path de-duplicates by label, as for Flat)
     if (n_ == 0 || syncDevice()) return nullptr;
     vsgpu_scorebuf *b = vsgpu_scorebuf_create(table_, processed_query);
     if (b && n_deleted_) {
@@ -806,6 +866,15 @@ void HnswIndex::iteratorDeviceEnd(vsgpu_scorebuf *b) {
 
 double HnswIndex::getDistanceFrom(size_t label, const void *blob) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    if (multi_) {   // hnsw_multi.h:138-162: the minimum over the label's vectors (std::fmin from INVALID_SCORE = NaN)
+        auto f = label_to_ids_.find(label);
+        if (f == label_to_ids_.end() || syncDevice()) return std::numeric_limits<double>::quiet_NaN();
+        std::vector<double> s(f->second.size());
+        if (vsgpu_scores_of(table_, blob, f->second.data(), f->second.size(), s.data())) return std::numeric_limits<double>::quiet_NaN();
+        double best = std::numeric_limits<double>::quiet_NaN();
+        for (double v : s) best = std::fmin(best, v);
+        return best;
+    }
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end() || syncDevice()) return std::numeric_limits<double>::quiet_NaN();
     uint32_t id = it->second;

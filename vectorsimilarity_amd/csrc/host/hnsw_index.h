@@ -29,7 +29,7 @@ public:
     int addVector(const void *blob, size_t label) override;
     int deleteVector(size_t label) override;
     size_t indexSize() const override { return n_ - n_deleted_; }
-    size_t indexLabelCount() const override { return label_to_id_.size(); }
+    size_t indexLabelCount() const override { return multi_ ? label_to_ids_.size() : label_to_id_.size(); }
     VecSimQueryReply *topKQuery(const void *query, size_t k, VecSimQueryParams *qp) override;
     int topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                        VecSimQueryReply_Order order, VecSimQueryReply **out) override;
@@ -132,6 +132,9 @@ private:
     std::vector<uint8_t> deleted_;
     std::vector<uint64_t> labels_;
     std::unordered_map<size_t, uint32_t> label_to_id_;
+    // multi-value index (hnsw_multi.h:16-247): a label owns any number of nodes; adds never overwrite, a delete marks them all
+    bool multi_ = false;
+    std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     uint32_t entry_ = 0xFFFFFFFFu;
     int max_level_ = -1;
     BuildCtx main_ctx_;                               // single-threaded inserts

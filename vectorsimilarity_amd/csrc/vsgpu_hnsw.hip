@@ -8,6 +8,7 @@ using namespace vsg;
 struct vsgpu_graph {
     vsgpu_table *t = nullptr;
     uint32_t M = 16, M0 = 32;
+    int multi = 0;   // labels may repeat: the search keeps one entry per label (vsgpu_graph_set_multi)
     size_t n = 0;
     DevBuf links0, cnt0, upper_off, upper, deleted, labels;
     uint32_t entry = 0xFFFFFFFFu;
@@ -32,6 +33,9 @@ extern "C" vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M) {
     g->M = (uint32_t)M;
     g->M0 = (uint32_t)(2 * M);
     return g;
+}
+extern "C" void vsgpu_graph_set_multi(vsgpu_graph *g, int multi) {
+    if (g) g->multi = multi ? 1 : 0;
 }
 extern "C" void vsgpu_graph_destroy(vsgpu_graph *g) {
     if (!g) return;
@@ -154,6 +158,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.M = g->M;
     P.entry = g->entry;
     P.max_level = g->max_level;
+    P.multi = g->multi;
     P.n = (uint32_t)g->tag_n;  // tag row pitch
     P.tags = (uint16_t *)g->tags.p;
     P.slot_epoch = (uint32_t *)g->slot_epoch.p;
