@@ -506,3 +506,81 @@ def test_multi_value_gpu_search_equals_reference_loops(vso, metric, dim, n, n_la
         last = d[0][-1]
         seen += l[0].tolist()
     assert len(seen) == len(set(seen)) == len(set(labels.tolist()) - {lab})
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FLOAT64 HNSW (index_factories/hnsw_factory.cpp:47: HNSWIndex<double, double>): rows scored in double in the reference's
+# AVX-512F fp64 order, heaps and replies keep every bit of the double scores
+@pytest.mark.parametrize("metric,dim,n,M,ef,k,multi", [
+    (VecSim.VecSimMetric_L2, 32, 3000, 16, 50, 10, False),
+    (VecSim.VecSimMetric_IP, 70, 2500, 8, 64, 10, False),
+    (VecSim.VecSimMetric_Cosine, 96, 2500, 12, 40, 5, False),
+    (VecSim.VecSimMetric_L2, 24, 3000, 12, 60, 10, True),
+])
+def test_fp64_gpu_search_equals_reference_loops_on_same_graph(vso, metric, dim, n, M, ef, k, multi):
+    rng = np.random.default_rng(dim + n)
+    rows = rng.uniform(-1, 1, (n, dim))
+    labels = rng.integers(0, n // 5, n) if multi else np.arange(n)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime, p.multi = VecSim.VecSimType_FLOAT64, dim, metric, M, 80, ef, multi
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(rows, labels)
+    g = ix.graph()
+    q = rng.uniform(-1, 1, (30, dim))
+    got_l, got_s = ix.knn_query(q, k)
+    evals = ix.last_distance_evals()
+
+    def stored64(a):
+        if metric != VecSim.VecSimMetric_Cosine:
+            return a
+        out = a.copy()
+        for i in range(len(out)):
+            vso.normalize(out[i], dim, vso.F64)
+        return out
+    srows, sq = stored64(rows), stored64(q)
+    km = 0 if metric == VecSim.VecSimMetric_L2 else 1
+    total = 0
+    for j in range(len(q)):
+        el, es, ev = vso.hnsw_search(vso.F64, km, srows, g, sq[j], k, ef, dim, multi=multi)
+        total += ev
+        assert np.array_equal(got_l[j][:len(el)], el.astype(np.int64)), (j, got_l[j], el)
+        assert np.array_equal(got_s[j][:len(es)], es), (j, got_s[j], es)     # doubles, bit for bit
+    assert evals == total - len(q)
+    assert np.any(got_s != got_s.astype(np.float32).astype(np.float64))      # (the scores really are doubles)
+    # range search in double as well
+    rad = float(np.sort(got_s[0])[min(k, len(got_s[0])) - 1])
+    if rad < 0:       # (IP scores of random vectors: the C API rejects a negative radius, as upstream)
+        return
+    l, d = ix.range_query(q[0], rad)
+    el, es, _ = vso.hnsw_range(vso.F64, km, srows, g, sq[0], rad, 0.01, dim)
+    if multi:
+        best = {}
+        for a, b in zip(el.tolist(), es.tolist()):
+            best[a] = min(best.get(a, np.inf), b)
+        want = sorted(best.items(), key=lambda t: (t[1], t[0]))
+    else:
+        want = sorted(zip(el.tolist(), es.tolist()), key=lambda t: (t[1], t[0]))
+    assert [int(x) for x in l[0]] == [a for a, _ in want] and d[0].tolist() == [b for _, b in want]
+
+
+def test_fp64_reference_known_answers():
+    """the reference's typed HNSW tests run on double as well (tests/unit/test_hnsw.cpp: DataTypeSet): closed forms on fp64 rows"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kat_hnsw.json")) as f:
+        kat = json.load(f)
+    for c in kat["topk"]:
+        if "expect_scores" not in c and "expect_labels" not in c:
+            continue
+        p = VecSim.HNSWParams()
+        p.type, p.dim, p.metric, p.M, p.efConstruction = VecSim.VecSimType_FLOAT64, c["dim"], getattr(VecSim, "VecSimMetric_" + c["metric"]), c["M"], c["efConstruction"]
+        ix = VecSim.HNSWIndex(p)
+        for v, lab in zip(c["vectors"], c["labels"]):
+            ix.add_vector(np.array(v, dtype=np.float64), lab)
+        l, d = ix.knn_query(np.array(c["query"], dtype=np.float64), c["k"], order=VecSim.BY_ID if c["order"] == "id" else VecSim.BY_SCORE)
+        if "expect_labels" in c:
+            assert l[0].tolist() == c["expect_labels"], c["name"]
+        if "expect_scores" in c:
+            assert d[0].tolist() == c["expect_scores"], c["name"]
+        if "expect_abs_diff" in c:
+            assert [abs(int(x) - c["expect_labels_abs_diff_from"]) for x in l[0]] == c["expect_abs_diff"], c["name"]

@@ -55,7 +55,7 @@ struct HnswParams {
     // search
     uint32_t ef, k, ccap;  // ccap = capacity of the candidate array (>= 2*ef)
     uint64_t *out_labels;  // [nq][k]
-    float *out_scores;     // [nq][k]
+    void *out_scores;      // [nq][k] float (double for fp64 tables: DistType = double, hnsw_factory.cpp:47)
     uint32_t *out_counts;  // [nq]
     uint64_t *stat_dists;  // optional: total distance evaluations (atomicAdd), may be null
     uint32_t *next_query;  // work queue head (zeroed before the launch): waves draw queries one at a time
@@ -65,7 +65,7 @@ struct HnswParams {
     // a label keeps its lowest distance, the heap's size counts labels
     int multi;
     int range;
-    float radius;
+    double radius;
     double epsilon;
     uint32_t rcap;
 };
@@ -73,14 +73,14 @@ struct HnswParams {
 // ---- wave-parallel sorted arrays in LDS (all 64 lanes call with uniform arguments) ----
 // top: ascending by (dist, label); cand: ascending by (dist, then id DESCENDING) so that the front is
 // the reference's candidate_set.top().
-__device__ __forceinline__ bool top_less(float d1, uint64_t l1, float d2, uint64_t l2) {
+template <typename D> __device__ __forceinline__ bool top_less(D d1, uint64_t l1, D d2, uint64_t l2) {
     return d1 < d2 || (d1 == d2 && l1 < l2);
 }
-__device__ __forceinline__ bool cand_less(float d1, uint32_t i1, float d2, uint32_t i2) {
+template <typename D> __device__ __forceinline__ bool cand_less(D d1, uint32_t i1, D d2, uint32_t i2) {
     return d1 < d2 || (d1 == d2 && i1 > i2);
 }
 
-__device__ __forceinline__ uint32_t top_insert(float *D, uint64_t *L, uint32_t n, float d, uint64_t lab, int lane) {
+template <typename DT> __device__ __forceinline__ uint32_t top_insert(DT *D, uint64_t *L, uint32_t n, DT d, uint64_t lab, int lane) {
     uint32_t pos = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t top_insert(float *D, uint64_t *L, uint32_t n
     // shift [pos, n) right by one, highest chunk first; within a chunk every read precedes every write
     for (int32_t base = (int32_t)((n - pos + 63) / 64 - 1) * 64; base >= 0; base -= 64) {
         const uint32_t i = pos + (uint32_t)base + lane;
-        float vd = 0.f;
+        DT vd = (DT)0;
         uint64_t vl = 0;
         const bool act = i < n;
         if (act) { vd = D[i]; vl = L[i]; }
@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t top_insert(float *D, uint64_t *L, uint32_t n
 }
 // updatable_max_heap::emplace (updatable_heap.h:93-113): a new label is inserted; a label already present keeps the lower of its
 // two distances (and its place in the order moves with it)
-__device__ __forceinline__ uint32_t top_emplace_label(float *D, uint64_t *L, uint32_t n, float d, uint64_t lab, int lane) {
+template <typename DT> __device__ __forceinline__ uint32_t top_emplace_label(DT *D, uint64_t *L, uint32_t n, DT d, uint64_t lab, int lane) {
     uint32_t at = 0xFFFFFFFFu;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t top_emplace_label(float *D, uint64_t *L, uin
         // close the gap at `at`: shift (at, n) left by one, lowest chunk first; within a chunk every read precedes every write
         for (uint32_t base = at + 1; base < n; base += 64) {
             const uint32_t i = base + lane;
-            float vd = 0.f;
+            DT vd = (DT)0;
             uint64_t vl = 0;
             const bool act = i < n;
             if (act) { vd = D[i]; vl = L[i]; }
@@ -126,7 +126,7 @@ __device__ __forceinline__ uint32_t top_emplace_label(float *D, uint64_t *L, uin
     }
     return top_insert(D, L, n, d, lab, lane);
 }
-__device__ __forceinline__ uint32_t cand_insert(float *D, uint32_t *I, uint32_t head, uint32_t tail, float d, uint32_t id,
+template <typename DT> __device__ __forceinline__ uint32_t cand_insert(DT *D, uint32_t *I, uint32_t head, uint32_t tail, DT d, uint32_t id,
                                                 int lane) {
     uint32_t pos = head;
     for (uint32_t base = head; base < tail; base += 64) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ uint32_t cand_insert(float *D, uint32_t *I, uint32_t 
     }
     for (int32_t base = (int32_t)((tail - pos + 63) / 64 - 1) * 64; base >= 0; base -= 64) {
         const uint32_t i = pos + (uint32_t)base + lane;
-        float vd = 0.f;
+        DT vd = (DT)0;
         uint32_t vi = 0;
         const bool act = i < tail;
         if (act) { vd = D[i]; vi = I[i]; }
@@ -156,6 +156,8 @@ template <int EK, int OPK>
 __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
     using E = Elem<EK>;
     using acc_t = typename E::acc_t;
+    using dist_t = typename E::score_t;   // float; double for fp64 rows
+    constexpr dist_t DIST_MAX = sizeof(dist_t) == 8 ? (dist_t)1.7976931348623157e308 : (dist_t)3.402823466e+38f;   // numeric_limits<DistType>::max()
     constexpr int VL = E::VL;
     constexpr int NG = 64 / VL;  // neighbour rows scored at a time
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,15 +171,15 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
     o += ((size_t)steps * VL * sizeof(acc_t) + 15) & ~(size_t)15;
     uint64_t *top_l = reinterpret_cast<uint64_t *>(smem + o);
     o += (size_t)(P.ef + 2) * 8;
-    float *top_d = reinterpret_cast<float *>(smem + o);
-    o += ((size_t)(P.ef + 2) * 4 + 15) & ~(size_t)15;
-    float *cand_d = reinterpret_cast<float *>(smem + o);
-    o += (size_t)(2 * P.ccap + 2) * 4;  // physical array = 2x the live window
+    dist_t *top_d = reinterpret_cast<dist_t *>(smem + o);
+    o += ((size_t)(P.ef + 2) * sizeof(dist_t) + 15) & ~(size_t)15;
+    dist_t *cand_d = reinterpret_cast<dist_t *>(smem + o);
+    o += ((size_t)(2 * P.ccap + 2) * sizeof(dist_t) + 15) & ~(size_t)15;  // physical array = 2x the live window
     uint32_t *cand_i = reinterpret_cast<uint32_t *>(smem + o);
     o += ((size_t)(2 * P.ccap + 2) * 4 + 15) & ~(size_t)15;
+    dist_t *nb_d = reinterpret_cast<dist_t *>(smem + o);
+    o += 64 * sizeof(dist_t);
     uint32_t *nb_id = reinterpret_cast<uint32_t *>(smem + o);  // unvisited neighbours of the current node
-    o += 64 * 4;
-    float *nb_d = reinterpret_cast<float *>(smem + o);
 
     for (int i = lane; i < steps * VL; i += 64) offs_s[i] = P.offs[i];
 
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                     const unsigned char *np = reinterpret_cast<const unsigned char *>(rp[u] + P.norm_off);
                     nrow = __uint_as_float((uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24));
                 }
-                nb_d[idx[u]] = epilogue_score<float>(a, P.epilogue, nrow, cur_qnorm);
+                nb_d[idx[u]] = epilogue_score<dist_t>(a, P.epilogue, nrow, cur_qnorm);
             }
         }
     };
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         score_nodes(nb_id, 0, 1);
         n_dists += 1;
         __syncthreads();
-        float curd = nb_d[0];
+        dist_t curd = nb_d[0];
         for (int level = P.max_level; level > 0; level--) {
             bool changed = true;
             while (changed) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                 __syncthreads();
                 // the reference walks the ORIGINAL node's link list to the end while updating the best
                 for (uint32_t i = 0; i < cnt; i++) {
-                    const float d = nb_d[i];
+                    const dist_t d = nb_d[i];
                     if (d < curd) { curd = d; cur = nb_id[i]; changed = true; }
                 }
             }
@@ -296,37 +298,38 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
             // ---- level 0, range search (searchRangeBottomLayer_WithTimeout + processCandidate_RangeSearch) ----
             uint32_t chead = 0, ctail = 0, nres = 0;
             bool overflow = false;
-            float dyn, bound, epd;
-            auto emit = [&](uint32_t id, float d) {
+            dist_t dyn, bound, epd;
+            const dist_t radius = (dist_t)P.radius;
+            auto emit = [&](uint32_t id, dist_t d) {
                 if (lane == 0 && nres < P.rcap) {
                     P.out_labels[(size_t)q * P.rcap + nres] = P.labels[id];
-                    P.out_scores[(size_t)q * P.rcap + nres] = d;
+                    reinterpret_cast<dist_t *>(P.out_scores)[(size_t)q * P.rcap + nres] = d;
                 }
                 nres++;
             };
             if (lane == 0) tags[cur] = tag;
             if (P.deleted[cur]) {
-                epd = 3.402823466e+38f;
+                epd = DIST_MAX;
                 dyn = bound = epd;
             } else {
                 epd = curd;
                 dyn = epd;
-                if (epd <= P.radius) {
+                if (epd <= radius) {
                     emit(cur, epd);
-                    dyn = P.radius;
+                    dyn = radius;
                 }
-                bound = (float)((double)dyn * (1.0 + P.epsilon));
+                bound = (dist_t)((double)dyn * (1.0 + P.epsilon));
             }
             ctail = cand_insert(cand_d, cand_i, chead, ctail, epd, cur, lane);
             __syncthreads();
             while (chead < ctail) {
-                const float cd = cand_d[chead];
+                const dist_t cd = cand_d[chead];
                 const uint32_t cnode = cand_i[chead];
                 if (cd > bound) break;
                 chead++;
-                if (cd < dyn && cd >= P.radius) {
+                if (cd < dyn && cd >= radius) {
                     dyn = cd;
-                    bound = (float)((double)dyn * (1.0 + P.epsilon));
+                    bound = (dist_t)((double)dyn * (1.0 + P.epsilon));
                 }
                 const uint32_t cnt = min((uint32_t)P.cnt0[cnode], P.M0);
                 uint32_t nid = 0;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                 n_dists += nfresh;
                 __syncthreads();
                 for (uint32_t i = 0; i < nfresh; i++) {
-                    const float d = nb_d[i];
+                    const dist_t d = nb_d[i];
                     const uint32_t id = nb_id[i];
                     if (d < bound) {
                         bool keep = true;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                                 const uint32_t live = ctail - chead;
                                 for (uint32_t b = 0; b < live; b += 64) {
                                     const uint32_t j = b + lane;
-                                    float vd = 0.f;
+                                    dist_t vd = (dist_t)0;
                                     uint32_t vi = 0;
                                     if (j < live) { vd = cand_d[chead + j]; vi = cand_i[chead + j]; }
                                     __syncthreads();
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                             }
                             ctail = cand_insert(cand_d, cand_i, chead, ctail, d, id, lane);
                         }
-                        if (d <= P.radius && !P.deleted[id]) emit(id, d);
+                        if (d <= radius && !P.deleted[id]) emit(id, d);
                         __syncthreads();
                     }
                 }
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
 
         // ---- level 0: ef-bounded best-first search (hnsw.h:1983-2035) ----
         uint32_t top_n = 0, chead = 0, ctail = 0;
-        float lower;
+        dist_t lower;
         if (lane == 0) tags[cur] = tag;
         if (!P.deleted[cur]) {
             // (the reference recomputes dist(ep): same value as curd)
@@ -391,13 +394,13 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
             top_n = top_insert(top_d, top_l, top_n, curd, P.labels[cur], lane);   // (the heap is empty: multi or not, one insert)
             ctail = cand_insert(cand_d, cand_i, chead, ctail, curd, cur, lane);
         } else {
-            lower = 3.402823466e+38f;
+            lower = DIST_MAX;
             ctail = cand_insert(cand_d, cand_i, chead, ctail, lower, cur, lane);
         }
         __syncthreads();
 
         while (chead < ctail) {
-            const float cd = cand_d[chead];
+            const dist_t cd = cand_d[chead];
             const uint32_t cnode = cand_i[chead];
             if (cd > lower && top_n >= P.ef) break;
             chead++;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
             n_dists += nfresh;
             __syncthreads();
             for (uint32_t i = 0; i < nfresh; i++) {
-                const float d = nb_d[i];
+                const dist_t d = nb_d[i];
                 const uint32_t id = nb_id[i];
                 if (lower > d || top_n < P.ef) {
                     // candidate_set.emplace(-d, id).  The live window [chead, ctail) holds at most ccap
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
                             const uint32_t live = ctail - chead;
                             for (uint32_t b = 0; b < live; b += 64) {
                                 const uint32_t j = b + lane;
-                                float vd = 0.f;
+                                dist_t vd = (dist_t)0;
                                 uint32_t vi = 0;
                                 if (j < live) { vd = cand_d[chead + j]; vi = cand_i[chead + j]; }
                                 __syncthreads();
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(64) void k_hnsw_search(HnswParams P) {
         for (uint32_t i = lane; i < P.k; i += 64) {
             if (i < nres) {
                 P.out_labels[(size_t)q * P.k + i] = top_l[i];
-                P.out_scores[(size_t)q * P.k + i] = top_d[i];
+                reinterpret_cast<dist_t *>(P.out_scores)[(size_t)q * P.k + i] = top_d[i];
             }
         }
         if (lane == 0) P.out_counts[q] = nres;

@@ -19,8 +19,8 @@ static constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     if (p.dim == 0 || p.metric > VecSimMetric_Cosine) return nullptr;
-    if ((unsigned)p.type > (unsigned)VecSimType_UINT8 || p.type == VecSimType_FLOAT64) {
-        std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/bf16/fp16/int8/uint8 (L2, IP, Cosine)\n");
+    if ((unsigned)p.type > (unsigned)VecSimType_UINT8) {
+        std::fprintf(stderr, "vecsim_amd: HNSW supports fp32/fp64/bf16/fp16/int8/uint8 (L2, IP, Cosine)\n");
         return nullptr;
     }
     const size_t M = p.M ? p.M : HNSW_DEFAULT_M;
@@ -824,6 +824,18 @@ int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair
     if (syncDevice()) return -1;
     std::vector<double> s(n_);
     if (vsgpu_scores(table_, processed_query, 0, n_, s.data())) return -1;
+    if (multi_) {   // one entry per label, its lowest score (as the Flat multi-value iterator: bfm_batch_iterator.h:24-53)
+        std::unordered_map<size_t, double> best;
+        for (size_t i = 0; i < n_; i++) {
+            if (deleted_[i]) continue;
+            auto f = best.find((size_t)labels_[i]);
+            if (f == best.end()) best.emplace((size_t)labels_[i], s[i]);
+            else if (f->second > s[i]) f->second = s[i];
+        }
+        out.reserve(best.size());
+        for (auto &p : best) out.emplace_back(p.second, p.first);
+        return 0;
+    }
     out.reserve(n_ - n_deleted_);
     for (size_t i = 0; i < n_; i++)
         if (!deleted_[i]) out.emplace_back(s[i], (size_t)labels_[i]);
@@ -952,7 +964,7 @@ VecSimIndexDebugInfo HnswIndex::debugInfo() const {
     VecSimIndexDebugInfo d{};
     d.commonInfo.basicInfo = basicInfo();
     d.commonInfo.indexSize = indexSize();
-    d.commonInfo.indexLabelCount = label_to_id_.size();
+    d.commonInfo.indexLabelCount = indexLabelCount();
     d.commonInfo.memory = statsInfo().memory;
     d.commonInfo.lastMode = last_mode_;
     d.hnswInfo.M = M_;

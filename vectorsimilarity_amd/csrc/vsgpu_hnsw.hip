@@ -24,10 +24,6 @@ extern "C" vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M) {
         fail(VSGPU_ERR_ARG, "graph: M must be in [2, 32] (2M neighbours are scored by one wavefront)");
         return nullptr;
     }
-    if (t->type == VSGPU_F64) {
-        fail(VSGPU_ERR_UNSUPPORTED, "graph search: fp64 tables are not supported yet");
-        return nullptr;
-    }
     vsgpu_graph *g = new vsgpu_graph();
     g->t = t;
     g->M = (uint32_t)M;
@@ -101,20 +97,21 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
     const size_t ab = acc_bytes(t->type);
+    const size_t db = t->type == VSGPU_F64 ? 8 : 4;   // distance bytes: float scores, double for fp64 rows (DistType = double)
     size_t ccap = 2 * ef;
     if (range) {
         // the reference's candidate set is unbounded: give the window what LDS allows (overflow is reported)
         const size_t fixed = 2 * (((size_t)t->prog.steps * t->prog.vl * std::max<size_t>(ab, 4) + 15) & ~(size_t)15) + 1024;
         ccap = 64;
-        while (ccap < 3072 && fixed + (2 * (2 * ccap) + 2) * 8 + 64 <= 60 * 1024) ccap *= 2;
+        while (ccap < 3072 && fixed + (2 * (2 * ccap) + 2) * (4 + db) + 64 <= 60 * 1024) ccap *= 2;
     }
     size_t lds = (((size_t)t->prog.steps * t->prog.vl * 4 + 15) & ~(size_t)15);
     lds += (((size_t)t->prog.steps * t->prog.vl * ab + 15) & ~(size_t)15);
     lds += (ef + 2) * 8;
-    lds += (((ef + 2) * 4 + 15) & ~(size_t)15);
-    lds += (2 * ccap + 2) * 4;
+    lds += (((ef + 2) * db + 15) & ~(size_t)15);
+    lds += (((2 * ccap + 2) * db + 15) & ~(size_t)15);
     lds += (((2 * ccap + 2) * 4 + 15) & ~(size_t)15);
-    lds += 64 * 4 + 64 * 4;
+    lds += 64 * db + 64 * 4;
     if (lds > 64 * 1024) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu / dim %zu need %zu B of LDS per query", ef, t->dim, lds);
     // resident search waves = tag slots
     const size_t slots = std::min<size_t>(nq, (size_t)c->n_cu * (size_t)c->opt_hnsw_slots);
@@ -130,7 +127,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
         g->tag_n = nn2;
     }
     if ((rc = ensure(c, g->out_labels, nq * k * 8))) return rc;
-    if ((rc = ensure(c, g->out_scores, nq * k * 4))) return rc;
+    if ((rc = ensure(c, g->out_scores, nq * k * db))) return rc;
     if ((rc = ensure(c, g->out_counts, nq * 4))) return rc;
     if ((rc = ensure(c, g->stat, 16))) return rc;
     HIPCHK(hipMemsetAsync(g->stat.p, 0, 16, c->stream));
@@ -166,13 +163,13 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.k = (uint32_t)k;
     P.ccap = (uint32_t)ccap;
     P.out_labels = (uint64_t *)g->out_labels.p;
-    P.out_scores = (float *)g->out_scores.p;
+    P.out_scores = g->out_scores.p;
     P.out_counts = (uint32_t *)g->out_counts.p;
     P.stat_dists = (uint64_t *)g->stat.p;
     P.next_query = (uint32_t *)((char *)g->stat.p + 8);
     if (range) {
         P.range = 1;
-        P.radius = (float)range[0];
+        P.radius = range[0];
         P.epsilon = range[1];
         P.rcap = (uint32_t)k;
     }
@@ -180,6 +177,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     const dim3 grid((unsigned)slots);
     switch (t->ek) {
     case EK_F32: launch_hnsw_ek<EK_F32>(t->opk, P, grid, lds, c->stream); break;
+    case EK_F64: launch_hnsw_ek<EK_F64>(t->opk, P, grid, lds, c->stream); break;
     case EK_BF16: launch_hnsw_ek<EK_BF16>(t->opk, P, grid, lds, c->stream); break;
     case EK_F16: launch_hnsw_ek<EK_F16>(t->opk, P, grid, lds, c->stream); break;
     case EK_I8: launch_hnsw_ek<EK_I8>(t->opk, P, grid, lds, c->stream); break;
@@ -187,14 +185,14 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    std::vector<float> hs(nq * k);
+    std::vector<float> hs(db == 4 ? nq * k : 0);
     uint64_t hstat = 0;
     HIPCHK(hipMemcpyAsync(labels, g->out_labels.p, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hs.data(), g->out_scores.p, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(db == 4 ? (void *)hs.data() : (void *)scores, g->out_scores.p, nq * k * db, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(counts, g->out_counts.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&hstat, g->stat.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < nq * k; i++) scores[i] = (double)hs[i];
+    for (size_t i = 0; i < hs.size(); i++) scores[i] = (double)hs[i];
     if (dist_evals) *dist_evals = hstat;
     {
         float ms = 0;
