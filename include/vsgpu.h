@@ -138,6 +138,9 @@ int vsgpu_table_set_sq8_block_bounds(vsgpu_table *t, const float bounds[8]);
 typedef struct vsgpu_graph vsgpu_graph;
 vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M);
 void vsgpu_graph_destroy(vsgpu_graph *g);
+/* a second reader of the same snapshot: `view_table` is a view (vsgpu_table_view_create) of the graph's table on another context;
+ * searches through the view use that context's stream and scratch and their own visited tags (no upload through a view) */
+vsgpu_graph *vsgpu_graph_view_create(vsgpu_graph *parent, vsgpu_table *view_table);
 /* multi-value index (hnsw_multi.h): labels repeat across nodes, top_candidates keeps one entry per label (its lowest distance) */
 void vsgpu_graph_set_multi(vsgpu_graph *g, int multi);
 /* upper_off[i]: index (in blocks of 1+M words) of node i's level-1 block inside `upper`, 0xFFFFFFFF

@@ -1028,6 +1028,7 @@ def test_concurrent_readers_on_one_index(vso):
     ix.add_vectors(rows, np.arange(n))
     qs = [rng.uniform(-1, 1, (1 + (i % 5), dim)).astype(np.float32) for i in range(24)]
     want = [ix.knn_query(q, 10) for q in qs]
+    want_r = [ix.range_query(q[0], float(w[1][0][3])) for q, w in zip(qs, want)]   # range queries run on reader lanes too
     errors = []
 
     def worker(t):
@@ -1038,7 +1039,7 @@ def test_concurrent_readers_on_one_index(vso):
                     if not (np.array_equal(l, want[i][0]) and np.array_equal(d, want[i][1])):
                         errors.append((t, i))
                     r = ix.range_query(qs[i][0], float(want[i][1][0][3]))
-                    if r[0].shape[1] < 4:
+                    if r[0].shape[1] < 4 or not (np.array_equal(r[0], want_r[i][0]) and np.array_equal(r[1], want_r[i][1])):
                         errors.append((t, i, "range"))
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))

@@ -584,3 +584,35 @@ def test_fp64_reference_known_answers():
             assert d[0].tolist() == c["expect_scores"], c["name"]
         if "expect_abs_diff" in c:
             assert [abs(int(x) - c["expect_labels_abs_diff_from"]) for x in l[0]] == c["expect_abs_diff"], c["name"]
+
+
+def test_concurrent_readers_on_one_hnsw_index(vso):
+    """several threads search (top-k and range) one HNSW index at once: a reader that finds the index's context busy runs on a
+    reader lane (a view of the same snapshot with its own stream, staging and visited tags); every reply equals the serial one"""
+    import threading
+    dim, n, k = 48, 20_000, 10
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=12, efc=80, ef=64)
+    rng = np.random.default_rng(4)
+    qs = [rng.uniform(-1, 1, (1 + 37 * (i % 4), dim)).astype(np.float32) for i in range(16)]
+    want = [ix.knn_query(q, k) for q in qs]
+    want_r = [ix.range_query(q[0], float(w[1][0][4])) for q, w in zip(qs, want)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(4):
+                for i in range(t, len(qs), 4):
+                    l, d = ix.knn_query(qs[i], k)
+                    if not (np.array_equal(l, want[i][0]) and np.array_equal(d, want[i][1])):
+                        errors.append((t, i, "knn"))
+                    r = ix.range_query(qs[i][0], float(want[i][1][0][4]))
+                    if not (np.array_equal(r[0], want_r[i][0]) and np.array_equal(r[1], want_r[i][1])):
+                        errors.append((t, i, "range"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]

@@ -159,7 +159,7 @@ GPU_EXPORTS = [
     "vsgpu_table_size", "vsgpu_table_bytes", "vsgpu_table_append", "vsgpu_table_write",
     "vsgpu_table_move", "vsgpu_table_truncate", "vsgpu_table_read", "vsgpu_table_read_range", "vsgpu_table_append_synthetic",
     "vsgpu_table_view_create", "vsgpu_table_view_sync",
-    "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_set_multi", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
+    "vsgpu_graph_create", "vsgpu_graph_destroy", "vsgpu_graph_set_multi", "vsgpu_graph_view_create", "vsgpu_graph_upload", "vsgpu_graph_search", "vsgpu_graph_range",
     "vsgpu_scorebuf_create", "vsgpu_scorebuf_destroy", "vsgpu_scorebuf_rows", "vsgpu_scorebuf_next", "vsgpu_scorebuf_retire",
     "vsgpu_scorebuf_read",
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_table_set_sq8_block_bounds", "vsgpu_stats_reset",

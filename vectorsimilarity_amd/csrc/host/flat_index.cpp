@@ -910,15 +910,33 @@ VecSimQueryReply *FlatIndex::topKQuery(const void *query, size_t k, VecSimQueryP
 
 VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp,
                                         VecSimQueryReply_Order order) {
-    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    // readers may call concurrently (vec_sim.h contract): a reader that finds the index's own context busy runs on a reader lane
+    // (a view of the same rows with its own stream and scratch), like a top-k batch does
+    std::unique_lock<std::recursive_mutex> gpu_lock(gpu_mu_, std::defer_lock);
+    Lane *lane = nullptr;
+    if (!gpu_lock.try_lock()) {
+        if (staged_rows_.load(std::memory_order_acquire) == 0) lane = tryLane();
+        if (!lane) gpu_lock.lock();
+    }
+    struct LaneRelease {
+        Lane *l;
+        ~LaneRelease() {
+            if (l) l->mu.unlock();
+        }
+    } lane_release{lane};
+    vsgpu_table *tbl = table_;
+    if (lane) {
+        vsgpu_table_view_sync(lane->view);
+        tbl = lane->view;
+    }
     auto *rep = new VecSimQueryReply();
     void *tctx = qp ? qp->timeoutCtx : nullptr;
-    last_mode_ = RANGE_QUERY;
+    if (!lane) last_mode_ = RANGE_QUERY;   // (a lane reader holds no lock: the plain member is the lock holder's to write)
     if (timed_out(tctx)) {
         rep->code = VecSim_QueryReply_TimedOut;
         return rep;
     }
-    if (flush() || count_ == 0) return rep;
+    if ((!lane && flush()) || count_ == 0) return rep;
     std::vector<char> q = preprocessQuery(query);
     size_t cap = 1024;
     std::vector<uint32_t> ids;
@@ -927,7 +945,7 @@ VecSimQueryReply *FlatIndex::rangeQuery(const void *query, double radius, VecSim
     for (;;) {
         ids.resize(cap);
         sc.resize(cap);
-        int rc = vsgpu_range(table_, q.data(), radius, cap, ids.data(), sc.data(), &cnt);
+        int rc = vsgpu_range(tbl, q.data(), radius, cap, ids.data(), sc.data(), &cnt);
         if (rc) {
             std::fprintf(stderr, "vecsim_amd: GPU range query failed: %s\n", vsgpu_last_error());
             rep->code = VecSim_QueryReply_TimedOut;

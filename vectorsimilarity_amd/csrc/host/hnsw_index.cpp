@@ -60,13 +60,43 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     }
     ix->multi_ = p.multi;
     vsgpu_graph_set_multi(ix->graph_, p.multi ? 1 : 0);
+    size_t n_lanes = 2;   // the index's own context + one reader lane; VECSIM_GPU_READER_LANES as for the Flat index
+    if (const char *e = std::getenv("VECSIM_GPU_READER_LANES")) n_lanes = (size_t)std::max(1, std::min(8, std::atoi(e)));
+    for (size_t i = 1; i < n_lanes; i++) {   // best effort: without lanes readers take turns
+        auto lane = std::make_unique<Lane>();
+        lane->ctx = vsgpu_ctx_create(dev);
+        if (!lane->ctx) break;
+        lane->view = vsgpu_table_view_create(ix->table_, lane->ctx);
+        lane->graph = lane->view ? vsgpu_graph_view_create(ix->graph_, lane->view) : nullptr;
+        if (!lane->graph) {
+            if (lane->view) vsgpu_table_destroy(lane->view);
+            vsgpu_ctx_destroy(lane->ctx);
+            break;
+        }
+        ix->lanes_.push_back(std::move(lane));
+    }
     return ix;
 }
 
 HnswIndex::~HnswIndex() {
+    for (auto &l : lanes_) {
+        if (l->graph) vsgpu_graph_destroy(l->graph);
+        if (l->view) vsgpu_table_destroy(l->view);
+        if (l->ctx) vsgpu_ctx_destroy(l->ctx);
+    }
     if (graph_) vsgpu_graph_destroy(graph_);
     if (table_) vsgpu_table_destroy(table_);
     if (ctx_) vsgpu_ctx_destroy(ctx_);
+}
+HnswIndex::Lane *HnswIndex::tryLane() {
+    for (auto &l : lanes_)
+        if (l->mu.try_lock()) return l.get();
+    return nullptr;
+}
+std::vector<vsgpu_ctx *> HnswIndex::gpus() {
+    std::vector<vsgpu_ctx *> v{ctx_};
+    for (auto &l : lanes_) v.push_back(l->ctx);
+    return v;
 }
 
 // ---- construction-time distance (ingest only; queries never come here) ----
@@ -597,9 +627,29 @@ HnswIndex::Export HnswIndex::exportGraph() {
 
 int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, size_t k, VecSimQueryParams *qp,
                               VecSimQueryReply_Order order, VecSimQueryReply **out) {
-    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    // readers may call concurrently (vec_sim.h contract): a reader that finds the index's own context busy searches on a reader
+    // lane -- unless the device snapshot is stale (rows or links not uploaded yet), which only the lock holder may refresh
+    std::unique_lock<std::recursive_mutex> gpu_lock(gpu_mu_, std::defer_lock);
+    Lane *lane = nullptr;
+    if (!gpu_lock.try_lock()) {
+        if (!graph_dirty_ && uploaded_rows_ == n_) lane = tryLane();
+        if (!lane) gpu_lock.lock();
+    }
+    struct LaneRelease {
+        Lane *l;
+        ~LaneRelease() {
+            if (l) l->mu.unlock();
+        }
+    } lane_release{lane};
+    vsgpu_graph *gr = graph_;
+    vsgpu_table *tbl = table_;
+    if (lane) {
+        vsgpu_table_view_sync(lane->view);
+        gr = lane->graph;
+        tbl = lane->view;
+    }
     void *tctx = qp ? qp->timeoutCtx : nullptr;
-    last_mode_ = STANDARD_KNN;
+    if (!lane) last_mode_ = STANDARD_KNN;
     if (nq == 0) return 0;
     std::vector<VecSimQueryReply *> reps(nq);
     for (auto &r : reps) r = new VecSimQueryReply();
@@ -638,8 +688,10 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
     std::vector<uint64_t> labs(nq * k_eff);
     std::vector<double> sc(nq * k_eff);
     std::vector<uint32_t> cnt(nq);
-    int rc = syncDevice();
-    if (!rc) rc = vsgpu_graph_search(graph_, qsrc, nq, qstride, k_eff, ef, labs.data(), sc.data(), cnt.data(), &last_dist_evals_);
+    int rc = lane ? 0 : syncDevice();
+    uint64_t evals = 0;
+    if (!rc) rc = vsgpu_graph_search(gr, qsrc, nq, qstride, k_eff, ef, labs.data(), sc.data(), cnt.data(), &evals);
+    last_dist_evals_ = evals;
     if (rc == VSGPU_ERR_UNSUPPORTED) {
         // ef beyond what the per-query LDS heaps hold (about 1.3 K at dim 768): the graph walk cannot be replayed, so
         // the batch is answered by the exact GPU scan of the table -- the k best live vectors, a reply at least as good
@@ -651,16 +703,16 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         using Item = std::pair<double, size_t>;
         for (size_t q = 0; q < nq; q++) {
             const char *qp1 = (const char *)qsrc + q * qstride;
-            rc = vsgpu_topk(table_, qp1, 1, qstride, kk, cap, ids.data(), s1.data(), c1.data());
+            rc = vsgpu_topk(tbl, qp1, 1, qstride, kk, cap, ids.data(), s1.data(), c1.data());
             std::vector<double> all;
             if (!rc && c1[0] == VSGPU_COUNT_OVERFLOW) {  // massive ties at the kk-th score: every row's score
                 all.resize(n_);
-                rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
+                rc = vsgpu_scores(tbl, qp1, 0, n_, all.data());
             }
             if (rc) break;
             if (multi_ && all.empty()) {   // the k best LABELS need every row's score (a label's best row may rank anywhere)
                 all.resize(n_);
-                rc = vsgpu_scores(table_, qp1, 0, n_, all.data());
+                rc = vsgpu_scores(tbl, qp1, 0, n_, all.data());
                 if (rc) break;
             }
             RefMaxHeap<Item> heap;
@@ -737,9 +789,27 @@ VecSimQueryReply *HnswIndex::topKQuery(const void *query, size_t k, VecSimQueryP
 // rangeQuery (hnsw.h:2153-2187): greedy descent to the bottom-layer entry point, then the epsilon-bounded
 // range search, both on the GPU (k_hnsw_search in range mode); the reply is then ordered like every range reply.
 VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
-    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);  // readers may call concurrently (vec_sim.h contract)
+    std::unique_lock<std::recursive_mutex> gpu_lock(gpu_mu_, std::defer_lock);   // (reader lanes as in topKQueryBatch)
+    Lane *lane = nullptr;
+    if (!gpu_lock.try_lock()) {
+        if (!graph_dirty_ && uploaded_rows_ == n_) lane = tryLane();
+        if (!lane) gpu_lock.lock();
+    }
+    struct LaneRelease {
+        Lane *l;
+        ~LaneRelease() {
+            if (l) l->mu.unlock();
+        }
+    } lane_release{lane};
+    vsgpu_graph *gr = graph_;
+    vsgpu_table *tbl = table_;
+    if (lane) {
+        vsgpu_table_view_sync(lane->view);
+        gr = lane->graph;
+        tbl = lane->view;
+    }
     auto *rep = new VecSimQueryReply();
-    last_mode_ = RANGE_QUERY;
+    if (!lane) last_mode_ = RANGE_QUERY;
     if (n_ == 0) return rep;
     void *tctx = qp ? qp->timeoutCtx : nullptr;
     if (timed_out(tctx)) {
@@ -749,7 +819,7 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     double eps = epsilon_;
     if (qp && qp->hnswRuntimeParams.epsilon != 0.0) eps = qp->hnswRuntimeParams.epsilon;
     std::vector<char> qbuf = preprocess(query);
-    if (syncDevice()) {
+    if (!lane && syncDevice()) {
         std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
         return rep;
     }
@@ -760,7 +830,10 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     for (;;) {
         labs.resize(cap);
         sc.resize(cap);
-        if (vsgpu_graph_range(graph_, qbuf.data(), 1, blob_bytes_, radius, eps, cap, labs.data(), sc.data(), &cnt, &last_dist_evals_)) {
+        uint64_t evals = 0;
+        const int rrc = vsgpu_graph_range(gr, qbuf.data(), 1, blob_bytes_, radius, eps, cap, labs.data(), sc.data(), &cnt, &evals);
+        last_dist_evals_ = evals;
+        if (rrc) {
             std::fprintf(stderr, "vecsim_amd: GPU HNSW range query failed: %s\n", vsgpu_last_error());
             return rep;
         }
@@ -778,7 +851,7 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
         std::vector<uint32_t> ids(n_);
         std::vector<double> s2(n_);
         uint32_t c2 = 0;
-        if (vsgpu_range(table_, qbuf.data(), radius, n_, ids.data(), s2.data(), &c2) || c2 == VSGPU_COUNT_OVERFLOW) return rep;
+        if (vsgpu_range(tbl, qbuf.data(), radius, n_, ids.data(), s2.data(), &c2) || c2 == VSGPU_COUNT_OVERFLOW) return rep;
         for (uint32_t i = 0; i < c2; i++)
             if (!deleted_[ids[i]]) rep->results.push_back(VecSimQueryResult{(size_t)labels_[ids[i]], s2[i]});
     } else {

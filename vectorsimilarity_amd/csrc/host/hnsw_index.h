@@ -72,7 +72,8 @@ public:
         const uint64_t *labels;
     };
     Export exportGraph();
-    uint64_t lastDistanceEvals() const { return last_dist_evals_; }
+    uint64_t lastDistanceEvals() const { return last_dist_evals_.load(); }
+    std::vector<vsgpu_ctx *> gpus() override;
 
 private:
     HnswIndex() = default;
@@ -119,8 +120,8 @@ private:
     int tier_ = 0;
     vsgpu_table *table_ = nullptr;
     vsgpu_graph *graph_ = nullptr;
-    size_t uploaded_rows_ = 0;
-    bool graph_dirty_ = true;
+    std::atomic<size_t> uploaded_rows_{0};   // (atomics: a reader looking for a lane peeks at these without the lock)
+    std::atomic<bool> graph_dirty_{true};
 
     // graph
     size_t n_ = 0, n_deleted_ = 0;
@@ -142,9 +143,20 @@ private:
     size_t node_lock_n_ = 0;
     std::mutex entry_mu_;
 
-    // one GPU context (staging buffers, stream) per index: concurrent readers take turns
+    // the index's own GPU context (staging buffers, stream) plus reader lanes: a reader that finds it busy searches through a
+    // view of the same snapshot -- own stream, query staging, visited tags and result buffers (vsgpu_graph_view_create) -- so one
+    // reader's query staging, download and reply construction overlap with the other's search kernel (the reference lets any
+    // number of readers in: bindings.cpp:250-283)
+    struct Lane {
+        std::mutex mu;
+        vsgpu_ctx *ctx = nullptr;
+        vsgpu_table *view = nullptr;
+        vsgpu_graph *graph = nullptr;
+    };
+    std::vector<std::unique_ptr<Lane>> lanes_;
+    Lane *tryLane();
     mutable std::recursive_mutex gpu_mu_;
-    uint64_t last_dist_evals_ = 0;
+    std::atomic<uint64_t> last_dist_evals_{0};
     mutable VecSearchMode last_mode_ = EMPTY_MODE;
 };
 

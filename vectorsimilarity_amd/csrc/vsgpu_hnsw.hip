@@ -7,6 +7,9 @@ using namespace vsg;
 // ------------------------------------------------------------------ HNSW graph snapshot + search
 struct vsgpu_graph {
     vsgpu_table *t = nullptr;
+    // non-null: a view for another reader (vsgpu_graph_view_create): the snapshot -- links, deletion marks, labels, entry point --
+    // is the parent's; visited tags, result buffers, query staging and the stream are this view's own (its table is a view too)
+    vsgpu_graph *parent = nullptr;
     uint32_t M = 16, M0 = 32;
     int multi = 0;   // labels may repeat: the search keeps one entry per label (vsgpu_graph_set_multi)
     size_t n = 0;
@@ -30,6 +33,18 @@ extern "C" vsgpu_graph *vsgpu_graph_create(vsgpu_table *t, size_t M) {
     g->M0 = (uint32_t)(2 * M);
     return g;
 }
+extern "C" vsgpu_graph *vsgpu_graph_view_create(vsgpu_graph *parent, vsgpu_table *view_table) {
+    if (!parent || parent->parent || !view_table || view_table->parent != parent->t) {
+        fail(VSGPU_ERR_ARG, "graph view: needs a graph and a view of its table");
+        return nullptr;
+    }
+    vsgpu_graph *g = new vsgpu_graph();
+    g->t = view_table;
+    g->parent = parent;
+    g->M = parent->M;
+    g->M0 = parent->M0;
+    return g;
+}
 extern "C" void vsgpu_graph_set_multi(vsgpu_graph *g, int multi) {
     if (g) g->multi = multi ? 1 : 0;
 }
@@ -39,12 +54,13 @@ extern "C" void vsgpu_graph_destroy(vsgpu_graph *g) {
     (void)hipStreamSynchronize(g->t->ctx->stream);
     for (DevBuf *b : {&g->links0, &g->cnt0, &g->upper_off, &g->upper, &g->deleted, &g->labels, &g->tags, &g->slot_epoch,
                       &g->out_labels, &g->out_scores, &g->out_counts, &g->stat})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) (void)hipFree(b->p);   // (a view never allocated the snapshot buffers)
     delete g;
 }
 extern "C" int vsgpu_graph_upload(vsgpu_graph *g, size_t n, const uint32_t *links0, const uint16_t *cnt0,
                                   const uint32_t *upper_off, const uint32_t *upper, size_t upper_words,
                                   const uint8_t *deleted, const uint64_t *labels, uint32_t entry, int max_level) {
+    if (g->parent) return fail(VSGPU_ERR_ARG, "graph upload through a view");
     vsgpu_ctx *c = g->t->ctx;
     HIPCHK(hipSetDevice(c->device));
     if (n > g->t->n) return fail(VSGPU_ERR_ARG, "graph has %zu nodes but the table holds %zu rows", n, g->t->n);
@@ -85,9 +101,10 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
                      uint64_t *labels, double *scores, uint32_t *counts, uint64_t *dist_evals) {
     vsgpu_table *t = g->t;
     vsgpu_ctx *c = t->ctx;
+    const vsgpu_graph *snap = g->parent ? g->parent : g;   // whose links / marks / labels / entry point are searched
     if (dist_evals) *dist_evals = 0;
     if (nq == 0) return VSGPU_OK;
-    if (k == 0 || g->n == 0 || g->entry == 0xFFFFFFFFu) {
+    if (k == 0 || snap->n == 0 || snap->entry == 0xFFFFFFFFu) {
         for (size_t q = 0; q < nq; q++) counts[q] = 0;
         return VSGPU_OK;
     }
@@ -115,8 +132,8 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     if (lds > 64 * 1024) return fail(VSGPU_ERR_UNSUPPORTED, "ef %zu / dim %zu need %zu B of LDS per query", ef, t->dim, lds);
     // resident search waves = tag slots
     const size_t slots = std::min<size_t>(nq, (size_t)c->n_cu * (size_t)c->opt_hnsw_slots);
-    if (slots > g->tag_slots || g->n > g->tag_n) {
-        const size_t ns = std::max(slots, g->tag_slots), nn = std::max(g->n, g->tag_n);
+    if (slots > g->tag_slots || snap->n > g->tag_n) {
+        const size_t ns = std::max(slots, g->tag_slots), nn = std::max(snap->n, g->tag_n);
         // grow with headroom on the node axis: the graph usually keeps growing between searches
         const size_t nn2 = std::max(nn, g->tag_n + g->tag_n / 2);
         if ((rc = ensure(c, g->tags, ns * nn2 * 2))) return rc;
@@ -145,17 +162,17 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     P.epilogue = t->epi;
     P.norm_off = (uint32_t)t->dim;
     P.qnorm = (const float *)c->qnorm.p;
-    P.links0 = (const uint32_t *)g->links0.p;
-    P.cnt0 = (const uint16_t *)g->cnt0.p;
-    P.upper_off = (const uint32_t *)g->upper_off.p;
-    P.upper = (const uint32_t *)g->upper.p;
-    P.deleted = (const uint8_t *)g->deleted.p;
-    P.labels = (const uint64_t *)g->labels.p;
+    P.links0 = (const uint32_t *)snap->links0.p;
+    P.cnt0 = (const uint16_t *)snap->cnt0.p;
+    P.upper_off = (const uint32_t *)snap->upper_off.p;
+    P.upper = (const uint32_t *)snap->upper.p;
+    P.deleted = (const uint8_t *)snap->deleted.p;
+    P.labels = (const uint64_t *)snap->labels.p;
     P.M0 = g->M0;
     P.M = g->M;
-    P.entry = g->entry;
-    P.max_level = g->max_level;
-    P.multi = g->multi;
+    P.entry = snap->entry;
+    P.max_level = snap->max_level;
+    P.multi = snap->multi;
     P.n = (uint32_t)g->tag_n;  // tag row pitch
     P.tags = (uint16_t *)g->tags.p;
     P.slot_epoch = (uint32_t *)g->slot_epoch.p;
