@@ -719,6 +719,15 @@ def test_reply_objects_and_array_entry_points_agree():
     ("f16", "L2", 8192, 2_500, 9, 10),
     ("bf16", "L2", 8191, 2_100, 16, 5),
     ("bf16", "IP", 6000, 2_000, 12, 10),        # width 6144 with one 16-query block (a batch of at most 16)
+    # int8 / uint8 rows of 4097 .. 16384 elements: the k-split filter on the stored bytes (k_mfma_filter_wide<.., EK = 3 | 4>),
+    # widths 6144 / 8192 / 12288 / 16384 -- these rows ran on the exact kernels (32-100 GB/s) before round 4
+    ("i8", "L2", 4097, 3_001, 20, 10),
+    ("i8", "Cosine", 8192, 2_000, 33, 10),
+    ("i8", "IP", 16384, 1_500, 17, 5),
+    ("i8", "L2", 12000, 1_200, 40, 10),         # width 12288 with 32 queries per workgroup
+    ("u8", "L2", 6144, 2_500, 16, 10),
+    ("u8", "IP", 8000, 2_000, 9, 10),
+    ("u8", "IP", 16384, 1_000, 64, 3),
     ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's exact query tile: 256 queries, top-100
     ("bf16", "IP", 768, 40_000, 128, 10),       # BASELINE config 4's exact query tile: 128 queries, top-10
 ])
@@ -733,6 +742,7 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     l1, d1 = ix.knn_query(q, k)
     st = ix.stats()
     assert st["scan_kernel"].startswith(("k_mfma_filter_wide(h16)",) if typ in ("bf16", "f16") and dim > 2048
+                                        else ("k_mfma_filter_wide(i8)",) if typ in ("i8", "u8") and dim > 4096
                                         else ("k_mfma_filter_lowp", "k_i8_filter_x32")), st
     # ints are heavy on exact ties (integer scores): the candidate lists may legitimately overflow
     if typ not in ("i8", "u8"):

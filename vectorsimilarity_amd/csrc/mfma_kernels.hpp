@@ -110,6 +110,7 @@ struct MfmaParams {
     float cE;                        // E = cE * (|x|^2 + |q|^2) + absE
     float absE;
     int is_l2;                       // 1: a = nx2 + nq2 - 2 dot ; 0: a = 1 - dot
+    int iepi;                        // k_mfma_filter_wide on int8 / uint8 rows: 2 = L2, 3 = IP, 4 = Cosine, 5 = uint8 IP (LowpEpi values)
     float *tilemin;                  // MF_PROBE: [q_tiles*64][tilemin_stride]
     size_t tilemin_stride;
     const float *tau;                // MF_FILTER: [q_tiles*64] (-inf for padding queries)

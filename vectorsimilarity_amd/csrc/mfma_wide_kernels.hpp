@@ -1,5 +1,7 @@
 // mfma_wide_kernels.hpp -- the MFMA filter for rows wider than the other filters' registers hold: fp32 3072 < dim <= 8192
-// (EK = 0), bf16 / fp16 2048 < dim <= 8192 (EK = 1 / 2: the stored elements are the MFMA operands, a stage holds 512 of them).
+// (EK = 0), bf16 / fp16 2048 < dim <= 8192 (EK = 1 / 2: the stored elements are the MFMA operands, a stage holds 512 of them),
+// int8 / uint8 4096 < dim <= 16384 (EK = 3 / 4: v_mfma_i32_16x16x64_i8 on the stored bytes, a stage holds 1024 of them; the
+// int32 dot is exact, so the epilogue applies the reference's own score -- IP/...VNNI_INT8.h:11-76 -- and nothing is re-ranked).
 //
 // k_mfma_filter keeps the bf16 fragments of 64 queries in registers (16 per wave); at dim 4096 those alone are the whole
 // register file of a CU.  This variant keeps 16 queries per WORKGROUP and splits the row's k range over the four waves by
@@ -12,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "mfma_kernels.hpp"
 
@@ -40,10 +44,13 @@ __device__ static inline void mfw_wait_vmcnt(int n) {
 template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RT = 16;
-    constexpr int EB = EK == 0 ? 4 : 2;              // bytes per stored element
-    constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) elements per row per stage
+    constexpr bool INT8 = EK >= 3;
+    constexpr int EB = EK == 0 ? 4 : (INT8 ? 1 : 2);   // bytes per stored element
+    constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) / 1024 (int8, uint8) elements per row per stage
     constexpr int SEG = KC * EB;                     // 1 KiB
-    constexpr int KSUB = KC / 32;                    // 8 / 16 MFMA k-steps per stage
+    constexpr int KSUB = KC / (INT8 ? 64 : 32);      // 8 / 16 / 16 MFMA k-steps per stage
+    typedef int i32x4w_t __attribute__((ext_vector_type(4)));
+    using acc_v = typename std::conditional<INT8, i32x4w_t, f32x4_t>::type;
     static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
     constexpr int KCH = KSTEPS / KSUB;               // stages per row tile (wave w takes stages w, w + 4, ...)
     constexpr int KMINE = ((KCH + 3) / 4) * KSUB;    // k-steps of one wave (the last quadruple may be short)
@@ -162,9 +169,9 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         pm_n = 0;
     };
     for (; tile < P.n_tiles; tile += step) {
-        f32x4_t acc[NQ];
+        acc_v acc[NQ];
 #pragma unroll
-        for (int nt = 0; nt < NQ; nt++) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NQ; nt++) acc[nt] = acc_v{0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
             {   // unit (tile, c) landed; the NS - 2 younger units (4 loads each, + the norm load of a unit that opens a tile) may be in flight
@@ -190,7 +197,17 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                 const char *sbase = lds + slot_c * MF_STAGE_BYTES;
 #pragma unroll
                 for (int j = 0; j < KSUB; j++) {
-                    if constexpr (EK == 0) {
+                    if constexpr (INT8) {
+                        // 8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride
+                        // the signed MFMA re-centred by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
+                        const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
+                        const int p = (4 * (j % 4) + kq) ^ m16;
+                        mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+                        if constexpr (EK == 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+#pragma unroll
+                        for (int nt = 0; nt < NQ; nt++)
+                            acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][(c / 4) * KSUB + j]), acc[nt], 0, 0, 0);
+                    } else if constexpr (EK == 0) {
                         const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
                         const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
                         const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
@@ -242,24 +259,41 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                              : "=&v"(p1), "=&v"(p2), "=&v"(p3)
                              : "v"(red_off + (uint32_t)(nt * MFW_RED_BYTES + lane * 16))
                              : "memory");
-                f32x4_t a4 = acc[nt];
-                a4 += __builtin_bit_cast(f32x4_t, p1);
-                a4 += __builtin_bit_cast(f32x4_t, p2);
-                a4 += __builtin_bit_cast(f32x4_t, p3);
+                acc_v a4 = acc[nt];
+                a4 += __builtin_bit_cast(acc_v, p1);
+                a4 += __builtin_bit_cast(acc_v, p2);
+                a4 += __builtin_bit_cast(acc_v, p3);
                 float tmin = INFINITY;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t row = r0 + kq * 4 + i;
-                    const float ssum = n4[i] + nq2[nt];
-                    const float dot = a4[i];
-                    const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
-                    const float E = P.cE * ssum + P.absE;
+                    float low, up;
+                    bool pass;
+                    if constexpr (INT8) {
+                        // exact integer dot: the reference's own score (mfma_lowp_kernels.hpp has the same four epilogues); aux =
+                        // sum x^2 (L2; of the re-centred bytes for uint8), sum x' (uint8 IP) or the stored float norm (Cosine)
+                        const int dot = (int)a4[i];
+                        const uint32_t av = nbits[i], qa = __float_as_uint(nq2[nt]);
+                        float sc;
+                        if (P.iepi == 2) sc = (float)((int)av + (int)qa - 2 * dot);
+                        else if (P.iepi == 3) sc = (float)(1 - dot);
+                        else if (P.iepi == 5) sc = (float)(1 - (dot + 128 * (int)av + (int)qa));
+                        else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qa))));
+                        low = up = sc;
+                        pass = sc <= tau[nt];
+                    } else {
+                        const float ssum = n4[i] + nq2[nt];
+                        const float dot = (float)a4[i];
+                        const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
+                        const float E = P.cE * ssum + P.absE;
+                        low = a - E;
+                        up = a + E;
+                        pass = !(low > tau[nt]);
+                    }
                     if (MODE == MF_PROBE) {
-                        const float up = a + E;
                         if (row < P.n_rows && up < tmin) tmin = up;
                     } else {
-                        const float low = a - E;
-                        if (row < P.n_rows && !(low > tau[nt])) {
+                        if (row < P.n_rows && pass) {
                             const uint32_t pos = mf_queue_reserve(eq_n_off);
                             if (pos < MF_EQ_CAP) {
                                 mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));

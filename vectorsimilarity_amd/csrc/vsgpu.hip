@@ -309,6 +309,21 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_qtile = 128;
             t->aux_bytes = 16;
         }
+        if ((type == VSGPU_I8 || type == VSGPU_U8) && dim > 4096 && dim <= 16384 && !(type == VSGPU_U8 && metric == VSGPU_COSINE)) {
+            // the k-split filter (mfma_wide_kernels.hpp, EK = 3 / 4): 16 (or 32) queries per workgroup, 1 KiB of the row per ring
+            // stage and wave.  uint8 Cosine needs two per-row values and stays on the exact kernels at these widths.
+            static const int ww[] = {96, 128, 192, 256};
+            for (int i = 0; i < 4; i++)
+                if ((size_t)ww[i] * 64 >= dim) {
+                    t->lowp_ok = true;
+                    t->lp_wide = true;
+                    t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;
+                    t->lp_ksteps = ww[i];
+                    t->lp_rt = 16;
+                    t->lp_qtile = 16;
+                    break;
+                }
+        }
         if ((type == VSGPU_I8 || type == VSGPU_U8) && dim > 1024 && dim <= 4096) {
             // widths 2048 / 3072: 8 waves x 16 queries (128 / 192 registers of fragments per wave), 16-row tiles, a 128-query
             // tile; width 4096: 4 waves x 16 queries, the 64 fragments of a wave in AGPRs, a 64-query tile

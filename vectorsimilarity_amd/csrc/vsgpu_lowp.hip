@@ -277,7 +277,14 @@ static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const
     P.counts = L.counts;
     P.cand = L.cand;
     P.cap = L.cap;
-    if (t->lp_kind == LP_BF16) {
+    P.iepi = L.epi;
+    if (t->lp_kind == LP_I8) {   // int8 / uint8 rows of 4097 .. 16384 elements: exact integer scores, no re-rank
+        if (mode == MF_PROBE) launch_wide_h16_m<3, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
+        else launch_wide_h16_m<3, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
+    } else if (t->lp_kind == LP_U8) {
+        if (mode == MF_PROBE) launch_wide_h16_m<4, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
+        else launch_wide_h16_m<4, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
+    } else if (t->lp_kind == LP_BF16) {
         if (mode == MF_PROBE) launch_wide_h16_m<1, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
         else launch_wide_h16_m<1, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
     } else {
@@ -646,7 +653,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
-                              is_sq8 ? "k_mfma_filter_lowp(sq8)" : t->lp_wide ? "k_mfma_filter_wide(h16)" : !is_int ? "k_mfma_filter_lowp(h16)"
+                              is_sq8 ? "k_mfma_filter_lowp(sq8)" : (t->lp_wide && is_int) ? "k_mfma_filter_wide(i8)" : t->lp_wide ? "k_mfma_filter_wide(h16)" : !is_int ? "k_mfma_filter_lowp(h16)"
                               : (tuning_ksplit_on(c) && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
                               : x32 ? "k_i8_filter_x32" : "k_mfma_filter_lowp(i8)", &chain);
 }
