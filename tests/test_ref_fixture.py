@@ -117,3 +117,37 @@ def test_oracle_scalar_tier_equals_the_live_reference_on_more_dims(vso):
     a = refgen.compute_sq8(vsref, (9, 100, 257, 1536))
     b = refgen.compute_sq8(OracleScalar(vso), (9, 100, 257, 1536))
     _diff("live sq8", b, a, key=lambda e: (e["kind"], e["metric"], e["dim"]))
+
+
+def test_product_merge_replays_like_the_reference_containers(fixture):
+    """the PRODUCT's host replay (libvecsim_amd.so: VecSimGpu_MergeTopK -> merge_topk over RefMaxHeap, host/ref_heap.h; no GPU
+    involved) on the fixture's tie-heavy score streams: labels, order and scores equal what the reference's own
+    max_priority_queue produced.  (NaN streams take the every-row replay of a live index: tests/test_gpu_flat_parity.py.)"""
+    from vectorsimilarity_amd.sharded import merge_topk
+    n_checked = 0
+    for e in fixture["topk"]:
+        n, k, levels, multi, wide, nan_every, distinct = e["case"]
+        if multi or nan_every:
+            continue
+        scores, labels = refgen.topk_inputs(tuple(e["case"]))
+        if not wide:
+            scores = scores.astype(np.float32).astype(np.float64)
+        kk = min(k, n)
+        # two "shards": even and odd ids, as a sharded index would hold them; gid = id
+        for parts in (1, 2):
+            cap = n
+            gids = np.zeros((parts, 1, cap), dtype=np.uint64)
+            labs = np.zeros((parts, 1, cap), dtype=np.uint64)
+            scs = np.zeros((parts, 1, cap), dtype=np.float64)
+            counts = np.zeros((parts, 1), dtype=np.uint32)
+            for p in range(parts):
+                ids = np.arange(p, n, parts)
+                counts[p, 0] = len(ids)
+                gids[p, 0, :len(ids)] = ids
+                labs[p, 0, :len(ids)] = labels[ids]
+                scs[p, 0, :len(ids)] = scores[ids]
+            ol, osc = merge_topk(counts, gids, labs, scs, kk)
+            assert [int(x) for x in ol[0]] == e["labels"], (e["case"], parts)
+            assert refgen.hexbits(osc[0]) == e["scores"], (e["case"], parts)
+        n_checked += 1
+    assert n_checked >= 8

@@ -52,8 +52,14 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     typedef int i32x4w_t __attribute__((ext_vector_type(4)));
     using acc_v = typename std::conditional<INT8, i32x4w_t, f32x4_t>::type;
     static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
-    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile (wave w takes stages w, w + 4, ...)
-    constexpr int KMINE = ((KCH + 3) / 4) * KSUB;    // k-steps of one wave (the last quadruple may be short)
+    constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
+    // Which k-steps a wave multiplies.  Round 3 dealt whole STAGES (wave w took the stages c with c % 4 == w): one wave worked
+    // per unit while three sat in the barrier, and the unit period -- that wave's 8-16 k-steps -- bounded a workgroup at
+    // ~21 GB/s.  Now every wave works in every unit: wave w takes the k-steps j with j % 4 == w of each stage, a quarter of
+    // the unit's work each, the same number of fragments per wave (KSTEPS / 4, no short last quadruple).
+    constexpr int KPW = KSUB / 4;                    // k-steps per wave per stage: 2 (fp32) or 4
+    static_assert(KSUB % 4 == 0, "a stage's k-steps are dealt over the four waves");
+    constexpr int KMINE = KCH * KPW;                 // k-steps (= fragments per query block) of one wave
     static_assert(NS - 1 <= KCH && (NS - 2) * 4 + 2 <= 33, "requests reach into the next tile at most");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -73,8 +79,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         const uint4 *src = P.qfrag + ((size_t)(qtile * NQ + nt) * KSTEPS) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
-            const int st = (i / KSUB) * 4 + wave;   // (a stage past the row's last: never multiplied)
-            const int s = (st < KCH ? st : 0) * KSUB + (i % KSUB);
+            const int s = (i / KPW) * KSUB + (i % KPW) * 4 + wave;   // stage i / KPW, its k-step (i % KPW) * 4 + wave
             uint4 v = src[(size_t)s * 64];
             qf[nt][i] = __builtin_bit_cast(bf16x8_t, v);
         }
@@ -193,10 +198,12 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                 if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
                 else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, parity ^ 1u);
             }
-            if ((c & 3) == wave) {   // this wave's stage
+            {   // this wave's k-steps of the stage
                 const char *sbase = lds + slot_c * MF_STAGE_BYTES;
 #pragma unroll
-                for (int j = 0; j < KSUB; j++) {
+                for (int jj = 0; jj < KPW; jj++) {
+                    const int j = jj * 4 + wave;
+                    const int fi = c * KPW + jj;   // the fragment of (stage c, k-step j)
                     if constexpr (INT8) {
                         // 8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride
                         // the signed MFMA re-centred by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                         if constexpr (EK == 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
                         for (int nt = 0; nt < NQ; nt++)
-                            acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][(c / 4) * KSUB + j]), acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
                     } else if constexpr (EK == 0) {
                         const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
                         const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                         bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
 #pragma unroll
                         for (int nt = 0; nt < NQ; nt++)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][(c / 4) * KSUB + j], acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][fi], acc[nt], 0, 0, 0);
                     } else {
                         // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
                         // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
                         for (int nt = 0; nt < NQ; nt++) {
                             if constexpr (EK == 1)
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][(c / 4) * KSUB + j], acc[nt], 0, 0, 0);
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][fi], acc[nt], 0, 0, 0);
                             else
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][(c / 4) * KSUB + j]), acc[nt], 0, 0, 0);
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][fi]), acc[nt], 0, 0, 0);
                         }
                     }
                 }

@@ -306,10 +306,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                      t->lp_rt == 32 && t->lp_qtile == X32_QT && !c->opt_lowp_variant && !c->opt_lowp_dbg
                      && !tuning_ksplit_on(c)
         ;
-    // k_mfma_filter_wide: 32 queries per workgroup at width 6144 (6 GB of bf16 rows, batch 64: 3.04 -> 2.03 ms); at widths 3072 / 4096
-    // four 16-query tiles sharing the rows through L2 measured faster than two 32-query tiles (1.90 against 2.16 ms); option
-    // wide_blocks: 1 = 16 everywhere, 2 = 32 wherever the registers allow
-    const int wide_blocks = (t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && (KS == 192 || (c->opt_wide_blocks == 2 && KS < 192))) ? 2 : 1;
+    // k_mfma_filter_wide: 32 queries per workgroup wherever the registers allow (every width but the widest: 2 x KSTEPS / 4 fragments
+    // per wave).  Since every wave works in every unit (round 4) two 32-query tiles beat four 16-query ones at every width
+    // (bf16 3072 / 4096, batch 64: 3.04 / 3.19 -> 4.15 / 4.55 TB/s; int8 6144 / 8192: 3.05 / 3.26 -> 3.73 / 4.04); option
+    // wide_blocks = 1: 16 everywhere
+    const int wide_blocks = (t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && KS <= 192) ? 2 : 1;
     const size_t QT = t->lp_wide ? (size_t)16 * wide_blocks : hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
