@@ -225,7 +225,22 @@ def test_multi_value_index_across_shards(vso, typ, metric, dim, G):
         gl, gs = sx.knn_query(q, k)
         sl, ss = one.knn_query(q, k)
         assert np.array_equal(gl, sl) and np.array_equal(gs, ss), (typ, metric, k)
-    assert sx.delete_vector(int(labels[0])) == -1   # (label-wise deletes across shards are not built: refused, nothing changes)
+    # label-wise deletes (brute_force_multi.h:133-150): every vector of the label goes, one swap-delete of the equivalent single
+    # index at a time -- rows cross shards on the way -- and the two indexes keep giving the same replies, ties included
+    for lab in [int(labels[0]), int(labels[17]), int(labels[n - 1]), 10 ** 9]:
+        want = int(np.sum(labels == lab))
+        assert sx.delete_vector(lab) == one.delete_vector(lab) == want
+        assert sx.index_size() == one.index_size()
+        labels = labels.copy()
+        labels[labels == lab] = -1
+        for k in (10, 300):
+            gl, gs = sx.knn_query(q, k)
+            sl, ss = one.knn_query(q, k)
+            assert np.array_equal(gl, sl) and np.array_equal(gs, ss), (typ, metric, lab, k)
+    # and new vectors after the deletes land where the single index puts them
+    extra = random_vectors(rng, 50, dim, typ, vso)
+    sx.add_vectors(extra, np.arange(50) % 7)
+    one.add_vectors(extra, np.arange(50) % 7)
     gl, gs = sx.knn_query(q, 10)
     sl, ss = one.knn_query(q, 10)
     assert np.array_equal(gl, sl) and np.array_equal(gs, ss)

@@ -456,9 +456,29 @@ int FlatIndex::readRows(uint32_t first, size_t n, void *stored_blobs) {
     if ((size_t)first + n > count_ || flush()) return -1;
     return vsgpu_table_read_range(table_, first, n, stored_blobs);
 }
+// (multi-value shards of a sharded index: a label's id list loses one entry / gains one; its order only matters to a local
+// deleteVector, which a sharded index never calls -- it deletes by global id)
+void FlatIndex::forgetIdOfLabel(size_t label, uint32_t id) {
+    auto f = label_to_ids_.find(label);
+    if (f == label_to_ids_.end()) return;
+    auto &v = f->second;
+    for (size_t i = v.size(); i-- > 0;)
+        if (v[i] == id) {
+            v.erase(v.begin() + (std::ptrdiff_t)i);
+            break;
+        }
+    if (v.empty()) label_to_ids_.erase(f);
+}
 int FlatIndex::overwriteRow(uint32_t id, const void *stored_blob, size_t new_label) {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
-    if (multi_ || id >= count_ || flush()) return -1;
+    if (id >= count_ || flush()) return -1;
+    if (multi_) {
+        forgetIdOfLabel(id_to_label_[id], id);
+        id_to_label_[id] = new_label;
+        label_to_ids_[new_label].push_back(id);
+        noteRow(id, stored_blob);
+        return vsgpu_table_write(table_, id, stored_blob);
+    }
     label_to_id_.erase(id_to_label_[id]);
     id_to_label_[id] = new_label;
     label_to_id_[new_label] = id;
@@ -467,8 +487,13 @@ int FlatIndex::overwriteRow(uint32_t id, const void *stored_blob, size_t new_lab
 }
 int FlatIndex::dropLastRow() {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
-    if (multi_ || count_ == 0 || flush()) return -1;
+    if (count_ == 0 || flush()) return -1;
     const uint32_t last = (uint32_t)(count_ - 1);
+    if (multi_) {
+        forgetIdOfLabel(id_to_label_[last], last);
+        removeRow(last);
+        return 0;
+    }
     auto f = label_to_id_.find(id_to_label_[last]);
     if (f != label_to_id_.end() && f->second == last) label_to_id_.erase(f);  // (relabelled elsewhere: keep that entry)
     removeRow(last);

@@ -148,6 +148,7 @@ public:
     // row-level operations for the sharded index (sharded_index.cpp), which replays the equivalent single index's
     // swap-delete (brute_force.h:196-224) across shards: the global last row moves into the hole
     int readRows(uint32_t first, size_t n, void *stored_blobs);                      // rows [first, first + n) by internal id
+    void forgetIdOfLabel(size_t label, uint32_t id);   // multi-value: drop one id from a label's list
     int readRow(uint32_t id, void *stored_blob);                                   // stored (preprocessed) bytes of a row
     int overwriteRow(uint32_t id, const void *stored_blob, size_t new_label);     // raw stored bytes, relabelled
     int dropLastRow();                                                             // forget the shard's last row

@@ -254,6 +254,7 @@ int ShardedIndex::addVector(const void *blob, size_t label) {
     }
     n_global_++;
     if (!params_.multi) label_to_gid_.emplace(label, gid);
+    else label_to_gids_[label].push_back(gid);
     gid_to_label_.push_back(label);
     return 1;
 }
@@ -278,15 +279,11 @@ long ShardedIndex::addSyntheticLocal(size_t rows_per_shard, uint64_t seed_base) 
     return (long)n_global_;
 }
 
-int ShardedIndex::deleteVector(size_t label) {
-    if (synthetic_rows_) return -1;
-    // every process takes the same decisions from the same state (SPMD): shards or transports that cannot move rows are
-    // refused before anything changes, and no process leaves between the collectives below on a locally evaluated condition
-    if (!shards_[0]->supportsRowOps() || (ex_ && !ex_->canBroadcast())) return -1;
-    if (params_.multi) return -1;   // (deleting a label's vectors one swap-delete at a time across shards: not built)
-    auto f = label_to_gid_.find(label);
-    if (f == label_to_gid_.end()) return 0;
-    const uint64_t hole = f->second, last = n_global_ - 1;
+// The swap-delete of ONE row of the equivalent single index (brute_force.h:196-224) across the shards: the last row moves into
+// the hole (from its owner to the hole's owner, status travelling with it), the outcome is agreed on with one 8-byte all-gather,
+// and only then do the maps move.  Every process makes the same call.
+int ShardedIndex::removeGid(uint64_t hole) {
+    const uint64_t last = n_global_ - 1;
     const size_t s_hole = plan_.owner(hole), s_last = plan_.owner(last);
     const size_t last_label = gid_to_label_[last];
     const size_t bytes = shards_[0]->storedBytes();
@@ -308,11 +305,48 @@ int ShardedIndex::deleteVector(size_t label) {
     if (failed) return -1;
     if (hole != last) {
         gid_to_label_[hole] = last_label;
-        label_to_gid_[last_label] = hole;
+        if (params_.multi) {   // replaceIdOfLabel (brute_force_multi.h:244-265): the LAST occurrence of the moved id
+            auto &v = label_to_gids_.at(last_label);
+            for (size_t i = v.size(); i-- > 0;)
+                if (v[i] == last) {
+                    v[i] = hole;
+                    break;
+                }
+        } else {
+            label_to_gid_[last_label] = hole;
+        }
     }
-    label_to_gid_.erase(label);
     gid_to_label_.pop_back();
     n_global_--;
+    return 0;
+}
+
+int ShardedIndex::deleteVector(size_t label) {
+    if (synthetic_rows_) return -1;
+    // every process takes the same decisions from the same state (SPMD): shards or transports that cannot move rows are
+    // refused before anything changes, and no process leaves between the collectives on a locally evaluated condition
+    if (!shards_[0]->supportsRowOps() || (ex_ && !ex_->canBroadcast())) return -1;
+    if (params_.multi) {
+        // brute_force_multi.h:133-150: every vector of the label goes, one swap-delete at a time, walking the label's id list
+        // while the removals rewrite its tail (a row of the same label may be the one that moves into a hole)
+        auto f = label_to_gids_.find(label);
+        if (f == label_to_gids_.end()) return 0;
+        int removed = 0;
+        for (size_t i = 0; i < f->second.size(); i++) {
+            if (removeGid(f->second[i])) return -1;
+            removed++;
+        }
+        label_to_gids_.erase(label);
+        return removed;
+    }
+    auto f = label_to_gid_.find(label);
+    if (f == label_to_gid_.end()) return 0;
+    const uint64_t hole = f->second;
+    label_to_gid_.erase(f);
+    if (removeGid(hole)) {
+        label_to_gid_.emplace(label, hole);   // nothing moved: the label is still there
+        return -1;
+    }
     return 1;
 }
 

@@ -122,6 +122,8 @@ private:
     size_t n_global_ = 0;
     size_t synthetic_rows_ = 0;  // > 0: filled by addSyntheticLocal (gid = shard * rows + local id, label = gid), append-only
     std::unordered_map<size_t, uint64_t> label_to_gid_;
+    std::unordered_map<size_t, std::vector<uint64_t>> label_to_gids_;   // multi-value: a label's rows, in the reference's list order
+    int removeGid(uint64_t hole);   // one swap-delete of the equivalent single index, across the shards
     std::vector<size_t> gid_to_label_;
     // exchange turns (seq order) and phase timers
     std::mutex turn_mu_;
