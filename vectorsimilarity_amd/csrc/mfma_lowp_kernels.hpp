@@ -282,6 +282,29 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         cosq[nt] = (omt - 1e-5f * (1.0f + fabsf(omt))) * __uint_as_float(qaux[nt]);
     }
 
+    // bf16 / fp16 rows, FILTER: whether ANY value of a tile survives is decided with two operations per value instead of six.
+    // The exact test keeps a value unless  a - E > tau,  a = (n + nq2) - 2 dot | 1 - dot,  E = cE (n + nq2) + absE  (n = the
+    // row's |x|^2).  Per query  fpq = tau + absE - nq2 (1 - cE)  |  (tau - 1) + cE nq2 + absE,  per row  rowt = n (1 - cE) | n cE,
+    // and the value is dropped when  rowt - 2 dot > fpq  |  -dot - rowt > fpq.  That form rounds differently from the exact
+    // one, so it is made strictly more permissive -- 2^-20 (16 ulp) of every magnitude involved on the keeping side -- and a
+    // tile it lets through runs the exact test as before: replies cannot change, only how rarely the slow path is entered.
+    float fpq[NQW];
+    float fp_rowc = 0.f;
+    if (MODE == MF_FILTER && !SQ8 && (LK == LP_BF16 || LK == LP_F16)) {
+        const bool l2q = P.epi == LE_FP_L2;
+        const float slk = 9.5367431640625e-07f;   // 2^-20
+        fp_rowc = l2q ? (1.0f - P.cE) - slk : P.cE + slk;
+#pragma unroll
+        for (int nt = 0; nt < NQW; nt++) {
+            const float nq2 = __uint_as_float(qaux[nt]);
+            const float tq = l2q ? (tau[nt] + P.absE) - nq2 * (1.0f - P.cE) : (tau[nt] - 1.0f) + (P.cE * nq2 + P.absE);
+            fpq[nt] = tau[nt] == -INFINITY ? -INFINITY : tq + slk * (fabsf(tau[nt]) + nq2 + 2.0f);   // (padding queries: tau = -inf)
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NQW; nt++) fpq[nt] = 0.f;
+    }
+
     // staging geometry: instruction g = wave*IPW + t fills LDS bytes [1024 g, 1024 g + 1024)
     uint32_t st_row[IPW], st_off[IPW];
     uint32_t st_row0[IPW], st_lane[IPW];   // UADDR: the piece's first row (uniform) and the lane's byte offset from that row's start
@@ -621,9 +644,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t av = auxv[mt][i];
+                        const float rowt = __uint_as_float(av) * fp_rowc;   // (fp kinds: see fpq above)
 #pragma unroll
                         for (int nt = 0; nt < NQW; nt++) {
-                            if (LK == LP_I8 || LK == LP_U8) {
+                            if (LK == LP_BF16 || LK == LP_F16) {
+                                const float dot = (float)acc[mt][nt][i];
+                                if (EPI == LE_FP_L2) any |= !(__builtin_fmaf(-2.0f, dot, rowt) > fpq[nt]);
+                                else any |= !((-dot - rowt) > fpq[nt]);
+                            } else if (LK == LP_I8 || LK == LP_U8) {
                                 const int dot = (int)acc[mt][nt][i];
                                 if (EPI == LE_I8_COS) any |= !((float)dot < cosq[nt] * __uint_as_float(av));
                                 else if (EPI == LE_I8_L2) any |= (float)((int)av + (int)qaux[nt] - 2 * dot) <= tau[nt];
