@@ -29,6 +29,7 @@ ap.add_argument("--slots", default="", help="comma list of hnsw_slots values to 
 ap.add_argument("--efs", default="", help="comma list of further efRuntime values: recall and QPS at each (same graph)")
 ap.add_argument("--threads", type=int, default=0, help="host linking threads (VECSIM_HNSW_BUILD_THREADS); 1 = the sequential insert path")
 ap.add_argument("--chunk", type=int, default=0, help="add the rows in chunks of this many (progress lines); 0 = one bulk call")
+ap.add_argument("--readers", type=int, default=0, help="also time this many reader threads, each submitting batches of --queries (reader lanes)")
 ap.add_argument("--exact-queries", type=int, default=0, help="recall on the first this-many queries only (0 = all)")
 a = ap.parse_args()
 if a.threads:
@@ -78,6 +79,19 @@ for sl in [int(x) for x in a.slots.split(",") if x]:
     print("hnsw_slots %d: %.2f ms per %d queries -> %.0f QPS" % (sl, tb * 1e3, a.queries, a.queries / tb), flush=True)
 evals = ix.last_distance_evals()
 st = ix.stats()
+if a.readers > 1:   # reader lanes: R threads, 6 batches each, against one thread answering the same 6 R batches
+    from concurrent.futures import ThreadPoolExecutor
+    nb = 6
+    t0 = time.perf_counter()
+    for _ in range(nb * a.readers):
+        ix.knn_query(q, a.k)
+    one = time.perf_counter() - t0
+    with ThreadPoolExecutor(a.readers) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(lambda t: [ix.knn_query(q, a.k) for _ in range(nb)], range(a.readers)))
+        many = time.perf_counter() - t0
+    print("readers: 1 thread %.0f QPS, %d threads %.0f QPS (x %.2f)" % (nb * a.readers * a.queries / one, a.readers,
+          nb * a.readers * a.queries / many, one / many), flush=True)
 bp = VecSim.BFParams()
 bp.type, bp.dim, bp.metric = VecSim.VecSimType_FLOAT32, a.dim, VecSim.VecSimMetric_L2
 bf = VecSim.BFIndex(bp)

@@ -470,6 +470,72 @@ static __global__ __launch_bounds__(256) void k_row_norms_f64(const char *rows, 
     if (lane == 0) out[row] = (float)s;   // (+inf beyond the float range: the bound turns NaN and the row goes to the re-rank)
 }
 
+// ---- stage 3: per-query selection among the exactly re-scored survivors ----
+// One workgroup per query: T = k-th smallest exact score (bitwise search over the order-preserving
+// integer image of the float), then every candidate with score <= T is compacted to out[q][...].
+// The host only sorts those few by id and replays the sequential heap.
+__device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
+    // unsigned order == float order; a NaN of either sign sorts after everything (a negative NaN -- 1 - NaN, 0 / 0 --
+    // would otherwise be the smallest key and become the k-th score nothing compares below)
+    if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
+    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+constexpr uint32_t SEL_LDS_KEYS = 8192;   // candidate keys kept in LDS for the 32 counting passes (the rest is re-read from L2)
+// one 256-thread workgroup selects query q: `keys` = KEYS words of LDS, nqs = number of queries (the raw counts sit behind the selected ones)
+template <uint32_t KEYS>
+__device__ __forceinline__ void select_upto_kth_body(uint32_t *keys, uint32_t (*red)[4], uint32_t *wpos, const uint2 *cand, const uint32_t *counts,
+                                                     uint32_t cap, uint32_t k, uint2 *out, uint32_t *out_counts, uint32_t out_cap, int q, uint32_t nqs) {
+    const uint32_t raw = counts[q];
+    if (threadIdx.x == 0) out_counts[nqs + q] = raw;   // the raw count rides along (statistics, "fewer than k" check)
+    // (a list that overflowed is selected from all the same: the k-th smallest exact score of the slots that were filled bounds
+    // the true k-th score from above, and the host runs one more filter pass with it -- collect_candidates; it knows from the
+    // raw count that the list is truncated)
+    const uint32_t n = min(raw, cap);
+    const uint2 *c = cand + (size_t)q * cap;
+    uint32_t T = 0xFFFFFFFFu;
+    if (n > k) {
+        const uint32_t nl = min(n, KEYS);
+        for (uint32_t i = threadIdx.x; i < nl; i += 256) keys[i] = float_sort_key(c[i].y);
+        __syncthreads();
+        T = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const uint32_t trial = T | (1u << bit);
+            uint32_t cnt = 0;
+            for (uint32_t i = threadIdx.x; i < nl; i += 256) cnt += (keys[i] < trial) ? 1u : 0u;
+            for (uint32_t i = nl + threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+            uint32_t *r = red[bit & 1];   // (alternating buffers: one barrier per pass)
+            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = cnt;
+            __syncthreads();
+            const uint32_t total = r[0] + r[1] + r[2] + r[3];
+            if (total < k) T = trial;  // fewer than k keys below `trial`: the k-th smallest has this bit set
+        }
+    }
+    if (threadIdx.x == 0) *wpos = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint2 r = c[i];
+        const uint32_t bits = r.y;
+        const bool is_nan = (bits & 0x7FFFFFFFu) > 0x7F800000u;
+        if (!is_nan && float_sort_key(bits) <= T) {
+            const uint32_t p = atomicAdd(wpos, 1u);
+            if (p < out_cap) out[(size_t)q * out_cap + p] = r;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = *wpos > out_cap ? 0xFFFFFFFFu : *wpos;
+}
+static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
+                                                         uint32_t k, uint2 *out, uint32_t *out_counts,
+                                                         uint32_t out_cap) {
+    __shared__ uint32_t keys[SEL_LDS_KEYS];
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t wpos;
+    select_upto_kth_body<SEL_LDS_KEYS>(keys, red, &wpos, cand, counts, cap, k, out, out_counts, out_cap, (int)blockIdx.x, gridDim.x);
+}
+
+
 // ---- stage 2: exact reference-order scores of the surviving (row, query) pairs ----
 // One VL-lane group per pair; pairs of query q are cand[q][0 .. min(counts[q], cap)).
 template <int EK, int OPK>
@@ -518,67 +584,27 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
             }
         }
     }
-}
-
-
-// ---- stage 3: per-query selection among the exactly re-scored survivors ----
-// One workgroup per query: T = k-th smallest exact score (bitwise search over the order-preserving
-// integer image of the float), then every candidate with score <= T is compacted to out[q][...].
-// The host only sorts those few by id and replays the sequential heap.
-__device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
-    // unsigned order == float order; a NaN of either sign sorts after everything (a negative NaN -- 1 - NaN, 0 / 0 --
-    // would otherwise be the smallest key and become the k-th score nothing compares below)
-    if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
-    return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
-}
-constexpr uint32_t SEL_LDS_KEYS = 8192;   // candidate keys kept in LDS for the 32 counting passes (the rest is re-read from L2)
-static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *cand, const uint32_t *counts, uint32_t cap,
-                                                         uint32_t k, uint2 *out, uint32_t *out_counts,
-                                                         uint32_t out_cap) {
-    __shared__ uint32_t keys[SEL_LDS_KEYS];
-    __shared__ uint32_t red[2][4];
-    __shared__ uint32_t wpos;
-    const int q = blockIdx.x;
-    const uint32_t raw = counts[q];
-    if (threadIdx.x == 0) out_counts[gridDim.x + q] = raw;   // the raw count rides along (statistics, "fewer than k" check)
-    // (a list that overflowed is selected from all the same: the k-th smallest exact score of the slots that were filled bounds
-    // the true k-th score from above, and the host runs one more filter pass with it -- collect_candidates; it knows from the
-    // raw count that the list is truncated)
-    const uint32_t n = min(raw, cap);
-    const uint2 *c = cand + (size_t)q * cap;
-    uint32_t T = 0xFFFFFFFFu;
-    if (n > k) {
-        const uint32_t nl = min(n, SEL_LDS_KEYS);
-        for (uint32_t i = threadIdx.x; i < nl; i += 256) keys[i] = float_sort_key(c[i].y);
-        __syncthreads();
-        T = 0;
-        for (int bit = 31; bit >= 0; bit--) {
-            const uint32_t trial = T | (1u << bit);
-            uint32_t cnt = 0;
-            for (uint32_t i = threadIdx.x; i < nl; i += 256) cnt += (keys[i] < trial) ? 1u : 0u;
-            for (uint32_t i = nl + threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-            uint32_t *r = red[bit & 1];   // (alternating buffers: one barrier per pass)
-            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = cnt;
+    if constexpr (EK != EK_F64) {
+        if (P.sel_done) {
+            // selection fused into the tail: every workgroup publishes its scores (release), takes a ticket, and the last one of
+            // the query (acquire: its L1 may hold lines of the list from before the others wrote) selects
+            __shared__ uint32_t f_keys[4096];
+            __shared__ uint32_t f_red[2][4];
+            __shared__ uint32_t f_wpos, f_last;
+            __threadfence();
             __syncthreads();
-            const uint32_t total = r[0] + r[1] + r[2] + r[3];
-            if (total < k) T = trial;  // fewer than k keys below `trial`: the k-th smallest has this bit set
+            if (threadIdx.x == 0) {
+                const uint32_t tk = atomicAdd(&P.sel_done[q], 1u);
+                f_last = tk == gridDim.x - 1 ? 1u : 0u;
+                if (f_last) P.sel_done[q] = 0;   // (self-resetting: zero again for the next launch)
+            }
+            __syncthreads();
+            if (f_last) {
+                __threadfence();
+                select_upto_kth_body<4096>(f_keys, f_red, &f_wpos, P.cand, P.counts, P.cap, P.sel_k, P.sel_out, P.sel_counts, P.sel_cap, q, gridDim.y);
+            }
         }
     }
-    if (threadIdx.x == 0) wpos = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint2 r = c[i];
-        const uint32_t bits = r.y;
-        const bool is_nan = (bits & 0x7FFFFFFFu) > 0x7F800000u;
-        if (!is_nan && float_sort_key(bits) <= T) {
-            const uint32_t p = atomicAdd(&wpos, 1u);
-            if (p < out_cap) out[(size_t)q * out_cap + p] = r;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) out_counts[q] = wpos > out_cap ? 0xFFFFFFFFu : wpos;
 }
 
 

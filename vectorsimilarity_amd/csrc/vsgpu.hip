@@ -136,7 +136,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock, &c->seldone})
         if (b->p && !b->alias) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -658,17 +658,25 @@ extern "C" int vsgpu_table_append_synthetic(vsgpu_table *t, size_t n, uint64_t s
 // ------------------------------------------------------------------ query staging
 
 // Build [nq][steps][vl] permuted/widened query images in pinned memory and upload them.
-int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride) {
+size_t staged_query_bytes(const vsgpu_table *t, size_t nq) { return nq * (size_t)t->prog.steps * t->prog.vl * acc_bytes(t->type); }
+// host_dst / dev_dst given: the images are written to host_dst and ctx->qperm becomes dev_dst -- a region of a block the CALLER
+// uploads (one copy per batch: vsgpu_mfma.hip); fp32 / fp64 / bf16 / fp16 tables only (no per-query metadata beside the images)
+int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, void *host_dst, void *dev_dst) {
     vsgpu_ctx *c = t->ctx;
     const LaneProgram &pg = t->prog;
     const size_t per_q = (size_t)pg.steps * pg.vl;
     const size_t ab = acc_bytes(t->type);
     const size_t bytes = nq * per_q * ab;
-    int rc = ensure_pinned(c, bytes + nq * 8);
-    if (rc) return rc;
-    rc = ensure(c, c->qperm, bytes);
-    if (rc) return rc;
-    char *dst = (char *)c->pinned;
+    int rc = VSGPU_OK;
+    if (host_dst) {
+        alias_into(c->qperm, dev_dst, bytes);
+    } else {
+        rc = ensure_pinned(c, bytes + nq * 8);
+        if (rc) return rc;
+        rc = ensure(c, c->qperm, bytes);
+        if (rc) return rc;
+    }
+    char *dst = host_dst ? (char *)host_dst : (char *)c->pinned;
     const int32_t *offs = pg.offs.data();
     bool identity = (t->type == VSGPU_F32 || t->type == VSGPU_F64);
     for (size_t i = 0; identity && i < per_q; i++) identity = offs[i] == (int32_t)(i * ab);
@@ -748,6 +756,7 @@ int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride
         }
         }
     }
+    if (host_dst) return VSGPU_OK;
     HIPCHK(hipMemcpyAsync(c->qperm.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
     if (t->type == VSGPU_SQ8 || t->type == VSGPU_SQ8H) {   // {y_sum, y_sum_squares} of every query blob (the second only exists for L2)
         rc = ensure_pinned(c, bytes + nq * 8);
@@ -1286,10 +1295,13 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
     int rc = ensure(c, c->sel, hdr + nq * ocap * sizeof(uint2));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
-                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
-                       (uint32_t *)c->sel.p, (uint32_t)ocap);
-    HIPCHK(hipGetLastError());
+    if (!c->sel_fused) {   // (fused: the last workgroup of every query in k_exact_pairs has done this already)
+        hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
+                           (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
+                           (uint32_t *)c->sel.p, (uint32_t)ocap);
+        HIPCHK(hipGetLastError());
+    }
+    c->sel_fused = false;
     // the last kernel of this batch is in the stream: the next reader lane's kernels may follow (its probe and scan then
     // overlap with this lane's downloads and host replay, not with its kernels -- a re-rank or select kernel sharing the
     // CUs with another lane's scan cost that scan more than the overlap saved: bf16 config 4, 3.18 -> 3.33 ms)
@@ -1457,9 +1469,26 @@ size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_r
 }
 
 
-int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
+int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap, size_t k, size_t out_cap) {
     vsgpu_ctx *c = t->ctx;
     ScanParams S{};
+    c->sel_fused = false;
+    if (k && out_cap && t->type != VSGPU_F64) {
+        // the block collect_candidates downloads: {selected counts [nq], raw counts [nq], records [nq][out_cap]}
+        const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
+        int rc = ensure(c, c->sel, hdr + nq * out_cap * sizeof(uint2));
+        if (rc) return rc;
+        const size_t before = c->seldone.cap;
+        rc = ensure(c, c->seldone, nq * 4);
+        if (rc) return rc;
+        if (c->seldone.cap != before) HIPCHK(hipMemsetAsync(c->seldone.p, 0, c->seldone.cap, c->stream));
+        S.sel_done = (uint32_t *)c->seldone.p;
+        S.sel_out = (uint2 *)((char *)c->sel.p + hdr);
+        S.sel_counts = (uint32_t *)c->sel.p;
+        S.sel_k = (uint32_t)std::min(k, t->n);
+        S.sel_cap = (uint32_t)out_cap;
+        c->sel_fused = true;
+    }
     S.slabs = t->d_slabs;
     S.slab_shift = t->slab_shift;
     S.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);

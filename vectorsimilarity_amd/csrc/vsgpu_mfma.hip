@@ -190,10 +190,12 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // ONE upload per batch: {fragments [q_tile][wave][kstep][lane][8], |q|^2, thresholds, zeroed candidate counters} are built in a
     // pinned staging block and land in regions of ctx->qblock (three copies and a fill were four operations on the stream -- 4-7 us
     // of blit kernel each -- in front of every batch; a single query's whole GPU time is 31 us)
+    // (round 4: the exact-order query images of the re-rank ride in the same block -- a second upload cost a single query 5-8 us)
     const size_t fb = (nqp * kdim * 2 + 255) & ~(size_t)255, ab = (nqp * 4 + 255) & ~(size_t)255;
-    rc = ensure(c, c->qblock, fb + 3 * ab);
+    const size_t qb = (staged_query_bytes(t, nq) + 255) & ~(size_t)255;
+    rc = ensure(c, c->qblock, fb + 3 * ab + qb);
     if (rc) return rc;
-    rc = ensure_pin_up(c, fb + 3 * ab);
+    rc = ensure_pin_up(c, fb + 3 * ab + qb);
     if (rc) return rc;
     uint16_t *frag = reinterpret_cast<uint16_t *>(c->pin_up);
     float *qn2 = reinterpret_cast<float *>((char *)c->pin_up + fb), *tau0 = reinterpret_cast<float *>((char *)c->pin_up + fb + ab);
@@ -241,13 +243,11 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
     if (have_tau)
         for (size_t q = 0; q < nq; q++) tau0[q] = c->tau_override[q];
-    HIPCHK(hipMemcpyAsync(c->qblock.p, c->pin_up, fb + 3 * ab, hipMemcpyHostToDevice, c->stream));
-    wm0.mark("uploads");
-    // the exact-order query images of the re-rank go up now too: queued behind the scan, their copy sat between the scan and the
-    // re-rank kernel, which then started after the other reader lane's probe had taken the CUs (155 us beside it, 54 us ahead of it)
-    rc = stage_queries(t, queries, nq, qstride);
+    rc = stage_queries(t, queries, nq, qstride, (char *)c->pin_up + fb + 3 * ab, (char *)c->qblock.p + fb + 3 * ab);
     if (rc) return rc;
     wm0.mark("stage_queries");
+    HIPCHK(hipMemcpyAsync(c->qblock.p, c->pin_up, fb + 3 * ab + qb, hipMemcpyHostToDevice, c->stream));
+    wm0.mark("uploads");
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
     const double u = std::ldexp(1.0, -24);
@@ -335,7 +335,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     VSG_POLL_POINT(c);
     wm0.mark("launches");
     wm0.flush("mfma_pre");
-    rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
+    rc = launch_exact_pairs(t, nq, ccap, k, cap);  // exact re-rank of the survivors, in place, + the selection in its tail
     if (rc) return rc;
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, wide ? "k_mfma_filter_wide" : "k_mfma_filter", &chain);
 }
