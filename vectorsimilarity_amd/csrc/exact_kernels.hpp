@@ -168,12 +168,6 @@ struct ScanParams {
     uint32_t *counts;      // [nq]
     uint2 *cand;           // [nq][cap] {table row, score bits}
     uint32_t cap;
-    // k_exact_pairs with the selection fused into its tail (round 4): the LAST workgroup of a query to finish -- a ticket per
-    // query, self-resetting -- keeps the candidates at or below the k-th smallest exact score, as k_select_upto_kth would
-    uint32_t *sel_done;    // [nq] tickets (zero between launches); null: no fused selection
-    uint2 *sel_out;        // [nq][sel_cap]
-    uint32_t *sel_counts;  // [2 nq]: selected counts, then raw counts
-    uint32_t sel_k, sel_cap;
 };
 
 template <typename S> __device__ inline S epilogue_score(long long acc, int epi, float nrow, float nq) {

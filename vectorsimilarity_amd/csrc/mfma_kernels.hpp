@@ -584,27 +584,6 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
             }
         }
     }
-    if constexpr (EK != EK_F64) {
-        if (P.sel_done) {
-            // selection fused into the tail: every workgroup publishes its scores (release), takes a ticket, and the last one of
-            // the query (acquire: its L1 may hold lines of the list from before the others wrote) selects
-            __shared__ uint32_t f_keys[4096];
-            __shared__ uint32_t f_red[2][4];
-            __shared__ uint32_t f_wpos, f_last;
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t tk = atomicAdd(&P.sel_done[q], 1u);
-                f_last = tk == gridDim.x - 1 ? 1u : 0u;
-                if (f_last) P.sel_done[q] = 0;   // (self-resetting: zero again for the next launch)
-            }
-            __syncthreads();
-            if (f_last) {
-                __threadfence();
-                select_upto_kth_body<4096>(f_keys, f_red, &f_wpos, P.cand, P.counts, P.cap, P.sel_k, P.sel_out, P.sel_counts, P.sel_cap, q, gridDim.y);
-            }
-        }
-    }
 }
 
 

@@ -136,7 +136,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock, &c->seldone})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock})
         if (b->p && !b->alias) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -1295,13 +1295,10 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
     int rc = ensure(c, c->sel, hdr + nq * ocap * sizeof(uint2));
     if (rc) return rc;
-    if (!c->sel_fused) {   // (fused: the last workgroup of every query in k_exact_pairs has done this already)
-        hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
-                           (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
-                           (uint32_t *)c->sel.p, (uint32_t)ocap);
-        HIPCHK(hipGetLastError());
-    }
-    c->sel_fused = false;
+    hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
+                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
+                       (uint32_t *)c->sel.p, (uint32_t)ocap);
+    HIPCHK(hipGetLastError());
     // the last kernel of this batch is in the stream: the next reader lane's kernels may follow (its probe and scan then
     // overlap with this lane's downloads and host replay, not with its kernels -- a re-rank or select kernel sharing the
     // CUs with another lane's scan cost that scan more than the overlap saved: bf16 config 4, 3.18 -> 3.33 ms)
@@ -1469,26 +1466,12 @@ size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_r
 }
 
 
-int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap, size_t k, size_t out_cap) {
+// (Round 4 tried the selection in this kernel's tail -- the last workgroup of a query to finish, by ticket, selects -- to save a
+// launch.  Correct (568 GPU tests) and 0.8-1.2 ms SLOWER per batch of 64-128 queries: every workgroup needs a device-scope
+// release before its ticket, which on this multi-XCD part writes back its L2 (buffer_wbl2 sc1); a kernel boundary pays that once.)
+int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     vsgpu_ctx *c = t->ctx;
     ScanParams S{};
-    c->sel_fused = false;
-    if (k && out_cap && t->type != VSGPU_F64) {
-        // the block collect_candidates downloads: {selected counts [nq], raw counts [nq], records [nq][out_cap]}
-        const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
-        int rc = ensure(c, c->sel, hdr + nq * out_cap * sizeof(uint2));
-        if (rc) return rc;
-        const size_t before = c->seldone.cap;
-        rc = ensure(c, c->seldone, nq * 4);
-        if (rc) return rc;
-        if (c->seldone.cap != before) HIPCHK(hipMemsetAsync(c->seldone.p, 0, c->seldone.cap, c->stream));
-        S.sel_done = (uint32_t *)c->seldone.p;
-        S.sel_out = (uint2 *)((char *)c->sel.p + hdr);
-        S.sel_counts = (uint32_t *)c->sel.p;
-        S.sel_k = (uint32_t)std::min(k, t->n);
-        S.sel_cap = (uint32_t)out_cap;
-        c->sel_fused = true;
-    }
     S.slabs = t->d_slabs;
     S.slab_shift = t->slab_shift;
     S.slab_mask = (uint32_t)(((size_t)1 << t->slab_shift) - 1);

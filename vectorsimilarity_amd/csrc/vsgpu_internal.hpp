@@ -43,8 +43,6 @@ struct vsgpu_ctx {
     DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qfrag2, qn2, sel, selcnt, qmeta;
     // one upload per batch: {query fragments, |q|^2, thresholds, zeroed counters} are regions of qblock, staged in pin_up
     DevBuf qblock;
-    DevBuf seldone;           // per-query tickets of the fused selection (zero between launches)
-    bool sel_fused = false;   // the batch's selection already ran in k_exact_pairs' tail
     void *pin_up = nullptr;
     size_t pin_up_cap = 0;
     void *pinned = nullptr;
@@ -257,8 +255,7 @@ uint32_t probe_run_shift(const vsgpu_ctx *c, size_t tile_bytes, uint32_t probe_t
 uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank);
 size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_rows);
 // stage 2 of the filter paths: reference-order exact re-score of the candidate lists in ctx->cand (in place)
-// k, out_cap given (and not an fp64 table): the selection of collect_candidates runs in the kernel's tail (ctx->sel_fused)
-int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap, size_t k = 0, size_t out_cap = 0);
+int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap);
 // threshold of every query from the probe's per-tile minima (ctx->dense -> ctx->tau)
 int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M);
 int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,

@@ -650,7 +650,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         return VSGPU_OK;
     }
     if (!is_int) {
-        rc = launch_exact_pairs(t, nq, ccap, k, cap);
+        rc = launch_exact_pairs(t, nq, ccap);
         if (rc) return rc;
     }
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,

@@ -335,7 +335,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     VSG_POLL_POINT(c);
     wm0.mark("launches");
     wm0.flush("mfma_pre");
-    rc = launch_exact_pairs(t, nq, ccap, k, cap);  // exact re-rank of the survivors, in place, + the selection in its tail
+    rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, wide ? "k_mfma_filter_wide" : "k_mfma_filter", &chain);
 }
