@@ -169,8 +169,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
     // UADDR: request addresses as a wave-uniform 64-bit base (SGPRs) + one constant 32-bit offset per lane and piece (the
     // scalar-base form of global_load_lds) instead of a 64-bit address per lane and piece.  Rows past the table's end are not
     // clamped: a tile never leaves its slab, whose allocation is whole, and the epilogues mask such rows (nvalid).
+    // Round 3 used it for SQ8 only; round 4, same-box A/B on config 4 (bf16 768, 128 queries): scan kernel 3.33 -> 3.26 ms, so every
+    // kind gets it (-DLOWP_UADDR_ALL=0 restores the per-lane addresses).
 #ifndef LOWP_UADDR_ALL
-#define LOWP_UADDR_ALL 0
+#define LOWP_UADDR_ALL 1
 #endif
     constexpr bool UADDR = (LK == LP_SQ8) || (LOWP_UADDR_ALL && !SKEW);
     static_assert(!SQ8 || (!SKEW && NQW == 1 && RT * 16 <= AUXBUF && NWAVES * 256 >= AUXBUF), "SQ8 aux geometry");
