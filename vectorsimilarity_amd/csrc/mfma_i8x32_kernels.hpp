@@ -197,9 +197,8 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     // the stream's test of one (row, query) value: passes every value the exact test passes (Cosine: one multiply against
     // cosq instead of the divide; NaN thresholds -- zero norms -- pass on to the exact test)
     auto screen_pass = [&](int dot, uint32_t av) -> bool {
-#ifdef X32_INT_SCREEN_TEST   // timing experiment only (replies wrong): what a one-compare integer screen would buy
-        if (EPI == LE_I8_COS) return dot >= (int)(cosq * 2300.0f);
-#endif
+        // (round 4 timing experiment: ONE integer compare per value here instead of cvt + mul + cmp moved config 3's kernel from
+        // 13.43 to 13.25 ms -- a per-unit norm extreme to make that exact is not worth its bookkeeping)
         if (EPI == LE_I8_COS) return !((float)dot < cosq * __uint_as_float(av));
         if (EPI == LE_I8_L2) return (float)((int)av + (int)qaux - 2 * dot) <= tau;
         if (EPI == LE_I8_IP) return (float)(1 - dot) <= tau;
