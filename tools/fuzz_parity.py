@@ -45,7 +45,7 @@ kernels = {}
 while time.time() < t_end:
     typ = rng.choice(["f32", "f32", "bf16", "f16", "i8", "u8", "f64", "sq8", "sq8"])
     metric = rng.choice(["L2", "IP", "Cosine"])
-    dmax = {"f32": 8192, "bf16": 8192, "f16": 8192, "i8": 4096, "u8": 4096, "f64": 2048, "sq8": 1024}[typ]
+    dmax = {"f32": 8192, "bf16": 8192, "f16": 8192, "i8": 16384, "u8": 16384, "f64": 2048, "sq8": 1024}[typ]   # (round 4: int8 / uint8 wide rows)
     dim = int(rng.choice([rng.integers(8, 200), rng.integers(200, 1100), rng.integers(min(1100, dmax), dmax + 1)], p=[0.3, 0.45, 0.25]))
     dim = min(dim, dmax)
     eb = {"f32": 4, "f64": 8, "bf16": 2, "f16": 2, "i8": 1, "u8": 1, "sq8": 1}[typ]
