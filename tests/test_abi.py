@@ -50,7 +50,7 @@ def test_libraries_export_every_declared_symbol():
     G = C.CDLL(_capi.GPU_LIB_PATH)
     inc = os.path.join(ROOT, "include")
     declared = set()
-    for h in ("VecSim/vec_sim.h", "VecSim/query_results.h", "VecSim/info_iterator.h", "VecSim/vec_sim_gpu.h"):
+    for h in ("VecSim/vec_sim.h", "VecSim/query_results.h", "VecSim/info_iterator.h", "VecSim/vec_sim_debug.h", "VecSim/vec_sim_gpu.h"):
         declared |= _declared(os.path.join(inc, h))
     assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
     for name in sorted(declared):

@@ -616,3 +616,44 @@ def test_concurrent_readers_on_one_hnsw_index(vso):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def test_debug_neighbours_dump_matches_the_exported_graph():
+    """VecSimDebug_GetElementNeighborsInHNSWGraph (vec_sim_debug.h:30-44): per level {count, neighbour LABELS...}, NULL-terminated;
+    BadIndex for a Flat index, LabelNotExists, MultiNotSupported -- as upstream"""
+    import ctypes as C
+    from vectorsimilarity_amd import _capi
+    lib = _capi.load()
+    fn = lib.VecSimDebug_GetElementNeighborsInHNSWGraph
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.POINTER(C.c_int)))]
+    rel = lib.VecSimDebug_ReleaseElementNeighborsInHNSWGraph
+    rel.restype = None
+    rel.argtypes = [C.POINTER(C.POINTER(C.c_int))]
+    ix, _ = build(16, 800, VecSim.VecSimMetric_L2, M=6, efc=40, ef=20, labels=np.arange(800) * 3 + 1)
+    g = ix.graph()
+    for node in (0, 17, 799, int(g["entry"])):
+        out = C.POINTER(C.POINTER(C.c_int))()
+        assert fn(ix._h, int(g["labels"][node]), C.byref(out)) == 0
+        level = 0
+        while out[level]:
+            n = out[level][0]
+            got = [out[level][1 + i] for i in range(n)]
+            if level == 0:
+                want = [int(g["labels"][j]) for j in g["links0"].reshape(-1, g["M0"])[node][: g["cnt0"][node]]]
+                assert got == want, (node, got, want)
+            assert n <= (g["M0"] if level == 0 else g["M"]) and all(x % 3 == 1 for x in got)
+            level += 1
+        assert level >= 1
+        rel(out)
+    out = C.POINTER(C.POINTER(C.c_int))()
+    assert fn(ix._h, 2, C.byref(out)) == 2 and not out          # LabelNotExists
+    p = VecSim.BFParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, 4, VecSim.VecSimMetric_L2
+    bf = VecSim.BFIndex(p)
+    assert fn(bf._h, 0, C.byref(out)) == 1                       # BadIndex
+    mp = VecSim.HNSWParams()
+    mp.type, mp.dim, mp.metric, mp.multi = VecSim.VecSimType_FLOAT32, 4, VecSim.VecSimMetric_L2, True
+    mx = VecSim.HNSWIndex(mp)
+    mx.add_vector(np.zeros(4, dtype=np.float32), 5)
+    assert fn(mx._h, 5, C.byref(out)) == 3                       # MultiNotSupported

@@ -443,6 +443,30 @@ extern "C" long VecSimGpu_ReadStoredRows(VecSimIndex *index, size_t first_id, si
     if (!f || !out || cap_bytes < n * f->storedBlobBytes()) return -1;
     return f->readRows((uint32_t)first_id, n, out) ? -1 : (long)n;
 }
+// vec_sim_debug.h (reference: src/VecSim/vec_sim_debug.cpp:15-80, hnsw.h getHNSWElementNeighbors)
+extern "C" int VecSimDebug_GetElementNeighborsInHNSWGraph(VecSimIndex *index, size_t label, int ***neighborsData) {
+    *neighborsData = nullptr;
+    auto *h = dynamic_cast<vsa::HnswIndex *>(index);
+    if (!h) return VecSimDebugCommandCode_BadIndex;
+    std::vector<std::vector<size_t>> levels;
+    const int rc = h->neighborLabels(label, levels);
+    if (rc == -2) return VecSimDebugCommandCode_MultiNotSupported;
+    if (rc) return VecSimDebugCommandCode_LabelNotExists;
+    int **out = new int *[levels.size() + 1];
+    for (size_t l = 0; l < levels.size(); l++) {
+        out[l] = new int[levels[l].size() + 1];
+        out[l][0] = (int)levels[l].size();
+        for (size_t i = 0; i < levels[l].size(); i++) out[l][i + 1] = (int)levels[l][i];
+    }
+    out[levels.size()] = nullptr;
+    *neighborsData = out;
+    return VecSimDebugCommandCode_OK;
+}
+extern "C" void VecSimDebug_ReleaseElementNeighborsInHNSWGraph(int **neighborsData) {
+    if (!neighborsData) return;
+    for (size_t l = 0; neighborsData[l]; l++) delete[] neighborsData[l];
+    delete[] neighborsData;
+}
 extern "C" uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index) {
     auto *h = dynamic_cast<vsa::HnswIndex *>(index);
     return h ? h->lastDistanceEvals() : 0;

@@ -608,6 +608,24 @@ int HnswIndex::syncDevice() {
     return 0;
 }
 
+int HnswIndex::neighborLabels(size_t label, std::vector<std::vector<size_t>> &out) {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    out.clear();
+    if (multi_) return -2;
+    auto f = label_to_id_.find(label);
+    if (f == label_to_id_.end()) return -1;
+    const uint32_t id = f->second;
+    for (int level = 0; level <= (int)level_[id]; level++) {
+        uint32_t *cnt = nullptr;
+        const uint32_t *links = level == 0 ? links0_.data() + (size_t)id * M0_ : linksAt(id, level, &cnt);
+        const uint32_t n = level == 0 ? (uint32_t)cnt0_[id] : *cnt;
+        std::vector<size_t> labs(n);
+        for (uint32_t i = 0; i < n; i++) labs[i] = (size_t)labels_[links[i]];
+        out.push_back(std::move(labs));
+    }
+    return 0;
+}
+
 HnswIndex::Export HnswIndex::exportGraph() {
     Export e{};
     e.n = (uint32_t)n_;

@@ -73,6 +73,8 @@ public:
     };
     Export exportGraph();
     uint64_t lastDistanceEvals() const { return last_dist_evals_.load(); }
+    // labels of `label`'s neighbours, level by level (VecSimDebug_GetElementNeighborsInHNSWGraph); -1: unknown label, -2: multi-value
+    int neighborLabels(size_t label, std::vector<std::vector<size_t>> &out);
     std::vector<vsgpu_ctx *> gpus() override;
 
 private:
