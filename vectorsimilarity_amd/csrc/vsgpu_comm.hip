@@ -63,6 +63,12 @@ struct vsgpu_comm {
     // records are tens of KB, so the PCIe hop inside the collective costs nothing next to that.
     void *h_send = nullptr, *h_recv = nullptr;
     size_t send_cap = 0, recv_cap = 0;
+    // Communicators of more than one rank use device buffers between the mapped host blocks and the collective by default
+    // (the canonical RCCL usage; mapped host memory as the collective's own buffers is measured on one rank only, where it
+    // removes the copies from behind the scans).  VECSIM_GPU_EXCHANGE=mapped | staged overrides.
+    bool staged = false;
+    void *d_send = nullptr, *d_recv = nullptr;
+    size_t dsend_cap = 0, drecv_cap = 0;
 };
 
 #define RCCLCHK(expr)                                                                                  \
@@ -106,6 +112,8 @@ extern "C" vsgpu_comm *vsgpu_comm_create(vsgpu_ctx *ctx, int rank, int world, co
         delete c;
         return nullptr;
     }
+    c->staged = world > 1;
+    if (const char *e = getenv("VECSIM_GPU_EXCHANGE")) c->staged = !strcmp(e, "staged") ? true : (!strcmp(e, "mapped") ? false : c->staged);
     // highest priority the device offers: the collective's kernel is dispatched ahead of whatever else is waiting for a CU
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -125,6 +133,8 @@ extern "C" void vsgpu_comm_destroy(vsgpu_comm *c) {
     if (c->comm) rccl()->CommDestroy(c->comm);
     if (c->h_send) (void)hipHostFree(c->h_send);
     if (c->h_recv) (void)hipHostFree(c->h_recv);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -144,6 +154,20 @@ static int comm_reserve(vsgpu_comm *c, size_t send_bytes, size_t recv_bytes) {
     };
     HIPCHK(grow(c->h_send, c->send_cap, send_bytes));
     HIPCHK(grow(c->h_recv, c->recv_cap, recv_bytes));
+    if (c->staged) {
+        auto dgrow = [](void *&p, size_t &cap, size_t need) -> hipError_t {
+            if (need <= cap) return hipSuccess;
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = (need + 0xFFFF) & ~(size_t)0xFFFF;
+            hipError_t e = hipMalloc(&p, want);
+            if (e == hipSuccess) cap = want;
+            return e;
+        };
+        HIPCHK(dgrow(c->d_send, c->dsend_cap, send_bytes));
+        HIPCHK(dgrow(c->d_recv, c->drecv_cap, recv_bytes));
+    }
     return VSGPU_OK;
 }
 
@@ -154,7 +178,13 @@ extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t byte
     int rc = comm_reserve(c, bytes, total);
     if (rc) return rc;
     memcpy(c->h_send, send, bytes);
-    RCCLCHK(rccl()->AllGather(c->h_send, c->h_recv, bytes, kRcclInt8, c->comm, c->stream));
+    if (c->staged) {
+        HIPCHK(hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
+        RCCLCHK(rccl()->AllGather(c->d_send, c->d_recv, bytes, kRcclInt8, c->comm, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, total, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        RCCLCHK(rccl()->AllGather(c->h_send, c->h_recv, bytes, kRcclInt8, c->comm, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(recv, c->h_recv, total);
     return VSGPU_OK;
@@ -167,7 +197,13 @@ extern "C" int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int 
     int rc = comm_reserve(c, bytes, bytes);
     if (rc) return rc;
     if (c->rank == root) memcpy(c->h_send, buf, bytes);
-    RCCLCHK(rccl()->Broadcast(c->h_send, c->h_send, bytes, kRcclInt8, root, c->comm, c->stream));
+    if (c->staged) {
+        if (c->rank == root) HIPCHK(hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
+        RCCLCHK(rccl()->Broadcast(c->d_send, c->d_send, bytes, kRcclInt8, root, c->comm, c->stream));
+        if (c->rank != root) HIPCHK(hipMemcpyAsync(c->h_send, c->d_send, bytes, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        RCCLCHK(rccl()->Broadcast(c->h_send, c->h_send, bytes, kRcclInt8, root, c->comm, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->rank != root) memcpy(buf, c->h_send, bytes);
     return VSGPU_OK;
