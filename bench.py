@@ -416,7 +416,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": st["scan_kernel"], "avg_kernel_ms": avg_ms, "launches": int(st["scan_launches"]),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "other_kernels_ms_per_step": st["other_ms"] / max(1, args.steps)}
+                # probe + threshold kernels by their own pair of events: off by default (an event record costs the stream 3-5 us,
+                # profiles/r04_event_cost.txt; the scan kernel's pair stays, it is what this object is computed from): --opt events=3
+                "other_kernels_ms_per_step": (st["other_ms"] / max(1, args.steps)) if st["other_ms"] > 0 else None}
         if args.dtype == "i8" and avg_ms > 0:
             rows_per_launch = st["scan_rows"] / launches
             tops = 2.0 * rows_per_launch * args.dim * args.batch / (avg_ms * 1e-3) / 1e12

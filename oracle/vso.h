@@ -142,6 +142,15 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
                       const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
                       uint32_t entry, int max_level, const void *query, double radius, double epsilon,
                       uint64_t *out_labels, double *out_scores, size_t out_cap, uint64_t *dist_evals);
+/* batch iterator (hnsw_batch_iterator.h:96-230 + the single / multi heaps): a whole iteration in one call, batch b asking for
+ * sizes[b] results; returns the batches taken, their results one after the other (out_counts[b] each) */
+size_t vso_hnsw_iterate(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                        const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                        const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                        uint32_t entry, int max_level, const void *query, size_t ef, int multi, size_t n_labels,
+                        const size_t *sizes, size_t max_batches, uint64_t *out_labels, double *out_scores, size_t *out_counts,
+                        int *depleted_out);
+
 
 /* ---- timing leg (bench.py cpu_baseline, kind "port") ----
  * Same arithmetic as VSO_TIER_AVX512, written with AVX-512 intrinsics when the host has them

@@ -396,6 +396,35 @@ def hnsw_search(vtype, metric, rows, graph, query, k, ef, dim, tier=TIER_AVX512,
     return ol[:c].copy(), osc[:c].copy(), ev.value
 
 
+def hnsw_iterate(vtype, metric, rows, graph, query, ef, sizes, dim, tier=TIER_AVX512, multi=False):
+    """the reference's HNSW batch iterator (hnsw_batch_iterator.h:96-230) over an exported graph: batch b asks for sizes[b]
+    results; returns ([(labels, scores) per batch taken], depleted)"""
+    rows = np.ascontiguousarray(rows)
+    query = np.ascontiguousarray(query)
+    g = graph
+    live = ~np.asarray(g["deleted"], dtype=bool)
+    n_labels = len(set(np.asarray(g["labels"])[live].tolist()))
+    sz = np.asarray(sizes, dtype=np.uint64)
+    cap = int(sz.sum()) + 1
+    ol = np.zeros(cap, dtype=np.uint64)
+    osc = np.zeros(cap, dtype=np.float64)
+    cnt = np.zeros(len(sz) + 1, dtype=np.uint64)
+    dep = C.c_int(0)
+    fn = lib().vso_hnsw_iterate
+    fn.restype = C.c_size_t
+    fn.argtypes = None
+    nb = fn(C.c_int(vtype), C.c_int(metric), C.c_int(tier), C.c_size_t(dim), _ptr(rows), C.c_size_t(rows.strides[0]), C.c_uint32(g["n"]),
+            _ptr(g["links0"]), _ptr(g["cnt0"]), C.c_uint32(g["M0"]), _ptr(g["upper_off"]), _ptr(g["upper"]), C.c_uint32(g["M"]),
+            _ptr(g["deleted"]), _ptr(g["labels"]), C.c_uint32(g["entry"]), C.c_int(g["max_level"]), _ptr(query), C.c_size_t(ef),
+            C.c_int(1 if multi else 0), C.c_size_t(n_labels), _ptr(sz), C.c_size_t(len(sz)), _ptr(ol), _ptr(osc), _ptr(cnt), C.byref(dep))
+    out, at = [], 0
+    for b in range(nb):
+        c = int(cnt[b])
+        out.append((ol[at:at + c].copy(), osc[at:at + c].copy()))
+        at += c
+    return out, bool(dep.value)
+
+
 def hnsw_range(vtype, metric, rows, graph, query, radius, epsilon, dim, tier=TIER_AVX512):
     """restated HNSW range search over an exported graph: (labels, scores) in discovery order"""
     rows = np.ascontiguousarray(rows)

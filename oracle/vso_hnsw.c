@@ -239,3 +239,175 @@ size_t vso_hnsw_range(int type, int metric, int tier, size_t dim, const void *ro
     if (dist_evals) *dist_evals = evals;
     return nres;
 }
+
+/*
+ * Batch iterator: the incremental walk of hnsw_batch_iterator.h:96-230 with the single-value heaps of
+ * hnsw_single_batch_iterator.h:36-80 or the label-keyed ones of hnsw_multi_batch_iterator.h:38-96.  One call plays a whole
+ * iteration: batch b asks for sizes[b] results (getNextResults: ef is raised to the batch size for that call), until the
+ * iterator reports depletion or `max_batches` were taken.  Batches are written one after the other: out_counts[b] results of batch b
+ * at offset sum(out_counts[0..b)).  Containers as plain arrays with linear scans: candidates and extras pop their smallest
+ * (dist, id | label), top_candidates its largest (dist, label); the multi-value top keeps one entry per label with its lowest
+ * distance (updatable_heap.h:93-113).  Returns the number of batches taken; *depleted_out = isDepleted() after the last one.
+ */
+typedef struct { top_t *v; size_t n, cap; } tvec_t;
+static void tv_push(tvec_t *t, double d, uint64_t label) {
+    if (t->n == t->cap) { t->cap = t->cap ? 2 * t->cap : 64; t->v = realloc(t->v, t->cap * sizeof(top_t)); }
+    t->v[t->n].d = d; t->v[t->n].label = label; t->n++;
+}
+static size_t tv_extreme(const tvec_t *t, int want_max) {   /* index of the largest / smallest (d, label) */
+    size_t b = 0;
+    for (size_t i = 1; i < t->n; i++) {
+        const int less = t->v[i].d < t->v[b].d || (t->v[i].d == t->v[b].d && t->v[i].label < t->v[b].label);
+        const int more = t->v[b].d < t->v[i].d || (t->v[i].d == t->v[b].d && t->v[b].label < t->v[i].label);
+        if (want_max ? more : less) b = i;
+    }
+    return b;
+}
+static void tv_remove(tvec_t *t, size_t i) { t->v[i] = t->v[t->n - 1]; t->n--; }
+/* top_candidates->emplace: multi-value tops keep a label's lower distance */
+static void top_emplace(tvec_t *top, int multi, double d, uint64_t label) {
+    if (multi)
+        for (size_t i = 0; i < top->n; i++)
+            if (top->v[i].label == label) {
+                if (top->v[i].d > d) top->v[i].d = d;
+                return;
+            }
+    tv_push(top, d, label);
+}
+static int label_in(const uint64_t *set, size_t n, uint64_t label) {
+    for (size_t i = 0; i < n; i++)
+        if (set[i] == label) return 1;
+    return 0;
+}
+
+size_t vso_hnsw_iterate(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n,
+                        const uint32_t *links0, const uint16_t *cnt0, uint32_t M0, const uint32_t *upper_off,
+                        const uint32_t *upper, uint32_t M, const uint8_t *deleted, const uint64_t *labels,
+                        uint32_t entry, int max_level, const void *query, size_t ef0, int multi, size_t n_labels,
+                        const size_t *sizes, size_t max_batches, uint64_t *out_labels, double *out_scores, size_t *out_counts,
+                        int *depleted_out) {
+    const char *base = rows;
+#define IDIST(node) (NARROW(type, vso_distance(type, metric, tier, dim, base + (size_t)(node)*stride, query)))
+    uint8_t *visited = calloc(n ? n : 1, 1);
+    cand_t *cand = malloc(((size_t)n + 1) * sizeof(cand_t));
+    size_t nc = 0;
+    tvec_t extras = {0, 0, 0};
+    uint64_t *returned = malloc(((size_t)n + 1) * sizeof(uint64_t));
+    size_t n_returned = 0, results = 0, written = 0, b = 0;
+    double lower = INFINITY;
+    int depleted = 0;
+    uint32_t ep = 0xFFFFFFFFu;
+    size_t ef = ef0;
+    for (; b < max_batches; b++) {
+        const size_t n_res = sizes[b];
+        const size_t orig_ef = ef;
+        if (orig_ef < n_res) ef = n_res;
+        if (results == 0) {   /* searchBottomLayerEP */
+            ep = entry;
+            if (n == 0) ep = 0xFFFFFFFFu;
+            if (ep != 0xFFFFFFFFu) {
+                double curd = IDIST(ep);
+                for (int level = max_level; level > 0; level--) {
+                    int changed = 1;
+                    while (changed) {
+                        changed = 0;
+                        uint32_t cnt;
+                        const uint32_t *lk = links_at(ep, level, links0, cnt0, M0, upper_off, upper, M, &cnt);
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            const double d = IDIST(lk[i]);
+                            if (d < curd) { curd = d; ep = lk[i]; changed = 1; }
+                        }
+                    }
+                }
+            }
+        }
+        /* scanGraph */
+        tvec_t top = {0, 0, 0};
+        if (ep == 0xFFFFFFFFu) {
+            depleted = 1;
+        } else {
+            if (results == 0 && extras.n == 0 && nc == 0) {
+                lower = deleted[ep] ? (type == VSO_F64 ? 1.7976931348623157e308 : (double)3.402823466e+38f) : IDIST(ep);
+                visited[ep] = 1;
+                cand[nc].d = lower; cand[nc].id = ep; nc++;
+            }
+            /* fillFromExtras */
+            while (top.n < ef && extras.n) {
+                const size_t m = tv_extreme(&extras, 0);
+                if (!multi || !label_in(returned, n_returned, extras.v[m].label)) top_emplace(&top, multi, extras.v[m].d, extras.v[m].label);
+                tv_remove(&extras, m);
+            }
+            if (top.n != ef) {
+                /* scanGraphInternal */
+                while (nc) {
+                    size_t m = 0;
+                    for (size_t i = 1; i < nc; i++)
+                        if (cand[i].d < cand[m].d || (cand[i].d == cand[m].d && cand[i].id < cand[m].id)) m = i;
+                    const double cd = cand[m].d;
+                    const uint32_t cnode = cand[m].id;
+                    if (cd > lower && top.n >= ef) break;
+                    if (!deleted[cnode]) {   /* updateHeaps */
+                        if (!multi) {
+                            if (top.n < ef) {
+                                tv_push(&top, cd, labels[cnode]);
+                                lower = top.v[tv_extreme(&top, 1)].d;
+                            } else if (lower > cd) {
+                                tv_push(&top, cd, labels[cnode]);
+                                const size_t w = tv_extreme(&top, 1);
+                                tv_push(&extras, top.v[w].d, top.v[w].label);
+                                tv_remove(&top, w);
+                                lower = top.v[tv_extreme(&top, 1)].d;
+                            }
+                        } else if (lower > cd || top.n < ef) {
+                            if (!label_in(returned, n_returned, labels[cnode])) {
+                                top_emplace(&top, 1, cd, labels[cnode]);
+                                if (top.n > ef) {
+                                    const size_t w = tv_extreme(&top, 1);
+                                    tv_push(&extras, top.v[w].d, top.v[w].label);
+                                    tv_remove(&top, w);
+                                }
+                                lower = top.v[tv_extreme(&top, 1)].d;
+                            }
+                        }
+                    }
+                    cand[m] = cand[nc - 1];
+                    nc--;
+                    const uint32_t cnt = cnt0[cnode];
+                    const uint32_t *lk = links0 + (size_t)cnode * M0;
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t c = lk[j];
+                        if (visited[c]) continue;
+                        visited[c] = 1;
+                        cand[nc].d = IDIST(c); cand[nc].id = c; nc++;
+                    }
+                }
+                if (top.n < ef) depleted = 1;
+            }
+        }
+        /* prepareResults */
+        while (top.n > n_res) {
+            const size_t w = tv_extreme(&top, 1);
+            tv_push(&extras, top.v[w].d, top.v[w].label);
+            tv_remove(&top, w);
+        }
+        const size_t got = top.n;
+        for (size_t i = got; i-- > 0;) {
+            const size_t w = tv_extreme(&top, 1);
+            out_labels[written + i] = top.v[w].label;
+            out_scores[written + i] = top.v[w].d;
+            if (multi) returned[n_returned++] = top.v[w].label;
+            tv_remove(&top, w);
+        }
+        free(top.v);
+        out_counts[b] = got;
+        written += got;
+        results += got;
+        if (results == n_labels) depleted = 1;
+        ef = orig_ef;
+        if (depleted && extras.n == 0) { b++; break; }
+    }
+    if (depleted_out) *depleted_out = depleted && extras.n == 0;
+    free(visited); free(cand); free(extras.v); free(returned);
+    return b;
+#undef IDIST
+}

@@ -207,9 +207,10 @@ def test_range_search_with_deleted_nodes_and_wide_radius(vso):
     assert wide[0].tolist() in (sorted(wl.astype(np.int64).tolist()), alive)
 
 
-def test_hnsw_batch_iterator_hands_out_exact_batches(vso):
-    """VecSimBatchIterator on an HNSW index: every batch is the exact next-best set (same machinery and the same
+def test_hnsw_batch_iterator_hands_out_exact_batches(vso, monkeypatch):
+    """VECSIM_HNSW_ITER_EXACT=1 (rounds 1-3's iterator): every batch is the exact next-best set (same machinery and the same
     GPU score pass as the Flat iterator), deleted vectors never appear"""
+    monkeypatch.setenv("VECSIM_HNSW_ITER_EXACT", "1")
     dim, n = 32, 2500
     ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=60, ef=40)
     for lab in (5, 77, 1200):
@@ -281,8 +282,9 @@ def test_typed_hnsw_search_equals_reference_loops(vso, typ, metric, dim):
     assert np.array_equal(ix.get_vector(5), bf.get_vector(5))
 
 
-def test_hnsw_batch_iterator_sparse_mode_with_deleted_nodes(vso):
-    """enough live nodes for the heap regime (device-resident scores): batches still exact, deleted nodes absent"""
+def test_hnsw_batch_iterator_sparse_mode_with_deleted_nodes(vso, monkeypatch):
+    """(exact iterator) enough live nodes for the heap regime (device-resident scores): batches still exact, deleted nodes absent"""
+    monkeypatch.setenv("VECSIM_HNSW_ITER_EXACT", "1")
     dim, n = 16, 120_000
     rng = np.random.default_rng(4)
     rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
@@ -497,15 +499,16 @@ def test_multi_value_gpu_search_equals_reference_loops(vso, metric, dim, n, n_la
     assert ix.delete_vector(lab) == len(mine) and ix.index_size() == n - len(mine)
     got_l, _ = ix.knn_query(q, k)
     assert lab not in set(got_l.ravel().tolist())
-    # batch iterator: every label once, ascending, the first batch = the exact best labels
+    # batch iterator (the graph walk; its batches against the oracle's: test_batch_iterator_walk_on_a_multi_value_index): a label
+    # is handed out once, each batch ascending
     it = ix.create_batch_iterator(q[0])
-    seen, last = [], -np.inf
+    seen = []
     while it.has_next():
         l, d = it.get_next_results(50)
-        assert np.all(np.diff(d[0]) >= 0) and d[0][0] >= last
-        last = d[0][-1]
-        seen += l[0].tolist()
-    assert len(seen) == len(set(seen)) == len(set(labels.tolist()) - {lab})
+        live = l[0] >= 0
+        assert np.all(np.diff(d[0][live]) >= 0)
+        seen += l[0][live].tolist()
+    assert len(seen) == len(set(seen)) and lab not in seen and set(seen) <= set(labels.tolist())
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -657,3 +660,200 @@ def test_debug_neighbours_dump_matches_the_exported_graph():
     mx = VecSim.HNSWIndex(mp)
     mx.add_vector(np.zeros(4, dtype=np.float32), 5)
     assert fn(mx._h, 5, C.byref(out)) == 3                       # MultiNotSupported
+
+
+# ---- the batch iterator's graph walk (hnsw_batch_iterator.h:96-230): product (host walk, GPU distances) == oracle twin ----
+def _walk_batches(ix, q, sizes, qp=None, order=VecSim.BY_SCORE):
+    it = ix.create_batch_iterator(q, qp)
+    out = []
+    for m in sizes:
+        if not it.has_next():
+            break
+        l, d = it.get_next_results(m, order)
+        out.append((l[0], d[0]))
+    return it, out
+
+
+@pytest.mark.parametrize("metric,dim,n,M,ef,sizes,dead", [
+    (VecSim.VecSimMetric_L2, 32, 3000, 16, 10, [10] * 12, 0),
+    (VecSim.VecSimMetric_L2, 24, 2500, 8, 20, [5, 7, 50, 1, 0, 33, 200, 3], 0),        # batches above and below ef, an empty one
+    (VecSim.VecSimMetric_Cosine, 100, 2000, 12, 16, [16, 16, 40, 8], 0),
+    (VecSim.VecSimMetric_IP, 64, 2000, 8, 12, [12, 30, 12, 12], 0),
+    (VecSim.VecSimMetric_L2, 16, 1500, 6, 10, [25] * 70, 0),                              # to depletion: every label exactly once
+    (VecSim.VecSimMetric_L2, 32, 3000, 16, 10, [10, 40, 10, 100], 7),                      # deleted nodes: traversed, never returned
+    (VecSim.VecSimMetric_L2, 768, 6000, 16, 128, [10, 10, 100], 0),                        # config 5's shape
+])
+def test_batch_iterator_walk_equals_the_reference_walk_on_the_same_graph(vso, metric, dim, n, M, ef, sizes, dead):
+    ix, rows = build(dim, n, metric, M=M, efc=200 if dim == 768 else 60, ef=ef)
+    if dead:
+        for lab in range(3, n, dead * 50):
+            ix.delete_vector(lab)
+    g = ix.graph()
+    srows = stored(vso, rows, metric)
+    km = 0 if metric == VecSim.VecSimMetric_L2 else 1
+    rng = np.random.default_rng(1234)
+    for trial in range(3):
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+        sq = stored(vso, q[None, :], metric)[0]
+        want, want_depleted = vso.hnsw_iterate(0, km, srows, g, sq, ef, sizes, dim)
+        it, got = _walk_batches(ix, q, sizes)
+        assert len(got) == len(want), (trial, len(got), len(want))
+        for b, ((gl, gd), (wl, wd)) in enumerate(zip(got, want)):
+            assert np.array_equal(gl[:len(wl)], wl.astype(np.int64)) and np.all(gl[len(wl):] == -1), (trial, b, gl, wl)
+            assert np.array_equal(gd[:len(wd)], wd), (trial, b)
+        assert (not it.has_next()) == want_depleted
+        if want_depleted:   # every live label exactly once
+            allv = np.concatenate([l[l >= 0] for l, _ in got])
+            live = np.asarray(g["labels"])[~np.asarray(g["deleted"], dtype=bool)]
+            assert sorted(allv.tolist()) == sorted(live.astype(np.int64).tolist())
+        # Reset: the same iteration again
+        it.reset()
+        l, d = it.get_next_results(sizes[0], VecSim.BY_SCORE)
+        assert np.array_equal(l[0][:len(want[0][0])], want[0][0].astype(np.int64)) and np.array_equal(d[0][:len(want[0][1])], want[0][1])
+
+
+def test_batch_iterator_walk_uses_the_query_params_ef_and_sorts_by_id(vso):
+    dim, n = 32, 2000
+    ix, rows = build(dim, n, VecSim.VecSimMetric_L2, M=8, efc=60, ef=10)
+    g = ix.graph()
+    q = np.random.default_rng(5).uniform(-1, 1, dim).astype(np.float32)
+    qp = VecSim.VecSimQueryParams()
+    qp.hnswRuntimeParams.efRuntime = 37
+    want, _ = vso.hnsw_iterate(0, 0, rows, g, q, 37, [9, 9, 9], dim)
+    _, got = _walk_batches(ix, q, [9, 9, 9], qp=qp, order=VecSim.BY_ID)
+    for (gl, gd), (wl, wd) in zip(got, want):
+        srt = np.argsort(wl, kind="stable")
+        assert np.array_equal(gl, wl[srt].astype(np.int64)) and np.array_equal(gd, wd[srt])
+    base, _ = vso.hnsw_iterate(0, 0, rows, g, q, 10, [9, 9, 9], dim)
+    assert any(not np.array_equal(a[0], b[0]) for a, b in zip(want, base)) or True   # (ef may or may not change the batches)
+
+
+def test_batch_iterator_walk_on_a_multi_value_index(vso):
+    dim, n, n_labels = 24, 2400, 400
+    rng = np.random.default_rng(31)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    labels = rng.integers(0, n_labels, n)
+    ix = build_multi(dim, rows, labels, M=8, efc=60, ef=10)
+    g = ix.graph()
+    for trial in range(3):
+        q = rng.uniform(-1, 1, dim).astype(np.float32)
+        sizes = [10, 25, 10, 3, 60] + [40] * 12
+        want, want_depleted = vso.hnsw_iterate(0, 0, rows, g, q, 10, sizes, dim, multi=True)
+        it, got = _walk_batches(ix, q, sizes)
+        assert len(got) == len(want)
+        seen = []
+        for (gl, gd), (wl, wd) in zip(got, want):
+            assert np.array_equal(gl[:len(wl)], wl.astype(np.int64)) and np.all(gl[len(wl):] == -1)
+            assert np.array_equal(gd[:len(wd)], wd)
+            seen += gl[gl >= 0].tolist()
+        assert len(seen) == len(set(seen))   # a label is handed out once
+        assert (not it.has_next()) == want_depleted
+
+
+def test_reference_hnsw_batch_iterator_known_answers():
+    """tests/unit/test_hnsw.cpp:912-1118 (hnsw_batch_iterator_basic / _reset / _batch_size_1 / _advanced), restated as data:
+    vectors (i,i,i,i) under label i, query (n,n,n,n): batches come back from the largest id down"""
+    def index(n, M, ef, labels=None):
+        p = VecSim.HNSWParams()
+        p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = VecSim.VecSimType_FLOAT32, 4, VecSim.VecSimMetric_L2, M, ef, ef
+        ix = VecSim.HNSWIndex(p)
+        for i in range(n):
+            ix.add_vector(np.full(4, float(i), dtype=np.float32), i if labels is None else labels[i])
+        return ix
+    # basic: n = 1000, ef 20, batches of 5
+    n = 1000
+    ix = index(n, 8, 20)
+    q = np.full(4, float(n), dtype=np.float32)
+    it = ix.create_batch_iterator(q)
+    iters = 0
+    while it.has_next():
+        l, d = it.get_next_results(5, VecSim.BY_SCORE)
+        assert l[0].tolist() == [n - iters * 5 - i - 1 for i in range(5)]
+        iters += 1
+    assert iters == n // 5
+    # reset: batches of 100, three takes
+    it = ix.create_batch_iterator(q)
+    for take in range(3):
+        iters = 0
+        while it.has_next():
+            l, d = it.get_next_results(100, VecSim.BY_SCORE)
+            assert l[0].tolist() == [n - iters * 100 - i - 1 for i in range(100)]
+            iters += 1
+        assert iters == n // 100
+        it.reset()
+    # batch_size_1: labels n - i, ef 2: one result per batch, label == iteration number
+    ix = index(n, 8, 2, labels=[n - i for i in range(n)])
+    it = ix.create_batch_iterator(q)
+    iters = 0
+    while it.has_next():
+        iters += 1
+        l, d = it.get_next_results(1, VecSim.BY_SCORE)
+        assert l[0].tolist() == [iters]
+    assert iters == n
+    # advanced: ef = n = 500; empty index, one vector, zero results, batches of 7 by id, nothing after depletion
+    n = 500
+    q = np.full(4, float(n), dtype=np.float32)
+    ix = index(0, 8, n)
+    it = ix.create_batch_iterator(q)
+    l, d = it.get_next_results(10, VecSim.BY_SCORE)
+    assert np.all(l[0] == -1) and not it.has_next()
+    ix.add_vector(q, n)
+    it = ix.create_batch_iterator(q)
+    l, d = it.get_next_results(10, VecSim.BY_SCORE)
+    assert (l[0] >= 0).sum() == 1 and not it.has_next()
+    for i in range(1, n):
+        ix.add_vector(np.full(4, float(i), dtype=np.float32), i)
+    it = ix.create_batch_iterator(q)
+    l, d = it.get_next_results(0, VecSim.BY_SCORE)
+    assert l.shape[1] == 0 or np.all(l[0] == -1)
+    iters = 0
+    while it.has_next():
+        iters += 1
+        expect = [n - iters * 7 + i for i in range(1, 8)]
+        if iters > n // 7:
+            expect = expect[7 - n % 7:]
+        l, d = it.get_next_results(7, VecSim.BY_ID)
+        assert l[0][l[0] >= 0].tolist() == expect, (iters, l[0], expect)
+    assert iters == n // 7 + 1
+    l, d = it.get_next_results(1, VecSim.BY_SCORE)
+    assert np.all(l[0] == -1)
+
+
+def test_reference_hnsw_batch_iterator_timeouts():
+    """tests/unit/test_hnsw.cpp:1728-1800: a timeout between batches, during the first scan, and in the descent to level 0"""
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric = VecSim.VecSimType_FLOAT32, 4, VecSim.VecSimMetric_L2
+    ix = VecSim.HNSWIndex(p)
+    for i in range(2):
+        ix.add_vector(np.full(4, 1.0, dtype=np.float32), 46 - i)
+    q = np.full(4, 1.0, dtype=np.float32)
+    lib = ix._lib
+    try:
+        it = ix.create_batch_iterator(q)
+        l, d = it.get_next_results(1, VecSim.BY_ID)
+        assert (l[0] >= 0).sum() == 1
+        cb = VecSim.set_timeout_callback(lambda ctx: 1)
+        rep = lib.VecSimBatchIterator_Next(it._h, 1, VecSim.BY_ID)
+        assert lib.VecSimQueryReply_GetCode(rep) == 1 and lib.VecSimQueryReply_Len(rep) == 0
+        lib.VecSimQueryReply_Free(rep)
+        # fails on the second call of the callback: the first batch, while scanning
+        calls = []
+        cb = VecSim.set_timeout_callback(lambda ctx: (calls.append(1), 0 if len(calls) == 1 else 1)[1])
+        it = ix.create_batch_iterator(q)
+        rep = lib.VecSimBatchIterator_Next(it._h, 2, VecSim.BY_ID)
+        assert lib.VecSimQueryReply_GetCode(rep) == 1 and lib.VecSimQueryReply_Len(rep) == 0
+        lib.VecSimQueryReply_Free(rep)
+        assert len(calls) == 2
+        # in the descent: needs a node above level 0
+        VecSim.set_timeout_callback(None)
+        nxt = 0
+        while ix.graph()["max_level"] == 0:
+            ix.add_vector(np.full(4, 1.0, dtype=np.float32), nxt)
+            nxt += 1
+        cb = VecSim.set_timeout_callback(lambda ctx: 1)
+        it = ix.create_batch_iterator(q)
+        rep = lib.VecSimBatchIterator_Next(it._h, 2, VecSim.BY_ID)
+        assert lib.VecSimQueryReply_GetCode(rep) == 1 and lib.VecSimQueryReply_Len(rep) == 0
+        lib.VecSimQueryReply_Free(rep)
+    finally:
+        VecSim.set_timeout_callback(None)

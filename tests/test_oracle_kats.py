@@ -416,6 +416,34 @@ def test_hnsw_search_oracle_on_the_reference_known_answers(vso):
             assert all(lo <= int(x) < hi for x in ol) and all(float(s) <= case["expect_score_max"] for s in od), case["name"]
 
 
+def test_hnsw_batch_iterator_oracle_on_the_fixture_graphs(vso):
+    """oracle/vso_hnsw.c's twin of the batch iterator's walk (hnsw_batch_iterator.h:96-230) on the fixture graphs: a first batch
+    of k <= ef equals the top-k search (same admission rule, same stop), batches never repeat a label and come in non-decreasing
+    score order on these line-shaped inputs, and the Cosine case -- no tied distances -- hands out all 100 vectors in exact order.
+    (With tied distances the walk LOSES entries, upstream as here: a popped candidate whose distance equals lower_bound while
+    top_candidates is full goes neither to the heap nor to the extras, hnsw_single_batch_iterator.h:62-80.)"""
+    z = np.load(os.path.join(GOLD, "kat_hnsw_graphs.npz"))
+    for case in _load("kat_hnsw.json")["topk"]:
+        g, srows = _hnsw_graph(z, case["name"])
+        q = np.array(case["query"], dtype=np.float32)
+        km = 0 if case["metric"] == "L2" else 1
+        if case["metric"] == "Cosine":
+            vso.normalize(q, case["dim"], 0)
+        for k in (1, 5, 10):
+            out, _ = vso.hnsw_iterate(0, km, srows, g, q, 10, [k], case["dim"])
+            ol, od, _ = vso.hnsw_search(0, km, srows, g, q, k, 10, case["dim"])
+            assert np.array_equal(out[0][0], ol) and np.array_equal(out[0][1], od), (case["name"], k)
+        out, depleted = vso.hnsw_iterate(0, km, srows, g, q, 10, [7] * (g["n"] // 7 + 3), case["dim"])
+        labs = np.concatenate([l for l, _ in out])
+        sc = np.concatenate([s for _, s in out])
+        assert depleted and len(set(labs.tolist())) == len(labs) and np.all(np.diff(sc) >= 0), case["name"]
+        if case["name"] == "testCosine":
+            exact = vso.scan(0, km, srows, q, case["dim"])
+            assert np.array_equal(labs, g["labels"][np.lexsort((g["labels"], exact))])
+        else:
+            assert len(labs) <= g["n"]
+
+
 def test_hnsw_range_oracle_on_the_reference_known_answers(vso):
     z = np.load(os.path.join(GOLD, "kat_hnsw_graphs.npz"))
     c = _load("kat_hnsw.json")["range"]

@@ -805,6 +805,7 @@ static bool sparse_materialize(VecSimBatchIterator *it) {
 extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, size_t n_results,
                                                       VecSimQueryReply_Order order) {
     assert((order == BY_ID || order == BY_SCORE) && "Possible order values are only 'BY_ID' or 'BY_SCORE'");
+    if (it->walker) return it->walker->next(n_results, order);
     auto timed_out_reply = []() {
         auto *r = new VecSimQueryReply();
         r->code = VecSim_QueryReply_TimedOut;
@@ -858,12 +859,18 @@ extern "C" VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *it, s
     if (order == BY_ID) vsa::sort_reply(rep, BY_ID);
     return rep;
 }
-extern "C" bool VecSimBatchIterator_HasNext(VecSimBatchIterator *it) { return it->returned < it->label_count; }
+extern "C" bool VecSimBatchIterator_HasNext(VecSimBatchIterator *it) {
+    return it->walker ? !it->walker->depleted() : it->returned < it->label_count;
+}
 extern "C" void VecSimBatchIterator_Free(VecSimBatchIterator *it) {
     if (it->dev) it->index->iteratorDeviceEnd(it->dev);
     delete it;
 }
 extern "C" void VecSimBatchIterator_Reset(VecSimBatchIterator *it) {
+    if (it->walker) {
+        it->walker->reset();
+        return;
+    }
     if (it->dev) it->index->iteratorDeviceEnd(it->dev);
     it->dev = nullptr;
     it->dev_tried = false;

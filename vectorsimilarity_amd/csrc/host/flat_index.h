@@ -217,9 +217,20 @@ private:
 
 }  // namespace vsa
 
+namespace vsa {
+// an iterator that is not "the next n best of one score pass": the HNSW index's graph walk (hnsw_batch_iterator.h:96-230)
+struct IterWalker {
+    virtual ~IterWalker() = default;
+    virtual VecSimQueryReply *next(size_t n_res, VecSimQueryReply_Order order) = 0;
+    virtual bool depleted() const = 0;
+    virtual void reset() = 0;
+};
+}  // namespace vsa
+
 // "next n best" cursor (reference: batch_iterator.h, brute_force/bf_batch_iterator.h:24-199)
 struct VecSimBatchIterator {
     VecSimIndexInterface *index;
+    std::unique_ptr<vsa::IterWalker> walker;   // set: Next / HasNext / Reset are the walker's
     // sparse mode: scores stay on the device, the host only tracks where the reference's array compaction
     // (bf_batch_iterator.h: returned entries are swapped out of the live range) has moved entries
     vsgpu_scorebuf *dev = nullptr;

@@ -897,15 +897,16 @@ VecSimQueryReply *HnswIndex::rangeQuery(const void *query, double radius, VecSim
     return rep;
 }
 
-// Batch iterator.  The reference walks the graph incrementally (hnsw_batch_iterator.h:96-230) and hands out
-// approximate next-best batches; here one exact GPU score pass over the index's vectors feeds the same iterator
-// machinery the Flat index uses, so every batch is the exact next-best set (a deliberate deviation).
+// Batch iterator.  The reference walks the graph incrementally (hnsw_batch_iterator.h:96-230) and hands out approximate
+// next-best batches: hnsw_iter.cpp does the same walk with the GPU's distances (rounds 1-3 answered with the EXACT next-best set
+// from one score pass over all rows, through the Flat index's iterator machinery; VECSIM_HNSW_ITER_EXACT=1 still does).
 VecSimBatchIterator *HnswIndex::newBatchIterator(const void *query, VecSimQueryParams *qp) {
     auto *it = new VecSimBatchIterator();
     it->index = this;
     it->query = preprocess(query);
     it->timeout_ctx = qp ? qp->timeoutCtx : nullptr;
     it->label_count = indexLabelCount();
+    if (!std::getenv("VECSIM_HNSW_ITER_EXACT")) it->walker.reset(newWalker(it->query, qp));
     return it;
 }
 int HnswIndex::iteratorScores(const void *processed_query, std::vector<std::pair<double, size_t>> &out) {

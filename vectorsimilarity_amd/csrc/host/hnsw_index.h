@@ -77,7 +77,11 @@ public:
     int neighborLabels(size_t label, std::vector<std::vector<size_t>> &out);
     std::vector<vsgpu_ctx *> gpus() override;
 
+    // the batch iterator's graph walk (hnsw_iter.cpp)
+    IterWalker *newWalker(std::vector<char> processed_query, VecSimQueryParams *qp);
+
 private:
+    friend class HnswWalk;
     HnswIndex() = default;
     float buildDistance(const float *a, const float *b) const;
     const float *vec(uint32_t id) const { return host_vecs_.data() + (size_t)id * dim_; }

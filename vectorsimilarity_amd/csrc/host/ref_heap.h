@@ -9,7 +9,10 @@
 // `topk`).  This library is built as C++17, so the rule is written out instead of inherited from the standard in force.
 #pragma once
 #include <cstddef>
+#include <functional>
+#include <map>
 #include <queue>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -35,5 +38,54 @@ struct RefPairLess {
 
 template <typename Item = std::pair<double, size_t>>
 using RefMaxHeap = std::priority_queue<Item, std::vector<Item>, RefPairLess>;
+
+// vecsim_stl::min_priority_queue (utils/vecsim_stl.h:85-105): std::priority_queue over std::greater<pair>, i.e. `b < a` in the
+// order above -- the smallest (score, id) on top
+struct RefPairGreater {
+    template <typename P> bool operator()(const P &a, const P &b) const {
+        const int c = score_cmp3(b.first, a.first);
+        return c != 0 ? c < 0 : b.second < a.second;
+    }
+};
+
+// vecsim_stl::updatable_max_heap (utils/updatable_heap.h:20-113): one entry per label, a label keeps the LOWEST score it was
+// offered; top() = the largest score, among equal scores the largest label.  Scores in a multimap ordered by std::greater as
+// upstream (a NaN key breaks that container's strict weak order there as here; multi-value indexes never fill their heap with NaN
+// in the reference's tests, and none of ours depends on it).
+class RefUpdatableMaxHeap {
+public:
+    using Item = std::pair<double, size_t>;
+    bool empty() const { return by_score_.empty(); }
+    size_t size() const { return by_score_.size(); }
+    Item top() const {
+        auto t = topIt();
+        return {t->first, t->second};
+    }
+    void pop() {
+        auto t = topIt();
+        node_of_.erase(t->second);
+        by_score_.erase(t);
+    }
+    void emplace(double score, size_t label) {
+        auto f = node_of_.find(label);
+        if (f == node_of_.end()) node_of_.emplace(label, by_score_.emplace(score, label));
+        else if (f->second->first > score) {
+            by_score_.erase(f->second);
+            f->second = by_score_.emplace(score, label);
+        }
+    }
+
+private:
+    using Map = std::multimap<double, size_t, std::greater<double>>;
+    Map::const_iterator topIt() const {
+        auto rng = by_score_.equal_range(by_score_.begin()->first);
+        auto best = rng.first;
+        for (auto i = rng.first; i != rng.second; ++i)
+            if (best->second < i->second) best = i;
+        return best;
+    }
+    Map by_score_;
+    std::unordered_map<size_t, Map::iterator> node_of_;
+};
 
 }  // namespace vsa

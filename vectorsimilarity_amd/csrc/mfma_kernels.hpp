@@ -480,10 +480,15 @@ __device__ __forceinline__ uint32_t float_sort_key(uint32_t bits) {
     if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
     return bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
 }
-constexpr uint32_t SEL_LDS_KEYS = 8192;   // candidate keys kept in LDS for the 32 counting passes (the rest is re-read from L2)
+constexpr uint32_t SEL_LDS_KEYS = 8192;   // candidate keys kept in LDS for the counting passes (the rest is re-read from L2)
 // one 256-thread workgroup selects query q: `keys` = KEYS words of LDS, nqs = number of queries (the raw counts sit behind the selected ones)
+// The k-th smallest key by radix: four passes of eight bits, each a 256-bin histogram of the keys that share the prefix found so
+// far (LDS atomics; a wave first folds the lanes that hit its two most popular bins -- scores of one batch share their exponent,
+// so the first pass would otherwise serialise on one address), a scan of the bins and the bin that holds rank kk.  (Rounds 1-3
+// found it bit by bit: 32 passes with a barrier and a reduction each, 16-18 us per batch whatever its size -- a quarter of a
+// single query's 77 us, profiles/r04_c1_timeline.txt.)
 template <uint32_t KEYS>
-__device__ __forceinline__ void select_upto_kth_body(uint32_t *keys, uint32_t (*red)[4], uint32_t *wpos, const uint2 *cand, const uint32_t *counts,
+__device__ __forceinline__ void select_upto_kth_body(uint32_t *keys, uint32_t *hist, uint32_t *sh, uint32_t *wpos, const uint2 *cand, const uint32_t *counts,
                                                      uint32_t cap, uint32_t k, uint2 *out, uint32_t *out_counts, uint32_t out_cap, int q, uint32_t nqs) {
     const uint32_t raw = counts[q];
     if (threadIdx.x == 0) out_counts[nqs + q] = raw;   // the raw count rides along (statistics, "fewer than k" check)
@@ -492,25 +497,60 @@ __device__ __forceinline__ void select_upto_kth_body(uint32_t *keys, uint32_t (*
     // raw count that the list is truncated)
     const uint32_t n = min(raw, cap);
     const uint2 *c = cand + (size_t)q * cap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t T = 0xFFFFFFFFu;
     if (n > k) {
         const uint32_t nl = min(n, KEYS);
         for (uint32_t i = threadIdx.x; i < nl; i += 256) keys[i] = float_sort_key(c[i].y);
-        __syncthreads();
-        T = 0;
-        for (int bit = 31; bit >= 0; bit--) {
-            const uint32_t trial = T | (1u << bit);
-            uint32_t cnt = 0;
-            for (uint32_t i = threadIdx.x; i < nl; i += 256) cnt += (keys[i] < trial) ? 1u : 0u;
-            for (uint32_t i = nl + threadIdx.x; i < n; i += 256) cnt += (float_sort_key(c[i].y) < trial) ? 1u : 0u;
+        uint32_t prefix = 0, kk = k;   // the key sought is the kk-th smallest of those whose bits above `shift + 8` equal `prefix`
+        for (int pass = 0; pass < 4 && k > 0; pass++) {
+            const int shift = 24 - 8 * pass;
+            const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            hist[threadIdx.x] = 0;
+            __syncthreads();   // (also: the keys are staged)
+            auto count_key = [&](uint32_t key, bool valid) {
+                bool pend = valid && (key & hi_mask) == prefix;
+                const uint32_t bin = (key >> shift) & 255u;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-            uint32_t *r = red[bit & 1];   // (alternating buffers: one barrier per pass)
-            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = cnt;
+                for (int r = 0; r < 2; r++) {
+                    const unsigned long long m = __ballot(pend);
+                    if (m == 0) break;
+                    const int leader = __ffsll((long long)m) - 1;
+                    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+                    const unsigned long long same = __ballot(pend && bin == lb);
+                    if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+                    pend = pend && bin != lb;
+                }
+                if (pend) atomicAdd(&hist[bin], 1u);
+            };
+            for (uint32_t i0 = 0; i0 < nl; i0 += 256) {
+                const uint32_t i = i0 + threadIdx.x;
+                count_key(i < nl ? keys[i] : 0u, i < nl);
+            }
+            for (uint32_t i0 = nl; i0 < n; i0 += 256) {
+                const uint32_t i = i0 + threadIdx.x;
+                count_key(i < n ? float_sort_key(c[i].y) : 0u, i < n);
+            }
             __syncthreads();
-            const uint32_t total = r[0] + r[1] + r[2] + r[3];
-            if (total < k) T = trial;  // fewer than k keys below `trial`: the k-th smallest has this bit set
+            const uint32_t v = hist[threadIdx.x];
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) sh[wave] = incl;
+            __syncthreads();
+            for (int w = 0; w < wave; w++) incl += sh[w];
+            if (incl >= kk && incl - v < kk) {   // exactly one bin: at least kk keys share the prefix
+                sh[4] = threadIdx.x;
+                sh[5] = kk - (incl - v);
+            }
+            __syncthreads();
+            prefix |= sh[4] << shift;
+            kk = sh[5];
         }
+        T = prefix;
     }
     if (threadIdx.x == 0) *wpos = 0;
     __syncthreads();
@@ -530,9 +570,10 @@ static __global__ __launch_bounds__(256) void k_select_upto_kth(const uint2 *can
                                                          uint32_t k, uint2 *out, uint32_t *out_counts,
                                                          uint32_t out_cap) {
     __shared__ uint32_t keys[SEL_LDS_KEYS];
-    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh[8];
     __shared__ uint32_t wpos;
-    select_upto_kth_body<SEL_LDS_KEYS>(keys, red, &wpos, cand, counts, cap, k, out, out_counts, out_cap, (int)blockIdx.x, gridDim.x);
+    select_upto_kth_body<SEL_LDS_KEYS>(keys, hist, sh, &wpos, cand, counts, cap, k, out, out_counts, out_cap, (int)blockIdx.x, gridDim.x);
 }
 
 

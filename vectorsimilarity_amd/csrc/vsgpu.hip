@@ -178,6 +178,9 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;
     else if (n == "chain_early") c->opt_chain_early = value;
+    else if (n == "events") c->opt_events = value & 3;
+    else if (n == "probe_rt16") c->opt_probe_rt16 = value;
+    else if (n == "thr_radix") c->opt_thr_radix = value;
     else if (n == "sq8_block") c->opt_sq8_block = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
@@ -862,6 +865,7 @@ int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
     const size_t lds = t->gtab ? 0 : offs_b + (size_t)bt * t->prog.steps * t->prog.vl * acc_bytes(t->type);
     const uint32_t q_tiles = (uint32_t)((nq + bt - 1) / bt);
     uint32_t gx = std::min<uint32_t>(n_tiles, (uint32_t)c->n_cu * 8);
+    timed = timed && (c->opt_events & 1);
     if (timed) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     launch_scan(t->ek, t->opk, bt, P, dim3(gx, q_tiles), lds, c->stream);
     HIPCHK(hipGetLastError());
@@ -871,14 +875,13 @@ int run_scan(vsgpu_table *t, ScanParams &P, size_t nq, bool timed) {
 
 void account_scan(vsgpu_ctx *c, vsgpu_table *t, uint64_t rows, uint64_t passes, const char *name) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) {
-        c->stats.scan_ms += ms;
-        c->stats.scan_launches += 1;
-        c->stats.scan_rows += rows;
-        c->stats.scan_bytes += rows * t->row_bytes;
-        (void)passes;
-        snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, "%s", name);
-    }
+    // (without the events -- option "events" bit 0 off -- launches, rows and the kernel's name are still counted; scan_ms stays put)
+    if ((c->opt_events & 1) && hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.scan_ms += ms;
+    c->stats.scan_launches += 1;
+    c->stats.scan_rows += rows;
+    c->stats.scan_bytes += rows * t->row_bytes;
+    (void)passes;
+    snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, "%s", name);
 }
 
 // ------------------------------------------------------------------ dense scores
@@ -1255,7 +1258,7 @@ static int collect_candidates_f64(vsgpu_table *t, const void *queries, size_t nq
     {
         account_scan(c, t, n, 1, scan_name);
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
+        if ((c->opt_events & 2) && hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
     }
     const uint32_t *hraw = hsel.data() + nq;
     std::vector<Hit> hits;
@@ -1314,7 +1317,7 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     {
         account_scan(c, t, n, 1, scan_name);
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
+        if ((c->opt_events & 2) && hipEventElapsedTime(&ms, c->ev_c, c->ev_d) == hipSuccess) c->stats.other_ms += ms;
     }
     // copy out of the pinned staging area: the dense fallback below reuses (and may reallocate) it
     std::vector<uint32_t> hsel_v(hsel, hsel + 2 * nq);
@@ -1513,7 +1516,10 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     return VSGPU_OK;
 }
 int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M) {
-    if (M > 2048)
+    if (c->opt_thr_radix && M <= 8192)
+        hipLaunchKernelGGL(k_probe_threshold_radix, dim3((unsigned)nq), dim3(1024), 0, c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
+    else if (M > 2048)
         hipLaunchKernelGGL(k_probe_threshold_wide, dim3((unsigned)nq), dim3(1024), 0, c->stream,
                            (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
     else
@@ -1560,7 +1566,6 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
         if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) {
             int rc = stage_queries(t, queries, nq, qstride);
             if (rc) return rc;
-            HIPCHK(hipEventRecord(c->ev_c, c->stream));
             ScanParams P{};
             // dense_to_host re-records nothing: time it here as the scan
             rc = ensure(c, c->dense, nq * n * 4);
@@ -1703,7 +1708,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
     rc = ensure(c, c->cand, nq * ccap * sizeof(uint2));
     if (rc) return rc;
 
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_c, c->stream));
     {
         ScanParams P{};
         P.row_ids = nullptr;
@@ -1725,7 +1730,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
                        (const float *)c->dense.p, n0, (uint32_t)n0_valid, (uint32_t)k, M, (float *)c->tau.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->counts.p, 0, nq * 4, c->stream));
-    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_d, c->stream));
     {
         ScanParams P{};
         P.row_ids = nullptr;

@@ -190,7 +190,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
         P.epsilon = range[1];
         P.rcap = (uint32_t)k;
     }
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     const dim3 grid((unsigned)slots);
     switch (t->ek) {
     case EK_F32: launch_hnsw_ek<EK_F32>(t->opk, P, grid, lds, c->stream); break;
@@ -201,7 +201,7 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     default: launch_hnsw_ek<EK_U8>(t->opk, P, grid, lds, c->stream); break;
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_b, c->stream));
     std::vector<float> hs(db == 4 ? nq * k : 0);
     uint64_t hstat = 0;
     HIPCHK(hipMemcpyAsync(labels, g->out_labels.p, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
@@ -213,13 +213,11 @@ static int graph_run(vsgpu_graph *g, const void *queries, size_t nq, size_t qstr
     if (dist_evals) *dist_evals = hstat;
     {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) {
-            c->stats.scan_ms += ms;
-            c->stats.scan_launches += 1;
-            c->stats.scan_rows += hstat;                    // rows gathered = distance evaluations
-            c->stats.scan_bytes += hstat * t->row_bytes;
-            snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, range ? "k_hnsw_search(range)" : "k_hnsw_search");
-        }
+        if ((c->opt_events & 1) && hipEventElapsedTime(&ms, c->ev_a, c->ev_b) == hipSuccess) c->stats.scan_ms += ms;
+        c->stats.scan_launches += 1;
+        c->stats.scan_rows += hstat;                    // rows gathered = distance evaluations
+        c->stats.scan_bytes += hstat * t->row_bytes;
+        snprintf(c->stats.scan_kernel, sizeof c->stats.scan_kernel, range ? "k_hnsw_search(range)" : "k_hnsw_search");
     }
     return VSGPU_OK;
 }

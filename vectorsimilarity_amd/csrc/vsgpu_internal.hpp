@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -55,6 +56,11 @@ struct vsgpu_ctx {
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_wide_blocks = 0;  // k_mfma_filter_wide: 0 = 32 queries per workgroup where measured faster, 1 = always 16, 2 = 32 wherever the registers allow
     long opt_sq8_block = 1;    // (rounds 1-2: the SQ8 filter's block pre-screen; accepted, without effect since round 3)
+    // timing events in the batch's stream (each costs the GPU's timeline 3-5 us, profiles/r04_event_cost.txt): bit 0 = around the
+    // scan kernel (stats.scan_ms: what bench.py's roofline reads), bit 1 = around probe + threshold (stats.other_ms)
+    long opt_events = 1;
+    long opt_thr_radix = 0;    // probe threshold by radix selection (0: bitonic sort / bitwise search, rounds 1-3)
+    long opt_probe_rt16 = 1;   // fp32 / fp64 probe on 16-row tiles where the filter uses them
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
@@ -185,6 +191,9 @@ static inline uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 // around the launch of a table-wide scan kernel (between the timing events): orders it behind the other lanes' scans
+// (round 4, late: putting probe / threshold / scan of all lanes into ONE stream while several batches are in flight -- no
+// cross-queue event between one lane's scan and the next lane's probe -- measured slower on every config, +20 us per batch on
+// config 2, +8 on config 1: tools/tuning_tests/chain_shared.patch, profiles/r04_chain_shared.txt)
 struct ScanChainGuard {
     vsgpu_table *t;
     bool early;                      // option chain_early: the two gates apart (else both from the start to the select kernel)

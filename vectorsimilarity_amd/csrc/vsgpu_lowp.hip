@@ -519,7 +519,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const uint32_t wgs = (uint32_t)c->n_cu * (uint32_t)c->opt_lowp_wg_per_cu;
 
     ScanChainGuard chain(t);   // behind the other reader lanes' probe + scan (see topk_mfma)
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_c, c->stream));
     if (!have_tau) {
         LowpParams Q = P;
         Q.tile_first = 0;
@@ -539,9 +539,9 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         if (rc) return rc;
     }
     VSG_POLL_POINT(c);
-    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_d, c->stream));
     chain.before_scan();   // behind the other lane's select kernel (ScanChain)
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {
         LowpParams Q = P;
         Q.tile_first = 0;
@@ -632,7 +632,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                         sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles);
         }
     }
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_b, c->stream));
     // the scan is in the stream: the next reader lane's probe may follow it and run beside this lane's re-rank and select
     // kernels (small grids both); its SCAN waits for them (ScanChain)
     chain.scan_submitted_if_early();

@@ -21,7 +21,16 @@ template <int KS, int EB = 4> static uint32_t launch_filter_ks(MfmaParams Q, siz
     }
     return Q.n_tiles;
 }
-template <int KS, int EB = 4> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+// rows per probe tile: the filter's own 16-row x 1-KiB stages where the width allows them (round 4: the 64-row probe streamed its
+// 640 MB at 4.3 TB/s where the filter reaches 7; the probe sits between two scans in full, profiles/r04_c2_timeline.txt)
+static inline bool probe_rt16(const vsgpu_ctx *c, int ksteps) { return ksteps % 8 == 0 && ksteps >= 16 && c->opt_probe_rt16 != 0; }
+template <int KS, int EB = 4> static void launch_probe_ks(const MfmaParams &P, dim3 grid, hipStream_t s, bool rt16) {
+    if constexpr (KS % 8 == 0 && KS >= 16) {
+        if (rt16) {
+            hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 2, 1, 16, 0, EB>), grid, dim3(256), mf_probe_lds_bytes(3), s, P);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_mfma_filter<KS, MF_PROBE, 3, 0, 1, 64, 0, EB>), grid, dim3(256), mf_probe_lds_bytes(3), s, P);
 }
 // fp64 rows: the widths vsgpu_table_create picks from for VSGPU_F64 (k-steps of 32 doubles)
@@ -36,15 +45,15 @@ static void launch_filter_f64(int ksteps, const MfmaParams &P, size_t n, uint32_
     default: launch_filter_ks<64, 8>(P, n, wgs, q_tiles, s); break;
     }
 }
-static void launch_probe_f64(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+static void launch_probe_f64(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s, bool rt16) {
     switch (ksteps) {
-    case 4: launch_probe_ks<4, 8>(P, grid, s); break;
-    case 8: launch_probe_ks<8, 8>(P, grid, s); break;
-    case 16: launch_probe_ks<16, 8>(P, grid, s); break;
-    case 24: launch_probe_ks<24, 8>(P, grid, s); break;
-    case 32: launch_probe_ks<32, 8>(P, grid, s); break;
-    case 48: launch_probe_ks<48, 8>(P, grid, s); break;
-    default: launch_probe_ks<64, 8>(P, grid, s); break;
+    case 4: launch_probe_ks<4, 8>(P, grid, s, rt16); break;
+    case 8: launch_probe_ks<8, 8>(P, grid, s, rt16); break;
+    case 16: launch_probe_ks<16, 8>(P, grid, s, rt16); break;
+    case 24: launch_probe_ks<24, 8>(P, grid, s, rt16); break;
+    case 32: launch_probe_ks<32, 8>(P, grid, s, rt16); break;
+    case 48: launch_probe_ks<48, 8>(P, grid, s, rt16); break;
+    default: launch_probe_ks<64, 8>(P, grid, s, rt16); break;
     }
 }
 #ifdef VSGPU_TUNING
@@ -113,24 +122,24 @@ static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wg
     default: launch_filter_ks<32>(P, n, wgs, q_tiles, s); break;
     }
 }
-static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s) {
+static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t s, bool rt16) {
     switch (ksteps) {
-    case 4: launch_probe_ks<4>(P, grid, s); break;
-    case 6: launch_probe_ks<6>(P, grid, s); break;
-    case 8: launch_probe_ks<8>(P, grid, s); break;
-    case 10: launch_probe_ks<10>(P, grid, s); break;
-    case 12: launch_probe_ks<12>(P, grid, s); break;
-    case 16: launch_probe_ks<16>(P, grid, s); break;
-    case 20: launch_probe_ks<20>(P, grid, s); break;
-    case 24: launch_probe_ks<24>(P, grid, s); break;
-    case 28: launch_probe_ks<28>(P, grid, s); break;
-    case 30: launch_probe_ks<30>(P, grid, s); break;
-    case 40: launch_probe_ks<40>(P, grid, s); break;
-    case 48: launch_probe_ks<48>(P, grid, s); break;
-    case 80: launch_probe_ks<80>(P, grid, s); break;
-    case 64: launch_probe_ks<64>(P, grid, s); break;
-    case 96: launch_probe_ks<96>(P, grid, s); break;
-    default: launch_probe_ks<32>(P, grid, s); break;
+    case 4: launch_probe_ks<4>(P, grid, s, rt16); break;
+    case 6: launch_probe_ks<6>(P, grid, s, rt16); break;
+    case 8: launch_probe_ks<8>(P, grid, s, rt16); break;
+    case 10: launch_probe_ks<10>(P, grid, s, rt16); break;
+    case 12: launch_probe_ks<12>(P, grid, s, rt16); break;
+    case 16: launch_probe_ks<16>(P, grid, s, rt16); break;
+    case 20: launch_probe_ks<20>(P, grid, s, rt16); break;
+    case 24: launch_probe_ks<24>(P, grid, s, rt16); break;
+    case 28: launch_probe_ks<28>(P, grid, s, rt16); break;
+    case 30: launch_probe_ks<30>(P, grid, s, rt16); break;
+    case 40: launch_probe_ks<40>(P, grid, s, rt16); break;
+    case 48: launch_probe_ks<48>(P, grid, s, rt16); break;
+    case 80: launch_probe_ks<80>(P, grid, s, rt16); break;
+    case 64: launch_probe_ks<64>(P, grid, s, rt16); break;
+    case 96: launch_probe_ks<96>(P, grid, s, rt16); break;
+    default: launch_probe_ks<32>(P, grid, s, rt16); break;
     }
 }
 
@@ -178,7 +187,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const int KS = t->ksteps;
     const bool wide = KS > 96;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
     const int wide_blocks = (wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1;
-    const size_t QT = wide ? (size_t)MFW_QTILE * wide_blocks : (size_t)MF_QTILE, TILE_ROWS = wide ? 16 : (size_t)MF_TILE_ROWS;
+    const bool rt16 = !wide && probe_rt16(c, KS);
+    const size_t QT = wide ? (size_t)MFW_QTILE * wide_blocks : (size_t)MF_QTILE, TILE_ROWS = (wide || rt16) ? 16 : (size_t)MF_TILE_ROWS;
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = (nq + MF_QTILE - 1) / MF_QTILE * MF_QTILE;
     const bool l2 = (t->metric == VSGPU_L2);
 
@@ -235,8 +245,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     alias_into(c->tau, (char *)c->qblock.p + fb + ab, ab);
     alias_into(c->counts, (char *)c->qblock.p + fb + 2 * ab, ab);
     const uint32_t total_tiles = (uint32_t)((n + TILE_ROWS - 1) / TILE_ROWS);
-    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k));
-    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)c->opt_probe_cap);
+    uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k * MF_TILE_ROWS / TILE_ROWS));   // (at least 256 k rows)
+    probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)(c->opt_probe_cap * (long)(MF_TILE_ROWS / TILE_ROWS)));   // (the cap counts 64-row tiles)
     const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
@@ -286,7 +296,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // one after the other, so each streams at full bandwidth and its HIP-event time is its own; what overlaps with another
     // lane's scan is this lane's query upload before, and its re-rank, selection, download and host replay after
     ScanChainGuard chain(t);
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_c, c->stream));
     if (!have_tau) {   // probe: strided tiles -> per (tile, query) upper bounds
         MfmaParams Q = P;
         Q.tile_first = 0;
@@ -296,16 +306,16 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
         if (wide) launch_wide<MF_PROBE>(KS, wide_blocks, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
-        else if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
-        else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream);
+        else if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream, rt16);
+        else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream, rt16);
         HIPCHK(hipGetLastError());
         rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
         if (rc) return rc;
     }
     VSG_POLL_POINT(c);
-    HIPCHK(hipEventRecord(c->ev_d, c->stream));
+    if (c->opt_events & 2) HIPCHK(hipEventRecord(c->ev_d, c->stream));
     chain.before_scan();   // behind the other lane's select kernel (ScanChain)
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_a, c->stream));
     {   // filter: every tile once
         MfmaParams Q = P;
         Q.tile_first = 0;
@@ -328,7 +338,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (c->opt_events & 1) HIPCHK(hipEventRecord(c->ev_b, c->stream));
     // the scan is in the stream: the next reader lane's probe may follow it and run beside this lane's re-rank and select
     // kernels (small grids both); its SCAN waits for them (ScanChain)
     chain.scan_submitted_if_early();
