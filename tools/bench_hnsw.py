@@ -31,6 +31,8 @@ ap.add_argument("--threads", type=int, default=0, help="host linking threads (VE
 ap.add_argument("--chunk", type=int, default=0, help="add the rows in chunks of this many (progress lines); 0 = one bulk call")
 ap.add_argument("--readers", type=int, default=0, help="also time this many reader threads, each submitting batches of --queries (reader lanes)")
 ap.add_argument("--exact-queries", type=int, default=0, help="recall on the first this-many queries only (0 = all)")
+ap.add_argument("--iterator", type=int, default=0, help="also time the batch iterator's graph walk on this many queries: 10 batches of --k results each, "
+                                                         "against the oracle's twin of the walk on the host (one thread)")
 a = ap.parse_args()
 if a.threads:
     os.environ["VECSIM_HNSW_BUILD_THREADS"] = str(a.threads)
@@ -112,6 +114,30 @@ for ef in [int(x) for x in a.efs.split(",") if x]:
         tb = dt if tb is None else min(tb, dt)
     ef_curve.append({"ef": ef, "qps": a.queries / tb, "recall": sum(len(set(le[i]) & set(exact[i])) for i in range(nx)) / (nx * a.k),
                      "dist_evals_per_query": ix.last_distance_evals() / a.queries})
+if a.iterator:
+    # the batch iterator (hnsw_batch_iterator.h:96-230): host walk, GPU distances fetched VECSIM_HNSW_ITER_AHEAD expansions ahead
+    from oracle import vso   # (the CPU twin of the walk: a baseline beside the number, as in bench.py)
+    g = ix.graph()
+    nbat = 10
+    t0 = time.perf_counter()
+    got = []
+    for i in range(a.iterator):
+        it = ix.create_batch_iterator(q[i])
+        got.append([it.get_next_results(a.k, VecSim.BY_SCORE) for _ in range(nbat)])
+    it_ms = (time.perf_counter() - t0) * 1e3 / (a.iterator * nbat)
+    t0 = time.perf_counter()
+    same = True
+    for i in range(a.iterator):
+        want, _ = vso.hnsw_iterate(0, 0, rows, g, q[i], a.ef, [a.k] * nbat, a.dim)
+        same = same and all(np.array_equal(l[0][:len(wl)], wl.astype(np.int64)) and np.array_equal(d[0][:len(wd)], wd)
+                            for (l, d), (wl, wd) in zip(got[i], want))
+    cpu_ms = (time.perf_counter() - t0) * 1e3 / (a.iterator * nbat)
+    # exactness of what the walk hands out: the first nbat * k labels against the exact order
+    hit = sum(len(set(np.concatenate([l[0] for l, _ in got[i]]).tolist()) & set(bf.knn_query(q[i:i + 1], nbat * a.k)[0][0].tolist()))
+              for i in range(min(a.iterator, 16))) / (min(a.iterator, 16) * nbat * a.k)
+    print(json.dumps({"iterator": "HNSW batch iterator, %d queries x %d batches of %d, efR %d" % (a.iterator, nbat, a.k, a.ef),
+                      "ms_per_batch": it_ms, "cpu_oracle_ms_per_batch": cpu_ms, "equal_to_oracle": bool(same),
+                      "recall_of_first_%d" % (nbat * a.k): hit, "ahead": os.environ.get("VECSIM_HNSW_ITER_AHEAD", "8")}), flush=True)
 kms = st["scan_ms"] / max(1, st["scan_launches"])
 print(json.dumps({"config": "HNSW fp32 L2 N=%d d=%d M=%d efC=%d efR=%d k=%d data=%s" % (a.rows, a.dim, a.M, a.efc, a.ef, a.k, a.data),
                   "host_build_s": build_s, "queries": a.queries, "batch_ms": best * 1e3, "qps": a.queries / best,

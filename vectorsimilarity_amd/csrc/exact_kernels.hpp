@@ -469,90 +469,9 @@ static __global__ __launch_bounds__(1024) void k_probe_threshold_wide(const floa
     }
 }
 
-// The same threshold by radix (round 4; M <= 8192): the keys stay in registers, the k-th smallest is found in four passes of
-// eight bits -- a 256-bin LDS histogram of the keys that share the prefix found so far, a scan of the bins by the first four
-// waves (the selection kernel's scheme, mfma_kernels.hpp) -- 16 barriers in all where the sort takes 55 and the bitwise search
-// 16 with a 48-word reduction each.  This kernel sits between a lane's probe and its scan, i.e. between two scans.
-static __global__ __launch_bounds__(1024) void k_probe_threshold_radix(const float *dense, size_t stride,
-                                                          uint32_t n0, uint32_t k, uint32_t M,
-                                                          float *tau) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh[8];
-    const float *src = dense + (size_t)blockIdx.x * stride;
-    const uint32_t ts = (n0 + M - 1) / M;  // rows per tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t key[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t t = threadIdx.x + 1024u * (uint32_t)j;
-        float m = INFINITY;
-        if (t < M) {
-            const uint32_t lo = t * ts, hi = min(n0, lo + ts);
-            for (uint32_t i = lo; i < hi; i++) {
-                float s = src[i];
-                if (s < m) m = s;  // NaN never wins: a NaN row cannot lower the bound
-            }
-        }
-        const uint32_t bits = __float_as_uint(m);
-        key[j] = bits ^ ((bits & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);   // unsigned order == float order
-    }
-    const uint32_t tiles = (n0 + ts - 1) / ts;   // non-empty tiles
-    if (!(k >= 1 && k <= tiles)) {
-        if (threadIdx.x == 0) tau[blockIdx.x] = INFINITY;
-        return;
-    }
-    uint32_t prefix = 0, kk = k;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 24 - 8 * pass;
-        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (1024u * (uint32_t)j >= M) break;   // (uniform)
-            bool pend = (threadIdx.x + 1024u * (uint32_t)j) < M && (key[j] & hi_mask) == prefix;
-            const uint32_t bin = (key[j] >> shift) & 255u;
-#pragma unroll
-            for (int r = 0; r < 2; r++) {   // the lanes that hit the wave's two most popular bins count as one add each
-                const unsigned long long m = __ballot(pend);
-                if (m == 0) break;
-                const int leader = __ffsll((long long)m) - 1;
-                const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
-                const unsigned long long same = __ballot(pend && bin == lb);
-                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
-                pend = pend && bin != lb;
-            }
-            if (pend) atomicAdd(&hist[bin], 1u);
-        }
-        __syncthreads();
-        uint32_t v = 0, incl = 0;
-        if (threadIdx.x < 256) {
-            v = hist[threadIdx.x];
-            incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) sh[wave] = incl;
-        }
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            for (int w = 0; w < wave; w++) incl += sh[w];
-            if (incl >= kk && incl - v < kk) {   // exactly one bin: at least kk keys share the prefix
-                sh[4] = threadIdx.x;
-                sh[5] = kk - (incl - v);
-            }
-        }
-        __syncthreads();
-        prefix |= sh[4] << shift;
-        kk = sh[5];
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t bits = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
-        tau[blockIdx.x] = __uint_as_float(bits);
-    }
-}
+// (Round 4 tried this threshold by radix selection -- keys in registers, four 8-bit passes over a 256-bin LDS histogram, the
+// selection kernel's scheme: parity-clean and no faster per batch on any config within the +-10 us the boxes scatter,
+// profiles/r04_thr_radix.txt; removed.)
 
 // ---- synthetic rows (bench / tests): identical to oracle/vso.c:vso_hash32 / vso_synth_f32 ----
 __device__ inline uint32_t hash32(uint64_t seed, uint64_t idx) {

@@ -180,7 +180,6 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "chain_early") c->opt_chain_early = value;
     else if (n == "events") c->opt_events = value & 3;
     else if (n == "probe_rt16") c->opt_probe_rt16 = value;
-    else if (n == "thr_radix") c->opt_thr_radix = value;
     else if (n == "sq8_block") c->opt_sq8_block = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
@@ -1516,10 +1515,7 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     return VSGPU_OK;
 }
 int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M) {
-    if (c->opt_thr_radix && M <= 8192)
-        hipLaunchKernelGGL(k_probe_threshold_radix, dim3((unsigned)nq), dim3(1024), 0, c->stream,
-                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
-    else if (M > 2048)
+    if (M > 2048)
         hipLaunchKernelGGL(k_probe_threshold_wide, dim3((unsigned)nq), dim3(1024), 0, c->stream,
                            (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);
     else
