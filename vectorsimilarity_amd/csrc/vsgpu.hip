@@ -1096,12 +1096,18 @@ extern "C" int vsgpu_scores_of(vsgpu_table *t, const void *query, const uint32_t
         if (ids[i] >= t->n) return fail(VSGPU_ERR_ARG, "row id %u beyond table size %zu", ids[i], t->n);
     vsgpu_ctx *c = t->ctx;
     HIPCHK(hipSetDevice(c->device));
-    int rc = stage_queries(t, query, 1, 0);
+    // the ids travel through the pinned staging block, behind the query image stage_queries puts at its start: no copy from
+    // pageable caller memory and no synchronisation before the kernel (the HNSW batch iterator's walk calls this once per group
+    // of expansions, host/hnsw_iter.cpp: one round trip per call)
+    const size_t qbytes = (staged_query_bytes(t, 1) + 8 + 15) & ~(size_t)15;
+    int rc = ensure_pinned(c, qbytes + n * 4);
+    if (rc) return rc;
+    rc = stage_queries(t, query, 1, 0);
     if (rc) return rc;
     rc = ensure(c, c->ids, n * 4);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->ids.p, ids, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // ids is caller memory: finish the copy before returning paths diverge
+    memcpy((char *)c->pinned + qbytes, ids, n * 4);
+    HIPCHK(hipMemcpyAsync(c->ids.p, (char *)c->pinned + qbytes, n * 4, hipMemcpyHostToDevice, c->stream));
     return dense_to_host(t, 1, (const uint32_t *)c->ids.p, 0, n, scores);
 }
 
