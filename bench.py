@@ -305,7 +305,19 @@ def main():
     my_rows = args.rows if args.scaling == "weak" else args.rows // world + (1 if rank < args.rows % world else 0)
     total_rows = args.rows * world if args.scaling == "weak" else args.rows
     if distributed:
-        ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)   # RCCL exchange
+        # RCCL exchange.  Should the communicator fail to come up on any rank (no librccl, no peer access), every rank falls back to
+        # the same records over torch.distributed (gloo) -- slower, still exact -- and the line says so; never a silent mix.
+        transport, why = "rccl", None
+        try:
+            ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)
+        except RuntimeError as e:
+            ix, why = None, str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, why)
+        if any(f is not None for f in flags):
+            transport = "gloo (RCCL communicator failed: %s)" % next(f for f in flags if f is not None)
+            ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank, transport="dist")
+        args.exchange_transport = transport
         ix.add_synthetic_local(my_rows, args.seed)     # shard r holds its vectors of seed + 1000 r
         local = ix.local
     else:
@@ -394,7 +406,7 @@ def main():
                      "fixed_ms_per_batch": float(t[7] - t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
                      "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
                      "rccl_world": int(t[6])} for r, t in enumerate(allr)]
-        assert all(p["rccl_world"] == world for p in per_rank), per_rank   # every communicator spans all N ranks
+        assert args.exchange_transport != "rccl" or all(p["rccl_world"] == world for p in per_rank), per_rank   # every communicator spans all N ranks
 
     if rank == 0:
         dists = total_rows * args.batch * args.steps
@@ -438,7 +450,8 @@ def main():
                        "rows_per_gpu": my_rows, "rows_total": total_rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
                        "reader_threads": readers,
-                       "exchange": ("rccl ncclAllGather of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
+                       "exchange": (("rccl ncclAllGather" if args.exchange_transport == "rccl" else args.exchange_transport) +
+                                    " of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
                                     "merge (C++ host library)" % world) if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},
             "roofline": roof,
             # step time beyond the scan kernel (probe, threshold, re-rank, select, copies, host replay not hidden, launch gaps)

@@ -162,6 +162,31 @@ def test_filtered_scan_path(vso, typ, metric, dim, n, nq, k):
         assert np.array_equal(d1[j], es), (typ, metric, j)
 
 
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [("f32", "L2", 128, 50_000, 3, 10), ("bf16", "IP", 256, 40_000, 20, 10), ("i8", "Cosine", 128, 40_000, 9, 100)])
+def test_timing_events_are_optional_and_change_nothing(vso, typ, metric, dim, n, nq, k):
+    """ctx option `events`: 0 = no timing event in the batch's stream (the lowest-latency setting), 1 = around the scan kernel
+    (default), 3 = around probe + threshold too.  The replies are the same; the counters that need no clock still count."""
+    rng = np.random.default_rng(n + dim + 1)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    got = {}
+    for ev in (1, 0, 3):
+        ix.set_option("events", ev)
+        ix.reset_stats()
+        got[ev] = ix.knn_query(q, k)
+        st = ix.stats()
+        assert st["scan_launches"] >= 1 and "filter" in st["scan_kernel"], (ev, st)
+        assert (st["scan_ms"] > 0) == bool(ev & 1) and (st["other_ms"] > 0) == bool(ev & 2), (ev, st)
+    for ev in (0, 3):
+        assert np.array_equal(got[ev][0], got[1][0]) and np.array_equal(got[ev][1], got[1][1])
+    for j in range(nq):
+        el, es = oracle_topk(vso, typ, metric, rows, q[j], k)
+        assert np.array_equal(got[0][0][j], el.astype(np.int64)) and np.array_equal(got[0][1][j], es)
+
+
 def test_reference_flat_kats_through_c_api(vso):
     with open(os.path.join(GOLD, "kat_flat.json")) as f:
         cases = json.load(f)["cases"]
