@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=47)
     ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--same-gpu", action="store_true", help="test aid: all ranks of a multi-rank run on GPU 0")
     ap.add_argument("--mfma", type=int, default=1)
     ap.add_argument("--readers", type=int, default=2,
                     help="threads submitting batches (the reference's readers: bindings.cpp:250-283 knn_parallel); 2 lets one "
@@ -285,6 +286,8 @@ def main():
         return run_c5(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_gpu:   # test aid: every rank on GPU 0 (a one-GPU box exercising the N > 1 code path; RCCL refuses duplicate devices,
+        local_rank = 0  # so the exchange then runs over the agreed gloo fallback below)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ["VECSIM_GPU_DEVICE"] = str(local_rank)
     # the product's libraries (and with them the ROCm runtime they were built against) come first
