@@ -210,14 +210,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
 
-    // MF_PROBE with tile_run_shift bit 31 ("blocked"): the workgroup's j-th tile (t = blockIdx.x + j gridDim.x) is sample position
-    // start(blockIdx.x) + j, i.e. a workgroup walks NEIGHBOURING sample tiles (tile_step tiles apart instead of gridDim.x * tile_step:
-    // its slab pointers stay put); tilemin keeps the index t.
+    // (round 4: a "blocked" probe -- a workgroup's j-th sample tile next to its (j - 1)-th instead of gridDim.x sample positions
+    // further, so that its slab pointers stay put -- changed no batch time: profiles/r04_probe_blocked.txt; removed)
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
-        if (MODE == MF_PROBE && (P.tile_run_shift >> 31)) {
-            const uint32_t G = gridDim.x, q = P.n_tiles / G, r = P.n_tiles % G, g = t % G, j = t / G;
-            return (P.tile_first + (g * q + min(g, r) + j) * P.tile_step) * RT;
-        }
         return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
     };
     const char *rp_cur[4], *rp_nxt[4];

@@ -359,10 +359,6 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
 
     const uint32_t step = pair_map ? gridDim.x / 2 : gridDim.x;
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
-        if (MODE == MF_PROBE && (P.tile_run_shift >> 31)) {   // "blocked" probe: see k_mfma_filter
-            const uint32_t G = step, q = P.n_tiles / G, r = P.n_tiles % G, g = t % G, j = t / G;
-            return (P.tile_first + (g * q + min(g, r) + j) * P.tile_step) * RT;
-        }
         return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
     };
     // Requests are issued strictly in unit order, so only the frontier tile's addresses are kept

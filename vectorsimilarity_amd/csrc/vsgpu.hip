@@ -180,7 +180,6 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "chain_early") c->opt_chain_early = value;
     else if (n == "events") c->opt_events = value & 3;
     else if (n == "probe_rt16") c->opt_probe_rt16 = value;
-    else if (n == "probe_blocked") c->opt_probe_blocked = value;
     else if (n == "sq8_block") c->opt_sq8_block = value;
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
@@ -1455,7 +1454,6 @@ uint32_t probe_run_shift(const vsgpu_ctx *c, size_t tile_bytes, uint32_t probe_t
     (void)tile_bytes;
     uint32_t s = c->opt_probe_run > 0 ? (uint32_t)c->opt_probe_run : 0;
     while (s > 0 && (probe_tiles >> s) < 64) s--;
-    if (s == 0 && c->opt_probe_blocked) s = 0x80000000u;   // a workgroup's sample tiles are neighbours (k_mfma_filter: tile_row0)
     return s;
 }
 uint32_t probe_divisor(const vsgpu_ctx *c, size_t n, size_t nq, size_t k, bool rerank) {

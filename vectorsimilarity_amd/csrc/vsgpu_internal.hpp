@@ -59,7 +59,6 @@ struct vsgpu_ctx {
     // timing events in the batch's stream (each costs the GPU's timeline 3-5 us, profiles/r04_event_cost.txt): bit 0 = around the
     // scan kernel (stats.scan_ms: what bench.py's roofline reads), bit 1 = around probe + threshold (stats.other_ms)
     long opt_events = 1;
-    long opt_probe_blocked = 0;   // probe: a workgroup samples neighbouring tiles (1) or tiles gridDim.x sample positions apart (0)
     long opt_probe_rt16 = 1;   // fp32 / fp64 probe on 16-row tiles where the filter uses them
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)

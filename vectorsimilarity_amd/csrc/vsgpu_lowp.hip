@@ -265,7 +265,7 @@ static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const
     P.tile_first = L.tile_first;
     P.tile_step = L.tile_step;
     P.n_tiles = L.n_tiles;
-    P.tile_run_shift = L.tile_run_shift & 31u;   // (the wide kernels know no blocked probe)
+    P.tile_run_shift = L.tile_run_shift;
     P.qfrag = L.qfrag;
     P.qn2 = reinterpret_cast<const float *>(L.qaux);
     P.cE = L.cE;

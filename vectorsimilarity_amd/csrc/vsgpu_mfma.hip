@@ -302,7 +302,6 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         Q.tile_first = 0;
         Q.tile_step = tile_step;
         Q.tile_run_shift = probe_run_shift(c, TILE_ROWS * t->row_bytes, probe_tiles);
-        if (wide) Q.tile_run_shift &= 31u;   // (the wide kernels know no blocked probe)
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
