@@ -203,14 +203,27 @@ def run_c5(args):
     build_s = time.perf_counter() - t0
     for w in range(max(1, args.warmup)):
         ix.knn_query(qsets[w % nb_distinct], k)
+    # batches from `--readers` threads, batch s on thread s % readers (the reference's parallel readers, bindings.cpp:250-283: a second
+    # reader searches through a graph view on its own stream, so its staging, download and reply construction overlap with the
+    # other's search kernel), as the Flat configs do
+    readers = max(1, min(args.readers, args.steps))
+    if readers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(readers)
+        list(pool.map(lambda t: ix.knn_query(qsets[t % nb_distinct], k), range(readers)))   # (every lane has searched once)
     ix.reset_stats()
     t0 = time.perf_counter()
-    evals, last = 0, None
-    for s in range(args.steps):
-        last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], k)
-        evals += ix.last_distance_evals()
+    if readers == 1:
+        last = None
+        for s in range(args.steps):
+            last = ix.knn_query(qsets[(args.warmup + s) % nb_distinct], k)
+    else:
+        res = list(pool.map(lambda t: [ix.knn_query(qsets[(args.warmup + s) % nb_distinct], k) for s in range(t, args.steps, readers)][-1:],
+                            range(readers)))
+        last = res[(args.steps - 1) % readers][0]
     dt = time.perf_counter() - t0
     st = ix.stats()
+    evals = st["scan_rows"]   # rows gathered = distance evaluations, summed over the lanes
     kms = st["scan_ms"] / max(1, st["scan_launches"])
     # recall@k against the exact answer (Flat index on the same GPU)
     bp = VecSim.BFParams()
@@ -229,7 +242,7 @@ def run_c5(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "c5: hnsw_f32_l2_top%d" % k, "rows_per_gpu": n, "dim": dim, "batch": nq, "k": k, "M": 16,
-                   "efConstruction": 200, "efRuntime": args.ef,
+                   "efConstruction": 200, "efRuntime": args.ef, "reader_threads": readers,
                    "rows_kind": "i.i.d. U[-1,1) (BASELINE's generator)" if args.data == "uniform" else
                                 "32 latent factors mixed into %d dims + 5%% noise (embedding-like)" % dim,
                    "note": "BASELINE quotes N = 10 M; the default run builds %d rows (host build %.0f s)" % (n, build_s)},
