@@ -630,32 +630,70 @@ __global__ __launch_bounds__(256) void k_exact_pairs(ScanParams P) {
 }
 
 
-// Dense variant: the scores of ALL n rows of one query are in `dense` (column = row id); same
-// bitwise k-th search, the survivors (score <= T_k) are compacted as {row, score} records.
+// Dense variant: the scores of ALL n rows of one query are in `dense` (column = row id); the k-th smallest key by the same radix
+// selection (four passes of eight bits over the n keys, re-read from L2 / HBM: n may be the whole table -- the fallback of a query
+// whose candidates overflowed twice, collect_candidates); the survivors (score <= T_k) are compacted as {row, score} records.
+// (Rounds 1-3: 32 bitwise counting passes over the n keys.)
 static __global__ __launch_bounds__(1024) void k_select_dense_upto_kth(const float *dense, size_t stride, uint32_t n, uint32_t k,
                                                                 uint2 *out, uint32_t *out_counts, uint32_t out_cap) {
-    __shared__ uint32_t red[16];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh[8];
     __shared__ uint32_t wpos;
     const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *c = reinterpret_cast<const uint32_t *>(dense + (size_t)q * stride);
     uint32_t T = 0xFFFFFFFFu;
-    if (n > k) {
-        T = 0;
-        for (int bit = 31; bit >= 0; bit--) {
-            const uint32_t trial = T | (1u << bit);
-            uint32_t cnt = 0;
-#pragma unroll 4
-            for (uint32_t i = threadIdx.x; i < n; i += 1024) cnt += (float_sort_key(c[i]) < trial) ? 1u : 0u;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (n > k && k > 0) {
+        uint32_t prefix = 0, kk = k;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
             __syncthreads();
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-            __syncthreads();
-            uint32_t total = 0;
+            for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+                const uint32_t i = i0 + threadIdx.x;
+                const uint32_t key = i < n ? float_sort_key(c[i]) : 0u;
+                bool pend = i < n && (key & hi_mask) == prefix;
+                const uint32_t bin = (key >> shift) & 255u;
 #pragma unroll
-            for (int w = 0; w < 16; w++) total += red[w];
-            if (total < k) T = trial;
+                for (int r = 0; r < 2; r++) {   // the lanes that hit the wave's two most popular bins count as one add each
+                    const unsigned long long m = __ballot(pend);
+                    if (m == 0) break;
+                    const int leader = __ffsll((long long)m) - 1;
+                    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+                    const unsigned long long same = __ballot(pend && bin == lb);
+                    if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+                    pend = pend && bin != lb;
+                }
+                if (pend) atomicAdd(&hist[bin], 1u);
+            }
+            __syncthreads();
+            uint32_t v = 0, incl = 0;
+            if (threadIdx.x < 256) {
+                v = hist[threadIdx.x];
+                incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (lane == 63) sh[wave] = incl;
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                for (int w = 0; w < wave; w++) incl += sh[w];
+                if (incl >= kk && incl - v < kk) {   // exactly one bin: at least kk keys share the prefix
+                    sh[4] = threadIdx.x;
+                    sh[5] = kk - (incl - v);
+                }
+            }
+            __syncthreads();
+            prefix |= sh[4] << shift;
+            kk = sh[5];
         }
+        T = prefix;
+    } else if (k == 0) {
+        T = 0;
     }
     if (threadIdx.x == 0) wpos = 0;
     __syncthreads();

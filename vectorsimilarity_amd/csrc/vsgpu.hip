@@ -1371,7 +1371,7 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
         }
     }
     std::vector<Hit> hits;
-    std::vector<size_t> retry_q;
+    std::vector<size_t> retry_q, dense_q;
     std::vector<float> retry_tau;
     for (size_t q = 0; q < nq; q++) {
         if (hraw[q] > ccap && !c->in_retry && qstride != 0 && hsel[q] != VSGPU_COUNT_OVERFLOW && hsel[q] >= std::min(k, n)) {
@@ -1393,10 +1393,10 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
             }
         }
         if (hraw[q] > ccap || hraw[q] < std::min(k, n)) {
-            // still more candidates than slots (massive ties) or a short list: exact dense fallback
+            // still more candidates than slots (massive ties) or a short list: exact dense fallback, below, runs of neighbouring
+            // queries together
             c->stats.fallbacks++;
-            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
-            if (rc) return rc;
+            dense_q.push_back(q);
             continue;
         }
         c->stats.candidates += hraw[q];
@@ -1413,6 +1413,13 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
         }
         std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
         emit(hits, q, cap, ids, scores, counts);
+    }
+    for (size_t i = 0; i < dense_q.size();) {
+        size_t j = i + 1;
+        while (j < dense_q.size() && dense_q[j] == dense_q[j - 1] + 1 && qstride != 0) j++;
+        rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, dense_q[i], j - i, queries, qstride);
+        if (rc) return rc;
+        i = j;
     }
     if (!retry_q.empty()) {
         const size_t m = retry_q.size();
@@ -1532,10 +1539,80 @@ int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t
 }
 
 // ------------------------------------------------------------------ top-K
+// Exact scores of ALL rows for nq queries in one dense matrix on the device, the k-th smallest per query by radix selection there
+// (k_select_dense_upto_kth), only the rows at or below it to the host.  The small-problem path of vsgpu_topk and the fallback of
+// queries whose candidate lists overflowed twice (collect_candidates).  fp32-scored tables; the caller bounds nq * n.
+static int dense_gpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
+                          double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n;
+    int rc = stage_queries(t, queries, nq, qstride);
+    if (rc) return rc;
+    ScanParams P{};
+    // dense_to_host re-records nothing: time it here as the scan
+    rc = ensure(c, c->dense, nq * n * 4);
+    if (rc) return rc;
+    P.row_ids = nullptr;
+    P.row_begin = 0;
+    P.row_end = (uint32_t)n;
+    P.n_compact = (uint32_t)n;
+    P.tile_step = (uint32_t)tile_rows_of(t->ek);
+    P.mode = MODE_DENSE;
+    P.out = c->dense.p;
+    P.out_stride = n;
+    rc = run_scan(t, P, nq, true);
+    if (rc) return rc;
+    // selection on the GPU: only the rows with score <= T_k travel to the host
+    const size_t ocap = cap;
+    rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
+    if (rc) return rc;
+    rc = ensure(c, c->selcnt, nq * 8);   // (selected counts, then the raw counts the kernel passes on)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_dense_upto_kth, dim3((unsigned)nq), dim3(1024), 0, c->stream, (const float *)c->dense.p,
+                       n, (uint32_t)n, (uint32_t)std::min(k, n), (uint2 *)c->sel.p, (uint32_t *)c->selcnt.p,
+                       (uint32_t)ocap);
+    HIPCHK(hipGetLastError());
+    rc = ensure_pinned(c, nq * 4 + nq * ocap * sizeof(uint2));
+    if (rc) return rc;
+    uint32_t *hsel = (uint32_t *)c->pinned;
+    uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 4);
+    HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    account_scan(c, t, n, 1, "k_exact_scan(dense)");
+    std::vector<Hit> hits;
+    for (size_t q = 0; q < nq; q++) {
+        if (hsel[q] == VSGPU_COUNT_OVERFLOW) {
+            counts[q] = VSGPU_COUNT_OVERFLOW;
+            continue;
+        }
+        hits.resize(hsel[q]);
+        for (size_t i = 0; i < hsel[q]; i++) {
+            float f;
+            memcpy(&f, &hrec[q * ocap + i].y, 4);
+            hits[i] = Hit{hrec[q * ocap + i].x, (double)f};
+        }
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
+        emit(hits, q, cap, ids, scores, counts);
+    }
+    return VSGPU_OK;
+}
+
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride) {
     // queries [q_first, q_first+q_count) answered from full score vectors
     const size_t n = t->n;
+    if (t->type != VSGPU_F64) {
+        // on the device, a group of queries per pass over the rows (the dense matrix stays below 1 GiB): rounds 1-3 brought every
+        // query's n scores to the host one query at a time -- 74 ms per query at 10 M x 768, tools/bench_overflow.py
+        const size_t group = std::max<size_t>(1, std::min<size_t>(q_count, ((size_t)1 << 30) / (n * 4)));
+        for (size_t q0 = q_first; q0 < q_first + q_count; q0 += group) {
+            const size_t g = std::min(group, q_first + q_count - q0);
+            int rc = dense_gpu_topk(t, (const char *)queries + q0 * qstride, g, qstride, k, cap, ids + q0 * cap, scores + q0 * cap, counts + q0);
+            if (rc) return rc;
+        }
+        return VSGPU_OK;
+    }
     std::vector<double> row(n);
     std::vector<Hit> hits;
     for (size_t q = q_first; q < q_first + q_count; q++) {
@@ -1565,58 +1642,7 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
     // small problems (and fp64 without the MFMA filter: narrow batches, scalar-tier dims): one dense score matrix
     const bool f64_filter = f64 && t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q;
     if ((f64 && !f64_filter) || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k) {
-        if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) {
-            int rc = stage_queries(t, queries, nq, qstride);
-            if (rc) return rc;
-            ScanParams P{};
-            // dense_to_host re-records nothing: time it here as the scan
-            rc = ensure(c, c->dense, nq * n * 4);
-            if (rc) return rc;
-            P.row_ids = nullptr;
-            P.row_begin = 0;
-            P.row_end = (uint32_t)n;
-            P.n_compact = (uint32_t)n;
-            P.tile_step = (uint32_t)tile_rows_of(t->ek);
-            P.mode = MODE_DENSE;
-            P.out = c->dense.p;
-            P.out_stride = n;
-            rc = run_scan(t, P, nq, true);
-            if (rc) return rc;
-            // selection on the GPU: only the rows with score <= T_k travel to the host
-            const size_t ocap = cap;
-            rc = ensure(c, c->sel, nq * ocap * sizeof(uint2));
-            if (rc) return rc;
-            rc = ensure(c, c->selcnt, nq * 8);   // (selected counts, then the raw counts the kernel passes on)
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_select_dense_upto_kth, dim3((unsigned)nq), dim3(1024), 0, c->stream, (const float *)c->dense.p,
-                               n, (uint32_t)n, (uint32_t)std::min(k, n), (uint2 *)c->sel.p, (uint32_t *)c->selcnt.p,
-                               (uint32_t)ocap);
-            HIPCHK(hipGetLastError());
-            rc = ensure_pinned(c, nq * 4 + nq * ocap * sizeof(uint2));
-            if (rc) return rc;
-            uint32_t *hsel = (uint32_t *)c->pinned;
-            uint2 *hrec = (uint2 *)((char *)c->pinned + nq * 4);
-            HIPCHK(hipMemcpyAsync(hsel, c->selcnt.p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(hrec, c->sel.p, nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            account_scan(c, t, n, 1, "k_exact_scan(dense)");
-            std::vector<Hit> hits;
-            for (size_t q = 0; q < nq; q++) {
-                if (hsel[q] == VSGPU_COUNT_OVERFLOW) {
-                    counts[q] = VSGPU_COUNT_OVERFLOW;
-                    continue;
-                }
-                hits.resize(hsel[q]);
-                for (size_t i = 0; i < hsel[q]; i++) {
-                    float f;
-                    memcpy(&f, &hrec[q * ocap + i].y, 4);
-                    hits[i] = Hit{hrec[q * ocap + i].x, (double)f};
-                }
-                std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.id < b.id; });
-                emit(hits, q, cap, ids, scores, counts);
-            }
-            return VSGPU_OK;
-        }
+        if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) return dense_gpu_topk(t, queries, nq, qstride, k, cap, ids, scores, counts);
         if (f64) {
             // fp64: dense double scores per group of queries, 64-bit selection on the GPU, survivors to the host
             const size_t ocap = cap;
