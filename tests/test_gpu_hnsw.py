@@ -857,3 +857,35 @@ def test_reference_hnsw_batch_iterator_timeouts():
         lib.VecSimQueryReply_Free(rep)
     finally:
         VecSim.set_timeout_callback(None)
+
+
+@pytest.mark.parametrize("typ,metric,dim", [("bf16", "L2", 64), ("f16", "IP", 48), ("i8", "Cosine", 64), ("u8", "L2", 40), ("f64", "L2", 32)])
+def test_batch_iterator_walk_over_the_other_stored_types(vso, typ, metric, dim):
+    """the walk's distances are the stored type's reference-order kernel (fp64: doubles, heaps and replies keep every bit)"""
+    from util import METRICS, TYPES, random_vectors, stored_rows
+    n, ef = 2000, 12
+    rng = np.random.default_rng(dim + 5)
+    if typ == "f64":
+        rows, q = rng.uniform(-1, 1, (n, dim)), rng.uniform(-1, 1, (6, dim))
+        vt, srows, sq = VecSim.VecSimType_FLOAT64, rows, q
+    else:
+        rows = random_vectors(rng, n, dim, typ, vso)
+        q = random_vectors(rng, 6, dim, typ, vso)
+        vt = TYPES[typ]
+        srows, sq = stored_rows(vso, rows, typ, metric), stored_rows(vso, q, typ, metric)
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = vt, dim, METRICS[metric], 10, 60, ef
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(rows, np.arange(n))
+    for lab in (7, 300):
+        ix.delete_vector(lab)
+    g = ix.graph()
+    km = METRICS["IP"] if (metric == "Cosine" and typ not in ("i8", "u8")) else METRICS[metric]
+    sizes = [12, 5, 40, 12]
+    for j in range(len(q)):
+        want, _ = vso.hnsw_iterate(vso.F64 if typ == "f64" else vt, km, srows, g, sq[j], ef, sizes, dim)
+        _, got = _walk_batches(ix, q[j], sizes)
+        assert len(got) == len(want)
+        for (gl, gd), (wl, wd) in zip(got, want):
+            assert np.array_equal(gl[:len(wl)], wl.astype(np.int64)) and np.all(gl[len(wl):] == -1), (typ, j)
+            assert np.array_equal(gd[:len(wd)], wd), (typ, j)
