@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--readers", type=int, default=0, help="> 1: every shape is also queried by this many threads at once (reader lanes)")
+ap.add_argument("--wide", action="store_true", help="only the wide-row kernels' shapes: 16-bit rows of 2049 .. 8192 elements, 8-bit rows of 4097 .. 16384, "
+                                                     "fp32 3073 .. 8192, batches above and below the 16 / 32 / 64 queries a workgroup holds")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 T = {"f32": VecSim.VecSimType_FLOAT32, "f64": VecSim.VecSimType_FLOAT64, "bf16": VecSim.VecSimType_BFLOAT16,
@@ -48,10 +50,16 @@ while time.time() < t_end:
     dmax = {"f32": 8192, "bf16": 8192, "f16": 8192, "i8": 16384, "u8": 16384, "f64": 2048, "sq8": 1024}[typ]   # (round 4: int8 / uint8 wide rows)
     dim = int(rng.choice([rng.integers(8, 200), rng.integers(200, 1100), rng.integers(min(1100, dmax), dmax + 1)], p=[0.3, 0.45, 0.25]))
     dim = min(dim, dmax)
+    if a.wide:
+        typ = rng.choice(["f32", "bf16", "f16", "i8", "u8"])
+        lo, hi = {"f32": (3073, 8192), "bf16": (2049, 8192), "f16": (2049, 8192), "i8": (4097, 16384), "u8": (4097, 16384)}[typ]
+        dim = int(rng.choice([rng.integers(lo, lo + (hi - lo) // 6), rng.integers(lo, hi + 1)]))   # (half of them in the narrowest kernel width)
     eb = {"f32": 4, "f64": 8, "bf16": 2, "f16": 2, "i8": 1, "u8": 1, "sq8": 1}[typ]
     budget = int(rng.choice([3e7, 1.5e8, 4e8]))                      # bytes of rows: one slab .. several
     n = max(300, min(400_000, budget // (dim * eb)))
     nq = int(rng.choice([1, 3, 16, 17, 40, 64, 100, 128, 200, 256]))
+    if a.wide:
+        nq = int(rng.choice([16, 31, 33, 48, 64, 65, 100, 128]))
     k = int(rng.choice([1, 10, 10, 37, 100]))
     scale = float(rng.choice([1.0, 1.0, 30.0, 1e-3]))
     p = VecSim.BFParams()

@@ -90,7 +90,12 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
     for (int nt = 0; nt < NQ; nt++) {
 #pragma unroll
-        for (int i = 0; i < KMINE; i++) asm volatile("" : "+v"(qf[nt][i]));
+        for (int i = 0; i < KMINE; i++) {
+            // more than ~220 registers of fragments (four column blocks at KSTEPS 96): the upper half is parked in AGPRs, which the
+            // MFMA reads directly (one wave per SIMD owns all 512 registers of a lane); left to hipcc they are spilled
+            if (NQ * KMINE * 4 > 224 && nt >= NQ / 2) asm volatile("" : "+a"(qf[nt][i]));
+            else asm volatile("" : "+v"(qf[nt][i]));
+        }
         asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]));
     }
 

@@ -248,7 +248,10 @@ template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blo
     // WIDE_NS_ALONE: see vsgpu_mfma.hip (a deeper ring for a workgroup alone on its CU measured no faster)
     constexpr int NA = WIDE_NS_ALONE;
     switch (ksteps) {
-    case 96: nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 96:   // (four column blocks -- 64 queries in ONE pass over the rows -- fit a wave's 512 registers at this width: half of them AGPRs)
+        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA>, 4, NA);
+        else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
+        break;
     case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
     case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
     default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA>, 1, NA); break;
@@ -310,7 +313,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // per wave).  Since every wave works in every unit (round 4) two 32-query tiles beat four 16-query ones at every width
     // (bf16 3072 / 4096, batch 64: 3.04 / 3.19 -> 4.15 / 4.55 TB/s; int8 6144 / 8192: 3.05 / 3.26 -> 3.73 / 4.04); option
     // wide_blocks = 1: 16 everywhere
-    const int wide_blocks = (t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && KS <= 192) ? 2 : 1;
+    // (round 4, late) at kernel width 96 k-steps -- 16-bit rows up to 3072 elements, 8-bit rows up to 6144 -- FOUR column blocks fit: 384
+    // registers of fragments per wave, half of them AGPRs, one wave per SIMD; a batch of 64 then crosses the rows once instead of twice
+    // (bf16 3072, batch 64: 4.18 -> 6.05 TB/s; int8 6144: 3.74 -> 4.91; profiles/r04_wide_blocks4.txt); option wide_blocks = 2: at most 32
+    const int wide_blocks = (t->lp_wide && nq > 32 && KS == 96 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 4)) ? 4
+                            : ((t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && KS <= 192) ? 2 : 1);
     const size_t QT = t->lp_wide ? (size_t)16 * wide_blocks : hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
     const bool is_sq8 = (t->lp_kind == LP_SQ8);
@@ -605,7 +612,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             }
         } else if (t->lp_wide) {
             // gridDim.x a multiple of 8: the query tiles of a row tile (blockIdx.y) land on one XCD and share its L2 (vsgpu_mfma.hip)
-            const uint32_t per_cu = (wide_blocks == 2 || KS > 192) ? 1u : 2u;   // (workgroups resident per CU)
+            const uint32_t per_cu = (wide_blocks >= 2 || KS > 192) ? 1u : 2u;   // (workgroups resident per CU)
             const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
             launch_wide_h16(t, MF_FILTER, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
