@@ -261,6 +261,36 @@ def test_all_identical_vectors_overflow_fallback(vso):
         assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es)
 
 
+@pytest.mark.parametrize("typ,dim", [("f16", 13), ("f32", 5), ("bf16", 20)])
+def test_overflow_on_a_table_without_an_mfma_filter(vso, typ, dim):
+    """tiny dims run the exact kernels' own filter path; when its candidate lists overflow (massive ties) there is no
+    MFMA filter to run a second pass with -- round 3 called one all the same (a GPU fault, found by the round-4 soak on fp16 dim 13,
+    400 K rows, k 37) -- and the queries are answered by the dense pass on the device"""
+    from util import TYPES
+    n, nq, k = 60_000, 3, 37
+    rng = np.random.default_rng(dim)
+    vals = np.tile(rng.integers(-1, 2, dim).astype(np.float32), (n, 1))     # every row the same vector: all of them tie at T_k
+    vals[::7] += 1.0                                                       # (and a second, farther group)
+    q32 = rng.integers(-1, 2, (nq, dim)).astype(np.float32)
+    if typ == "f16":
+        rows, q = vals.astype(np.float16).view(np.uint16), q32.astype(np.float16).view(np.uint16)
+    elif typ == "bf16":
+        rows, q = (vals.view(np.uint32) >> 16).astype(np.uint16), (q32.view(np.uint32) >> 16).astype(np.uint16)
+    else:
+        rows, q = vals, q32
+    ix = make_index(typ, "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    ix.set_option("cand_cap", 64)
+    ix.reset_stats()
+    l, d = ix.knn_query(q, k)
+    st = ix.stats()
+    assert "k_exact_scan" in st["scan_kernel"] and st["fallbacks"] > 0 and st["retries"] == 0, st
+    for j in range(nq):
+        el, es = oracle_topk(vso, typ, "L2", rows, q[j], k)
+        assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es), (typ, j)
+
+
 def test_delete_and_overwrite_keep_the_device_mirror_coherent(vso):
     rng = np.random.default_rng(9)
     dim, n = 24, 3000

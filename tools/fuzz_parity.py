@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--readers", type=int, default=0, help="> 1: every shape is also queried by this many threads at once (reader lanes)")
+ap.add_argument("--verbose", action="store_true", help="print every shape before it runs (the last line names the shape a crash happened in)")
 ap.add_argument("--wide", action="store_true", help="only the wide-row kernels' shapes: 16-bit rows of 2049 .. 8192 elements, 8-bit rows of 4097 .. 16384, "
                                                      "fp32 3073 .. 8192, batches above and below the 16 / 32 / 64 queries a workgroup holds")
 a = ap.parse_args()
@@ -71,6 +72,8 @@ while time.time() < t_end:
     for r0 in range(0, n, 100_000):
         ix.add_vectors(rows[r0:r0 + 100_000], np.arange(r0, min(n, r0 + 100_000)))
     q = vectors(typ, nq, dim, scale)
+    if a.verbose:
+        print("shape", runs, typ, metric, "dim", dim, "n", n, "nq", nq, "k", k, "scale", scale, flush=True)
     ix.set_option("dense_pairs", 0)
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)

@@ -1374,7 +1374,10 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     std::vector<size_t> retry_q, dense_q;
     std::vector<float> retry_tau;
     for (size_t q = 0; q < nq; q++) {
-        if (hraw[q] > ccap && !c->in_retry && qstride != 0 && hsel[q] != VSGPU_COUNT_OVERFLOW && hsel[q] >= std::min(k, n)) {
+        // (only behind an MFMA filter: `chain` is theirs.  The exact-kernel filter path of a table without one -- tiny dims, the scalar
+        // tier -- has no second filter to run and goes to the dense pass below; round 3 sent it into topk_mfma, a fault on such a
+        // table: found by the round-4 soak, fp16 dim 13, 400 K rows, k 37)
+        if (chain != nullptr && hraw[q] > ccap && !c->in_retry && qstride != 0 && hsel[q] != VSGPU_COUNT_OVERFLOW && hsel[q] >= std::min(k, n)) {
             // More candidates than slots (near-duplicate clusters: the probe's threshold sits inside the cluster).  The slots
             // that were filled hold real rows with exact scores, so the k-th smallest of THEM -- the largest score the selection
             // kept -- bounds the true k-th score from above and is far tighter than the probe's: one more filter pass over all
