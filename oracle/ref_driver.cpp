@@ -12,6 +12,7 @@
  *   bf16 / fp16 conversions            types/bfloat16.h:23-39, types/float16.h:33-117
  *   the Flat top-k container           utils/vecsim_stl.h:63-83 (max_priority_queue)
  *   the multi-value top-k container    utils/updatable_heap.h:20-113
+ *   the min-heap of the HNSW iterator  utils/vecsim_stl.h:85-89 (min_priority_queue; vsref_heap_script)
  * The two heap loops below are the caller side of those containers: the statements of brute_force.h:257-288
  * (insert when `score < upperBound || size < k`, pop when over k, upperBound = top) -- BruteForceIndex itself
  * cannot be compiled here (vec_sim_index.h reaches spaces/space_includes.h:13, the cpu_features headers).
@@ -137,6 +138,42 @@ size_t vsref_topk(const double *scores, const size_t *labels, size_t n, size_t k
                   size_t *out_labels, double *out_scores) {
     return wide ? topk_loop<double>(scores, labels, n, k, multi, out_labels, out_scores)
                 : topk_loop<float>(scores, labels, n, k, multi, out_labels, out_scores);
+}
+
+/* A script of container operations on the reference's own heaps -- the ones the HNSW batch iterator keeps between batches
+ * (hnsw_batch_iterator.h:33-52: candidates and top_candidates_extras are vecsim_stl::min_priority_queue, top_candidates is
+ * max_priority_queue or, for multi-value indexes, updatable_max_heap).  kind 0 = min_priority_queue<double, size_t>,
+ * 1 = max_priority_queue, 2 = updatable_max_heap.  op[i] = 0: emplace(score[i], label[i]); 1: pop (ignored when empty).
+ * After every operation: out_size[i], and the top's score / label (NaN / ~0 when empty). */
+void vsref_heap_script(int kind, const int *op, const double *score, const size_t *label, size_t n, size_t *out_size,
+                       double *out_top_score, size_t *out_top_label) {
+    auto alloc = VecSimAllocator::newVecsimAllocator();
+    vecsim_stl::min_priority_queue<double, size_t> mn(alloc);
+    vecsim_stl::max_priority_queue<double, size_t> mx(alloc);
+    vecsim_stl::updatable_max_heap<double, size_t> up(alloc);
+    for (size_t i = 0; i < n; i++) {
+        if (op[i] == 0) {
+            if (kind == 0) mn.emplace(score[i], label[i]);
+            else if (kind == 1) mx.emplace(score[i], label[i]);
+            else up.emplace(score[i], label[i]);
+        } else {
+            if (kind == 0) { if (!mn.empty()) mn.pop(); }
+            else if (kind == 1) { if (!mx.empty()) mx.pop(); }
+            else { if (!up.empty()) up.pop(); }
+        }
+        const size_t sz = kind == 0 ? mn.size() : (kind == 1 ? mx.size() : up.size());
+        out_size[i] = sz;
+        if (sz == 0) {
+            out_top_score[i] = std::numeric_limits<double>::quiet_NaN();
+            out_top_label[i] = ~(size_t)0;
+        } else if (kind == 0) {
+            out_top_score[i] = mn.top().first; out_top_label[i] = mn.top().second;
+        } else if (kind == 1) {
+            out_top_score[i] = mx.top().first; out_top_label[i] = mx.top().second;
+        } else {
+            out_top_score[i] = up.top().first; out_top_label[i] = up.top().second;
+        }
+    }
 }
 
 } /* extern "C" */

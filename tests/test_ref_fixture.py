@@ -151,3 +151,41 @@ def test_product_merge_replays_like_the_reference_containers(fixture):
             assert refgen.hexbits(osc[0]) == e["scores"], (e["case"], parts)
         n_checked += 1
     assert n_checked >= 8
+
+
+def test_product_heaps_equal_the_reference_containers_on_scripts():
+    """vectorsimilarity_amd/csrc/host/ref_heap.h -- the min-heap order, the max-heap order and the label-keyed updatable heap the HNSW
+    batch iterator's walk, the Flat replay and the sharded merge keep their state in -- against the reference's OWN containers
+    (utils/vecsim_stl.h:63-89, utils/updatable_heap.h:20-113, compiled as gnu++20 into oracle/_ref): random scripts of emplace / pop
+    with ties, +-inf and (std::priority_queue kinds) NaN scores; size and top after every operation
+    (tests/golden/ref_heap_scripts.json <- make_ref_heap_scripts.py).  With the reference build present the live library is run too."""
+    import ctypes as C
+    import importlib.util
+    import subprocess
+    helpers = os.path.join(os.path.dirname(__file__), "helpers")
+    so, src = os.path.join(helpers, "libref_heap_probe.so"), os.path.join(helpers, "ref_heap_probe.cpp")
+    hdr = os.path.join(os.path.dirname(__file__), "..", "vectorsimilarity_amd", "csrc", "host", "ref_heap.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", so, src], check=True)
+    probe = C.CDLL(so).heap_script
+    spec = importlib.util.spec_from_file_location("make_ref_heap_scripts", os.path.join(GOLD, "make_ref_heap_scripts.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(GOLD, "ref_heap_scripts.json")) as f:
+        cases = json.load(f)["cases"]
+    assert [(c["seed"], c["kind"], c["n"]) for c in cases] == gen.CASES
+    live = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libvsref.so")
+    ref = C.CDLL(live).vsref_heap_script if os.path.exists(live) else None
+    nan_tops = 0
+    for c in cases:
+        op, score, label = gen.script(c["seed"], c["kind"], c["n"])
+        sz, ts, tl = gen.run(probe, c["kind"], op, score, label)
+        want_ts = np.array(c["top_score_bits"], dtype=np.uint64).view(np.float64)
+        assert sz.tolist() == c["size"], (c["seed"], c["kind"])
+        assert np.array_equal(ts, want_ts, equal_nan=True), (c["seed"], c["kind"], np.nonzero(~((ts == want_ts) | (np.isnan(ts) & np.isnan(want_ts))))[0][:5])
+        assert tl.tolist() == c["top_label"], (c["seed"], c["kind"])
+        nan_tops += int(np.isnan(want_ts[np.array(c["size"]) > 0]).sum())
+        if ref is not None:
+            rsz, rts, rtl = gen.run(ref, c["kind"], op, score, label)
+            assert rsz.tolist() == c["size"] and rtl.tolist() == c["top_label"] and np.array_equal(rts, want_ts, equal_nan=True)
+    assert nan_tops > 0   # (NaN scores did reach the top of a heap: the gnu++20 pair order was exercised)
