@@ -38,3 +38,13 @@ def test_random_hnsw_indexes_batch_iterator_equals_the_oracle_walk():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_random_wide_row_shapes_filter_path_equals_exact_path():
+    """tools/fuzz_parity.py --wide: only the wide-row kernels' shapes (16-bit rows of 2049 .. 8192 elements, 8-bit rows of 4097 .. 16384, fp32
+    3073 .. 8192; batches on both sides of the 16 / 32 / 64 queries a workgroup holds -- four column blocks at kernel width 96), two reader
+    threads (the soaks: 642 + 492 shapes, no mismatch)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--wide", "--seconds", "15", "--seed", "21", "--readers", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout, r.stdout[-2000:]
