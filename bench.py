@@ -12,13 +12,16 @@ Configs (BASELINE.json `configs`; default c2 = the one `metric` is quoted on):
                                                           on the host cores first: ~3 min per million rows); --data uniform | lowrank
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (one rank
-per GPU).  Every rank holds its own shard of `rows` vectors (weak scaling; --scaling strong: rows / N of them, the job's
-total stays `rows`), scans it for the same query batch, and the
+per GPU).  Every rank holds its shard, scans it for the same query batch, and the
 per-shard candidate records are exchanged by ONE ncclAllGather per batch -- RCCL over xGMI, issued by the C++ host
 library (csrc/vsgpu_comm.hip behind VecSimGpu_Sharded*, include/VecSim/vec_sim_gpu.h) -- and merged into the exact
 single-index reply on every rank.  torch.distributed is the control plane only (gloo: rank 0's RCCL id, barriers, the
 max-over-ranks of the wall time); it never touches the GPU, so the timed region is bracketed by barrier + the library's
 own device drain (every C-API call returns with its HIP streams synchronised).  Rank 0 prints ONE JSON line.
+Scaling: N > 1 runs TWO phases by default (--scaling both) -- strong (the job holds `rows` vectors, rows / N per rank: what
+BASELINE's metric "N = 10 M at 1 / 2 / 4 / 8 GPUs" names) and weak (`rows` per rank: config 4's own definition) --; the line's
+value / ms_per_step / scaling are the config's own kind (c2: strong, c4: weak), the other phase is reported under "also".
+On one GPU (c2) the line also carries the MEASURED steps of rows / 2, / 4, / 8 shards: the pieces of the strong-scaling curve.
 
 value        = distances/s = rows(all shards) * batch * steps / wall (max over ranks).  Vectors are resident in HBM
                before timing; query upload, kernels, candidate download, exchange, host replay and reply construction
@@ -77,10 +80,13 @@ def parse():
                     help="c5 only.  uniform: BASELINE's i.i.d. U[-1,1) rows (intrinsic dimension = d: no graph index finds neighbours "
                          "there); lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
     ap.add_argument("--ef", type=int, default=128, help="c5: efRuntime")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1.  weak (default, what the driver's plain --gpus N run measures): every rank holds --rows vectors, the "
-                         "job holds N x rows (config 4 is defined that way: 100 M rows over 8 GPUs).  strong: the job holds --rows "
-                         "vectors, rank r holds its share of them (BASELINE's headline reads N = 10 M at 1 / 2 / 4 / 8 GPUs)")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
+                    help="N > 1.  strong: the job holds --rows vectors, rank r holds its share of them (BASELINE's headline reads N = 10 M "
+                         "at 1 / 2 / 4 / 8 GPUs).  weak: every rank holds --rows vectors, the job holds N x rows (config 4 is defined that "
+                         "way: 100 M rows over 8 GPUs).  both (default): two phases in one run -- the config's own kind first (c2: strong, "
+                         "c4: weak: the line's value / scaling), the other kind under \"also\"")
+    ap.add_argument("--no-shard-curve", dest="shard_curve", action="store_false",
+                    help="one GPU, c2: skip measuring the rows / G shards (G = 2, 4, 8) the strong-scaling estimate is built from")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning: VecSimGpu_SetOption on the index (e.g. probe_div=64); not used by the default run")
     a = ap.parse_args()
@@ -123,9 +129,15 @@ def cpu_baseline(args, VecSim, synth):
     small.add_synthetic(n, args.seed)
     small.set_option("mfma", args.mfma)
     rows = small.stored_rows(0, n)
-    head = gen(args.seed, 0, min(n, 64), args.dim)              # host twin on the first rows: same bytes
-    assert np.array_equal(rows[:len(head), :head.view(np.uint8).reshape(len(head), -1).shape[1]], head.view(np.uint8).reshape(len(head), -1)) \
-        or args.metric_name == "Cosine", "device and host generators disagree"
+    # checker independence (round-4 advisor finding): the CPU leg reads its rows back from the GPU index it is then compared with, so
+    # the rows themselves are checked against the HOST generator -- the first 64 and 31 runs of 8 spread over the whole sample
+    spots = [(0, min(n, 64))] + [(r0, min(8, n - r0)) for r0 in sorted({(i * (n // 31) + 7 * i) % max(1, n - 8) for i in range(1, 32)}) if n > 72]
+    eb = args.dim * {"FLOAT32": 4, "INT8": 1, "BFLOAT16": 2}[args.type_name]
+    hosts = [(r0, gen(args.seed, r0, cnt, args.dim)) for r0, cnt in spots]
+    for r0, h in hosts:
+        hb = h.view(np.uint8).reshape(len(h), -1)
+        assert np.array_equal(rows[r0:r0 + len(h), :eb], hb[:, :eb]), "device and host generators disagree at row %d" % r0
+    head = hosts[0][1]
     qraw = gen(args.seed + 1, 0, args.batch, args.dim)
     if args.metric_name == "Cosine":                         # int8 Cosine: stored blob = elements + float norm
         def with_norm(a):
@@ -163,8 +175,12 @@ def cpu_baseline(args, VecSim, synth):
     # checker: the GPU index over the same n rows must give the same labels, order and scores
     gl, gs = small.knn_query(qraw, args.topk)
     same = bool(np.array_equal(gl, labels.astype(np.int64)) and np.array_equal(gs, scores))
+    row_bytes = rows.shape[1] * rows.dtype.itemsize
     return {"value": n * args.batch / tall, "unit": "distances/s", "cores": threads, "kind": "port",
-            "single_thread": {"value": n * nq1 / t1, "unit": "distances/s", "cores": 1,
+            # every thread scans the whole sample for its query: the all-cores figure is bound by the host's DRAM (the sample does not
+            # fit the caches), so it moves with the sample size and the box's memory, not with the kernel -- read it next to its GB/s
+            "effective_GBps": n * row_bytes * args.batch / tall / 1e9,
+            "single_thread": {"value": n * nq1 / t1, "unit": "distances/s", "cores": 1, "effective_GBps": n * row_bytes * nq1 / t1 / 1e9,
                               "note": "the reference scans single-threaded (brute_force.h:264-281)"},
             "cpu": cpu_model(), "nproc": nproc,
             "tier": tier_name,
@@ -241,7 +257,9 @@ def run_c5(args):
         "value": nq * args.steps / dt, "unit": "queries/s", "qps": nq * args.steps / dt,
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "c5: hnsw_f32_l2_top%d" % k, "rows_per_gpu": n, "dim": dim, "batch": nq, "k": k, "M": 16,
+        "config": {"workload": "c5: hnsw_f32_l2_top%d, N=%d of BASELINE's 10000000 rows%s" % (
+                       k, n, "" if n == 10_000_000 else " (REDUCED: the graph is built on the host cores first, ~36 min at 10 M; --rows 10000000 runs it)"),
+                   "rows_per_gpu": n, "rows_baseline": 10_000_000, "dim": dim, "batch": nq, "k": k, "M": 16,
                    "efConstruction": 200, "efRuntime": args.ef, "reader_threads": readers,
                    "rows_kind": "i.i.d. U[-1,1) (BASELINE's generator)" if args.data == "uniform" else
                                 "32 latent factors mixed into %d dims + 5%% noise (embedding-like)" % dim,
@@ -291,6 +309,121 @@ def run_c5(args):
     print(json.dumps(out))
 
 
+def build_index(args, p, my_rows, rank, world, local_rank, dist, distributed, VecSim, ShardedFlatIndex):
+    """this rank's index over `my_rows` device-generated rows: a plain Flat index, or (launched through torch.distributed.run) its
+    shard of a sharded one with the RCCL exchange -- falling back, on ALL ranks alike, to the same records over gloo should any
+    rank's communicator fail to come up; the line then says so"""
+    if not distributed:
+        ix = VecSim.BFIndex(p)
+        ix.add_synthetic(my_rows, args.seed)
+        ix.set_option("mfma", args.mfma)
+        for o in args.opt:
+            name, val = o.split("=", 1)
+            ix.set_option(name, int(val))
+        return ix, ix, None
+    transport, why = "rccl", None
+    try:
+        ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)
+    except RuntimeError as e:
+        ix, why = None, str(e)
+    flags = [None] * world
+    dist.all_gather_object(flags, why)
+    if any(f is not None for f in flags):
+        transport = "gloo (RCCL communicator failed: %s)" % next(f for f in flags if f is not None)
+        ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank, transport="dist")
+    ix.add_synthetic_local(my_rows, args.seed)     # shard r holds its vectors of seed + 1000 r
+    local = ix.local
+    local.set_option("mfma", args.mfma)
+    for o in args.opt:
+        name, val = o.split("=", 1)
+        local.set_option(name, int(val))
+    return ix, local, transport
+
+
+def timed_phase(args, ix, local, transport, my_rows, steps, qsets, rank, world, dist, distributed, readers, nwarm):
+    """nwarm untimed batches, then exactly `steps` timed ones bracketed by barrier + device synchronisation on both sides; the wall
+    time is the MAX over ranks.  Returns what the JSON line is made of."""
+    from vectorsimilarity_amd import _capi
+    nb_distinct = len(qsets)
+
+    def sync():
+        # the timed region is bracketed by a barrier and a device-wide synchronisation on both sides (the query calls are
+        # synchronous, so the device is idle here anyway; hipDeviceSynchronize through the product's library covers every stream
+        # of this process on its GPU, torch's included, without initialising a second HIP context through torch.cuda)
+        if dist is not None:
+            dist.barrier()
+        _capi.load().VecSimGpu_DeviceSynchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # The sharded exchange is a collective, so every rank must pair the same batches: batch b carries sequence number b and is
+    # answered by reader thread b % readers on every rank (the library issues the exchanges in sequence order whatever the
+    # threads' relative speed), so one batch's exchange + merge runs under the next batch's scan, as on a single GPU.
+    def answer(b, qs):
+        return ix.knn_query(qs, args.topk, seq=b) if distributed else ix.knn_query(qs, args.topk)
+
+    pool = None
+    if readers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(readers)
+
+    def run_batches(first_seq, qsel, count):
+        """`count` batches, batch j (sequence number first_seq + j) on thread j % readers; returns the last batch's reply"""
+        if readers == 1:
+            out = None
+            for j in range(count):
+                out = answer(first_seq + j, qsets[qsel(j) % nb_distinct])
+            return out
+        res = list(pool.map(lambda t: [answer(first_seq + j, qsets[qsel(j) % nb_distinct]) for j in range(t, count, readers)][-1:],
+                            range(readers)))
+        return res[(count - 1) % readers][0]
+
+    run_batches(0, lambda j: j, nwarm)
+    local.reset_stats()
+    if distributed:
+        ix.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    last = run_batches(nwarm, lambda j: args.warmup + j, steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.shutdown()
+    st = local.stats()
+    per_rank, my_dt = None, dt
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # where a rank's time went, per batch: scan kernel (HIP events), shard scan call (wall), waiting for the exchange turn,
+        # exchange, merge + replies -- gathered so that a scaling line can show where non-linearity comes from
+        sst = ix.stats()
+        nb = max(1, sst["batches"])
+        mine = torch.tensor([st["scan_ms"] / max(1, st["scan_launches"]), sst["scan_ms"] / nb, sst["turn_wait_ms"] / nb,
+                             sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h)),
+                             my_dt / steps * 1e3, float(my_rows)],
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        # fixed_ms_per_batch: what a batch costs this rank beyond its scan kernel (probe, threshold, re-rank, select, exchange,
+        # merge, launch gaps) -- the part that does NOT shrink with rows / N under strong scaling
+        per_rank = [{"rank": r, "rows": int(t[8]), "ms_per_batch": float(t[7]), "scan_kernel_ms": float(t[0]),
+                     "fixed_ms_per_batch": float(t[7] - t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
+                     "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
+                     "rccl_world": int(t[6])} for r, t in enumerate(allr)]
+        assert transport != "rccl" or all(q["rccl_world"] == world for q in per_rank), per_rank   # every communicator spans all N ranks
+    launches = max(1, st["scan_launches"])
+    return {"dt": dt, "steps": steps, "st": st, "per_rank": per_rank, "last": last, "avg_kernel_ms": st["scan_ms"] / launches,
+            "ms_per_step": dt / steps * 1e3, "fixed_ms_per_batch": dt / steps * 1e3 - st["scan_ms"] / launches,
+            "candidates_per_query": st["candidates"] / max(1, steps * args.batch)}
+
+
+# which kind of scaling a config's own definition names (BASELINE.json): the headline metric reads "N = 10 M at 1 / 2 / 4 / 8 GPUs"
+# -- the job's rows are fixed, strong --; config 4 is "100 M rows over 8 GPUs", 12.5 M per GPU whatever the count -- weak
+HEADLINE_SCALING = {"c1": "strong", "c2": "strong", "c3": "strong", "c4": "weak"}
+
+
 def main():
     args = parse()
     if args.config == "c5":
@@ -311,118 +444,51 @@ def main():
     # the same RCCL exchange as the 2/4/8-rank runs
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
-        import torch
+        import torch  # noqa: F401
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)
-    # rows this rank holds.  weak: --rows each.  strong: the job's --rows dealt evenly (the first rows % N ranks hold one more).
-    my_rows = args.rows if args.scaling == "weak" else args.rows // world + (1 if rank < args.rows % world else 0)
-    total_rows = args.rows * world if args.scaling == "weak" else args.rows
-    if distributed:
-        # RCCL exchange.  Should the communicator fail to come up on any rank (no librccl, no peer access), every rank falls back to
-        # the same records over torch.distributed (gloo) -- slower, still exact -- and the line says so; never a silent mix.
-        transport, why = "rccl", None
-        try:
-            ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)
-        except RuntimeError as e:
-            ix, why = None, str(e)
-        flags = [None] * world
-        dist.all_gather_object(flags, why)
-        if any(f is not None for f in flags):
-            transport = "gloo (RCCL communicator failed: %s)" % next(f for f in flags if f is not None)
-            ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank, transport="dist")
-        args.exchange_transport = transport
-        ix.add_synthetic_local(my_rows, args.seed)     # shard r holds its vectors of seed + 1000 r
-        local = ix.local
-    else:
-        ix = local = VecSim.BFIndex(p)
-        ix.add_synthetic(args.rows, args.seed)
-    local.set_option("mfma", args.mfma)
-    for o in args.opt:
-        name, val = o.split("=", 1)
-        local.set_option(name, int(val))
-
-    n_batches = args.warmup + args.steps
+    # Phases.  One GPU: a single phase (strong and weak coincide).  N > 1 and --scaling both (default): the config's headline kind
+    # first -- its figures are the line's `value` / `ms_per_step` / `scaling` --, then the other kind, reported under "also".
+    # weak: every rank holds --rows.  strong: the job's --rows dealt evenly (the first rows % N ranks hold one more).
+    head = HEADLINE_SCALING[args.config] if args.scaling == "both" else args.scaling
+    kinds = [head] if (world == 1 or args.scaling != "both") else [head, "weak" if head == "strong" else "strong"]
     gen = getattr(synth, args.gen)
-    nb_distinct = min(n_batches, 8)                       # host-side query sets, cycled
+    nb_distinct = min(args.warmup + args.steps, 8)                       # host-side query sets, cycled
     qsets = [gen(args.seed + 1 + b, 0, args.batch, args.dim) for b in range(nb_distinct)]
-
-    from vectorsimilarity_amd import _capi
-
-    def sync():
-        # the timed region is bracketed by a barrier and a device-wide synchronisation on both sides (the query calls are
-        # synchronous, so the device is idle here anyway; hipDeviceSynchronize through the product's library covers every stream
-        # of this process on its GPU, torch's included, without initialising a second HIP context through torch.cuda)
-        if dist is not None:
-            dist.barrier()
-        _capi.load().VecSimGpu_DeviceSynchronize()
-        if dist is not None:
-            dist.barrier()
-
-    # The sharded exchange is a collective, so every rank must pair the same batches: batch b carries sequence number b and is
-    # answered by reader thread b % readers on every rank (the library issues the exchanges in sequence order whatever the
-    # threads' relative speed), so one batch's exchange + merge runs under the next batch's scan, as on a single GPU.
     readers = max(1, min(args.readers, args.steps))
-    seq = [0]   # next sequence number of this rank's sharded index (same on every rank by construction)
+    # (the reader lanes' scratch is sized on their first batches; the low-precision filters' first launches run 15-30 % slow --
+    # profiles/r04c_c4_kernel_stats.txt: 3726 4200 3702 3582 us, then 3150 -- so their steady state needs ten warm-up batches)
+    nwarm = max(args.warmup, 2 * readers if readers > 1 else 0, 10 if args.dtype in ("i8", "bf16") else 0)
+    phases = []
+    for kind in kinds:
+        my_rows = args.rows if kind == "weak" else args.rows // world + (1 if rank < args.rows % world else 0)
+        total_rows = args.rows * world if kind == "weak" else args.rows
+        ix, local, transport = build_index(args, p, my_rows, rank, world, local_rank, dist, distributed, VecSim, ShardedFlatIndex)
+        ph = timed_phase(args, ix, local, transport, my_rows, args.steps, qsets, rank, world, dist, distributed, readers, nwarm)
+        ph.update(kind=kind, my_rows=my_rows, total_rows=total_rows, transport=transport)
+        phases.append(ph)
+        del ix, local                          # (the next phase's rows need the room)
+    ph = phases[0]
+    st, dt, my_rows, total_rows = ph["st"], ph["dt"], ph["my_rows"], ph["total_rows"]
+    args.exchange_transport = ph["transport"]
 
-    def answer(b, qs):
-        return ix.knn_query(qs, args.topk, seq=b) if distributed else ix.knn_query(qs, args.topk)
-
-    def run_batches(first_seq, qsel, count):
-        """`count` batches, batch j (sequence number first_seq + j) on thread j % readers; returns the last batch's reply"""
-        if readers == 1:
-            out = None
-            for j in range(count):
-                out = answer(first_seq + j, qsets[qsel(j) % nb_distinct])
-            return out
-        res = list(pool.map(lambda t: [answer(first_seq + j, qsets[qsel(j) % nb_distinct]) for j in range(t, count, readers)][-1:],
-                            range(readers)))
-        return res[(count - 1) % readers][0]
-    pool = None
-    if readers > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(readers)
-    nwarm = max(args.warmup, 2 * readers if readers > 1 else 0)   # (the reader lanes' scratch is sized on their first batches)
-    run_batches(seq[0], lambda j: j, nwarm)
-    seq[0] += nwarm
-    local.reset_stats()
-    if distributed:
-        ix.reset_stats()
-    sync()
-    t0 = time.perf_counter()
-    last = run_batches(seq[0], lambda j: args.warmup + j, args.steps)
-    seq[0] += args.steps
-    sync()
-    dt = time.perf_counter() - t0
-    if pool is not None:
-        pool.shutdown()
-    st = local.stats()
-    per_rank = None
-    my_dt = dt
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # where a rank's time went, per batch: scan kernel (HIP events), shard scan call (wall), waiting for the exchange turn,
-        # exchange, merge + replies -- gathered so that a scaling line can show where non-linearity comes from
-        sst = ix.stats()
-        nb = max(1, sst["batches"])
-        mine = torch.tensor([st["scan_ms"] / max(1, st["scan_launches"]), sst["scan_ms"] / nb, sst["turn_wait_ms"] / nb,
-                             sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h)),
-                             my_dt / args.steps * 1e3, float(my_rows)],
-                            dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        # fixed_ms_per_batch: what a batch costs this rank beyond its scan kernel (probe, threshold, re-rank, select, exchange,
-        # merge, launch gaps) -- the part that does NOT shrink with rows / N under strong scaling
-        per_rank = [{"rank": r, "rows": int(t[8]), "ms_per_batch": float(t[7]), "scan_kernel_ms": float(t[0]),
-                     "fixed_ms_per_batch": float(t[7] - t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
-                     "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
-                     "rccl_world": int(t[6])} for r, t in enumerate(allr)]
-        assert args.exchange_transport != "rccl" or all(p["rccl_world"] == world for p in per_rank), per_rank   # every communicator spans all N ranks
+    # One GPU, config 2: the strong-scaling curve's per-shard pieces, MEASURED here -- the step of a shard of rows / G vectors on
+    # this GPU through the same path (same readers, same exchange when launched through torch.distributed.run) for G = 2, 4, 8.
+    # What a G-GPU job adds to that is the exchange across G ranks, the one term this box cannot measure.
+    shard_curve = None
+    if world == 1 and args.shard_curve and args.config in ("c2",):
+        shard_curve = {}
+        for g in (2, 4, 8):
+            rows_g = args.rows // g
+            ixg, localg, trg = build_index(args, p, rows_g, rank, world, local_rank, dist, distributed, VecSim, ShardedFlatIndex)
+            pg = timed_phase(args, ixg, localg, trg, rows_g, args.steps, qsets, rank, world, dist, distributed, readers, nwarm)
+            shard_curve[str(g)] = {"rows": rows_g, "ms_per_step": pg["ms_per_step"], "scan_kernel_ms": pg["avg_kernel_ms"],
+                                   "fixed_ms_per_batch": pg["fixed_ms_per_batch"], "candidates_per_query": pg["candidates_per_query"],
+                                   "exchange_ms_one_rank": (pg["per_rank"][0]["exchange_ms"] if pg["per_rank"] else None)}
+            del ixg, localg
 
     if rank == 0:
         dists = total_rows * args.batch * args.steps
@@ -434,15 +500,16 @@ def main():
         try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 passes; committed summary, not this run)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(st["scan_kernel"])
-            if t and t["workload"] == {"rows": args.rows, "dim": args.dim, "batch": args.batch}:
+            if t and t["workload"] == {"rows": my_rows, "dim": args.dim, "batch": args.batch}:
                 traffic = t["bytes_per_launch"]
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate run; not measured by this run)"
         except (OSError, ValueError, KeyError):
             pass
-        rows_tag = "%dM" % (args.rows // 1_000_000) if args.rows % 1_000_000 == 0 else str(args.rows)
+        rows_tag = "%dM" % (total_rows // 1_000_000) if total_rows % 1_000_000 == 0 else str(total_rows)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": st["scan_kernel"], "avg_kernel_ms": avg_ms, "launches": int(st["scan_launches"]),
+                "warmup_batches": nwarm,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 # probe + threshold kernels by their own pair of events: off by default (an event record costs the stream 3-5 us,
                 # profiles/r04_event_cost.txt; the scan kernel's pair stays, it is what this object is computed from): --opt events=3
@@ -460,7 +527,7 @@ def main():
             "qps": args.batch * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": ph["kind"], "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: flat_%s_%s_top%d" % (args.config, args.dtype, args.metric_name.lower(), args.topk),
                        "rows_per_gpu": my_rows, "rows_total": total_rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
@@ -472,24 +539,36 @@ def main():
             "roofline": roof,
             # step time beyond the scan kernel (probe, threshold, re-rank, select, copies, host replay not hidden, launch gaps)
             "fixed_ms_per_batch": dt / args.steps * 1e3 - avg_ms,
-            "per_rank_ms_per_batch": per_rank,
+            "per_rank_ms_per_batch": ph["per_rank"],
             "candidates_per_query": st["candidates"] / max(1, args.steps * args.batch),
             "fallbacks": int(st["fallbacks"]),
         }
-        if world == 1:
-            # A PREDICTION, not a measurement (no run on more than one GPU exists): strong scaling of this workload from the
-            # pieces measured above -- the scan kernel shrinks with rows / G, the fixed part does not, and the exchange is priced
-            # at what a 1-rank RCCL communicator cost on this box (README).  efficiency = t_1 / (G * t_G).
-            fixed = dt / args.steps * 1e3 - avg_ms
+        if len(phases) > 1:
+            o = phases[1]
+            ol = max(1, o["st"]["scan_launches"])
+            out["also"] = {"scaling": o["kind"], "value": o["total_rows"] * args.batch * args.steps / o["dt"], "unit": "distances/s",
+                           "qps": args.batch * args.steps / o["dt"], "ms_per_step": o["ms_per_step"], "rows_per_gpu": o["my_rows"],
+                           "rows_total": o["total_rows"], "scan_kernel_ms": o["avg_kernel_ms"],
+                           "hbm_frac": (o["st"]["scan_bytes"] / ol / (o["avg_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if o["avg_kernel_ms"] > 0 else 0.0,
+                           "fixed_ms_per_batch": o["fixed_ms_per_batch"], "per_rank_ms_per_batch": o["per_rank"],
+                           "note": "same run, second phase: the other kind of scaling (the line's value / scaling are the config's own "
+                                   "definition: %s)" % ph["kind"]}
+        if shard_curve is not None:
+            # t_G = the MEASURED step of a rows / G shard on this GPU + the exchange across G ranks (ASSUMED: not measurable on one
+            # GPU; 0.10 ms, not hidden -- conservative: with two batches in flight batch i's exchange runs under batch i+1's scan).
+            # efficiency = t_1 / (G * t_G).
             exch = 0.10
-            out["predicted_strong_scaling"] = {
-                "note": "prediction from 1-GPU pieces: t_G = scan_kernel / G + fixed + exchange (%.2f ms assumed); unmeasured" % exch,
-                "t_ms": {str(g): avg_ms / g + fixed + (exch if g > 1 else 0.0) for g in (1, 2, 4, 8)},
-                "efficiency": {str(g): (avg_ms + fixed) / (g * (avg_ms / g + fixed + exch)) for g in (2, 4, 8)}}
+            t1 = dt / args.steps * 1e3
+            out["strong_scaling_from_measured_shards"] = {
+                "note": "per-shard steps measured on ONE GPU (rows / G vectors, same path); only the cross-GPU exchange term (%.2f ms, "
+                        "not hidden) is assumed; no run on more than one GPU" % exch,
+                "shards": shard_curve, "exchange_ms_assumed": exch,
+                "t_ms": dict([("1", t1)] + [(g, v["ms_per_step"] + exch) for g, v in shard_curve.items()]),
+                "efficiency": {g: t1 / (int(g) * (v["ms_per_step"] + exch)) for g, v in shard_curve.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, VecSim, synth)
         # size-independent property at full size: replies are ascending in score
-        labels, scores = last
+        labels, scores = ph["last"]
         out["sorted"] = bool(np.all(np.diff(scores, axis=1) >= 0) and np.all(labels >= 0))
         print(json.dumps(out))
     if dist is not None:

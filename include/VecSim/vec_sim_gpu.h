@@ -109,6 +109,13 @@ void VecSimGpu_ShardedResetStats(VecSimShardedIndex *index);
 void VecSimGpu_ShardedResetSeq(VecSimShardedIndex *index);
 /* the Flat index of a shard held by this process (stats, options); NULL for shards of other processes */
 VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *index, int shard);
+/* Gives up on the other processes: exchanges in flight on this process return an error, later queries are refused (RCCL:
+ * ncclCommAbort, which also lets the peers' collectives end).  The library does this itself when an exchange fails or the
+ * peers do not arrive within $VECSIM_GPU_EXCHANGE_TIMEOUT_MS (default 120 000 ms); the call is for a caller that learns of a
+ * dead peer some other way. */
+void VecSimGpu_ShardedAbort(VecSimShardedIndex *index);
+/* "rccl-staged" | "rccl-mapped" (csrc/vsgpu_comm.hip, $VECSIM_GPU_EXCHANGE) | "transport" (caller's callbacks) | "local" */
+const char *VecSimGpu_ShardedExchangeMode(VecSimShardedIndex *index);
 int VecSimGpu_ShardedWorld(VecSimShardedIndex *index);
 int VecSimGpu_ShardedRank(VecSimShardedIndex *index); /* -1: all shards live in this process */
 
@@ -181,6 +188,10 @@ const char *VecSimGpu_LastError(void);
  * overrides.  VecSimGpu_IndexTier: the tier an existing index answers in (VecSimIndex_DebugInfoIterator carries exactly the
  * reference's fields). */
 const char *VecSimGpu_HostTier(void);
+/* Feature names (comma separated) this host lacks for ITS OWN reference build to run the kernel order restated for `type`
+ * ("" = none: the reference here runs exactly the restated order; "avx512bw,avx512vbmi2" = its bf16 chooser would fall to a
+ * lower tier, L2_space.cpp:332-337).  Index creation prints the same once per type on stderr.  Valid until the thread's next call. */
+const char *VecSimGpu_HostTierNote(VecSimType type);
 const char *VecSimGpu_IndexTier(VecSimIndex *index);
 
 /* HIP-event timing of the dominant scan kernel since the last reset (bench.py roofline leg) */
@@ -193,7 +204,9 @@ typedef struct {
     uint64_t candidates;
     uint64_t fallbacks;
     char scan_kernel[64];
-    uint64_t retries;   /* (new fields go at the end: the layout in front is what earlier callers compiled against) */
+    uint64_t retries;   /* offset 120.  LAYOUT HISTORY: rounds 1-2 ended at scan_kernel (120 bytes); round 3 put `retries` in FRONT of
+                         * scan_kernel, round 4 moved it here -- a caller compiled against the round-3 header alone must be rebuilt.
+                         * From here on fields are only appended; tests/test_abi.py pins every offset and the size (128). */
 } VecSimGpuStats;
 void VecSimGpu_ResetStats(VecSimIndex *index);
 void VecSimGpu_GetStats(VecSimIndex *index, VecSimGpuStats *out);

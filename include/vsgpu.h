@@ -173,6 +173,14 @@ int vsgpu_comm_rank(const vsgpu_comm *c);
 int vsgpu_comm_world(const vsgpu_comm *c);
 int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t bytes, void *recv);
 int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int root);
+/* A collective that fails on a rank (RCCL / HIP error, or the peers not arriving within $VECSIM_GPU_EXCHANGE_TIMEOUT_MS, default
+ * 120 000) aborts that rank's communicator (ncclCommAbort) before it returns the error, so that its peers' collectives end -- by
+ * the asynchronous error or by their own time limit -- instead of waiting for ever; later calls on it are refused.
+ * vsgpu_comm_abort does the same on the caller's decision.  vsgpu_comm_staged: 1 = device send / receive buffers with copies to
+ * and from the mapped host blocks (default for world > 1), 0 = the mapped host blocks are the collective's buffers
+ * ($VECSIM_GPU_EXCHANGE = staged | mapped overrides). */
+int vsgpu_comm_abort(vsgpu_comm *c);
+int vsgpu_comm_staged(const vsgpu_comm *c);
 
 /* ---- measurement hooks (bench.py roofline leg) ----
  * HIP-event time of the dominant scan kernel, accumulated per ctx on the stream it runs on. */
@@ -185,7 +193,8 @@ typedef struct {
     uint64_t candidates;   /* candidate pairs that reached the exact re-rank */
     uint64_t fallbacks;    /* queries answered by a dense exact pass (candidate list overflowed twice, or fewer than k candidates) */
     char scan_kernel[64];  /* name of the kernel timed as "scan" */
-    uint64_t retries;      /* queries whose candidate list overflowed and that a second filter pass with a tighter threshold answered */
+    uint64_t retries;      /* queries whose candidate list overflowed and that a second filter pass with a tighter threshold answered.
+                            * Same layout and history as VecSimGpuStats (VecSim/vec_sim_gpu.h): append-only from here, pinned by tests/test_abi.py */
 } vsgpu_stats;
 void vsgpu_stats_reset(vsgpu_ctx *ctx);
 void vsgpu_stats_get(vsgpu_ctx *ctx, vsgpu_stats *out);

@@ -92,3 +92,30 @@ def test_public_headers_compile_as_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_stats_struct_layout_is_pinned(tmp_path):
+    """round-4 advisor finding: VecSimGpuStats / vsgpu_stats changed field order between rounds 3 and 4.  The layout is append-only
+    from here: every offset and the size are pinned, in the C headers and in the ctypes mirror."""
+    import subprocess
+    from vectorsimilarity_amd import _capi
+    fields = ["scan_ms", "scan_launches", "scan_rows", "scan_bytes", "other_ms", "candidates", "fallbacks", "scan_kernel", "retries"]
+    want = {"scan_ms": 0, "scan_launches": 8, "scan_rows": 16, "scan_bytes": 24, "other_ms": 32, "candidates": 40, "fallbacks": 48,
+            "scan_kernel": 56, "retries": 120, "sizeof": 128}
+    src = tmp_path / "stats_layout.c"
+    body = "".join('    printf("%%s %%s %%zu\\n", "%s", "%s", offsetof(%s, %s));\n' % (t, f, t, f)
+                   for t in ("VecSimGpuStats", "vsgpu_stats") for f in fields)
+    body += "".join('    printf("%%s sizeof %%zu\\n", "%s", sizeof(%s));\n' % (t, t) for t in ("VecSimGpuStats", "vsgpu_stats"))
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "VecSim/vec_sim_gpu.h"\n#include "vsgpu.h"\nint main(void) {\n' + body +
+                   "    return 0;\n}\n")
+    exe = tmp_path / "stats_layout"
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        t, f, off = line.split()
+        got.setdefault(t, {})[f] = int(off)
+    assert got["VecSimGpuStats"] == want and got["vsgpu_stats"] == want, got
+    for f in fields:
+        assert getattr(_capi.VecSimGpuStats, f).offset == want[f], f
+    assert C.sizeof(_capi.VecSimGpuStats) == want["sizeof"]

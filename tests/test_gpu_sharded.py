@@ -163,6 +163,135 @@ def test_rccl_world1_exchange_in_process(vso):
     assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
 
 
+@pytest.mark.parametrize("mode", ["staged", "mapped"])
+def test_rccl_exchange_modes_on_a_communicator_of_one(vso, monkeypatch, mode):
+    """round-4 review: a communicator of MORE than one rank defaults to `staged` (device send / receive buffers + two copies,
+    csrc/vsgpu_comm.hip), and no test had ever executed that branch.  Both forms, forced through $VECSIM_GPU_EXCHANGE on a
+    communicator of one: the sharded index (all-gather per batch, two readers) equals the single index and the oracle."""
+    monkeypatch.setenv("VECSIM_GPU_EXCHANGE", mode)
+    rng = np.random.default_rng(80)
+    dim, n, nq, k = 48, 30_000, 12, 10
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    queries = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    labels = np.arange(n) + 5
+    sx = ShardedFlatIndex(params("f32", "L2", dim, 1024), rank=0, world=1, device=0)
+    assert sx.exchange_mode() == "rccl-" + mode
+    one = VecSim.BFIndex(params("f32", "L2", dim, 1024))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    check_equal(vso, sx, one, "f32", "L2", rows, labels, queries, k, oracle_queries=range(0, nq, 4))
+    assert sx.delete_vector(5 + 17) == 1 and one.delete_vector(5 + 17) == 1
+    from concurrent.futures import ThreadPoolExecutor
+    want = one.knn_query(queries, k)
+    sx.reset_seq()
+    with ThreadPoolExecutor(2) as pool:
+        for gl, gs in pool.map(lambda b: sx.knn_query(queries, k, seq=b), range(6)):
+            assert np.array_equal(gl, want[0]) and np.array_equal(gs, want[1])
+    st = sx.stats()
+    assert st["exchange_ms"] > 0 and st["exchange_bytes"] > 0, st
+
+
+@pytest.mark.parametrize("mode", ["staged", "mapped"])
+def test_comm_allgather_broadcast_abort_through_the_c_abi(monkeypatch, mode):
+    """include/vsgpu.h comm group on its own (no index): ncclAllGather and ncclBroadcast in both buffer forms on a communicator of
+    one -- a single-rank delete never reaches the broadcast (hole and last row share the owner), so it is exercised here --, then
+    the failure path: the test hook fails the chosen collective the way an RCCL error would, the communicator is aborted
+    (ncclCommAbort) and refuses further calls instead of leaving peers inside a collective."""
+    import ctypes as C
+    from vectorsimilarity_amd import _capi
+    monkeypatch.setenv("VECSIM_GPU_EXCHANGE", mode)
+    monkeypatch.setenv("VECSIM_GPU_EXCHANGE_FAIL_AT", "4")
+    G = C.CDLL(_capi.GPU_LIB_PATH)
+    G.vsgpu_ctx_create.restype = C.c_void_p
+    G.vsgpu_ctx_create.argtypes = [C.c_int]
+    G.vsgpu_ctx_destroy.argtypes = [C.c_void_p]
+    G.vsgpu_comm_create.restype = C.c_void_p
+    G.vsgpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for f in ("vsgpu_comm_destroy", "vsgpu_comm_staged", "vsgpu_comm_abort"):
+        getattr(G, f).argtypes = [C.c_void_p]
+    G.vsgpu_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    G.vsgpu_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    G.vsgpu_last_error.restype = C.c_char_p
+    ctx = G.vsgpu_ctx_create(0)
+    assert ctx
+    uid = (C.c_char * 128)()
+    assert G.vsgpu_comm_unique_id(uid) == 0
+    comm = G.vsgpu_comm_create(ctx, 0, 1, uid)
+    assert comm, G.vsgpu_last_error()
+    assert G.vsgpu_comm_staged(comm) == (1 if mode == "staged" else 0)
+    rng = np.random.default_rng(3)
+    for nbytes in (8, 81_920, 1_300_000):          # an agreement word, config 4's record, config 3's (k = 100) record
+        send = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        recv = np.zeros(nbytes, dtype=np.uint8)
+        assert G.vsgpu_comm_allgather(comm, send.ctypes.data, nbytes, recv.ctypes.data) == 0, G.vsgpu_last_error()
+        assert np.array_equal(send, recv)
+    buf = rng.integers(0, 256, 3072 + 8, dtype=np.uint8)   # a moved row with its status word
+    keep = buf.copy()
+    assert G.vsgpu_comm_broadcast(comm, buf.ctypes.data, buf.size, 0) == 0, G.vsgpu_last_error()
+    assert np.array_equal(buf, keep)
+    assert G.vsgpu_comm_broadcast(comm, buf.ctypes.data, buf.size, 1) != 0      # no such root: refused before any collective
+    # collective number 4 (0-based) fails: aborted, then dead
+    recv = np.zeros(8, dtype=np.uint8)
+    assert G.vsgpu_comm_allgather(comm, keep.ctypes.data, 8, recv.ctypes.data) != 0
+    assert b"aborted" in G.vsgpu_last_error()
+    assert G.vsgpu_comm_allgather(comm, keep.ctypes.data, 8, recv.ctypes.data) != 0
+    assert b"aborted by an earlier failure" in G.vsgpu_last_error()
+    G.vsgpu_comm_destroy(comm)
+    G.vsgpu_ctx_destroy(ctx)
+
+
+def test_query_after_abort_is_refused_not_hung(vso):
+    """VecSimGpu_ShardedAbort: the next exchange returns an error at once"""
+    rng = np.random.default_rng(9)
+    dim, n = 32, 5000
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    sx = ShardedFlatIndex(params("f32", "L2", dim, 1024), rank=0, world=1, device=0)
+    sx.add_vectors(rows, np.arange(n))
+    sx.knn_query(rows[:4], 5)
+    sx.abort()
+    with pytest.raises(RuntimeError, match="abort"):
+        sx.knn_query(rows[:4], 5)
+
+
+def test_multi_value_delete_that_fails_half_way_can_be_retried(vso, monkeypatch):
+    """round-4 advisor finding (sharded_index.cpp deleteVector, multi-value): a label's vectors go one swap-delete at a time; when
+    one of them failed, the ids already removed stayed in the label's list although they then named OTHER rows (swapped into the
+    holes), and a retried delete removed unrelated rows.  The third row move reports a failed read on its owner (test hook: the
+    failure that leaves every shard untouched): the delete returns -1, the retry removes exactly the rest, and the three-shard
+    index keeps answering like a single index that deleted the label."""
+    monkeypatch.setenv("VECSIM_GPU_TEST_FAIL_REMOVE_AT", "2")
+    rng = np.random.default_rng(12)
+    dim, n, block, G = 16, 600, 8, 3
+    rows = rng.integers(-3, 4, (n, dim)).astype(np.float32)
+    labels = rng.integers(0, 40, n)                        # ~15 vectors per label
+    pm = params("f32", "L2", dim, block)
+    pm.multi = True
+    sx = ShardedFlatIndex(pm, shards=G)
+    monkeypatch.delenv("VECSIM_GPU_TEST_FAIL_REMOVE_AT")
+    one = VecSim.BFIndex(pm)
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    lab = int(labels[3])
+    want = int(np.sum(labels == lab))
+    assert want >= 6
+    assert sx.delete_vector(lab) == -1
+    gone = n - sx.index_size()
+    assert 2 <= gone < want                                # (2, or more when a removed row was the last one: no move, no hook)
+    assert sx.delete_vector(lab) == want - gone            # the retry takes up where the failed call stopped
+    assert one.delete_vector(lab) == want
+    assert sx.index_size() == one.index_size() == n - want
+    q = rows[:9].copy()
+    for k in (10, 50):
+        gl, gs = sx.knn_query(q, k)
+        sl, ss = one.knn_query(q, k)
+        assert np.array_equal(gl, sl) and np.array_equal(gs, ss), k
+    other = int(labels[5]) if int(labels[5]) != lab else int(labels[6])
+    assert sx.delete_vector(other) == one.delete_vector(other) > 0
+    gl, gs = sx.knn_query(q, 10)
+    sl, ss = one.knn_query(q, 10)
+    assert np.array_equal(gl, sl) and np.array_equal(gs, ss)
+
+
 @pytest.mark.parametrize("typ,metric,dim,k", [("f32", "L2", 64, 10), ("f32", "Cosine", 32, 5), ("bf16", "IP", 72, 10), ("i8", "Cosine", 64, 8)])
 def test_nan_score_rows_and_queries_across_shards(vso, typ, metric, dim, k):
     """brute_force.h:272 lets a NaN-score row into the heap only while it fills (internal ids below k): rows that can score NaN

@@ -169,6 +169,23 @@ def test_host_tier_rule(monkeypatch, flags, override, expect):
     assert lib.VecSimGpu_HostTier().decode() == expect
 
 
+@pytest.mark.parametrize("flags,typ,expect", [
+    ("avx512f,avx512bw,avx512vl,avx512vbmi2", 2, ""),                      # bf16: L2_space.cpp:332-337 satisfied
+    ("avx512f", 2, "avx512bw,avx512vbmi2"),                                # avx512f alone: the reference's bf16 chooser falls lower
+    ("avx512f,avx512bw", 2, "avx512vbmi2"),
+    ("avx512f,avx512vl", 3, "avx512bw"),                                   # fp16 needs avx512bw && avx512vl
+    ("avx512f", 0, ""), ("avx512f", 4, ""), ("avx512f", 5, ""),            # fp32; integers: every tier gives the same number
+    ("avx,fma3", 0, "avx512f"),
+])
+def test_host_tier_note_names_missing_features(monkeypatch, flags, typ, expect):
+    """round-4 advisor finding: a host with avx512f but without avx512bw / avx512vbmi2 reports AVX512 for bf16 / fp16 tables although
+    its own reference build would run lower-tier kernels: the library says which feature is missing (stderr at index creation,
+    VecSimGpu_HostTierNote to callers)"""
+    from vectorsimilarity_amd import _capi
+    monkeypatch.setenv("VECSIM_GPU_HOST_FLAGS", flags)
+    assert _capi.load().VecSimGpu_HostTierNote(typ).decode() == expect
+
+
 def test_host_tier_probe_matches_proc_cpuinfo(monkeypatch):
     """without the test hook the probe is the CPU's own feature list"""
     from vectorsimilarity_amd import _capi

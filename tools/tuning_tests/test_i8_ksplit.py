@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from util import METRICS, TYPES, random_vectors, stored_rows  # noqa: E402
 from test_gpu_flat_parity import kernel_metric, make_index  # noqa: E402
 
+pytestmark = pytest.mark.gpu   # (a plain `pytest -m "not gpu"` from the repo root must not run these)
+
 
 @pytest.fixture(scope="session")
 def vso():

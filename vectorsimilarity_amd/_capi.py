@@ -142,14 +142,14 @@ EXPORTS = [
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
-    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_IndexTier", "VecSimGpu_ResetStats",
+    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_HostTierNote", "VecSimGpu_IndexTier", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
     "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
     "VecSimGpu_ShardedAddVectorsBulk", "VecSimGpu_ShardedAddSyntheticLocal", "VecSimGpu_ShardedDeleteVector",
     "VecSimGpu_ShardedIndexSize", "VecSimGpu_ShardedTopKQueryBatch", "VecSimGpu_ShardedTopKQueryBatchArrays",
     "VecSimGpu_ShardedTopKQueryBatchArraysSeq", "VecSimGpu_ShardedGetStats", "VecSimGpu_ShardedResetStats", "VecSimGpu_ShardedResetSeq",
-    "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
+    "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedAbort", "VecSimGpu_ShardedExchangeMode", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
 ]
@@ -165,7 +165,7 @@ GPU_EXPORTS = [
     "vsgpu_topk", "vsgpu_range", "vsgpu_scores", "vsgpu_scores_of", "vsgpu_sq8_pair_scores", "vsgpu_table_set_sq8_mean_sum_squares", "vsgpu_table_set_sq8_block_bounds", "vsgpu_stats_reset",
     "vsgpu_stats_get", "vsgpu_set_option", "vsgpu_set_poll",
     "vsgpu_comm_unique_id", "vsgpu_comm_create", "vsgpu_comm_destroy", "vsgpu_comm_rank", "vsgpu_comm_world",
-    "vsgpu_comm_allgather", "vsgpu_comm_broadcast",
+    "vsgpu_comm_allgather", "vsgpu_comm_broadcast", "vsgpu_comm_abort", "vsgpu_comm_staged",
 ]
 
 _lib = None
@@ -308,6 +308,8 @@ def load():
     L.VecSimGpu_DeviceSynchronize.argtypes = []
     L.VecSimGpu_LastError.restype = C.c_char_p
     L.VecSimGpu_HostTier.restype = C.c_char_p
+    L.VecSimGpu_HostTierNote.restype = C.c_char_p
+    L.VecSimGpu_HostTierNote.argtypes = [C.c_int]
     L.VecSimGpu_IndexTier.restype = C.c_char_p
     L.VecSimGpu_IndexTier.argtypes = [C.c_void_p]
     L.VecSimGpu_ResetStats.restype = None
@@ -352,6 +354,10 @@ def load():
     L.VecSimGpu_ShardedResetSeq.argtypes = [vp]
     L.VecSimGpu_ShardedLocalIndex.restype = vp
     L.VecSimGpu_ShardedLocalIndex.argtypes = [vp, i]
+    L.VecSimGpu_ShardedAbort.restype = None
+    L.VecSimGpu_ShardedAbort.argtypes = [vp]
+    L.VecSimGpu_ShardedExchangeMode.restype = C.c_char_p
+    L.VecSimGpu_ShardedExchangeMode.argtypes = [vp]
     L.VecSimGpu_ShardedWorld.restype = i
     L.VecSimGpu_ShardedWorld.argtypes = [vp]
     L.VecSimGpu_ShardedRank.restype = i

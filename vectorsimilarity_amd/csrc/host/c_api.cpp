@@ -306,6 +306,12 @@ VecSim_InfoField f64_field(const char *name, double v) {
 }  // namespace
 // the tier a new index would get on this host (VECSIM_GPU_TIER override, else CPUID): "AVX512" | "AVX512_BF16" | "SCALAR"
 extern "C" const char *VecSimGpu_HostTier(void) { return vsa::tier_name(vsa::resolve_tier()); }
+// what this host lacks for its own reference build to run the restated order for `type` ("" = nothing; host_tier.h)
+extern "C" const char *VecSimGpu_HostTierNote(VecSimType type) {
+    static thread_local std::string note;
+    note = vsa::reference_order_missing(vsa::host_features(), (int)type);
+    return note.c_str();
+}
 extern "C" const char *VecSimGpu_IndexTier(VecSimIndex *index) { return index ? vsa::tier_name(index->distanceTier()) : ""; }
 extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
     const VecSimIndexDebugInfo info = index->debugInfo();
@@ -557,6 +563,8 @@ extern "C" VecSimShardedIndex *VecSimGpu_ShardedNewLocal(const VecSimParams *par
     return wrap(vsa::ShardedIndex::createLocal(params->algoParams.bfParams, params->logCtx, n_shards, devices));
 }
 extern "C" void VecSimGpu_ShardedFree(VecSimShardedIndex *ix) { delete ix; }
+extern "C" void VecSimGpu_ShardedAbort(VecSimShardedIndex *ix) { ix->impl->abortExchange(); }
+extern "C" const char *VecSimGpu_ShardedExchangeMode(VecSimShardedIndex *ix) { return ix->impl->exchangeMode(); }
 extern "C" int VecSimGpu_ShardedAddVector(VecSimShardedIndex *ix, const void *blob, size_t label) {
     return ix->impl->addVector(blob, label);
 }

@@ -77,7 +77,7 @@ FlatIndex *FlatIndex::create(const BFParams &p, void *logCtx) {
     ix->multi_ = p.multi;
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
-    ix->tier_ = resolve_tier();   // from the host's CPUID, as the reference's choosers do (host_tier.h)
+    ix->tier_ = resolve_tier((int)p.type);   // from the host's CPUID, as the reference's choosers do (host_tier.h)
     ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, ix->tier_, p.dim, ix->stored_bytes_);
     if (!ix->table_) {
         vsgpu_ctx_destroy(ctx);

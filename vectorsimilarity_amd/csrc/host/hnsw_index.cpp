@@ -51,7 +51,7 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
     // (the search kernel scores rows with the lane program of the host's tier as well; the scalar tier is not wired into it)
-    ix->tier_ = resolve_tier() == VSGPU_TIER_AVX512_BF16 ? VSGPU_TIER_AVX512_BF16 : VSGPU_TIER_AVX512;
+    ix->tier_ = resolve_tier((int)p.type) == VSGPU_TIER_AVX512_BF16 ? VSGPU_TIER_AVX512_BF16 : VSGPU_TIER_AVX512;
     ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, ix->tier_, p.dim, ix->blob_bytes_);
     ix->graph_ = ix->table_ ? vsgpu_graph_create(ix->table_, M) : nullptr;
     if (!ix->table_ || !ix->graph_) {
@@ -721,18 +721,18 @@ int HnswIndex::topKQueryBatch(const void *queries, size_t nq, size_t stride, siz
         using Item = std::pair<double, size_t>;
         for (size_t q = 0; q < nq; q++) {
             const char *qp1 = (const char *)qsrc + q * qstride;
-            rc = vsgpu_topk(tbl, qp1, 1, qstride, kk, cap, ids.data(), s1.data(), c1.data());
             std::vector<double> all;
-            if (!rc && c1[0] == VSGPU_COUNT_OVERFLOW) {  // massive ties at the kk-th score: every row's score
+            if (multi_) {   // the k best LABELS need every row's score (a label's best row may rank anywhere): no top-k pass first
                 all.resize(n_);
                 rc = vsgpu_scores(tbl, qp1, 0, n_, all.data());
+            } else {
+                rc = vsgpu_topk(tbl, qp1, 1, qstride, kk, cap, ids.data(), s1.data(), c1.data());
+                if (!rc && c1[0] == VSGPU_COUNT_OVERFLOW) {  // massive ties at the kk-th score: every row's score
+                    all.resize(n_);
+                    rc = vsgpu_scores(tbl, qp1, 0, n_, all.data());
+                }
             }
             if (rc) break;
-            if (multi_ && all.empty()) {   // the k best LABELS need every row's score (a label's best row may rank anywhere)
-                all.resize(n_);
-                rc = vsgpu_scores(tbl, qp1, 0, n_, all.data());
-                if (rc) break;
-            }
             RefMaxHeap<Item> heap;
             std::unordered_map<size_t, double> best_of;   // multi: per-label minimum first, then the plain heap over labels
             if (multi_) {

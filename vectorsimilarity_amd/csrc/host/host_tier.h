@@ -16,8 +16,8 @@
 // -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar overrides it.  Also not restated: the AVX512-FP16 tier of gcc >= 12
 // builds (fp16 accumulate).  The reference asks for more than avx512f per type (bf16: avx512bw && avx512vbmi2,
 // L2_space.cpp:332-337; int8 / uint8: avx512bw && avx512vl && avx512vnni, L2_space.cpp:451-455; fp16: avx512bw && avx512vl):
-// reference_order_modelled() says whether the host's own reference build would run the order this library restates for
-// a type, and the one-line note names what is missing.
+// reference_order_missing() names what the host lacks for its own reference build to run the order this library restates for
+// a type; index creation prints it once per type (VecSimGpu_HostTierNote returns the same text to callers and tests).
 // VECSIM_GPU_HOST_FLAGS = comma-separated feature names replaces the CPUID probe (tests).
 #pragma once
 #include <cstdio>
@@ -59,19 +59,23 @@ inline int tier_from_features(const HostFeatures &f) {
     return VSGPU_TIER_AVX512;
 }
 
-// would a reference build on this host run the kernel order restated for `type` (VSGPU_F32 ...)?
-inline bool reference_order_modelled(const HostFeatures &f, int type) {
-    if (!f.avx512f) return false;
-    switch (type) {
-    case VSGPU_BF16: return f.avx512bw && f.avx512vbmi2;
-    case VSGPU_F16: return f.avx512bw && f.avx512vl;
-    case VSGPU_I8:
-    case VSGPU_U8: return true;   // exact integers: every tier gives the same number
-    default: return true;
-    }
+// What a reference build on this host would need, beyond avx512f, to run the kernel order restated for `type` (VSGPU_F32 ...):
+// the missing feature names, comma separated; empty when the host's own reference build runs the restated order (integers:
+// every tier gives the same number).  "avx512f" alone when the host has no AVX-512 at all.
+inline std::string reference_order_missing(const HostFeatures &f, int type) {
+    if (!f.avx512f) return "avx512f";
+    std::string m;
+    auto need = [&](bool have, const char *n) {
+        if (!have) m += (m.empty() ? "" : ",") + std::string(n);
+    };
+    if (type == VSGPU_BF16) need(f.avx512bw, "avx512bw"), need(f.avx512vbmi2, "avx512vbmi2");   // L2_space.cpp:332-337
+    if (type == VSGPU_F16) need(f.avx512bw, "avx512bw"), need(f.avx512vl, "avx512vl");           // L2_space.cpp:391-409
+    return m;
 }
 
-inline int resolve_tier() {
+// `type` < 0: no per-type note (VecSimGpu_HostTier); otherwise index creation, one line on stderr per process and type when the
+// host's own reference build would run other kernels than the ones whose order this library restates
+inline int resolve_tier(int type = -1) {
     if (const char *e = std::getenv("VECSIM_GPU_TIER")) {
         if (!std::strcmp(e, "scalar")) return VSGPU_TIER_SCALAR;
         if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
@@ -84,6 +88,15 @@ inline int resolve_tier() {
             said = true;
             std::fprintf(stderr, "vecsim_amd: host CPU has no AVX-512: scores follow the reference's AVX-512 kernel order (its AVX2 / SSE "
                                  "orders are not restated); set VECSIM_GPU_TIER=scalar for the scalar kernels' order\n");
+        }
+    } else if (type >= 0 && type < 16) {
+        static bool said_for[16] = {};
+        const std::string miss = reference_order_missing(f, type);
+        if (!miss.empty() && !said_for[type]) {
+            said_for[type] = true;
+            std::fprintf(stderr, "vecsim_amd: host CPU lacks %s: a reference build here runs a lower tier for %s rows; scores follow the "
+                                 "AVX-512 kernels' order (the lower tiers' orders are not restated)\n",
+                         miss.c_str(), type == VSGPU_BF16 ? "bf16" : "fp16");
         }
     }
     return tier_from_features(f);

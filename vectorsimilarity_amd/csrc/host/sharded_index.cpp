@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -23,6 +24,8 @@ struct RcclExchange final : Exchange {
     ~RcclExchange() override { vsgpu_comm_destroy(comm); }
     int allgather(const void *send, size_t bytes, void *recv) override { return vsgpu_comm_allgather(comm, send, bytes, recv); }
     int broadcast(void *buf, size_t bytes, int root) override { return vsgpu_comm_broadcast(comm, buf, bytes, root); }
+    void abort() override { (void)vsgpu_comm_abort(comm); }
+    const char *mode() const override { return vsgpu_comm_staged(comm) ? "rccl-staged" : "rccl-mapped"; }
 };
 
 // a shard held by this process: a GPU Flat index
@@ -194,6 +197,7 @@ ShardedIndex *ShardedIndex::createDistributed(const BFParams &p, void *logCtx, i
                                               std::unique_ptr<Exchange> ex, std::unique_ptr<ShardOps> external) {
     if (world < 1 || rank < 0 || rank >= world) return nullptr;
     auto *sx = new ShardedIndex();
+    if (const char *e = std::getenv("VECSIM_GPU_TEST_FAIL_REMOVE_AT")) sx->test_fail_remove_at_ = std::atol(e);
     sx->params_ = p;
     sx->plan_.block = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     sx->plan_.world = (size_t)world;
@@ -211,6 +215,7 @@ ShardedIndex *ShardedIndex::createDistributed(const BFParams &p, void *logCtx, i
 ShardedIndex *ShardedIndex::createLocal(const BFParams &p, void *logCtx, int n_shards, const int *devices) {
     if (n_shards < 1) return nullptr;
     auto *sx = new ShardedIndex();
+    if (const char *e = std::getenv("VECSIM_GPU_TEST_FAIL_REMOVE_AT")) sx->test_fail_remove_at_ = std::atol(e);
     sx->params_ = p;
     sx->plan_.block = p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE;
     sx->plan_.world = (size_t)n_shards;
@@ -292,6 +297,9 @@ int ShardedIndex::removeGid(uint64_t hole) {
         // the last row of the equivalent single index moves into the hole; the owner's status travels with the row
         std::vector<char> row(8 + bytes, 0);
         if (owns(s_last) && shard(s_last)->readRow((uint32_t)plan_.local(last), row.data() + 8)) row[0] = 1;
+        // test hook ($VECSIM_GPU_TEST_FAIL_REMOVE_AT = n): the n-th row move reports a failed read on its owner -- the one failure
+        // that leaves every shard untouched, so the caller may retry (tests/test_gpu_sharded.py)
+        if (owns(s_last) && test_fail_remove_at_ >= 0 && test_removes_++ == test_fail_remove_at_) row[0] = 1;
         if (ex_ && s_hole != s_last && ex_->broadcast(row.data(), 8 + bytes, (int)s_last)) return -1;   // (transport failure: fatal everywhere)
         if (row[0]) failed = 1;
         else if (owns(s_hole) && shard(s_hole)->overwriteRow((uint32_t)plan_.local(hole), row.data() + 8, last_label)) failed = 1;
@@ -333,7 +341,13 @@ int ShardedIndex::deleteVector(size_t label) {
         if (f == label_to_gids_.end()) return 0;
         int removed = 0;
         for (size_t i = 0; i < f->second.size(); i++) {
-            if (removeGid(f->second[i])) return -1;
+            if (removeGid(f->second[i])) {
+                // the ids already removed now name OTHER rows (swapped into the holes): they leave the label's list, so that
+                // the maps keep agreeing with gid_to_label_ and a retried delete takes up where this one stopped
+                f->second.erase(f->second.begin(), f->second.begin() + removed);
+                if (f->second.empty()) label_to_gids_.erase(f);
+                return -1;
+            }
             removed++;
         }
         label_to_gids_.erase(label);

@@ -38,6 +38,10 @@ struct Exchange {
     virtual int allgather(const void *send, size_t bytes, void *recv) = 0;  // recv: world * bytes, rank order
     virtual int broadcast(void *buf, size_t bytes, int root) = 0;
     virtual bool canBroadcast() const { return true; }
+    // gives up on the peers: collectives in flight on this process come back with an error, later ones are refused (RCCL:
+    // ncclCommAbort; a caller-provided transport has its own means)
+    virtual void abort() {}
+    virtual const char *mode() const { return "transport"; }
 };
 
 // what the sharded index needs from one shard; FlatIndex (GPU) in the product, caller-provided for external shards
@@ -93,6 +97,10 @@ public:
     void setExchange(std::unique_ptr<Exchange> ex) { ex_ = std::move(ex); }
     int world() const { return (int)plan_.world; }
     int rank() const { return rank_; }
+    void abortExchange() {
+        if (ex_) ex_->abort();
+    }
+    const char *exchangeMode() const { return ex_ ? ex_->mode() : "local"; }
     // the exchange + merge step on its own (also the body of topKQueryBatch): `mine` = this process's records
     static size_t recordBytes(size_t nq, size_t cap) { return 32 + nq * 8 * (1 + 3 * cap); }
 
@@ -124,6 +132,7 @@ private:
     std::unordered_map<size_t, uint64_t> label_to_gid_;
     std::unordered_map<size_t, std::vector<uint64_t>> label_to_gids_;   // multi-value: a label's rows, in the reference's list order
     int removeGid(uint64_t hole);   // one swap-delete of the equivalent single index, across the shards
+    long test_fail_remove_at_ = -1, test_removes_ = 0;   // $VECSIM_GPU_TEST_FAIL_REMOVE_AT (removeGid)
     std::vector<size_t> gid_to_label_;
     // exchange turns (seq order) and phase timers
     std::mutex turn_mu_;

@@ -1238,6 +1238,24 @@ static void emit(const std::vector<Hit> &hits, size_t q, size_t cap, uint32_t *i
 // {score <= T_k} in id order; queries whose list overflowed fall back to a dense exact pass.
 static int topk_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores,
                            uint32_t *counts, size_t q_first, size_t q_count, const void *queries, size_t qstride);
+// The fallback's form of it: a table-wide pass like any scan, so it is ordered behind the other reader lanes' scans through the
+// scan chain (round-4 advisor finding: it ran beside them), and the score matrix it grew -- up to 1 GiB per context, every reader
+// lane has one -- is released again instead of staying with the lane for the life of the index.
+constexpr size_t DENSE_KEEP_BYTES = (size_t)1 << 28;   // what the small-problem path of vsgpu_topk uses routinely
+static int fallback_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, uint32_t *ids, double *scores, uint32_t *counts,
+                               size_t q_first, size_t q_count, const void *queries, size_t qstride) {
+    vsgpu_ctx *c = t->ctx;
+    ScanChainGuard g(t);
+    g.before_scan();
+    const int rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q_first, q_count, queries, qstride);
+    (void)hipStreamSynchronize(c->stream);   // (the pass ends drained on success; an error may have left work queued)
+    g.submitted();
+    if (c->dense.p && !c->dense.alias && c->dense.cap > DENSE_KEEP_BYTES) {
+        (void)hipFree(c->dense.p);
+        c->dense = DevBuf{};
+    }
+    return rc;
+}
 // fp64 tables: the exact pair scores are doubles in c->dense ([nq][ccap], launch_exact_pairs), selection on 64-bit keys
 static int collect_candidates_f64(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap,
                                   size_t ccap, uint32_t *ids, double *scores, uint32_t *counts, const char *scan_name,
@@ -1270,7 +1288,7 @@ static int collect_candidates_f64(vsgpu_table *t, const void *queries, size_t nq
     for (size_t q = 0; q < nq; q++) {
         if (hraw[q] > ccap || hraw[q] < std::min(k, n)) {   // more candidates than slots: exact dense fallback
             c->stats.fallbacks++;
-            rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
+            rc = fallback_dense_path(t, nq, k, cap, ids, scores, counts, q, 1, queries, qstride);
             if (rc) return rc;
             continue;
         }
@@ -1358,11 +1376,8 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
                     if (hc[q * ccap + j].x == (uint32_t)i) at = j;
                 float stored = 0;
                 if (at >= 0) memcpy(&stored, &hc[q * ccap + at].y, 4);
-                size_t dup = 0, oob = 0;
-                for (uint32_t j = 0; j < cn; j++) {
-                    oob += hc[q * ccap + j].x >= n;
-                    for (uint32_t j2 = j + 1; j2 < cn && j2 < j + 2; j2++) dup += 0;
-                }
+                size_t oob = 0;
+                for (uint32_t j = 0; j < cn; j++) oob += hc[q * ccap + j].x >= n;
                 fprintf(stderr,
                         "VSGPU_VERIFY MISS %s q=%zu row=%zu exact=%.9g T_k=%.9g tau=%.9g cand_slot=%ld stored=%.9g count=%u "
                         "raw=%u sel=%u oob_rows=%zu n=%zu\n",
@@ -1420,7 +1435,7 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     for (size_t i = 0; i < dense_q.size();) {
         size_t j = i + 1;
         while (j < dense_q.size() && dense_q[j] == dense_q[j - 1] + 1 && qstride != 0) j++;
-        rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, dense_q[i], j - i, queries, qstride);
+        rc = fallback_dense_path(t, nq, k, cap, ids, scores, counts, dense_q[i], j - i, queries, qstride);
         if (rc) return rc;
         i = j;
     }

@@ -6,10 +6,13 @@
 // libvsgpu.so carry no RCCL dependency and a process that already holds an RCCL (e.g. torch's) shares it.
 #include <dlfcn.h>
 
+#include <chrono>
+
 #include "vsgpu_internal.hpp"
 
 namespace {
-// the slice of rccl.h this file uses (ABI of RCCL 2.x: rccl/rccl.h:40-43, 187, 220, 260, 339, 459-470, 591, 678)
+// the slice of rccl.h this file uses (ABI of RCCL 2.x: rccl/rccl.h:40-43, 187, 220, 260, 339, 459-470, 591, 678; ncclCommAbort,
+// ncclCommGetAsyncError)
 struct RcclUniqueId {
     char internal[VSGPU_COMM_ID_BYTES];
 };
@@ -20,6 +23,8 @@ struct Rccl {
     int (*GetUniqueId)(RcclUniqueId *) = nullptr;
     int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
+    int (*CommAbort)(RcclComm) = nullptr;
+    int (*CommGetAsyncError)(RcclComm, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -38,6 +43,8 @@ Rccl *rccl() {
             r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
             r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
             r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+            r.CommAbort = (decltype(r.CommAbort))dlsym(r.so, "ncclCommAbort");                        // (optional: old RCCLs lack them)
+            r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(r.so, "ncclCommGetAsyncError");
             r.AllGather = (decltype(r.AllGather))dlsym(r.so, "ncclAllGather");
             r.Broadcast = (decltype(r.Broadcast))dlsym(r.so, "ncclBroadcast");
             r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
@@ -69,12 +76,59 @@ struct vsgpu_comm {
     bool staged = false;
     void *d_send = nullptr, *d_recv = nullptr;
     size_t dsend_cap = 0, drecv_cap = 0;
+    // A collective that failed on this rank (RCCL error, HIP error, the peers not arriving within the time limit) ABORTS the
+    // communicator: a rank that merely returned an error would leave its peers inside the collective for ever.  Their kernels see
+    // the abort (or their own time limit) and every rank comes back with an error.  A dead communicator refuses further calls.
+    bool dead = false;
+    long timeout_ms = 0;         // VECSIM_GPU_EXCHANGE_TIMEOUT_MS (default 120 s; 0 = wait for ever)
+    uint64_t collectives = 0;    // issued so far
+    long fail_at = -1;           // VECSIM_GPU_EXCHANGE_FAIL_AT = n: the n-th collective reports an RCCL failure (test hook)
 };
+static int comm_abort(vsgpu_comm *c, const char *why) {
+    if (!c->dead) {
+        c->dead = true;
+        Rccl *r = rccl();
+        if (c->comm && r && r->CommAbort) {
+            (void)r->CommAbort(c->comm);   // frees the communicator and releases kernels waiting inside it
+            c->comm = nullptr;
+        }
+    }
+    return fail(VSGPU_ERR_HIP, "shard exchange failed on rank %d of %d (%s): communicator aborted", c->rank, c->world, why);
+}
+// waits for the collective's stream: like hipStreamSynchronize, but a peer that never arrives (it failed and aborted, or died)
+// shows up as an asynchronous RCCL error or as the time limit instead of a hang
+static int comm_wait(vsgpu_comm *c) {
+    Rccl *r = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 1;; spin++) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return VSGPU_OK;
+        if (e != hipErrorNotReady) return comm_abort(c, hipGetErrorString(e));
+        if ((spin & 0x3FF) != 0) continue;
+        int async = kRcclSuccess;
+        if (r->CommGetAsyncError && c->comm && r->CommGetAsyncError(c->comm, &async) == kRcclSuccess && async != kRcclSuccess)
+            return comm_abort(c, rccl_err(async));
+        if (c->timeout_ms > 0 &&
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > c->timeout_ms)
+            return comm_abort(c, "peers did not arrive within VECSIM_GPU_EXCHANGE_TIMEOUT_MS");
+    }
+}
 
 #define RCCLCHK(expr)                                                                                  \
     do {                                                                                               \
         int _rc = (expr);                                                                              \
         if (_rc != kRcclSuccess) return fail(VSGPU_ERR_HIP, "%s failed: %s", #expr, rccl_err(_rc));  \
+    } while (0)
+// inside a collective: a failure aborts the communicator (comm_abort), so that the peers come back too
+#define COMMCHK_RCCL(c, expr)                                          \
+    do {                                                               \
+        int _rc = (expr);                                              \
+        if (_rc != kRcclSuccess) return comm_abort(c, rccl_err(_rc)); \
+    } while (0)
+#define COMMCHK_HIP(c, expr)                                               \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) return comm_abort(c, hipGetErrorString(_e)); \
     } while (0)
 
 extern "C" int vsgpu_comm_unique_id(void *id128) {
@@ -114,6 +168,9 @@ extern "C" vsgpu_comm *vsgpu_comm_create(vsgpu_ctx *ctx, int rank, int world, co
     }
     c->staged = world > 1;
     if (const char *e = getenv("VECSIM_GPU_EXCHANGE")) c->staged = !strcmp(e, "staged") ? true : (!strcmp(e, "mapped") ? false : c->staged);
+    c->timeout_ms = 120000;
+    if (const char *e = getenv("VECSIM_GPU_EXCHANGE_TIMEOUT_MS")) c->timeout_ms = atol(e);
+    if (const char *e = getenv("VECSIM_GPU_EXCHANGE_FAIL_AT")) c->fail_at = atol(e);
     // highest priority the device offers: the collective's kernel is dispatched ahead of whatever else is waiting for a CU
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -138,6 +195,13 @@ extern "C" void vsgpu_comm_destroy(vsgpu_comm *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+extern "C" int vsgpu_comm_abort(vsgpu_comm *c) {
+    if (!c) return VSGPU_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)comm_abort(c, "aborted by the caller");
+    return VSGPU_OK;
+}
+extern "C" int vsgpu_comm_staged(const vsgpu_comm *c) { return c->staged ? 1 : 0; }
 extern "C" int vsgpu_comm_rank(const vsgpu_comm *c) { return c->rank; }
 extern "C" int vsgpu_comm_world(const vsgpu_comm *c) { return c->world; }
 
@@ -171,21 +235,35 @@ static int comm_reserve(vsgpu_comm *c, size_t send_bytes, size_t recv_bytes) {
     return VSGPU_OK;
 }
 
+// entry of every collective: a dead communicator refuses; the test hook's chosen collective fails the way an RCCL call would
+static int comm_enter(vsgpu_comm *c) {
+    if (c->dead) return fail(VSGPU_ERR_HIP, "shard exchange: the communicator of rank %d was aborted by an earlier failure", c->rank);
+    if (c->fail_at >= 0 && (long)c->collectives == c->fail_at) {
+        c->collectives++;
+        return comm_abort(c, "VECSIM_GPU_EXCHANGE_FAIL_AT (test hook)");
+    }
+    c->collectives++;
+    return VSGPU_OK;
+}
+
 extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t bytes, void *recv) {
     if (bytes == 0) return VSGPU_OK;
     HIPCHK(hipSetDevice(c->ctx->device));
-    const size_t total = bytes * (size_t)c->world;
-    int rc = comm_reserve(c, bytes, total);
+    int rc = comm_enter(c);
     if (rc) return rc;
+    const size_t total = bytes * (size_t)c->world;
+    rc = comm_reserve(c, bytes, total);
+    if (rc) return comm_abort(c, "buffer allocation");
     memcpy(c->h_send, send, bytes);
     if (c->staged) {
-        HIPCHK(hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
-        RCCLCHK(rccl()->AllGather(c->d_send, c->d_recv, bytes, kRcclInt8, c->comm, c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, total, hipMemcpyDeviceToHost, c->stream));
+        COMMCHK_HIP(c, hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
+        COMMCHK_RCCL(c, rccl()->AllGather(c->d_send, c->d_recv, bytes, kRcclInt8, c->comm, c->stream));
+        COMMCHK_HIP(c, hipMemcpyAsync(c->h_recv, c->d_recv, total, hipMemcpyDeviceToHost, c->stream));
     } else {
-        RCCLCHK(rccl()->AllGather(c->h_send, c->h_recv, bytes, kRcclInt8, c->comm, c->stream));
+        COMMCHK_RCCL(c, rccl()->AllGather(c->h_send, c->h_recv, bytes, kRcclInt8, c->comm, c->stream));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = comm_wait(c);
+    if (rc) return rc;
     memcpy(recv, c->h_recv, total);
     return VSGPU_OK;
 }
@@ -194,17 +272,20 @@ extern "C" int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int 
     if (bytes == 0) return VSGPU_OK;
     if (root < 0 || root >= c->world) return fail(VSGPU_ERR_ARG, "broadcast root %d of %d", root, c->world);
     HIPCHK(hipSetDevice(c->ctx->device));
-    int rc = comm_reserve(c, bytes, bytes);
+    int rc = comm_enter(c);
     if (rc) return rc;
+    rc = comm_reserve(c, bytes, bytes);
+    if (rc) return comm_abort(c, "buffer allocation");
     if (c->rank == root) memcpy(c->h_send, buf, bytes);
     if (c->staged) {
-        if (c->rank == root) HIPCHK(hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
-        RCCLCHK(rccl()->Broadcast(c->d_send, c->d_send, bytes, kRcclInt8, root, c->comm, c->stream));
-        if (c->rank != root) HIPCHK(hipMemcpyAsync(c->h_send, c->d_send, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (c->rank == root) COMMCHK_HIP(c, hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, c->stream));
+        COMMCHK_RCCL(c, rccl()->Broadcast(c->d_send, c->d_send, bytes, kRcclInt8, root, c->comm, c->stream));
+        if (c->rank != root) COMMCHK_HIP(c, hipMemcpyAsync(c->h_send, c->d_send, bytes, hipMemcpyDeviceToHost, c->stream));
     } else {
-        RCCLCHK(rccl()->Broadcast(c->h_send, c->h_send, bytes, kRcclInt8, root, c->comm, c->stream));
+        COMMCHK_RCCL(c, rccl()->Broadcast(c->h_send, c->h_send, bytes, kRcclInt8, root, c->comm, c->stream));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = comm_wait(c);
+    if (rc) return rc;
     if (c->rank != root) memcpy(buf, c->h_send, bytes);
     return VSGPU_OK;
 }

@@ -9,6 +9,7 @@ its caller).  torch never touches the data path.
     ShardedFlatIndex(params, rank, world, dist)           one process per GPU, RCCL exchange
     ShardedFlatIndex(params, shards=G, devices=[...])      one process drives G shards (may share a GPU)
     ShardedFlatIndex(params, rank, world, dist, transport="dist")   exchange through `dist` itself (gloo in CPU tests)
+    ShardedFlatIndex(params, rank, world, transport=(allgather, broadcast))   the caller's own callables (_capi.ALLGATHER_FN shapes)
 """
 import ctypes as C
 import os
@@ -90,7 +91,11 @@ class ShardedFlatIndex:
         else:
             if device is None:
                 device = int(os.environ.get("VECSIM_GPU_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            if transport == "dist":
+            if isinstance(transport, tuple):   # the caller's own (allgather, broadcast) callables: MPI, a test's failing transport
+                ag, bc = _capi.ALLGATHER_FN(transport[0]), _capi.BROADCAST_FN(transport[1])
+                self._keep += [ag, bc]
+                self._h = lib.VecSimGpu_ShardedNewWithTransport(C.byref(p), rank, world, device, ag, bc, None)
+            elif transport == "dist":
                 ag, bc = _dist_transport(dist)
                 self._keep += [ag, bc]
                 self._h = lib.VecSimGpu_ShardedNewWithTransport(C.byref(p), rank, world, device, ag, bc, None)
@@ -197,6 +202,13 @@ class ShardedFlatIndex:
 
     def reset_stats(self):
         self._lib.VecSimGpu_ShardedResetStats(self._h)
+
+    def abort(self):
+        """give up on the other processes (VecSimGpu_ShardedAbort): exchanges in flight fail, later queries are refused"""
+        self._lib.VecSimGpu_ShardedAbort(self._h)
+
+    def exchange_mode(self):
+        return self._lib.VecSimGpu_ShardedExchangeMode(self._h).decode()
 
     def reset_seq(self):
         """start a new stream of numbered batches at 0 (every process, nothing in flight)"""
