@@ -321,16 +321,40 @@ def build_index(args, p, my_rows, rank, world, local_rank, dist, distributed, Ve
             name, val = o.split("=", 1)
             ix.set_option(name, int(val))
         return ix, ix, None
-    transport, why = "rccl", None
-    try:
-        ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)
-    except RuntimeError as e:
-        ix, why = None, str(e)
-    flags = [None] * world
-    dist.all_gather_object(flags, why)
-    if any(f is not None for f in flags):
-        transport = "gloo (RCCL communicator failed: %s)" % next(f for f in flags if f is not None)
+    # Which buffers the collective runs on (csrc/vsgpu_comm.hip): `mapped` -- the records' host blocks, mapped into the device, ARE the
+    # all-gather's send / receive buffers: one kernel on the exchange stream -- or `staged` -- device buffers with a copy in front
+    # and behind: the canonical RCCL shape and the library's default for more than one rank, +0.2 ms per batch on a busy GPU
+    # (profiles/r05a_*).  No multi-GPU box was available to the builder, so the choice is made HERE, by test: every rank tries
+    # `mapped`, all-gathers rank-stamped bytes of a record's size and checks every slice (VecSimGpu_ShardedExchangeSelfTest, 20 s
+    # limit); unless every rank passes, all of them build a fresh communicator in `staged` form and test again; should that fail
+    # too, the same records travel over torch.distributed (gloo) -- slower, still exact -- and the line says which one ran.
+    def attempt(mode):
+        if mode is not None:
+            os.environ["VECSIM_GPU_EXCHANGE"] = mode
+        os.environ.setdefault("VECSIM_GPU_EXCHANGE_TIMEOUT_MS", "20000")
+        ix, why = None, None
+        try:
+            ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank)
+            if not ix.exchange_self_test(81920):
+                why = "self-test of the %s exchange failed: %s" % (ix.exchange_mode(), ix._lib.VecSimGpu_LastError().decode())
+        except RuntimeError as e:
+            why = str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, why)
+        bad = [f for f in flags if f is not None]
+        return (ix, None) if not bad else (None, bad[0])
+    forced = os.environ.get("VECSIM_GPU_EXCHANGE")
+    transport, notes = None, []
+    for mode in ([forced] if forced else ["mapped", "staged"]):
+        ix, why = attempt(mode)
+        if ix is not None:
+            transport = "rccl"
+            break
+        notes.append("%s: %s" % (mode, why))
+    if transport is None:
+        transport = "gloo (RCCL exchange failed: %s)" % "; ".join(notes)
         ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=local_rank, transport="dist")
+    args.exchange_mode = ix.exchange_mode() + (" (after %s)" % "; ".join(notes) if notes and transport == "rccl" else "")
     ix.add_synthetic_local(my_rows, args.seed)     # shard r holds its vectors of seed + 1000 r
     local = ix.local
     local.set_option("mfma", args.mfma)
@@ -487,7 +511,9 @@ def main():
             pg = timed_phase(args, ixg, localg, trg, rows_g, args.steps, qsets, rank, world, dist, distributed, readers, nwarm)
             shard_curve[str(g)] = {"rows": rows_g, "ms_per_step": pg["ms_per_step"], "scan_kernel_ms": pg["avg_kernel_ms"],
                                    "fixed_ms_per_batch": pg["fixed_ms_per_batch"], "candidates_per_query": pg["candidates_per_query"],
-                                   "exchange_ms_one_rank": (pg["per_rank"][0]["exchange_ms"] if pg["per_rank"] else None)}
+                                   "exchange_ms_one_rank": (pg["per_rank"][0]["exchange_ms"] if pg["per_rank"] else None),
+                                   "turn_wait_ms": (pg["per_rank"][0]["turn_wait_ms"] if pg["per_rank"] else None),
+                                   "merge_ms": (pg["per_rank"][0]["merge_ms"] if pg["per_rank"] else None)}
             del ixg, localg
 
     if rank == 0:
@@ -533,6 +559,7 @@ def main():
                        "rows_per_gpu": my_rows, "rows_total": total_rows, "dim": args.dim, "batch": args.batch, "k": args.topk,
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
                        "reader_threads": readers,
+                       "exchange_buffers": getattr(args, "exchange_mode", None),
                        "exchange": (("rccl ncclAllGather" if args.exchange_transport == "rccl" else args.exchange_transport) +
                                     " of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
                                     "merge (C++ host library)" % world) if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},

@@ -114,6 +114,10 @@ VecSimIndex *VecSimGpu_ShardedLocalIndex(VecSimShardedIndex *index, int shard);
  * peers do not arrive within $VECSIM_GPU_EXCHANGE_TIMEOUT_MS (default 120 000 ms); the call is for a caller that learns of a
  * dead peer some other way. */
 void VecSimGpu_ShardedAbort(VecSimShardedIndex *index);
+/* SPMD check of the transport: every process all-gathers `bytes` rank-stamped bytes, checks every rank's slice and agrees on the
+ * verdict: 0 on every process when the exchange moves bytes correctly, -1 on every process otherwise (or after an error /
+ * $VECSIM_GPU_EXCHANGE_TIMEOUT_MS: the communicator is then aborted).  How bench.py decides between the two buffer forms. */
+int VecSimGpu_ShardedExchangeSelfTest(VecSimShardedIndex *index, size_t bytes);
 /* "rccl-staged" | "rccl-mapped" (csrc/vsgpu_comm.hip, $VECSIM_GPU_EXCHANGE) | "transport" (caller's callbacks) | "local" */
 const char *VecSimGpu_ShardedExchangeMode(VecSimShardedIndex *index);
 int VecSimGpu_ShardedWorld(VecSimShardedIndex *index);

@@ -80,6 +80,8 @@ def _worker(rank, world, port, out):
     p.type, p.dim, p.metric, p.blockSize = 0, dim, 0, block
     shard = OracleShard(dim)
     ix = ShardedFlatIndex(p, rank=rank, world=world, dist=dist, external=(shard.add, shard.candidates))
+    # the SPMD transport check bench.py chooses its exchange buffers by: rank-stamped bytes through the all-gather, every slice checked
+    assert ix.exchange_self_test(4096) and ix.exchange_mode() == "transport"
     ix.add_vectors(rows[:700], labels[:700])
     for i in range(700, n):
         assert ix.add_vector(rows[i], labels[i]) == 1

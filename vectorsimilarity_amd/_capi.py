@@ -149,7 +149,7 @@ EXPORTS = [
     "VecSimGpu_ShardedAddVectorsBulk", "VecSimGpu_ShardedAddSyntheticLocal", "VecSimGpu_ShardedDeleteVector",
     "VecSimGpu_ShardedIndexSize", "VecSimGpu_ShardedTopKQueryBatch", "VecSimGpu_ShardedTopKQueryBatchArrays",
     "VecSimGpu_ShardedTopKQueryBatchArraysSeq", "VecSimGpu_ShardedGetStats", "VecSimGpu_ShardedResetStats", "VecSimGpu_ShardedResetSeq",
-    "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedAbort", "VecSimGpu_ShardedExchangeMode", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
+    "VecSimGpu_ShardedLocalIndex", "VecSimGpu_ShardedAbort", "VecSimGpu_ShardedExchangeSelfTest", "VecSimGpu_ShardedExchangeMode", "VecSimGpu_ShardedWorld", "VecSimGpu_ShardedRank",
     "VecSimDebugInfoIterator_NumberOfFields", "VecSimDebugInfoIterator_HasNextField",
     "VecSimDebugInfoIterator_NextField", "VecSimDebugInfoIterator_Free",
 ]
@@ -356,6 +356,8 @@ def load():
     L.VecSimGpu_ShardedLocalIndex.argtypes = [vp, i]
     L.VecSimGpu_ShardedAbort.restype = None
     L.VecSimGpu_ShardedAbort.argtypes = [vp]
+    L.VecSimGpu_ShardedExchangeSelfTest.restype = i
+    L.VecSimGpu_ShardedExchangeSelfTest.argtypes = [vp, C.c_size_t]
     L.VecSimGpu_ShardedExchangeMode.restype = C.c_char_p
     L.VecSimGpu_ShardedExchangeMode.argtypes = [vp]
     L.VecSimGpu_ShardedWorld.restype = i

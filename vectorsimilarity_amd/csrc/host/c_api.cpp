@@ -564,6 +564,7 @@ extern "C" VecSimShardedIndex *VecSimGpu_ShardedNewLocal(const VecSimParams *par
 }
 extern "C" void VecSimGpu_ShardedFree(VecSimShardedIndex *ix) { delete ix; }
 extern "C" void VecSimGpu_ShardedAbort(VecSimShardedIndex *ix) { ix->impl->abortExchange(); }
+extern "C" int VecSimGpu_ShardedExchangeSelfTest(VecSimShardedIndex *ix, size_t bytes) { return ix->impl->exchangeSelfTest(bytes); }
 extern "C" const char *VecSimGpu_ShardedExchangeMode(VecSimShardedIndex *ix) { return ix->impl->exchangeMode(); }
 extern "C" int VecSimGpu_ShardedAddVector(VecSimShardedIndex *ix, const void *blob, size_t label) {
     return ix->impl->addVector(blob, label);

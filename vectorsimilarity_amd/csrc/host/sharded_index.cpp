@@ -329,6 +329,27 @@ int ShardedIndex::removeGid(uint64_t hole) {
     return 0;
 }
 
+int ShardedIndex::exchangeSelfTest(size_t bytes) {
+    if (!ex_ || rank_ < 0) return 0;
+    bytes = std::max<size_t>(bytes, 64);
+    const size_t world = plan_.world;
+    auto stamp = [](size_t r, size_t i) { return (unsigned char)((r * 131 + i * 7 + (i >> 8) * 13 + 5) & 0xFF); };
+    std::vector<unsigned char> mine(bytes), all(bytes * world, 0);
+    for (size_t i = 0; i < bytes; i++) mine[i] = stamp((size_t)rank_, i);
+    if (ex_->allgather(mine.data(), bytes, all.data())) return -1;
+    uint64_t bad = 0;
+    for (size_t r = 0; r < world && !bad; r++)
+        for (size_t i = 0; i < bytes; i++)
+            if (all[r * bytes + i] != stamp(r, i)) {
+                bad = 1;
+                break;
+            }
+    std::vector<uint64_t> verdicts(world, 0);
+    if (ex_->allgather(&bad, 8, verdicts.data())) return -1;
+    for (uint64_t v : verdicts) bad |= v;
+    return bad ? -1 : 0;
+}
+
 int ShardedIndex::deleteVector(size_t label) {
     if (synthetic_rows_) return -1;
     // every process takes the same decisions from the same state (SPMD): shards or transports that cannot move rows are

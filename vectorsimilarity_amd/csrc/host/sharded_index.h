@@ -101,6 +101,9 @@ public:
         if (ex_) ex_->abort();
     }
     const char *exchangeMode() const { return ex_ ? ex_->mode() : "local"; }
+    // every process all-gathers `bytes` rank-stamped bytes and checks every rank's slice; also agrees on the verdict (a second
+    // 8-byte all-gather), so every process returns the same value: 0 = the exchange moves bytes correctly between all ranks
+    int exchangeSelfTest(size_t bytes);
     // the exchange + merge step on its own (also the body of topKQueryBatch): `mine` = this process's records
     static size_t recordBytes(size_t nq, size_t cap) { return 32 + nq * 8 * (1 + 3 * cap); }
 

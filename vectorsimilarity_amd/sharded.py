@@ -207,6 +207,10 @@ class ShardedFlatIndex:
         """give up on the other processes (VecSimGpu_ShardedAbort): exchanges in flight fail, later queries are refused"""
         self._lib.VecSimGpu_ShardedAbort(self._h)
 
+    def exchange_self_test(self, nbytes=81920):
+        """SPMD: True on every process iff the exchange moves rank-stamped bytes correctly between all of them"""
+        return self._lib.VecSimGpu_ShardedExchangeSelfTest(self._h, nbytes) == 0
+
     def exchange_mode(self):
         return self._lib.VecSimGpu_ShardedExchangeMode(self._h).decode()
 
