@@ -637,7 +637,7 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
         ix.set_option("mfma", mfma)
         ix.reset_stats()
         replies.append(ix.knn_query(q, k))
-        assert ix.stats()["scan_kernel"].startswith(("k_mfma_filter_lowp", "k_i8_filter_x32") if mfma else "k_exact_scan")
+        assert ix.stats()["scan_kernel"].startswith(("k_mfma_filter_lowp", "k_i8_filter_x32") if mfma else "k_exact_scan")   # (x32 and x32l)
     for r in replies[1:]:
         assert np.array_equal(replies[0][0], r[0]) and np.array_equal(replies[0][1], r[1])
     el, es = oracle_topk(vso, typ, metric, rows, q[0], k)
@@ -864,22 +864,28 @@ def test_lowp_mfma_filter_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     ("u8", "IP", 800, 20_005, 130, 100),
 ])
 def test_i8_x32_filter_bit_exact(vso, typ, metric, dim, n, nq, k):
-    """the 32 x 32 x 32 int8 filter (mfma_i8x32_kernels.hpp: kernel width 1024, more than 128 queries; wave-private candidate
-    queues finalised at flush) against the 16 x 16 x 64 filter and the oracle, exact integer scores both ways"""
+    """the two 32 x 32 x 32 int8 filters (mfma_i8x32_kernels.hpp: kernel width 1024, more than 128 queries; wave-private candidate
+    queues finalised at flush) -- k_i8_filter_x32 (per-value screen in the stream) and k_i8_filter_x32l (round 5: one integer
+    threshold per query from the table-wide aux extremes, running maxima, exact test on demand; waves 4-7 half a unit apart) --
+    against the 16 x 16 x 64 filter and the oracle, exact integer scores all ways"""
     rng = np.random.default_rng(dim * 7 + n + nq)
     rows = random_vectors(rng, n, dim, typ, vso)
     q = random_vectors(rng, nq, dim, typ, vso)
     ix = make_index(typ, metric, dim)
     ix.add_vectors(rows, np.arange(n))
     ix.set_option("dense_pairs", 0)
-    ix.reset_stats()
-    l1, d1 = ix.knn_query(q, k)
-    assert ix.stats()["scan_kernel"] == "k_i8_filter_x32", ix.stats()
     ix.set_option("lowp_x32", 0)
     ix.reset_stats()
     l0, d0 = ix.knn_query(q, k)
     assert ix.stats()["scan_kernel"] == "k_mfma_filter_lowp(i8)", ix.stats()
-    assert np.array_equal(l0, l1) and np.array_equal(d0, d1)
+    replies = {}
+    for name, opt in (("k_i8_filter_x32", 32770), ("k_i8_filter_x32l", 262144 + 4 + 16384 + 1)):
+        ix.set_option("lowp_x32", opt)
+        ix.reset_stats()
+        replies[name] = ix.knn_query(q, k)
+        assert ix.stats()["scan_kernel"] == name and ix.stats()["fallbacks"] == 0, ix.stats()
+        assert np.array_equal(l0, replies[name][0]) and np.array_equal(d0, replies[name][1]), name
+    l1, d1 = replies["k_i8_filter_x32l"]
     srows = stored_rows(vso, rows, typ, metric)
     sq = stored_rows(vso, q, typ, metric)
     km = kernel_metric(typ, metric)
@@ -890,7 +896,49 @@ def test_i8_x32_filter_bit_exact(vso, typ, metric, dim, n, nq, k):
         assert np.array_equal(d1[j], es), (typ, metric, dim, j)
 
 
-def test_i8_x32_many_tiles_per_workgroup_ties_and_queue_flushes(vso):
+def test_i8_x32_kernel_choice_follows_the_tables_aux_spread(vso):
+    """option lowp_x32 = 1 (default): a table nothing is known about gets the per-value screen; once the pinned copy of the aux
+    extremes has arrived (behind the first batch) uniform rows -- norms within a few percent -- take the lean stream, a table whose
+    norms spread widely keeps the per-value screen; rows added later are noticed.  The replies never differ."""
+    rng = np.random.default_rng(77)
+    dim, n, nq, k = 1024, 20_000, 160, 10
+    rows = random_vectors(rng, n, dim, "i8", vso)
+    q = random_vectors(rng, nq, dim, "i8", vso)
+    ix = make_index("i8", "Cosine", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    names, replies = [], []
+    for _ in range(3):
+        ix.reset_stats()
+        replies.append(ix.knn_query(q, k))
+        names.append(ix.stats()["scan_kernel"])
+    assert names == ["k_i8_filter_x32", "k_i8_filter_x32l", "k_i8_filter_x32l"], names
+    for r in replies[1:]:
+        assert np.array_equal(r[0], replies[0][0]) and np.array_equal(r[1], replies[0][1])
+    # quiet rows (a third of the amplitude): the norms now spread 3 : 1
+    quiet = (random_vectors(rng, 2_000, dim, "i8", vso).astype(np.int32) // 3).astype(np.int8)
+    ix.add_vectors(quiet, np.arange(n, n + 2_000))
+    allrows = np.concatenate([rows, quiet])
+    names = []
+    for _ in range(3):
+        ix.reset_stats()
+        l, d = ix.knn_query(q, k)
+        names.append(ix.stats()["scan_kernel"])
+    assert names == ["k_i8_filter_x32l", "k_i8_filter_x32", "k_i8_filter_x32"], names   # (the first batch still ran on the old extremes)
+    srows = stored_rows(vso, allrows, "i8", "Cosine")
+    sq = stored_rows(vso, q, "i8", "Cosine")
+    for j in range(0, nq, 11):
+        sc = vso.scan(TYPES["i8"], kernel_metric("i8", "Cosine"), srows, sq[j], dim)
+        el, es = vso.topk_replay(sc, k)
+        assert np.array_equal(l[j], el.astype(np.int64)) and np.array_equal(d[j], es), j
+    # ... and the lean stream on that table (forced): loose threshold, exact test on most units, same reply
+    ix.set_option("lowp_x32", 262144 + 4 + 16384 + 1)
+    l2, d2 = ix.knn_query(q, k)
+    assert np.array_equal(l, l2) and np.array_equal(d, d2)
+
+
+@pytest.mark.parametrize("opt,name", [(32770, "k_i8_filter_x32"), (262144 + 4 + 16384 + 1, "k_i8_filter_x32l")])
+def test_i8_x32_many_tiles_per_workgroup_ties_and_queue_flushes(vso, opt, name):
     """every workgroup walks several tiles, rows repeat (exact score ties), and a loose threshold (k = 2000) makes the
     wave-private candidate queues flush inside the scan"""
     rng = np.random.default_rng(5)
@@ -901,9 +949,10 @@ def test_i8_x32_many_tiles_per_workgroup_ties_and_queue_flushes(vso):
     ix = make_index("i8", "Cosine", dim)
     ix.add_vectors(rows, np.arange(n))
     ix.set_option("dense_pairs", 0)
+    ix.set_option("lowp_x32", opt)
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)
-    assert ix.stats()["scan_kernel"] == "k_i8_filter_x32", ix.stats()
+    assert ix.stats()["scan_kernel"] == name, ix.stats()
     srows = stored_rows(vso, rows, "i8", "Cosine")
     sq = stored_rows(vso, q, "i8", "Cosine")
     for j in range(0, nq, 13):

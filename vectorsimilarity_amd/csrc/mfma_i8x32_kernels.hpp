@@ -37,17 +37,43 @@ constexpr int X32_KS = 32;            // k-steps of 32 bytes
 constexpr int X32_AUXB = 8;           // per-unit aux buffers (256 B each; a unit's values live from its request to its screening)
 constexpr int X32_QT = 256;           // queries per workgroup
 constexpr int X32_WQ_CAP = 64;         // records per wave-private candidate queue (one ballot's worth always fits)
-constexpr int x32_lds_bytes(int ns) { return ns * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16; }
+constexpr int x32_lds_bytes(int ns) { return ns * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16 + 64; }   // (+ the FREE ring's two counters)
 
-// VAR bits (the shipped build instantiates 32768 | 1 only; the rest is the tuning build's, profiles/r03_c3_x32.txt):
+// VAR bits (the shipped build instantiates one variant; the rest is the tuning build's, profiles/r03_c3_x32.txt, r05_c3_*.txt):
 // 1 = EARLY (rows land one barrier early, fragments prefetched across the barrier), 2 = requests spread over the stream
-// instead of behind the first MFMAs, 8 = two accumulator chains (even / odd k-steps), 16 = s_setprio 1 for the
+// instead of behind the first MFMAs, 4 = SHIFT (the two waves of a SIMD half a unit apart: waves 4-7 meet the ring barrier in the
+// MIDDLE of their stream, see below; needs X32_D <= X32_NS - 2), 8 = two accumulator chains (even / odd k-steps), 16 = s_setprio 1 for the
 // second-dispatched half of the waves, 16384 = inline-asm fragment reads with counted waits, 32768 = only waves 0-3 request rows
 // X32_NS ring slots, X32_D units requested ahead
 template <int LK, int EPI, int VAR, int X32_NS = 4, int X32_D = 3>
 __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) {
     static_assert(X32_D >= 1 && X32_D < X32_NS && (!((VAR & 1) != 0) || X32_D >= 2), "ring geometry");
+    // SHIFT: every wave still meets ONE s_barrier per unit, but waves 4-7 -- the second wave of each SIMD -- meet it between their
+    // k-steps 15 and 16 instead of at the end of their stream.  In lock step both waves of a SIMD leave the matrix pipe idle through
+    // the same tail (last reads returning, aux reads, frontier arithmetic, vmcnt wait), barrier and restart; half a unit apart, one
+    // wave's tail and restart fall into the middle of the other's MFMA stream.  Ring: at barrier j the late waves are still reading
+    // unit j's slot (and will until half a period later), so the requests of the early waves' unit j + 1 may only overwrite the slot
+    // of unit j - 1: X32_D <= X32_NS - 2.
+    constexpr bool SHIFT = (VAR & 4) != 0;
+    static_assert(!SHIFT || X32_D <= X32_NS - 2, "SHIFT: the late waves read a unit's slot half a period past its barrier");
+    static_assert(!SHIFT || (VAR & 32768), "SHIFT: the late waves must not request rows (they would have to wait for them at their barrier)");
     static_assert(LK == LP_I8 || LK == LP_U8, "int8 / uint8 rows with 4-byte aux values");
+    // FREE (VAR bit 1024): no s_barrier in the loop at all.  The stamps of the lock-step kernel (profiles/r05_c3_batch1.txt) show
+    // every wave 720-1140 of its ~4000 cycles per unit inside the ring barrier: eight waves whose unit times vary (request issue
+    // blocked by the memory pipeline, arbitration for the matrix pipe, a candidate to queue) wait for the slowest of the eight,
+    // every unit.  Two monotonic LDS counters carry what the barrier carried:
+    //   landed += 1 by each of the 4 requesting waves once ITS rows of a unit are in LDS (its vmcnt says so): unit w may be read once
+    //              landed >= 4 (w + 1);
+    //   done   += 1 by each of the 8 waves once its last fragment read of a unit is in its LDS queue (the queue is served in order,
+    //              so the add runs behind the reads): the slot of unit w may be overwritten once done >= 8 (w + 1).
+    // A wave reads a counter where it drains lgkmcnt anyway (in front of the fragment reads of the next unit), and with the ring's
+    // slack -- X32_D units requested ahead, X32_NS - X32_D - 1 slots for laggards -- the first look almost always passes, so nobody
+    // spins; waves drift up to that slack apart, which also takes the two waves of a SIMD out of phase by itself.
+    // No deadlock: the wave that is furthest behind (unit m) waits only for `landed`, i.e. for requesting waves to reach their
+    // publication point in iteration m, and those wait only for done(m - 2), which every wave at or past unit m has signalled.
+    constexpr bool FREE = (VAR & 1024) != 0;
+    static_assert(!FREE || ((VAR & 1) && (VAR & 32768) && !(VAR & 4) && !(VAR & 2)), "FREE: EARLY + requests by waves 0-3, no SHIFT / SPREAD");
+    static_assert(!FREE || X32_D <= X32_NS - 2, "FREE: one slot of slack for laggards");
     constexpr bool EARLY = (VAR & 1) != 0;
     constexpr bool SPREAD = (VAR & 2) != 0;
     constexpr bool ACC2 = (VAR & 8) != 0;
@@ -66,6 +92,7 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n32 = lane & 31, h = lane >> 5;
     const int qtile = (int)blockIdx.y;
+    const bool late_wave = SHIFT && wave >= X32_NW / 2;   // (wave-uniform: a scalar branch)
 
     i32x4_t qf[X32_KS];
     {
@@ -102,6 +129,25 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     const uint32_t wq_off = mf_lds_offset(lds + X32_NS * X32_UNIT + X32_AUXB * 256) + (uint32_t)wave * (X32_WQ_CAP * 16);
     uint32_t wq_n = 0;
     const uint32_t aux_lds_off = mf_lds_offset(aux_lds);
+    // FREE: the two counters behind the wave queues
+    const uint32_t landed_off = mf_lds_offset(lds + X32_NS * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16), done_off = landed_off + 32;
+    auto ring_signal = [&](uint32_t off) {
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(off), "v"(1u) : "memory");
+    };
+    auto ring_wait = [&](uint32_t off, uint32_t target) {   // returns once the counter has reached `target`
+        for (;;) {
+            uint32_t v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+            if ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    if (FREE) {
+        if (tid == 0) {
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(landed_off), "v"(0u), "v"(done_off) : "memory");
+        }
+        __syncthreads();
+    }
     if (VAR & 16) {
         if (wave >= X32_NW / 2) __builtin_amdgcn_s_setprio(1);
     }
@@ -177,8 +223,16 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         if (wave == 0) lowp_wait_vmcnt(units * (IPWX + 1));
         else if (issuer) lowp_wait_vmcnt(units * IPWX);
     };
-    wait_units_in_flight(EARLY ? X32_D - 2 : X32_D - 1);
-    mf_ring_barrier();
+    if (FREE) {
+        if (issuer) {   // unit 0 of this wave's rows has landed: publish it; iteration `it` publishes unit it + 1
+            wait_units_in_flight(X32_D - 1);
+            ring_signal(landed_off);
+        }
+        ring_wait(landed_off, 4u);
+    } else {
+        wait_units_in_flight(EARLY ? X32_D - 2 : X32_D - 1);
+        mf_ring_barrier();
+    }
 
     const uint32_t frag_lane_off = (uint32_t)n32 * X32_ROWB + (uint32_t)h * 16u;
     const uint32_t frag_lds_off = mf_lds_offset(lds) + frag_lane_off;
@@ -259,6 +313,10 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0, acc_b[i] = 0;
         stamp(it ? 4 : -1);
+        if (FREE) {
+            // the requests of this iteration (unit it + D) overwrite the slot of unit it + D - NS: every wave is done with it
+            if (issuer && it + X32_D >= (uint32_t)X32_NS) ring_wait(done_off, 8u * (it + X32_D - X32_NS + 1));
+        }
         issue_aux();   // (a wave-uniform branch: kept out of the stream's scheduling region)
         if (!EARLY) {
 #pragma unroll
@@ -271,6 +329,14 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
             constexpr int PBASE = SPREAD ? 2 : 1, PSTEP = SPREAD ? 32 / IPWX : 1;
 #pragma unroll
             for (int ks = 0; ks < X32_KS; ks++) {
+                if (SHIFT && ks == X32_KS / 2) {
+                    // the late waves' barrier of this unit (they request no rows: no vmcnt to wait for)
+                    if (late_wave) {
+                        stamp(5);
+                        mf_ring_barrier();
+                        stamp(3);
+                    }
+                }
                 if (!NO_MMA) {
                     if (ASMRD) {
                         // fragment ks has returned once at most this many later reads are outstanding (LDS returns in order;
@@ -284,10 +350,24 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
                     if (ACC2 && (ks & 1)) acc_b = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc_b, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc, 0, 0, 0);
                     const int f = ks + PF;
+                    if (FREE && f == X32_KS) {
+                        // every fragment read of this unit is in the LDS queue: the slot is done with, as far as this wave goes;
+                        // the next unit's rows must have landed before its first fragments are read
+                        ring_signal(done_off);
+                        ring_wait(landed_off, 4u * (it + 2));
+                    }
                     if (f < X32_KS) afr[ks % PF] = read_frag(cslot, f);
                     else if (EARLY) afr[ks % PF] = read_frag(nslot, f - X32_KS);
                 }
                 if (ks >= PBASE && (ks - PBASE) % PSTEP == 0 && (ks - PBASE) / PSTEP < IPWX) issue_piece((ks - PBASE) / PSTEP);
+                if (FREE && ks == PBASE + IPWX + 3) {
+                    // a few MFMAs behind this iteration's requests: the rows of unit it + 1 (requested one iteration ago) have
+                    // landed once only this iteration's requests are outstanding -- publish them
+                    if (issuer) {
+                        wait_units_in_flight(X32_D - 1);
+                        ring_signal(landed_off);
+                    }
+                }
                 if (STAMPS && !SPREAD && ks == PBASE + IPWX - 1) stamp(0);
                 // screening of unit u-1, one accumulator register per k-step
                 if (!NO_SCREEN && ks >= 8 && ks < 24) {
@@ -354,11 +434,13 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
         advance_frontier();
         // the next unit (EARLY: the one after it as well) has landed; every read of this unit's slot, and the aux reads
         // above, have returned (mf_ring_barrier waits lgkmcnt(0))
-        stamp(5);
-        wait_units_in_flight(EARLY ? X32_D - 2 : X32_D - 1);
-        stamp(2);
-        mf_ring_barrier();
-        stamp(3);
+        if (!late_wave && !FREE) {
+            stamp(5);
+            wait_units_in_flight(EARLY ? X32_D - 2 : X32_D - 1);
+            stamp(2);
+            mf_ring_barrier();
+            stamp(3);
+        }
         asm volatile("" : "+v"(auxv[0]), "+v"(auxv[1]), "+v"(auxv[2]), "+v"(auxv[3]));
         if (ASMRD && EARLY) {
 #pragma unroll
@@ -381,5 +463,375 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (wq_n) flush_wave_queue();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_i8_filter_x32l -- the same filter with a THIRD fewer instructions per unit (round 5).
+//
+// What round 5 measured on k_i8_filter_x32 (profiles/r05_c3_batch1.txt, r05_c3_batch2.txt): the kernel is bound by instruction
+// ISSUE, not by a pipe.  Two waves share a SIMD's issue port; per 32-row unit they issue ~760 instructions for 64 MFMAs (2048
+// cycles of matrix pipe), and every elimination run moves the time in proportion to the instructions it removes (screening off:
+// -17 % instructions, -22 % time; no row requests: -8 %, -27 % with their issue stalls) while removing the ring barrier altogether
+// (two LDS counters instead, VAR bit 1024) or prefetching deeper changes nothing.  So this kernel issues less:
+//   * screening: ONE integer threshold per query for the whole scan -- from the table-wide extremes of the rows' aux values
+//     (LowpParams::sq8_max, k_row_aux_i8) -- and a running maximum over the 16 accumulators of the previous unit (8 v_max3_i32
+//     + 1 compare per unit, was 48 VALU + 20 SALU).  A lane whose maximum reaches the threshold sends the wave into the exact
+//     per-value test (the reference's epilogue order, as before), which reads the unit's aux values only then;
+//   * the accumulators alternate between two register sets from unit to unit instead of being copied (16 v_mov per unit);
+//   * row requests take the row's address from a scalar base that is bumped by the row stride (global_load_lds with an SGPR
+//     base: 5 scalar instructions per 1 KiB piece, was 8 of which 2 VALU), and the requesting waves (0-3) run their own copy of
+//     the loop: the other four never see a request or the branch around it;
+//   * tile -> row arithmetic is the filter's (consecutive tiles), no probe strides.
+// Thresholds (T = smallest dot that can still pass; every value the exact test passes has dot >= T):
+//   Cosine   exact test  !(float(dot) < cosq * norm_x)            T = ceil(cosq * (cosq >= 0 ? min norm : max norm))
+//   L2       float(sum_x + sum_q - 2 dot) <= tau                  T = ceil((min sum_x + sum_q - tau') / 2)
+//   IP       float(1 - dot) <= tau                                T = ceil(1 - tau')
+//   uint8 IP float(1 - (dot + 128 s_x + c_q)) <= tau              T = ceil(1 - tau' - 128 max s_x - c_q)
+// with tau' = tau + |tau| 2^-22 (the int -> float conversion of the left side rounds to nearest: monotone, relative error 2^-24).
+// A table whose aux values spread widely gets a loose threshold and takes the exact test often: vsgpu_lowp.hip picks
+// k_i8_filter_x32 (per-value screen in the stream) for those.
+// VAR bits: 4 = SHIFT (as above), 1 = EARLY is always on; ring X32_NS / X32_D as above.
+template <int EPI> __device__ static inline int x32l_threshold(float tau, uint32_t qaux, int ext_min, int ext_max) {
+    if (tau != tau) return (int)0x80000000;                       // NaN threshold: everything goes to the exact test
+    if (EPI == LE_I8_COS) {
+        if (tau == -INFINITY) return 0x7FFFFFFF;                     // padding query
+        const float omt = 1.0f - tau;
+        const float cosq = (omt - 1e-5f * (1.0f + fabsf(omt))) * __uint_as_float(qaux);   // (k_i8_filter_x32's cosq)
+        if (cosq != cosq) return (int)0x80000000;
+        const float t = cosq * __int_as_float(cosq >= 0.0f ? ext_min : ext_max);
+        if (t != t) return (int)0x80000000;
+        if (t >= 2147483520.0f) return 0x7FFFFFFF;
+        if (t <= -2147483520.0f) return (int)0x80000000;
+        return (int)ceilf(t);
+    }
+    const double tb = (double)tau + fabs((double)tau) * (1.0 / 4194304.0);
+    double t;
+    if (EPI == LE_I8_L2) t = ((double)ext_min + (double)(int)qaux - tb) * 0.5;
+    else if (EPI == LE_I8_IP) t = 1.0 - tb;
+    else t = 1.0 - tb - 128.0 * (double)ext_max - (double)(int)qaux;
+    if (t >= 2147483000.0) return 0x7FFFFFFF;
+    if (t <= -2147483000.0) return (int)0x80000000;
+    return (int)ceil(t);
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int LK, int EPI, int VAR, int X32_NS = 4, int X32_D = 3>
+__global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P) {
+    static_assert(X32_D >= 2 && X32_D < X32_NS, "ring geometry (rows land one barrier early)");
+    static_assert(LK == LP_I8 || LK == LP_U8, "int8 / uint8 rows with 4-byte aux values");
+    constexpr bool SHIFT = (VAR & 4) != 0;
+    static_assert(!SHIFT || X32_D <= X32_NS - 2, "SHIFT: the late waves read a unit's slot half a period past its barrier");
+    // ASMRD (VAR bit 16384): fragment reads in inline asm with counted lgkmcnt waits (hipcc keeps two reads ahead of
+    // their MFMAs and waits out an LDS round trip per pair: with two waves per SIMD that alone caps the matrix pipe near 60 %)
+    constexpr bool ASMRD = (VAR & 16384) != 0;
+    // NODEF (VAR bit 8): no deferred screening -- the unit's own accumulators are reduced and tested behind its last MFMA, so one
+    // accumulator set (16 registers) goes and 8 fragments in flight fit without spilling
+    constexpr bool NODEF = (VAR & 8) != 0;
+    // diagnosis (replies meaningless; tuning build): 128 = the threshold test never fires, 64 = no aux requests
+    // QDEFER (VAR bit 32): a value at or above the integer threshold is QUEUED as it is -- {row, query, dot} --, and the queue's flush
+    // fetches the row's aux value from global memory for the exact score.  The stream then needs no aux values at all (no aux
+    // request per unit, no LDS round trip in front of the per-value test: with ~0.3 values per wave and unit over the threshold
+    // some wave of the eight took that round trip in nearly every unit, and the ring barrier made the other seven wait for it).
+    constexpr bool QDEFER = (VAR & 32) != 0;
+    constexpr bool NO_TEST = (VAR & 128) != 0, NO_AUX = (VAR & 64) != 0 || QDEFER;
+    constexpr int PF = (ASMRD && NODEF) ? 8 : 4;   // A fragments in flight; must divide the 32 k-steps (fragment f lives in afr[f % PF] in
+                                                   // every unit); 8 with two accumulator sets would spill (scratch traffic would also
+                                                   // break the counted vmcnt waits)
+    static_assert(X32_KS % PF == 0, "fragment ring");
+    constexpr int IPWX = 8;        // row pieces per requesting wave (waves 0-3) and unit
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, h = lane >> 5;
+    const int qtile = (int)blockIdx.y;
+    const bool late_wave = SHIFT && wave >= X32_NW / 2;
+
+    i32x4_t qf[X32_KS];
+    {
+        const i32x4_t *src = reinterpret_cast<const i32x4_t *>(P.qfrag) + ((size_t)(qtile * X32_NW + wave) * X32_KS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < X32_KS; s++) qf[s] = src[(size_t)s * 64];
+    }
+    const int qidx = qtile * X32_QT + wave * 32 + n32;
+    uint32_t qaux = P.qaux[qidx];
+    float tau = P.tau[qidx];
+    const int ext_min = (int)P.sq8_max[0], ext_max = (int)P.sq8_max[1];
+#pragma unroll
+    for (int s = 0; s < X32_KS; s++) asm volatile("" : "+v"(qf[s]));
+    asm volatile("" : "+v"(qaux), "+v"(tau));
+    int thr = x32l_threshold<EPI>(tau, qaux, ext_min, ext_max);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr));   // (every ordinary load has returned: the counted vmcnt waits below see DMA only)
+    const float omt = 1.0f - tau;
+    const float cosq = tau == -INFINITY ? INFINITY : (omt - 1e-5f * (1.0f + fabsf(omt))) * __uint_as_float(qaux);
+
+    const uint32_t lds_base = mf_lds_offset(lds);
+    const uint32_t aux_lds_off = lds_base + X32_NS * X32_UNIT;
+    const uint32_t wq_off = aux_lds_off + X32_AUXB * 256 + (uint32_t)wave * (X32_WQ_CAP * 16);
+    uint32_t wq_n = 0;
+    const uint32_t lane16 = (uint32_t)lane * 16u, lane4 = (uint32_t)lane * 4u;
+    // one 1 KiB row piece / one 256-byte aux piece: global address = scalar base + the lane's offset, LDS address = M0 + the lane's
+    auto dma16 = [&](uint64_t sbase, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(lane16), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+    };
+    auto dma4 = [&](uint64_t sbase, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane4), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+    };
+
+    const uint32_t step = gridDim.x;
+    // frontier = the unit requested next (wave-uniform state, all of it in scalar registers)
+    uint32_t cur_slab = 0xFFFFFFFFu;
+    uint64_t cur_sbase = 0, cur_abase = 0;
+    uint32_t ftile = blockIdx.x, fslot = 0, fbuf = 0;
+    auto request_unit = [&](auto piece_filter) {
+        // rows of tile ftile (clamped to the last tile: requests past the end re-read it, never consumed) -> slot fslot
+        const uint32_t tt = ftile < P.n_tiles ? ftile : P.n_tiles - 1;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((P.tile_first + tt) * X32_RT));
+        const uint32_t sidx = r0 >> P.slab_shift;
+        if (sidx != cur_slab) {
+            cur_slab = sidx;
+            const char *const *sp = P.slabs + sidx;
+            const uint32_t *const *axp = P.aux_slabs + sidx;
+            asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(cur_sbase), "=&s"(cur_abase)
+                         : "s"(sp), "s"(axp)
+                         : "memory");
+        }
+        piece_filter(r0);
+    };
+    auto advance_frontier = [&]() {
+        ftile += step;
+        fslot = fslot + 1 == X32_NS ? 0 : fslot + 1;
+        fbuf = (fbuf + 1) & (X32_AUXB - 1);
+    };
+    // per unit: wave 0 the aux piece, waves 0-3 eight row pieces each (piece i of wave w = row 8 w + i of the unit)
+    // Rows past the table's end (the last, partial tile) and tiles past the last one are READ like any other -- a slab is allocated
+    // whole (vsgpu.hip ensure_rows: slab_rows * row_bytes + 1 KiB), tiles never straddle slabs -- and ignored: nvalid masks them.
+    uint64_t pbase = 0;        // global address of this wave's next row piece
+    uint32_t plds = 0;         // its LDS address
+    auto begin_requests = [&]() {
+        request_unit([&](uint32_t r0) {
+            if (wave == 0 && !NO_AUX) {
+                // 64 aux values from row r0 on: the unit's 32 at lanes 0..31, the next unit's (unused) behind them -- only at the end
+                // of the table or of a slab (the aux slabs carry no padding) do the lanes need the clamp
+                if (r0 + 64 <= P.n_rows && (r0 & P.slab_mask) + 64 <= P.slab_mask + 1u) dma4(cur_abase + (uint64_t)(r0 & P.slab_mask) * 4u, aux_lds_off + fbuf * 256u);
+                else {
+                    uint32_t arow = r0 + (uint32_t)lane;
+                    if (arow >= P.n_rows) arow = P.n_rows - 1;
+                    glds4(reinterpret_cast<const uint32_t *>(cur_abase) + (size_t)(arow & P.slab_mask), fbuf * 256u, lds + X32_NS * X32_UNIT);
+                }
+            }
+            pbase = cur_sbase + (uint64_t)((r0 & P.slab_mask) + (uint32_t)(IPWX * wave)) * P.row_stride;
+            plds = lds_base + fslot * X32_UNIT + (uint32_t)(wave * IPWX * X32_ROWB);
+        });
+    };
+    auto issue_piece = [&]() {
+        dma16(pbase, plds);
+        pbase += P.row_stride;
+        plds += X32_ROWB;
+    };
+    const bool issuer = wave < 4;
+    if (issuer) {
+#pragma unroll
+        for (int u = 0; u < X32_D; u++) {
+            begin_requests();
+#pragma unroll
+            for (int i = 0; i < IPWX; i++) issue_piece();
+            advance_frontier();
+        }
+    }
+    auto wait_units_in_flight = [&](int units) {
+        if (wave == 0 && !NO_AUX) lowp_wait_vmcnt(units * (IPWX + 1));
+        else if (issuer) lowp_wait_vmcnt(units * IPWX);
+    };
+    wait_units_in_flight(X32_D - 2);
+    mf_ring_barrier();
+
+    const uint32_t frag_lane_off = (uint32_t)n32 * X32_ROWB + (uint32_t)h * 16u;
+    const uint32_t frag_lds_off = lds_base + frag_lane_off;
+    auto read_frag = [&](uint32_t slot, int ks) -> i32x4_t {
+        i32x4_t v;
+        if (ASMRD) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(frag_lds_off + slot * X32_UNIT), "n"(ks * 32));
+        } else {
+            v = *reinterpret_cast<const i32x4_t *>(lds + slot * X32_UNIT + frag_lane_off + ks * 32);
+            if (LK == LP_U8) v ^= (int)0x80808080;
+        }
+        return v;
+    };
+    auto screen_pass = [&](int dot, uint32_t av) -> bool {
+        if (EPI == LE_I8_COS) return !((float)dot < cosq * __uint_as_float(av));
+        if (EPI == LE_I8_L2) return (float)((int)av + (int)qaux - 2 * dot) <= tau;
+        if (EPI == LE_I8_IP) return (float)(1 - dot) <= tau;
+        return (float)(1 - (dot + 128 * (int)av + (int)qaux)) <= tau;
+    };
+    auto flush_wave_queue = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((uint32_t)lane < wq_n) {
+            u32x4_t rec;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rec) : "v"(wq_off + (uint32_t)lane * 16u) : "memory");
+            const uint32_t row = rec[0], q = rec[1];
+            uint32_t av = rec[3];
+            const int dot = (int)rec[2];
+            if (QDEFER && EPI != LE_I8_IP) av = P.aux_slabs[row >> P.slab_shift][row & P.slab_mask];
+            const uint32_t qa = P.qaux[q];
+            const float tq = P.tau[q];
+            float sc;
+            if (EPI == LE_I8_L2) sc = (float)((int)av + (int)qa - 2 * dot);
+            else if (EPI == LE_I8_IP) sc = (float)(1 - dot);
+            else if (EPI == LE_U8_IP) sc = (float)(1 - (dot + 128 * (int)av + (int)qa));
+            else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qa))));
+            if (sc <= tq) {
+                const uint32_t s = atomicAdd(&P.counts[q], 1u);
+                if (s < P.cap) P.cand[(size_t)q * P.cap + s] = make_uint2(row, __float_as_uint(sc));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wq_n = 0;
+    };
+    // the exact per-value test of ONE group of four accumulators of a unit (rare: some lane's maximum over the group reached its
+    // threshold): rows 8 g + 4 h + (0..3) of the unit, whose aux values are one 16-byte read
+    auto exact_group = [&](const i32x16_t &acc, int g, uint32_t r0, uint32_t nvalid, uint32_t buf) {
+        u32x4_t auxv = {0u, 0u, 0u, 0u};
+        if (!QDEFER)
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(auxv) : "v"(aux_lds_off + buf * 256u + (uint32_t)h * 16u), "n"(g * 32) : "memory");
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const uint32_t lrow = (uint32_t)(rr + 8 * g + 4 * h);
+            const uint32_t av = auxv[rr];
+            const int dot = acc[4 * g + rr];
+            const bool hit = (QDEFER ? dot >= thr : screen_pass(dot, av)) && lrow < nvalid;
+            const unsigned long long b = __ballot(hit);
+            if (b == 0) continue;
+            const uint32_t nb = (uint32_t)__builtin_popcountll(b);
+            if (wq_n + nb > (uint32_t)X32_WQ_CAP) flush_wave_queue();
+            if (hit) {
+                const uint32_t pos = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                const u32x4_t rec = {r0 + lrow, (uint32_t)qidx, (uint32_t)dot, av};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(wq_off + pos * 16u), "v"(rec) : "memory");
+            }
+            wq_n += nb;
+        }
+    };
+
+    i32x4_t afr[PF];
+#pragma unroll
+    for (int f = 0; f < PF; f++) afr[f] = read_frag(0, f);
+    if (ASMRD) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < PF; f++) asm volatile("" : "+v"(afr[f]));
+    }
+
+    uint32_t r0_prev = 0, nvalid_prev = 0, buf_prev = 0;
+    uint32_t cslot = 0, cbuf = 0;
+    uint32_t tile = blockIdx.x;
+    const uint32_t my_tiles = tile < P.n_tiles ? (P.n_tiles - tile + step - 1) / step : 0;
+
+    // one unit: `acc` takes this unit's products, `prev` (the unit before) is screened meanwhile.  ISS = this wave requests rows.
+    auto unit = [&](auto iss_c, i32x16_t &acc, const i32x16_t &prev, bool last) __attribute__((always_inline)) {
+        constexpr bool ISS = decltype(iss_c)::value;
+        const uint32_t nslot = cslot + 1 == X32_NS ? 0 : cslot + 1;
+        if (ISS) begin_requests();
+        int mg[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+#pragma unroll
+        for (int ks = 0; ks < X32_KS; ks++) {
+            if (SHIFT && ks == X32_KS / 2) {
+                if (late_wave) mf_ring_barrier();
+            }
+            if (ASMRD) {
+                // fragment ks has returned once at most PF - 1 later reads are outstanding (the LDS queue is served in order; other
+                // LDS operations in the queue only make the wait stricter)
+                lowp_wait_lgkmcnt(PF - 1, afr[ks % PF]);
+                if (LK == LP_U8) afr[ks % PF] ^= (int)0x80808080;
+            }
+            const i32x4_t a = afr[ks % PF];
+            if (ks == 0) {
+                i32x16_t z;
+#pragma unroll
+                for (int i = 0; i < 16; i++) z[i] = 0;
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], z, 0, 0, 0);
+            } else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc, 0, 0, 0);
+            const int f = ks + PF;
+            afr[ks % PF] = f < X32_KS ? read_frag(cslot, f) : read_frag(nslot, f - X32_KS);
+            if (ISS && ks >= 1 && ks <= IPWX) issue_piece();
+            if (!NODEF && ks >= 12 && ks < 20) {   // the previous unit's accumulators: maxima of the four groups of four, two instructions each
+                const int g = (ks - 12) >> 1;
+                if ((ks & 1) == 0) mg[g] = max(max(prev[4 * g], prev[4 * g + 1]), prev[4 * g + 2]);
+                else mg[g] = max(mg[g], prev[4 * g + 3]);
+            }
+        }
+        // the interleave, pinned (left alone hipcc reads two fragments right in front of their two MFMAs and waits out the LDS
+        // round trip): per k-step one MFMA, the read of fragment ks + PF, at most one VALU
+#pragma unroll
+        for (int ks = 0; ks < X32_KS; ks++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (!ASMRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, LK == LP_U8 ? 5 : 1, 0);
+        }
+        const uint32_t tt = tile < P.n_tiles ? tile : P.n_tiles - 1;
+        if (NODEF) {   // this unit's own accumulators, behind its last MFMA
+            r0_prev = (P.tile_first + tt) * X32_RT;
+            nvalid_prev = last ? 0u : P.n_rows - r0_prev;
+            buf_prev = cbuf;
+#pragma unroll
+            for (int g = 0; g < 4; g++) mg[g] = max(max(acc[4 * g], acc[4 * g + 1]), max(acc[4 * g + 2], acc[4 * g + 3]));
+        }
+        // a lane of the wave may hold a candidate of the unit under test: the exact test, value by value, group by group
+        const int m = max(max(mg[0], mg[1]), max(mg[2], mg[3]));
+        if (NO_TEST) asm volatile("" ::"v"(m));
+        if (!NO_TEST && __ballot(m >= thr) != 0) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (__ballot(mg[g] >= thr) != 0) exact_group(NODEF ? acc : prev, g, r0_prev, nvalid_prev, buf_prev);
+        }
+        r0_prev = (P.tile_first + tt) * X32_RT;
+        nvalid_prev = last ? 0u : P.n_rows - r0_prev;
+        buf_prev = cbuf;
+        cbuf = (cbuf + 1) & (X32_AUXB - 1);
+        cslot = nslot;
+        tile += step;
+        if (ISS) advance_frontier();
+        if (!late_wave) {
+            if (ISS) wait_units_in_flight(X32_D - 2);
+            mf_ring_barrier();
+        }
+        if (ASMRD) {
+#pragma unroll
+            for (int f = 0; f < PF; f++) asm volatile("" : "+v"(afr[f]));
+        }
+    };
+    i32x16_t acc_a, acc_b;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc_a[i] = 0, acc_b[i] = 0;
+    // one iteration past the last tile: its MFMAs run on the clamped refill (discarded), its screening is the last tile's
+    // (NODEF: nothing left to screen there, the iteration only keeps the barrier counts of the waves equal)
+    if (NODEF) {
+        if (issuer) {
+            for (uint32_t it = 0; it <= my_tiles; it++) unit(std::true_type{}, acc_a, acc_a, it == my_tiles);
+        } else {
+            for (uint32_t it = 0; it <= my_tiles; it++) unit(std::false_type{}, acc_a, acc_a, it == my_tiles);
+        }
+    } else if (issuer) {
+        for (uint32_t it = 0;;) {
+            unit(std::true_type{}, acc_a, acc_b, it == my_tiles);
+            if (it++ == my_tiles) break;
+            unit(std::true_type{}, acc_b, acc_a, it == my_tiles);
+            if (it++ == my_tiles) break;
+        }
+    } else {
+        for (uint32_t it = 0;;) {
+            unit(std::false_type{}, acc_a, acc_b, it == my_tiles);
+            if (it++ == my_tiles) break;
+            unit(std::false_type{}, acc_b, acc_a, it == my_tiles);
+            if (it++ == my_tiles) break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (wq_n) flush_wave_queue();
+}
+#pragma clang diagnostic pop
+
 
 }  // namespace vsg

@@ -94,7 +94,7 @@ struct LowpParams {
     uint32_t tile_run_shift;                   // ... probe: in runs of 2^shift consecutive tiles (see MfmaParams)
     // SQ8 filter, per-value screen: {max delta, max |min|, max sum_squares} over the table (float bits, k_row_aux_sq8) and
     // the largest |code dot + K| / |c - 128|_2 any row of this width can have
-    const uint32_t *sq8_max;
+    const uint32_t *sq8_max;             // (int8 / uint8 tables: {min, max} of the rows' aux values as ints, k_row_aux_i8)
     float sq8_fmax, sq8_ncmax;
     const uint4 *qfrag;                  // [q_tile][wave][NQW][KSTEPS][lane] 16-B B-operand fragments
     const uint32_t *qaux;                // per query: float |q|^2 | int32 sum q^2 | float norm
@@ -1021,16 +1021,25 @@ static __global__ __launch_bounds__(256) void k_row_aux_u8c(const char *rows, ui
     }
 }
 // int8: sum x^2 as int32 (mode 0) or the float norm stored after the elements (mode 1, Cosine rows)
+// ext (may be null): {min, max} of the aux values over every row ever stored, signed order of the bit patterns (ints; non-negative
+// floats order like their bits); looked at before the atomic, so that only the rows that move an extreme pay for one
 static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uint32_t row_stride, uint32_t dim, uint32_t n,
-                                                    int mode, uint32_t *out) {
+                                                    int mode, uint32_t *out, int *ext) {
     const int lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const char *p = rows + (size_t)row * row_stride;
+    auto note = [&](uint32_t bits) {
+        if (!ext) return;
+        const int v = (int)bits;
+        if (v < __hip_atomic_load(&ext[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&ext[0], v);
+        if (v > __hip_atomic_load(&ext[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ext[1], v);
+    };
     if (mode == 1) {
         if (lane == 0) {
             const unsigned char *np = reinterpret_cast<const unsigned char *>(p + dim);
             out[row] = (uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24);
+            note(out[row]);
         }
         return;
     }
@@ -1042,7 +1051,10 @@ static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uin
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) out[row] = (uint32_t)s;
+    if (lane == 0) {
+        out[row] = (uint32_t)s;
+        note((uint32_t)s);
+    }
 }
 
 }  // namespace vsg

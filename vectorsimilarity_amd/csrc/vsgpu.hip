@@ -366,6 +366,17 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
         delete t;
         return nullptr;
     }
+    if (t->lowp_ok && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8)) {
+        // int8 / uint8 rows: {min, max} of the per-row aux value over every row ever stored (k_row_aux_i8; signed order of the bit
+        // patterns: the sums are ints, the Cosine norms non-negative floats).  The 32 x 32 x 32 filter screens a unit of rows with
+        // ONE integer threshold per query derived from them (mfma_i8x32_kernels.hpp, k_i8_filter_x32l).
+        const int init[4] = {0x7FFFFFFF, (int)0x80000000, 0, 0};
+        if (hipMalloc((void **)&t->d_sq8_max, 16) != hipSuccess || hipMemcpy(t->d_sq8_max, init, 16, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(VSGPU_ERR_HIP, "int8 aux allocation failed");
+            delete t;
+            return nullptr;
+        }
+    }
     return t;
 }
 
@@ -418,6 +429,7 @@ extern "C" void vsgpu_table_destroy(vsgpu_table *t) {
     if (t->chain_ev) (void)hipEventDestroy(t->chain_ev);
     if (t->scan_ev) (void)hipEventDestroy(t->scan_ev);
     if (t->chain && --t->chain->users == 0) delete t->chain;
+    if (t->h_i8_ext) (void)hipHostFree(t->h_i8_ext);
     if (t->parent) {   // a view owns nothing else
         delete t;
         return;
@@ -536,7 +548,7 @@ static int update_norms(vsgpu_table *t, size_t first, size_t n) {
             hipLaunchKernelGGL(k_row_aux_i8, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab,
                                t->lp_kind == LP_U8 ? (t->metric == VSGPU_L2 ? 2 : 3) : (t->metric == VSGPU_COSINE ? 1 : 0),
-                               (uint32_t *)np);
+                               (uint32_t *)np, (int *)t->d_sq8_max);
         else
             hipLaunchKernelGGL(k_row_norms_h16, g, dim3(256), 0, t->ctx->stream, (const char *)row_ptr(t, id),
                                (uint32_t)t->row_bytes, (uint32_t)t->dim, (uint32_t)in_slab, t->type, (uint32_t *)np);

@@ -63,7 +63,9 @@ struct vsgpu_ctx {
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
-    long opt_lowp_x32 = 32770; // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filter (mfma_i8x32_kernels.hpp); 0 = the 16x16x64
+    long opt_lowp_x32 = 1; // int8/uint8 1 KiB rows, batches wider than 128: the 32x32x32 filters (mfma_i8x32_kernels.hpp).  1 = by the table's
+                           // aux spread (lean stream k_i8_filter_x32l when one integer threshold per query screens well, else the per-value
+                           // screen of k_i8_filter_x32); 0 = the 16x16x64 filter; other values = VAR + 1 of a kernel variant (tuning)
                                // kernel, value - 1 = VAR bits (tuning build; the shipped build has 32769 only)
     long opt_lowp_ksplit = 0;  // int8/uint8 1 KiB rows: K-split filter kernel (mfma_i8ks_kernels.hpp); 2 = with s_setprio
     long opt_lowp_dbg = 0;   // diagnosis only: bit0 skip epilogue, bit1 skip LDS reads + MFMA, bit2 skip row DMA
@@ -162,6 +164,8 @@ struct vsgpu_table {
     float sq8_blk[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // extremes of the rows' metadata for the filter's block pre-screen (vsgpu.h)
     bool sq8_blk_set = false;
     size_t aux_bytes = 4;   // per-row aux of the MFMA filters: 4 B, or 16 B for SQ8 rows (k_row_aux_sq8: four arrays per 64 rows)
+    int *h_i8_ext = nullptr;         // int8 / uint8 tables: pinned host copy of {min, max} of the aux values (d_sq8_max), refreshed behind a
+    size_t i8_ext_n = (size_t)-1;    // batch whenever rows were added since (a heuristic input only: which filter kernel to launch)
     uint32_t *d_sq8_max = nullptr;   // SQ8: {max delta, max |min|, max sum_squares} over the rows ever stored (k_row_aux_sq8)
     std::vector<float *> norm_slabs;
     float **d_norm_slabs = nullptr;

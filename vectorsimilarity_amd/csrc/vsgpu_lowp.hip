@@ -198,12 +198,58 @@ template <int LK, int EPI> static void launch_i8_x32_e(int var, const LowpParams
     X32_CASE(16384) X32_CASE(16385) X32_CASE(32768 + 16384) X32_CASE(32769 + 16384)
     X32_CASE(32) X32_CASE(64) X32_CASE(128) X32_CASE(256) X32_CASE(512) X32_CASE(32769 + 128) X32_CASE(32769 + 256) X32_CASE(32769 + 512) X32_CASE(32769 + 32)
     case 65536 + 32769: go(k_i8_filter_x32<LK, EPI, 32769, 3, 2>, 3); break;
+    case 131072 + 32769: go(k_i8_filter_x32<LK, EPI, 32769, 4, 2>, 4); break;            // the shipped stream, two units ahead
+#define X32_SHIFT_CASE(V) case V: go(k_i8_filter_x32<LK, EPI, V, 4, 2>, 4); break;      // SHIFT variants: 4 slots, 2 ahead
+    X32_SHIFT_CASE(32769 + 4) X32_SHIFT_CASE(32769 + 4 + 16384) X32_SHIFT_CASE(32769 + 4 + 16) X32_SHIFT_CASE(32769 + 4 + 512)
+    X32_SHIFT_CASE(32769 + 4 + 128) X32_SHIFT_CASE(32769 + 4 + 32) X32_SHIFT_CASE(32769 + 4 + 2) X32_SHIFT_CASE(32769 + 4 + 16384 + 512)
+    X32_SHIFT_CASE(32768 + 4) X32_SHIFT_CASE(32769 + 4 + 8)
+    // FREE: no barrier in the loop (two LDS counters), 4 slots, 2 units ahead
+    X32_SHIFT_CASE(32769 + 1024) X32_SHIFT_CASE(32769 + 1024 + 16384) X32_SHIFT_CASE(32769 + 1024 + 512) X32_SHIFT_CASE(32769 + 1024 + 128)
+    X32_SHIFT_CASE(32769 + 1024 + 32) X32_SHIFT_CASE(32769 + 1024 + 16) X32_SHIFT_CASE(32769 + 1024 + 8)
+#undef X32_SHIFT_CASE
+    X32_CASE(32769 + 16384 + 512) X32_CASE(32769 + 16384 + 128)
 #undef X32_CASE
 #endif
     default: go(k_i8_filter_x32<LK, EPI, 32769>, 4); break;
     }
 }
+// k_i8_filter_x32l (the lean stream): var bit 262144 selects it, bit 4 = SHIFT, bit 131072 = ring 4 / 2 without SHIFT
+template <int LK, int EPI> static void launch_i8_x32l_e(int var, const LowpParams &P, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kern, int ns) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, x32_lds_bytes(ns));
+        hipLaunchKernelGGL(kern, grid, dim3(X32_NW * 64), x32_lds_bytes(ns), s, P);
+    };
+    // shipped: SHIFT (waves 4-7 meet the barrier mid-stream) + counted fragment waits for int8 rows; the uint8 stream's sign flips
+    // leave no registers for the inline-asm reads (they would spill): SHIFT alone
+    constexpr int SHIP = LK == LP_U8 ? 5 : 5 + 16384;
+#ifdef VSGPU_TUNING
+    if ((var & 4) && (var & 16384) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 8, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 32)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 32, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 128) && (var & 64)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 128 + 64, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 128)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 128, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384)) go(k_i8_filter_x32l<LK, EPI, SHIP, 4, 2>, 4);
+    else if ((var & 16384) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 1 + 16384 + 8, 4, 3>, 4);
+    else if ((var & 4) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 5 + 8, 4, 2>, 4);
+    else if (var & 4) go(k_i8_filter_x32l<LK, EPI, 5, 4, 2>, 4);
+    else if (var & 131072) go(k_i8_filter_x32l<LK, EPI, 1, 4, 2>, 4);
+    else if (var & 16384) go(k_i8_filter_x32l<LK, EPI, 1 + 16384, 4, 3>, 4);
+    else go(k_i8_filter_x32l<LK, EPI, 1, 4, 3>, 4);
+#else
+    (void)var;
+    go(k_i8_filter_x32l<LK, EPI, SHIP, 4, 2>, 4);
+#endif
+}
 static void launch_i8_x32(const vsgpu_table *t, int var, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if (var & 262144) {
+        if (t->lp_kind == LP_U8) {
+            var &= ~16384;   // (see SHIP above)
+            if (P.epi == LE_U8_IP) launch_i8_x32l_e<LP_U8, LE_U8_IP>(var, P, grid, s);
+            else launch_i8_x32l_e<LP_U8, LE_I8_L2>(var, P, grid, s);
+        } else if (P.epi == LE_I8_COS) launch_i8_x32l_e<LP_I8, LE_I8_COS>(var, P, grid, s);
+        else if (P.epi == LE_I8_L2) launch_i8_x32l_e<LP_I8, LE_I8_L2>(var, P, grid, s);
+        else launch_i8_x32l_e<LP_I8, LE_I8_IP>(var, P, grid, s);
+        return;
+    }
     if (t->lp_kind == LP_U8) {
         if (P.epi == LE_U8_IP) launch_i8_x32_e<LP_U8, LE_U8_IP>(var, P, grid, s);
         else launch_i8_x32_e<LP_U8, LE_I8_L2>(var, P, grid, s);
@@ -305,6 +351,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const bool hsplit = tuning_hsplit(t, c, nq);   // (tuning build only: 64-query bf16 tiles, measured slower)
     const bool narrow = !hsplit && !qsplit && lowp_narrow_qtile(t) && nq <= lowp_narrow_qtile(t) && c->opt_lowp_narrow;
     // int8 / uint8 rows of kernel width 1024, more than 128 queries: the filter pass runs on the 32 x 32 x 32 kernel
+    bool x32_lean = false;   // (which of the two 32 x 32 x 32 filters ran: the kernel name in the statistics)
     const bool x32 = c->opt_lowp_x32 && !narrow && !qsplit && (t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 &&
                      t->lp_rt == 32 && t->lp_qtile == X32_QT && !c->opt_lowp_variant && !c->opt_lowp_dbg
                      && !tuning_ksplit_on(c)
@@ -499,6 +546,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         P.sq8_fmax = (float)(2.0 * 128.0 * 127.0 * (double)kdim * (1.0 + 1e-6));   // |D| <= 128 * 127 * width, |K| likewise
         P.sq8_ncmax = (float)(128.0 * std::sqrt((double)kdim) * 1.00001);
     } else if (is_int) {
+        P.sq8_max = t->d_sq8_max;   // {min, max} of the rows' aux values (null for the 16-byte-record kinds)
         P.epi = t->epi == EPI_INT_L2 ? LE_I8_L2 : (t->epi == EPI_INT_IP ? (is_u8 ? LE_U8_IP : LE_I8_IP) : LE_I8_COS);
     } else {
         P.epi = t->metric == VSGPU_L2 ? LE_FP_L2 : LE_FP_IP;
@@ -566,7 +614,27 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         }
         if (x32) {
             Q.qfrag = (const uint4 *)c->qfrag2.p;
-            const int var = (int)c->opt_lowp_x32 - 1;
+            int var = (int)c->opt_lowp_x32 - 1;
+            if (c->opt_lowp_x32 == 1) {
+                // Which 32 x 32 x 32 filter: the lean stream screens a unit of rows with ONE integer threshold per query, derived from
+                // the table-wide extremes of the rows' aux values (norms / sums of squares) -- fine while those spread little (the
+                // benchmark's uniform rows: +-8 % over 50 M rows); a table whose rows differ widely would send it into the exact
+                // test on most units, so such tables, and tables nothing is known about yet, get the per-value screen.  The extremes
+                // live on the device; a pinned host copy is refreshed BEHIND a batch whenever rows were added since, and read by the
+                // next one -- stale values only understate the spread, and the choice affects speed alone, never a result.
+                bool lean = Q.epi == LE_I8_IP;
+                if (!lean && Q.epi != LE_U8_IP && t->h_i8_ext && t->i8_ext_n != (size_t)-1) {
+                    const int lo = t->h_i8_ext[0], hi = t->h_i8_ext[1];
+                    if (Q.epi == LE_I8_COS) {
+                        float flo, fhi;
+                        memcpy(&flo, &lo, 4);
+                        memcpy(&fhi, &hi, 4);
+                        lean = lo <= hi && flo > 0.0f && flo >= 0.88f * fhi;
+                    } else lean = lo <= hi && lo > 0 && (double)lo >= 0.77 * (double)hi;
+                }
+                var = lean ? (262144 | 4 | 16384) : 32769;
+                x32_lean = lean;
+            } else x32_lean = (var & 262144) != 0;
             const uint32_t gx = std::min(total_tiles, (uint32_t)c->n_cu);
             uint64_t *d_clk = nullptr;
             const size_t clk_words = (size_t)gx * q_tiles * ((var & 512) ? X32_NW * 8 : 2);
@@ -576,6 +644,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                 Q.tilemin = reinterpret_cast<float *>(d_clk);
             }
             launch_i8_x32(t, var, Q, dim3(gx, (unsigned)q_tiles), c->stream);
+            if (t->i8_ext_n != t->n && t->d_sq8_max) {   // (see above: the next batch's choice)
+                if (!t->h_i8_ext) HIPCHK(hipHostMalloc((void **)&t->h_i8_ext, 16, hipHostMallocDefault));
+                HIPCHK(hipMemcpyAsync(t->h_i8_ext, t->d_sq8_max, 8, hipMemcpyDeviceToHost, c->stream));
+                t->i8_ext_n = t->n;
+            }
             if (d_clk) {
                 std::vector<uint64_t> h(clk_words);
                 HIPCHK(hipMemcpyAsync(h.data(), d_clk, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -644,7 +717,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // kernels (small grids both); its SCAN waits for them (ScanChain)
     chain.scan_submitted_if_early();
     VSG_POLL_POINT(c);
-    if (x32 && (((int)c->opt_lowp_x32 - 1) & (32 | 64 | 128 | 512))) {  // diagnosis variants of the 32x32x32 kernel: time only
+    if (x32 && c->opt_lowp_x32 != 1 && (((int)c->opt_lowp_x32 - 1) & ((((int)c->opt_lowp_x32 - 1) & 262144) ? (64 | 128 | 512) : (32 | 64 | 128 | 512)))) {  // diagnosis variants of the 32x32x32 kernels: time only
         HIPCHK(hipStreamSynchronize(c->stream));
         account_scan(c, t, n, 1, "k_i8_filter_x32(dbg)");
         for (size_t q = 0; q < nq; q++) counts[q] = 0;
@@ -663,5 +736,5 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts,
                               is_sq8 ? "k_mfma_filter_lowp(sq8)" : (t->lp_wide && is_int) ? "k_mfma_filter_wide(i8)" : t->lp_wide ? "k_mfma_filter_wide(h16)" : !is_int ? "k_mfma_filter_lowp(h16)"
                               : (tuning_ksplit_on(c) && KS == 16 && RT == 32 && !qsplit && !c->opt_lowp_variant) ? "k_i8_filter_ksplit"
-                              : x32 ? "k_i8_filter_x32" : "k_mfma_filter_lowp(i8)", &chain);
+                              : x32 ? (x32_lean ? "k_i8_filter_x32l" : "k_i8_filter_x32") : "k_mfma_filter_lowp(i8)", &chain);
 }
