@@ -823,6 +823,11 @@ def test_reply_objects_and_array_entry_points_agree():
     ("u8", "L2", 6144, 2_500, 16, 10),
     ("u8", "IP", 8000, 2_000, 9, 10),
     ("u8", "IP", 16384, 1_000, 64, 3),
+    # uint8 Cosine at these widths (round 5: EK = 5, two per-row values in 16-byte aux records; on the exact kernels before)
+    ("u8", "Cosine", 8192, 2_000, 33, 10),
+    ("u8", "Cosine", 16384, 1_000, 64, 5),
+    ("u8", "Cosine", 4100, 3_001, 17, 10),      # width 6144, four column blocks off (17 queries: two blocks)
+    ("u8", "Cosine", 6000, 2_000, 70, 10),      # width 6144, 64 queries per workgroup
     ("i8", "Cosine", 1024, 40_000, 256, 100),   # BASELINE config 3's exact query tile: 256 queries, top-100
     ("bf16", "IP", 768, 40_000, 128, 10),       # BASELINE config 4's exact query tile: 128 queries, top-10
 ])

@@ -24,7 +24,15 @@ for dim in a.dims:
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = T[0], dim, getattr(VecSim, "VecSimMetric_" + a.metric)
     ix = VecSim.BFIndex(p)
-    ix.add_synthetic(n, 47)
+    try:
+        ix.add_synthetic(n, 47)
+    except RuntimeError:   # (no device-side generator for this type: uint8) host rows, uploaded in chunks; a smaller table
+        import numpy as np
+        n = n // 4
+        rng = np.random.default_rng(47)
+        for r0 in range(0, n, 65536):
+            cnt = min(65536, n - r0)
+            ix.add_vectors(rng.integers(0, 256, (cnt, dim), dtype=np.uint8), np.arange(r0, r0 + cnt))
     for o in a.opt:
         ix.set_option(o.split("=")[0], int(o.split("=")[1]))
     q = T[2](48, 0, a.batch, dim)

@@ -117,6 +117,7 @@ struct MfmaParams {
     uint32_t *counts;                // [q_tiles*64]
     uint2 *cand;                     // [q_tiles*64][cap] {row, lower-bound bits}
     uint32_t cap;
+    const float *qmeta;              // k_mfma_filter_wide on uint8 Cosine rows (EK = 5): [queries][8] = {norm_q, bits(int 128 sum q' + 16384 dim), ...}
 };
 
 template <int AUX>

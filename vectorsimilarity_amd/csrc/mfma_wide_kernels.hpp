@@ -1,7 +1,9 @@
 // mfma_wide_kernels.hpp -- the MFMA filter for rows wider than the other filters' registers hold: fp32 3072 < dim <= 8192
 // (EK = 0), bf16 / fp16 2048 < dim <= 8192 (EK = 1 / 2: the stored elements are the MFMA operands, a stage holds 512 of them),
 // int8 / uint8 4096 < dim <= 16384 (EK = 3 / 4: v_mfma_i32_16x16x64_i8 on the stored bytes, a stage holds 1024 of them; the
-// int32 dot is exact, so the epilogue applies the reference's own score -- IP/...VNNI_INT8.h:11-76 -- and nothing is re-ranked).
+// int32 dot is exact, so the epilogue applies the reference's own score -- IP/...VNNI_INT8.h:11-76 -- and nothing is re-ranked;
+// EK = 5: uint8 Cosine, whose score needs TWO per-row values -- the stored float norm and sum (x - 128) for the re-centred dot,
+// IP_AVX512F_BW_VL_VNNI_UINT8.h:12-106 -- in the 16-byte aux records of the narrower uint8 Cosine path, k_row_aux_u8c).
 //
 // k_mfma_filter keeps the bf16 fragments of 64 queries in registers (16 per wave); at dim 4096 those alone are the whole
 // register file of a CU.  This variant keeps 16 queries per WORKGROUP and splits the row's k range over the four waves by
@@ -21,10 +23,12 @@
 
 namespace vsg {
 
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int MFW_QTILE = 16;               // queries per column block; a workgroup holds NQ of them (1 or 2)
 constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block
-constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3) {
-    return ns * MF_STAGE_BYTES + 512 + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
+constexpr int mfw_norm_bytes(int ek) { return ek == 5 ? 2048 : 512; }   // two parities of 64 aux values (4 B) / records (16 B)
+constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3, int ek = 0) {
+    return ns * MF_STAGE_BYTES + mfw_norm_bytes(ek) + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
 }
 // s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
 __device__ static inline void mfw_wait_vmcnt(int n) {
@@ -45,6 +49,8 @@ template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RT = 16;
     constexpr bool INT8 = EK >= 3;
+    constexpr bool U8C = EK == 5;                      // uint8 Cosine: 16-byte aux records {norm, sum (x - 128), 0, 0}
+    constexpr int NORM_BYTES = mfw_norm_bytes(EK), NORM_PAR = NORM_BYTES / 2;
     constexpr int EB = EK == 0 ? 4 : (INT8 ? 1 : 2);   // bytes per stored element
     constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) / 1024 (int8, uint8) elements per row per stage
     constexpr int SEG = KC * EB;                     // 1 KiB
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     // this wave's fragments: the k-steps of stages wave, wave + 4, ...
     bf16x8_t qf[NQ][KMINE];
     int qidx[NQ];
-    float nq2[NQ], tau[NQ];
+    float nq2[NQ], tau[NQ], qnorm[NQ];
 #pragma unroll
     for (int nt = 0; nt < NQ; nt++) {
         const uint4 *src = P.qfrag + ((size_t)(qtile * NQ + nt) * KSTEPS) * 64 + lane;
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         }
         qidx[nt] = (qtile * NQ + nt) * MFW_QTILE + m16;
         nq2[nt] = P.qn2[qidx[nt]];
+        qnorm[nt] = U8C ? P.qmeta[(size_t)qidx[nt] * 8] : 0.f;
         tau[nt] = MODE == MF_FILTER ? P.tau[qidx[nt]] : 0.f;
     }
 #pragma unroll
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
             if (NQ * KMINE * 4 > 224 && nt >= NQ / 2) asm volatile("" : "+a"(qf[nt][i]));
             else asm volatile("" : "+v"(qf[nt][i]));
         }
-        asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]));
+        asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]), "+v"(qnorm[nt]));
     }
 
     uint32_t st_row[4], st_off[4];
@@ -110,10 +117,10 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
     char *norm_lds = lds + NS * MF_STAGE_BYTES;
     const bool norm_loader = wave == 0;
-    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + 512);
-    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + 512 + 16);
+    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + NORM_BYTES);
+    uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + NORM_BYTES + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
-    const uint32_t red_off = mf_lds_offset(lds + NS * MF_STAGE_BYTES + 512 + MF_EQ_BYTES);
+    const uint32_t red_off = mf_lds_offset(lds + NS * MF_STAGE_BYTES + NORM_BYTES + MF_EQ_BYTES);
     if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
 
     const uint32_t step = gridDim.x;
@@ -147,13 +154,16 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         }
         uint32_t nrow = r0 + lane;
         if (nrow >= P.n_rows) nrow = P.n_rows - 1;
-        np = nbase + (nrow & P.slab_mask);
+        np = nbase + (size_t)(nrow & P.slab_mask) * (U8C ? 4 : 1);
     };
     auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_parity) {
         const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
 #pragma unroll
         for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
-        if (with_norm && norm_loader) glds4(np, norm_parity * 256, norm_lds);
+        if (with_norm && norm_loader) {
+            if constexpr (U8C) glds16<0>(np, norm_parity * NORM_PAR, norm_lds);   // 64 records of 16 bytes (the tile's 16 in front)
+            else glds4(np, norm_parity * 256, norm_lds);
+        }
     };
 
     uint32_t tile = blockIdx.x;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
     for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
 
-    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS) + (uint32_t)m16 * 4u;
+    const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS, EK) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
     auto flush_probe_minima = [&]() {   // (wave 0 only)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                         const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
                         const int p = (4 * (j % 4) + kq) ^ m16;
                         mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-                        if constexpr (EK == 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                        if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
                         for (int nt = 0; nt < NQ; nt++)
                             acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
@@ -260,9 +270,19 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         const uint32_t r0 = tile_row0(tile);
         bool emitted = false;
         if (wave == 0) {
-            const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * 256);
-            mf_u32x4 nbits;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
+            const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * NORM_PAR);
+            mf_u32x4 nbits, sxbits = {0u, 0u, 0u, 0u};
+            if constexpr (U8C) {   // rows kq * 4 + i: the record's first two words
+                u32x2_t r2[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(r2[i]) : "v"(mf_lds_offset(nrm) + (uint32_t)((kq * 4 + i) * 16)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) nbits[i] = r2[i][0], sxbits[i] = r2[i][1];
+            } else {
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
+            }
             const f32x4_t n4 = __builtin_bit_cast(f32x4_t, nbits);
 #pragma unroll
             for (int nt = 0; nt < NQ; nt++) {
@@ -284,8 +304,13 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                     if constexpr (INT8) {
                         // exact integer dot: the reference's own score (mfma_lowp_kernels.hpp has the same four epilogues); aux =
                         // sum x^2 (L2; of the re-centred bytes for uint8), sum x' (uint8 IP) or the stored float norm (Cosine)
-                        const int dot = (int)a4[i];
-                        const uint32_t av = nbits[i], qa = __float_as_uint(nq2[nt]);
+                        int dot = (int)a4[i];
+                        const uint32_t av = nbits[i];
+                        uint32_t qa = __float_as_uint(nq2[nt]);
+                        if constexpr (U8C) {   // sum x q = sum x'q' + 128 sum x' + (128 sum q' + 128^2 dim); the score from the two stored norms
+                            dot += 128 * (int)sxbits[i] + (int)qa;
+                            qa = __float_as_uint(qnorm[nt]);
+                        }
                         float sc;
                         if (P.iepi == 2) sc = (float)((int)av + (int)qa - 2 * dot);
                         else if (P.iepi == 3) sc = (float)(1 - dot);

@@ -311,15 +311,16 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_qtile = 128;
             t->aux_bytes = 16;
         }
-        if ((type == VSGPU_I8 || type == VSGPU_U8) && dim > 4096 && dim <= 16384 && !(type == VSGPU_U8 && metric == VSGPU_COSINE)) {
-            // the k-split filter (mfma_wide_kernels.hpp, EK = 3 / 4): 16 (or 32) queries per workgroup, 1 KiB of the row per ring
-            // stage and wave.  uint8 Cosine needs two per-row values and stays on the exact kernels at these widths.
+        if ((type == VSGPU_I8 || type == VSGPU_U8) && dim > 4096 && dim <= 16384) {
+            // the k-split filter (mfma_wide_kernels.hpp, EK = 3 / 4 / 5): 16 (or 32) queries per workgroup, 1 KiB of the row per ring
+            // stage and wave.  uint8 Cosine (EK = 5, round 5) needs two per-row values: the 16-byte aux records of the narrower widths.
             static const int ww[] = {96, 128, 192, 256};
             for (int i = 0; i < 4; i++)
                 if ((size_t)ww[i] * 64 >= dim) {
                     t->lowp_ok = true;
                     t->lp_wide = true;
-                    t->lp_kind = type == VSGPU_I8 ? LP_I8 : LP_U8;
+                    t->lp_kind = type == VSGPU_I8 ? LP_I8 : (metric == VSGPU_COSINE ? LP_U8C : LP_U8);
+                    if (t->lp_kind == LP_U8C) t->aux_bytes = 16;
                     t->lp_ksteps = ww[i];
                     t->lp_rt = 16;
                     t->lp_qtile = 16;

@@ -285,7 +285,7 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
 #endif
 template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     auto go = [&](auto kern, int nqb, int ns) {
-        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns);
+        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns, EK);
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
@@ -327,7 +327,11 @@ static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const
     P.cand = L.cand;
     P.cap = L.cap;
     P.iepi = L.epi;
-    if (t->lp_kind == LP_I8) {   // int8 / uint8 rows of 4097 .. 16384 elements: exact integer scores, no re-rank
+    P.qmeta = L.qmeta;
+    if (t->lp_kind == LP_U8C) {   // uint8 Cosine rows of 4097 .. 16384 elements: 16-byte aux records {norm, sum (x - 128)}
+        if (mode == MF_PROBE) launch_wide_h16_m<5, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
+        else launch_wide_h16_m<5, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
+    } else if (t->lp_kind == LP_I8) {   // int8 / uint8 rows of 4097 .. 16384 elements: exact integer scores, no re-rank
         if (mode == MF_PROBE) launch_wide_h16_m<3, MF_PROBE>(t->lp_ksteps, nq_blocks, P, grid, s);
         else launch_wide_h16_m<3, MF_FILTER>(t->lp_ksteps, nq_blocks, P, grid, s);
     } else if (t->lp_kind == LP_U8) {
