@@ -27,6 +27,7 @@
 namespace vsg {
 
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2l_t __attribute__((ext_vector_type(2)));
 
 constexpr int X32_RT = 32;            // rows per unit (= per tile)
 constexpr int X32_ROWB = 1040;        // LDS bytes per row image: 1 KiB + 16, so that 32 rows x one 16-byte chunk (ds_read_b128 in
@@ -37,7 +38,7 @@ constexpr int X32_KS = 32;            // k-steps of 32 bytes
 constexpr int X32_AUXB = 8;           // per-unit aux buffers (256 B each; a unit's values live from its request to its screening)
 constexpr int X32_QT = 256;           // queries per workgroup
 constexpr int X32_WQ_CAP = 64;         // records per wave-private candidate queue (one ballot's worth always fits)
-constexpr int x32_lds_bytes(int ns) { return ns * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16 + 64; }   // (+ the FREE ring's two counters)
+constexpr int x32_lds_bytes(int ns) { return ns * X32_UNIT + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16 + 128; }   // (+ the FREE ring's two counters, + k_i8_filter_x32l's per-unit aux extremes)
 
 // VAR bits (the shipped build instantiates one variant; the rest is the tuning build's, profiles/r03_c3_x32.txt, r05_c3_*.txt):
 // 1 = EARLY (rows land one barrier early, fragments prefetched across the barrier), 2 = requests spread over the stream
@@ -533,7 +534,18 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
     // request per unit, no LDS round trip in front of the per-value test: with ~0.3 values per wave and unit over the threshold
     // some wave of the eight took that round trip in nearly every unit, and the ring barrier made the other seven wait for it).
     constexpr bool QDEFER = (VAR & 32) != 0;
-    constexpr bool NO_TEST = (VAR & 128) != 0, NO_AUX = (VAR & 64) != 0 || QDEFER;
+    constexpr bool NO_TEST = (VAR & 128) != 0 && (VAR & 512) == 0, NO_AUX = (VAR & 64) != 0 || QDEFER;
+    constexpr bool NEVER = (VAR & 128) != 0 && (VAR & 512) != 0;
+    constexpr bool COUNT = (VAR & 1024) != 0;   // tuning build: every wave prints how many of its units sent it into the exact test
+    uint32_t n_fired = 0, n_groups = 0, n_units = 0;   // the test and the exact path stay in the code, the threshold is unreachable
+    // UNITTHR (VAR bit 256; Cosine, with ASMRD; tuning build only -- measured: the exact test fires on 57 % instead of 73 % of the
+    // wave-units at 8 Mi rows, and the kernel time does not move, 12.3 against 12.2 ms at 50 M rows: what the tighter threshold saves,
+    // its own bookkeeping costs, profiles/r05_c3_batches.txt): the threshold of a unit comes from the extremes of ITS 32 norms instead of the
+    // table's (over 50 M uniform rows the table-wide minimum sits 7.7 % under the typical norm, a unit's 2.8 %: the exact test fires
+    // on 14 % of the wave-units instead of 27 %).  Wave 7 -- it requests no rows and meets the barrier mid-stream: the wave with the
+    // most slack -- reduces the next unit's aux values (DPP butterflies) and leaves {min, max} in an 8-deep LDS ring; every wave
+    // reads the pair of the unit under test early in its stream and rebuilds its threshold with five VALU operations.
+    constexpr bool UNITTHR = (VAR & 256) != 0 && EPI == LE_I8_COS && ASMRD && !NO_AUX;
     constexpr int PF = (ASMRD && NODEF) ? 8 : 4;   // A fragments in flight; must divide the 32 k-steps (fragment f lives in afr[f % PF] in
                                                    // every unit); 8 with two accumulator sets would spill (scratch traffic would also
                                                    // break the counted vmcnt waits)
@@ -565,12 +577,43 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr));   // (every ordinary load has returned: the counted vmcnt waits below see DMA only)
     const float omt = 1.0f - tau;
     const float cosq = tau == -INFINITY ? INFINITY : (omt - 1e-5f * (1.0f + fabsf(omt))) * __uint_as_float(qaux);
+    if (NEVER) {
+        thr = 0x7FFFFFFF;
+        asm volatile("" : "+v"(thr));
+    }
+    // UNITTHR: lanes whose threshold is a constant whatever the rows (padding queries, NaN thresholds) keep it
+    const int thr_table = thr;
+    const bool thr_fixed = thr == (int)0x80000000 || thr == 0x7FFFFFFF;
+    const bool cosq_neg = cosq < 0.0f;
 
     const uint32_t lds_base = mf_lds_offset(lds);
     const uint32_t aux_lds_off = lds_base + X32_NS * X32_UNIT;
     const uint32_t wq_off = aux_lds_off + X32_AUXB * 256 + (uint32_t)wave * (X32_WQ_CAP * 16);
     uint32_t wq_n = 0;
     const uint32_t lane16 = (uint32_t)lane * 16u, lane4 = (uint32_t)lane * 4u;
+    const uint32_t ext_off = aux_lds_off + X32_AUXB * 256 + X32_NW * X32_WQ_CAP * 16 + 64;   // UNITTHR: [8] x {min bits, max bits}
+    // wave 7: {min, max} of the norms of the valid rows of the unit whose aux values sit in ring buffer `buf` -> ext ring
+    auto reduce_unit_aux = [&](uint32_t buf, uint32_t nvalid) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(aux_lds_off + buf * 256u + (uint32_t)(lane & 31) * 4u) : "memory");
+        const bool ok = (uint32_t)(lane & 31) < nvalid;
+        int lo = ok ? (int)v : 0x7F800000, hi = ok ? (int)v : 0;   // (norms are non-negative floats: their bits order like ints)
+        // butterflies within rows of 16 lanes: quad xor 1, quad xor 2, half-row mirror, row mirror
+        lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false));
+        hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false));
+        hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false));
+        hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false));
+        hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false));
+        const int lo2 = min(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, 16));
+        const int hi2 = max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 16));
+        if (lane == 0) {
+            const u32x2l_t e = {(uint32_t)lo2, (uint32_t)hi2};
+            asm volatile("ds_write_b64 %0, %1" ::"v"(ext_off + buf * 8u), "v"(e) : "memory");
+        }
+    };
     // one 1 KiB row piece / one 256-byte aux piece: global address = scalar base + the lane's offset, LDS address = M0 + the lane's
     auto dma16 = [&](uint64_t sbase, uint32_t lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(lane16), "s"(sbase), "s"(lds_addr) : "memory", "m0");
@@ -647,6 +690,10 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
     };
     wait_units_in_flight(X32_D - 2);
     mf_ring_barrier();
+    if (UNITTHR && wave == X32_NW - 1) {
+        const uint32_t t0 = blockIdx.x < P.n_tiles ? blockIdx.x : P.n_tiles - 1;
+        reduce_unit_aux(0u, P.n_rows - (P.tile_first + t0) * X32_RT);
+    }
 
     const uint32_t frag_lane_off = (uint32_t)n32 * X32_ROWB + (uint32_t)h * 16u;
     const uint32_t frag_lds_off = lds_base + frag_lane_off;
@@ -734,6 +781,15 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
         constexpr bool ISS = decltype(iss_c)::value;
         const uint32_t nslot = cslot + 1 == X32_NS ? 0 : cslot + 1;
         if (ISS) begin_requests();
+        u32x2l_t uext = {0u, 0u};
+        if (UNITTHR) {
+            if (!ISS && wave == X32_NW - 1) {   // the next unit's rows (and aux values) landed a barrier ago
+                const uint32_t tn = tile + step < P.n_tiles ? tile + step : P.n_tiles - 1;
+                reduce_unit_aux((cbuf + 1) & (X32_AUXB - 1), P.n_rows - (P.tile_first + tn) * X32_RT);
+            }
+            // {min, max} of the unit under test: the read returns in order with the fragment reads, long before the stream ends
+            asm volatile("ds_read_b64 %0, %1" : "=v"(uext) : "v"(ext_off + buf_prev * 8u));
+        }
         int mg[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
 #pragma unroll
         for (int ks = 0; ks < X32_KS; ks++) {
@@ -770,6 +826,13 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
             if (!ASMRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, LK == LP_U8 ? 5 : 1, 0);
         }
+        int thr_u = thr;
+        if (UNITTHR) {
+            // (the counted fragment waits have long passed the pair's read: at most PF - 1 younger reads were outstanding by k-step PF)
+            asm volatile("" : "+v"(uext));
+            const float t = cosq * __uint_as_float(cosq_neg ? uext[1] : uext[0]);
+            thr_u = thr_fixed ? thr_table : (int)ceilf(t);
+        }
         const uint32_t tt = tile < P.n_tiles ? tile : P.n_tiles - 1;
         if (NODEF) {   // this unit's own accumulators, behind its last MFMA
             r0_prev = (P.tile_first + tt) * X32_RT;
@@ -781,10 +844,15 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
         // a lane of the wave may hold a candidate of the unit under test: the exact test, value by value, group by group
         const int m = max(max(mg[0], mg[1]), max(mg[2], mg[3]));
         if (NO_TEST) asm volatile("" ::"v"(m));
-        if (!NO_TEST && __ballot(m >= thr) != 0) {
+        if (COUNT) n_units++;
+        if (!NO_TEST && __ballot(m >= thr_u) != 0) {
+            if (COUNT) n_fired++;
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                if (__ballot(mg[g] >= thr) != 0) exact_group(NODEF ? acc : prev, g, r0_prev, nvalid_prev, buf_prev);
+                if (__ballot(mg[g] >= thr_u) != 0) {
+                    if (COUNT) n_groups++;
+                    exact_group(NODEF ? acc : prev, g, r0_prev, nvalid_prev, buf_prev);
+                }
         }
         r0_prev = (P.tile_first + tt) * X32_RT;
         nvalid_prev = last ? 0u : P.n_rows - r0_prev;
@@ -830,6 +898,7 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32l(LowpParams P)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (wq_n) flush_wave_queue();
+    if (COUNT && lane == 0 && blockIdx.x < 4) printf("x32l wg %u wave %d: exact test in %u of %u units, %u groups\n", blockIdx.x, wave, n_fired, n_units, n_groups);
 }
 #pragma clang diagnostic pop
 

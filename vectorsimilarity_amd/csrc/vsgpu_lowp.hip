@@ -225,8 +225,12 @@ template <int LK, int EPI> static void launch_i8_x32l_e(int var, const LowpParam
 #ifdef VSGPU_TUNING
     if ((var & 4) && (var & 16384) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 8, 4, 2>, 4);
     else if ((var & 4) && (var & 16384) && (var & 32)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 32, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 256) && (var & 1024)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 256 + 1024, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 1024)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 1024, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 128) && (var & 512)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 128 + 512, 4, 2>, 4);
     else if ((var & 4) && (var & 16384) && (var & 128) && (var & 64)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 128 + 64, 4, 2>, 4);
     else if ((var & 4) && (var & 16384) && (var & 128)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 128, 4, 2>, 4);
+    else if ((var & 4) && (var & 16384) && (var & 256)) go(k_i8_filter_x32l<LK, EPI, 5 + 16384 + 256, 4, 2>, 4);   // per-unit thresholds: no gain at 50 M rows
     else if ((var & 4) && (var & 16384)) go(k_i8_filter_x32l<LK, EPI, SHIP, 4, 2>, 4);
     else if ((var & 16384) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 1 + 16384 + 8, 4, 3>, 4);
     else if ((var & 4) && (var & 8)) go(k_i8_filter_x32l<LK, EPI, 5 + 8, 4, 2>, 4);
@@ -642,7 +646,7 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             const uint32_t gx = std::min(total_tiles, (uint32_t)c->n_cu);
             uint64_t *d_clk = nullptr;
             const size_t clk_words = (size_t)gx * q_tiles * ((var & 512) ? X32_NW * 8 : 2);
-            if (var & (256 | 512)) {   // diagnosis: shader clock = s_memtime ticks per 100 MHz s_memrealtime tick; phase sums
+            if (!(var & 262144) && (var & (256 | 512))) {   // (k_i8_filter_x32's diagnosis bits; the lean kernel's 256 is its per-unit threshold)   // diagnosis: shader clock = s_memtime ticks per 100 MHz s_memrealtime tick; phase sums
                 HIPCHK(hipMalloc(&d_clk, clk_words * 8));
                 HIPCHK(hipMemsetAsync(d_clk, 0, clk_words * 8, c->stream));
                 Q.tilemin = reinterpret_cast<float *>(d_clk);
