@@ -12,6 +12,7 @@ import sys
 CONFIGS = {
     "k_mfma_filter": ("", "k_mfma_filter<", {"rows": 10_000_000, "dim": 768, "batch": 64}),
     "k_i8_filter_x32": ("cfg_c3", "k_i8_filter_x32<", {"rows": 50_000_000, "dim": 1024, "batch": 256}),
+    "k_i8_filter_x32l": ("cfg_c3", "k_i8_filter_x32l<", {"rows": 50_000_000, "dim": 1024, "batch": 256}),
     "k_mfma_filter_lowp(h16)": ("cfg_c4", "k_mfma_filter_lowp<", {"rows": 12_500_000, "dim": 768, "batch": 128}),
 }
 

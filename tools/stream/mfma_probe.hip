@@ -343,8 +343,77 @@ template <int MMA, int PSTEP, int SCREEN> static void run_dma64(const char *name
     hipFree(d_sink);
 }
 
+// ---- how fast can CUs ingest rows that another CU of the same XCD streams too (two query tiles of a wide-row batch)?  Ring DMA only,
+// `share` workgroups walk the SAME tile sequence (ids 8 apart land on one XCD); the table crosses HBM once, L2 / MALL serve the rest.
+template <int NW> __global__ __launch_bounds__(NW * 64, 2) void k_probe_share(const char *rows, unsigned n_rows, int units, int share, int *sink) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    constexpr int NS = 4, D = 3, UNIT = 32 * 1040, IPW = 32 / NW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // workgroup b: stream id = (b / (8 * share)) * 8 + b % 8 -- the `share` workgroups b, b + 8, ... of one XCD slot walk one stream
+    const unsigned b = blockIdx.x, stream = (b / (8u * share)) * 8u + b % 8u, n_streams = gridDim.x / share;
+    unsigned ftile = stream, fslot = 0;
+    unsigned long long pbase = 0;
+    unsigned plds = 0;
+    auto begin = [&]() {
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((ftile % (n_rows / 32)) * 32));
+        pbase = (unsigned long long)rows + (unsigned long long)(r0 + IPW * wave) * 1024ull;
+        plds = lds_base + fslot * UNIT + (unsigned)(wave * IPW * 1040);
+    };
+    auto piece = [&]() {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(pbase), "s"(plds) : "memory");
+        pbase += 1024;
+        plds += 1040;
+    };
+    for (int u = 0; u < D; u++) {
+        begin();
+        for (int i = 0; i < IPW; i++) piece();
+        ftile += n_streams;
+        fslot = fslot + 1 == NS ? 0 : fslot + 1;
+    }
+    for (int u = 0; u < units; u++) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (32 / NW)) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        begin();
+#pragma unroll
+        for (int i = 0; i < IPW; i++) piece();
+        ftile += n_streams;
+        fslot = fslot + 1 == NS ? 0 : fslot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (reinterpret_cast<int *>(lds)[lane] == 0x12345678) sink[0] = 1;
+}
+static void run_share(const char *name, const char *rows, unsigned n_rows, int share, int wgs) {
+    int *d_sink;
+    hipMalloc(&d_sink, 64);
+    auto kern = k_probe_share<4>;
+    const int lds_bytes = 4 * 32 * 1040;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const int units = (int)((size_t)n_rows / 32 / (wgs / share));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds_bytes, 0, rows, n_rows, units, share, d_sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double table = (double)units * (wgs / share) * 32 * 1024;
+    printf("%-64s wall %.3f ms  => table %.0f GB/s, LDS-DMA ingest %.0f GB/s (%.1f B/clk/CU at 2.1 GHz)\n", name, best, table / (best * 1e-3) / 1e9,
+           table * share / (best * 1e-3) / 1e9, table * share / (best * 1e-3) / 256 / 2.1e9);
+    hipFree(d_sink);
+}
+
 int main() {
     const int U = 2000;
+    if (!getenv("PROBE_SHARE_ONLY")) {
     run<1, 0, 0, 8>("1 chain, no reads, no barrier", U);
     run<2, 0, 0, 8>("2 chains", U);
     run<4, 0, 0, 8>("4 chains", U);
@@ -357,6 +426,7 @@ int main() {
     run<2, 1, 1, 8>("2 chains + reads + barrier per unit", U);
     run<1, 1, 0, 4>("1 chain + reads, one wave per SIMD", U);
     run<2, 1, 0, 4>("2 chains + reads, one wave per SIMD", U);
+    }
     {
         const unsigned n_rows = 8u << 20;   // 8 Mi rows x 1 KiB
         char *rows;
@@ -374,6 +444,11 @@ int main() {
         run_dma64<1, 2, 0>("4 waves x 64 queries: a row every 2nd pair", rows, n_rows);
         run_dma64<1, 4, 0>("4 waves x 64 queries: a row every 4th pair", rows, n_rows);
         run_dma64<1, 2, 1>("4 waves x 64 queries: every 2nd pair + screening", rows, n_rows);
+        run_share("DMA only, 256 workgroups, every row once", rows, n_rows, 1, 256);
+        run_share("DMA only, 512 workgroups (2 per CU), every row once", rows, n_rows, 1, 512);
+        run_share("DMA only, 256 workgroups, pairs share a row stream (2 x)", rows, n_rows, 2, 256);
+        run_share("DMA only, 512 workgroups, pairs share a row stream (2 x)", rows, n_rows, 2, 512);
+        run_share("DMA only, 512 workgroups, four share a row stream (4 x)", rows, n_rows, 4, 512);
         hipFree(rows);
     }
     return 0;

@@ -625,9 +625,10 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             int var = (int)c->opt_lowp_x32 - 1;
             if (c->opt_lowp_x32 == 1) {
                 // Which 32 x 32 x 32 filter: the lean stream screens a unit of rows with ONE integer threshold per query, derived from
-                // the table-wide extremes of the rows' aux values (norms / sums of squares) -- fine while those spread little (the
-                // benchmark's uniform rows: +-8 % over 50 M rows); a table whose rows differ widely would send it into the exact
-                // test on most units, so such tables, and tables nothing is known about yet, get the per-value screen.  The extremes
+                // the table-wide extremes of the rows' aux values (norms / sums of squares) -- fine while those spread moderately (the
+                // benchmark's uniform rows: min / max norm 0.857 over 50 M rows, the exact test then runs on a quarter of the
+                // wave-units and the lean stream is 11 % ahead; it would lose once the test ran on ~90 % of them); a table whose rows
+                // differ widely (min / max below 0.75), and a table nothing is known about yet, get the per-value screen.  The extremes
                 // live on the device; a pinned host copy is refreshed BEHIND a batch whenever rows were added since, and read by the
                 // next one -- stale values only understate the spread, and the choice affects speed alone, never a result.
                 bool lean = Q.epi == LE_I8_IP;
@@ -637,8 +638,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
                         float flo, fhi;
                         memcpy(&flo, &lo, 4);
                         memcpy(&fhi, &hi, 4);
-                        lean = lo <= hi && flo > 0.0f && flo >= 0.88f * fhi;
-                    } else lean = lo <= hi && lo > 0 && (double)lo >= 0.77 * (double)hi;
+                        lean = lo <= hi && flo > 0.0f && flo >= 0.75f * fhi;
+                    } else lean = lo <= hi && lo > 0 && (double)lo >= 0.56 * (double)hi;
                 }
                 var = lean ? (262144 | 4 | 16384) : 32769;
                 x32_lean = lean;
