@@ -96,8 +96,12 @@ def test_deleted_and_overwritten_vectors_are_traversed_not_returned(vso):
     labels, dists = ix.knn_query(q, k)
     assert not (set(labels.ravel().tolist()) & gone)
     g = ix.graph()
+    # (300 of 2500 deletes cross the compaction threshold: dead nodes were removed in one batch and the last live nodes moved into
+    # the holes, so the graph's internal order is no longer the insertion order -- the oracle gets the rows in the graph's order)
+    assert g["n"] < n and g["n"] >= n - 300
+    grows = rows[(g["labels"].astype(np.int64) - 5)]
     for j in range(len(q)):
-        el, es, _ = vso.hnsw_search(0, 0, rows, g, q[j], k, 40, dim)
+        el, es, _ = vso.hnsw_search(0, 0, grows, g, q[j], k, 40, dim)
         assert np.array_equal(labels[j][:len(el)], el.astype(np.int64)) and np.array_equal(dists[j][:len(es)], es)
     # overwrite: the old vector is retired, the new one is reachable under the same label
     v = rng.uniform(-1, 1, dim).astype(np.float32)
@@ -105,6 +109,88 @@ def test_deleted_and_overwritten_vectors_are_traversed_not_returned(vso):
     assert ix.add_vector(v, keep) == 0
     l, d = ix.knn_query(v, 1)
     assert l[0, 0] == keep and d[0, 0] == 0.0
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_deleted_nodes_are_removed_in_batches_and_the_graph_stays_searchable(vso, multi):
+    """round-4 review: deletes were mark-only, dead nodes accumulated and were traversed for ever.  Now a sixteenth of dead nodes
+    triggers a compaction (csrc/host/hnsw_index.cpp compactDeleted; the reference repairs on every delete, hnsw.h:1796-1852): every
+    live node that pointed at a dead one gets its list rebuilt from its own and the dead ones' live neighbours, the entry point is
+    replaced if it died, the last live nodes move into the holes.  Checked: the exported graph holds live nodes only (none flagged,
+    every link in range, no node links to itself), labels and stored vectors survive the renumbering, the GPU search equals the
+    reference's loops on that graph, recall against the exact answer over the live vectors stays where a fresh build puts it,
+    evaluations per query do not grow, and the index keeps taking adds, overwrites and deletes afterwards."""
+    dim, n, k, ef = 32, 6000, 10, 64
+    rng = np.random.default_rng(31)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    labels = (np.arange(n) // 2 if multi else np.arange(n)) + 100
+    p = VecSim.HNSWParams()
+    p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime, p.multi = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2, 12, 80, ef, multi
+    ix = VecSim.HNSWIndex(p)
+    ix.add_vectors(rows, labels)
+    q = rng.uniform(-1, 1, (50, dim)).astype(np.float32)
+    ix.knn_query(q, k)
+    evals_before = ix.last_distance_evals()
+    alive = np.ones(n, bool)
+    dead_labels = rng.choice(np.unique(labels), (len(np.unique(labels)) * 2) // 5, replace=False)   # 40 % of the labels go
+    for lab in dead_labels:
+        assert ix.delete_vector(int(lab)) == (2 if multi else 1)
+        alive[labels == lab] = False
+    live_n = int(alive.sum())
+    assert ix.index_size() == live_n
+    g = ix.graph()
+    # compactions ran: at most a sixteenth of the graph is dead nodes waiting for the next one
+    assert live_n <= g["n"] <= live_n + live_n // 15 + 32, (g["n"], live_n)
+    cnt0, links0 = g["cnt0"].astype(int), g["links0"]
+    for i in range(g["n"]):
+        li = links0[i, :cnt0[i]]
+        assert np.all(li < g["n"]) and i not in li and len(set(li.tolist())) == len(li)
+    gl = g["labels"].astype(np.int64)
+    live_ids = np.nonzero(g["deleted"] == 0)[0]
+    assert sorted(gl[live_ids].tolist()) == sorted(labels[alive].tolist())
+    if multi:   # a label's two vectors survive the renumbering
+        for lab in np.unique(gl[live_ids])[::97]:
+            vs = ix.get_vector(int(lab))
+            want = rows[labels == lab]
+            assert len(vs) == len(want) and sorted(map(bytes, vs)) == sorted(map(bytes, want))
+    else:
+        grows = rows[gl - 100]   # rows in the graph's order, for the oracle below
+        for lab in (int(gl[live_ids[0]]), int(gl[live_ids[-1]]), int(gl[live_ids[len(live_ids) // 2]])):
+            assert np.array_equal(ix.get_vector(lab)[0], rows[lab - 100])
+    got_l, got_d = ix.knn_query(q, k)
+    evals_after = ix.last_distance_evals()
+    assert not (set(got_l.ravel().tolist()) & set(int(x) for x in dead_labels))
+    if not multi:
+        for j in range(0, len(q), 5):
+            el, es, _ = vso.hnsw_search(0, 0, grows, g, q[j], k, ef, dim)
+            assert np.array_equal(got_l[j][:len(el)], el.astype(np.int64)) and np.array_equal(got_d[j][:len(es)], es), j
+    # recall against the exact answer over the live vectors
+    bp = VecSim.BFParams()
+    bp.type, bp.dim, bp.metric, bp.multi = VecSim.VecSimType_FLOAT32, dim, VecSim.VecSimMetric_L2, multi
+    bf = VecSim.BFIndex(bp)
+    bf.add_vectors(rows[alive], labels[alive])
+    exact, _ = bf.knn_query(q, k)
+    recall = sum(len(set(got_l[i]) & set(exact[i])) for i in range(len(q))) / (len(q) * k)
+    assert recall > 0.9, recall
+    assert evals_after <= evals_before * 1.05, (evals_before, evals_after)   # no dead weight in the walk
+    # the index goes on: new vectors, overwrites (each leaves a dead node behind), more deletes
+    extra = rng.uniform(-1, 1, (500, dim)).astype(np.float32)
+    ix.add_vectors(extra, np.arange(500) + 10 ** 6)
+    bf.add_vectors(extra, np.arange(500) + 10 ** 6)
+    if not multi:
+        for i in range(0, 500, 2):
+            v = rng.uniform(-1, 1, dim).astype(np.float32)
+            assert ix.add_vector(v, 10 ** 6 + i) == 0
+            bf.add_vector(v, 10 ** 6 + i)
+    for i in range(1, 500, 5):
+        assert ix.delete_vector(10 ** 6 + i) == bf.delete_vector(10 ** 6 + i) == 1
+    assert ix.index_size() == bf.index_size()
+    got_l, _ = ix.knn_query(q, k)
+    exact, _ = bf.knn_query(q, k)
+    recall = sum(len(set(got_l[i]) & set(exact[i])) for i in range(len(q))) / (len(q) * k)
+    assert recall > 0.9, recall
+    l1, d1 = ix.knn_query(extra[3], 1)   # (label 10^6 + 3: neither overwritten nor deleted above)
+    assert l1[0, 0] == 10 ** 6 + 3 and d1[0, 0] == 0.0
 
 
 def test_hnsw_edge_cases():
@@ -192,17 +278,18 @@ def test_range_search_with_deleted_nodes_and_wide_radius(vso):
     for lab in range(0, n, 7):
         ix.delete_vector(lab)
     g = ix.graph()
+    grows = rows[g["labels"].astype(np.int64)]   # (the deletes crossed the compaction threshold: rows in the graph's order)
     q = np.random.default_rng(2).uniform(-1, 1, dim).astype(np.float32)
     sc = vso.scan(0, 0, rows, q, dim)
     radius = float(np.sort(sc)[300])
-    el, es, _ = vso.hnsw_range(0, 0, rows, g, q, radius, 0.01, dim)
+    el, es, _ = vso.hnsw_range(0, 0, grows, g, q, radius, 0.01, dim)
     labels, dists = ix.range_query(q, radius, order=VecSim.BY_ID)
     assert sorted(labels[0].tolist()) == sorted(el.astype(np.int64).tolist())
     assert not any(l % 7 == 0 for l in labels[0].tolist())
     # a radius covering the whole index: still the graph walk's answer while its candidate window fits in LDS,
     # the exact table scan (every live vector) once it does not
     wide, _ = ix.range_query(q, float(sc.max()) + 1.0, order=VecSim.BY_ID)
-    wl, _, _ = vso.hnsw_range(0, 0, rows, g, q, float(sc.max()) + 1.0, 0.01, dim)
+    wl, _, _ = vso.hnsw_range(0, 0, grows, g, q, float(sc.max()) + 1.0, 0.01, dim)
     alive = [i for i in range(n) if i % 7 != 0]
     assert wide[0].tolist() in (sorted(wl.astype(np.int64).tolist()), alive)
 

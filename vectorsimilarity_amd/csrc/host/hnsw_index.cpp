@@ -494,6 +494,7 @@ int HnswIndex::addVector(const void *blob, size_t label) {
     main_ctx_.locked = false;
     insertNode(id, vec(id), main_ctx_);
     graph_dirty_ = true;
+    if (!is_new) maybeCompact();   // (an overwrite leaves a dead node behind)
     return is_new;
 }
 
@@ -582,15 +583,146 @@ int HnswIndex::deleteVector(size_t label) {
         }
         label_to_ids_.erase(f);
         graph_dirty_ = true;
+        maybeCompact();
         return removed;
     }
     auto it = label_to_id_.find(label);
     if (it == label_to_id_.end()) return 0;
-    deleted_[it->second] = 1;  // mark only: the node stays traversable (hnsw.h:572-573), never returned
+    deleted_[it->second] = 1;  // marked: never returned, still traversable (hnsw.h:572-573) until the next compaction
     n_deleted_++;
     label_to_id_.erase(it);
     graph_dirty_ = true;
+    maybeCompact();
     return 1;
+}
+
+void HnswIndex::maybeCompact() {
+    if (n_deleted_ == 0 || walkers_.load() != 0) return;
+    if (n_deleted_ < n_ && (n_deleted_ < 32 || n_deleted_ * 16 < n_)) return;
+    if (compactDeleted()) std::fprintf(stderr, "vecsim_amd: HNSW compaction failed: %s\n", vsgpu_last_error());
+}
+
+// see hnsw_index.h.  Writers are the caller's to serialise (vec_sim.h); readers on lanes are kept out here.
+int HnswIndex::compactDeleted() {
+    std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
+    std::vector<std::unique_lock<std::mutex>> lane_locks;
+    for (auto &l : lanes_) lane_locks.emplace_back(l->mu);
+    const size_t n = n_, n_new = n - n_deleted_;
+    // 1. every live node that points at a dead one: a new list, level by level
+    std::vector<uint32_t> mark(n, 0xFFFFFFFFu);
+    uint32_t stamp = 0;
+    std::vector<std::pair<float, uint32_t>> cands;
+    for (size_t p = 0; p < n; p++) {
+        if (deleted_[p]) continue;
+        for (int level = 0; level <= (int)level_[p]; level++) {
+            uint32_t *cntw = nullptr;
+            uint32_t *links = level == 0 ? links0_.data() + p * M0_ : linksAt((uint32_t)p, level, &cntw);
+            const uint32_t cnt = level == 0 ? (uint32_t)cnt0_[p] : *cntw;
+            bool touched = false;
+            for (uint32_t i = 0; i < cnt; i++) touched |= deleted_[links[i]] != 0;
+            if (!touched) continue;
+            stamp++;
+            cands.clear();
+            auto add = [&](uint32_t w) {
+                if (w == p || deleted_[w] || mark[w] == stamp) return;
+                mark[w] = stamp;
+                cands.emplace_back(0.0f, w);
+            };
+            for (uint32_t i = 0; i < cnt; i++)
+                if (!deleted_[links[i]]) add(links[i]);
+            for (uint32_t i = 0; i < cnt; i++) {
+                const uint32_t d = links[i];
+                if (!deleted_[d] || (int)level_[d] < level) continue;
+                uint32_t *dcw = nullptr;
+                const uint32_t *dl = level == 0 ? links0_.data() + (size_t)d * M0_ : linksAt(d, level, &dcw);
+                const uint32_t dn = level == 0 ? (uint32_t)cnt0_[d] : *dcw;
+                for (uint32_t j = 0; j < dn; j++) add(dl[j]);
+            }
+            const size_t max_links = level == 0 ? M0_ : M_;
+            if (cands.size() > max_links) {
+                for (auto &c : cands) c.first = buildDistance(vec(c.second), vec((uint32_t)p));
+                selectNeighbors(cands, max_links);
+            }
+            const uint32_t kept = (uint32_t)std::min(cands.size(), max_links);
+            for (uint32_t i = 0; i < kept; i++) links[i] = cands[i].second;
+            if (level == 0) cnt0_[p] = (uint16_t)kept;
+            else *cntw = kept;
+        }
+    }
+    // 2. the entry point (replaceEntryPoint, hnsw.h:1455-1500: a live node of the highest level left)
+    if (entry_ != 0xFFFFFFFFu && deleted_[entry_]) {
+        entry_ = 0xFFFFFFFFu;
+        max_level_ = -1;
+        for (size_t p = 0; p < n; p++)
+            if (!deleted_[p] && (int)level_[p] > max_level_) {
+                max_level_ = (int)level_[p];
+                entry_ = (uint32_t)p;
+            }
+    }
+    // 3. the last live nodes move into the holes
+    std::vector<uint32_t> new_id(n - n_new, 0xFFFFFFFFu);   // for ids >= n_new
+    const bool rows_on_device = uploaded_rows_ == n;
+    {
+        size_t t = n;
+        for (size_t h = 0; h < n_new; h++) {
+            if (!deleted_[h]) continue;
+            do t--; while (deleted_[t]);   // (t >= n_new: there are exactly as many live nodes up there as holes down here)
+            new_id[t - n_new] = (uint32_t)h;
+            std::memcpy(raw_.data() + h * blob_bytes_, raw_.data() + t * blob_bytes_, blob_bytes_);
+            std::memcpy(host_vecs_.data() + h * dim_, host_vecs_.data() + t * dim_, dim_ * sizeof(float));
+            labels_[h] = labels_[t];
+            level_[h] = level_[t];
+            cnt0_[h] = cnt0_[t];
+            std::memcpy(links0_.data() + h * M0_, links0_.data() + t * M0_, M0_ * sizeof(uint32_t));
+            upper_off_[h] = upper_off_[t];
+            deleted_[h] = 0;
+            if (multi_) {
+                for (uint32_t &v : label_to_ids_.at((size_t)labels_[h]))
+                    if (v == (uint32_t)t) v = (uint32_t)h;
+            } else label_to_id_[(size_t)labels_[h]] = (uint32_t)h;
+            if (rows_on_device && vsgpu_table_move(table_, h, t)) return -1;
+        }
+    }
+    auto remap = [&](uint32_t v) { return v >= n_new ? new_id[v - n_new] : v; };
+    if (entry_ != 0xFFFFFFFFu) entry_ = remap(entry_);
+    // 4. links renumbered, the upper-level blocks packed, the arrays shrunk
+    std::vector<uint32_t> upper_new;
+    upper_new.reserve(upper_.size());
+    for (size_t p = 0; p < n_new; p++) {
+        uint32_t *l0 = links0_.data() + p * M0_;
+        for (uint32_t i = 0; i < cnt0_[p]; i++) l0[i] = remap(l0[i]);
+        if (level_[p] == 0) {
+            upper_off_[p] = 0xFFFFFFFFu;
+            continue;
+        }
+        const uint32_t *blk = upper_.data() + (size_t)upper_off_[p] * (M_ + 1);
+        const uint32_t off_new = (uint32_t)(upper_new.size() / (M_ + 1));
+        for (int level = 1; level <= (int)level_[p]; level++, blk += M_ + 1) {
+            upper_new.push_back(blk[0]);
+            for (size_t i = 0; i < M_; i++) upper_new.push_back(i < blk[0] ? remap(blk[1 + i]) : 0u);
+        }
+        upper_off_[p] = off_new;
+    }
+    upper_.swap(upper_new);
+    raw_.resize(n_new * blob_bytes_);
+    host_vecs_.resize(n_new * dim_);
+    labels_.resize(n_new);
+    level_.resize(n_new);
+    cnt0_.resize(n_new);
+    links0_.resize(n_new * M0_);
+    upper_off_.resize(n_new);
+    deleted_.resize(n_new);
+    n_ = n_new;
+    n_deleted_ = 0;
+    if (rows_on_device) {
+        if (vsgpu_table_truncate(table_, n_new)) return -1;
+        uploaded_rows_ = n_new;
+    } else {   // rows were still pending: start the device table over (the next query appends every row)
+        if (vsgpu_table_truncate(table_, 0)) return -1;
+        uploaded_rows_ = 0;
+    }
+    graph_dirty_ = true;
+    return 0;
 }
 
 int HnswIndex::syncDevice() {

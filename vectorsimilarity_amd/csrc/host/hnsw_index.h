@@ -108,7 +108,19 @@ private:
     }
     void unlockNode(uint32_t id) { node_lock_[id].clear(std::memory_order_release); }
     int syncDevice();
+    // Deleted nodes are marked at once (never returned, still traversed: hnsw.h:572-573) and REMOVED in batches -- the reference
+    // repairs in place on every delete (hnsw.h:1796-1852) with per-node incoming-edge sets; this index keeps none, so finding who
+    // points at a dead node is one pass over the graph, worth making once per batch of deletes: when a sixteenth of the nodes is
+    // dead (and no batch iterator holds node ids), every live node that points at a dead one gets its list rebuilt from its live
+    // neighbours and the dead ones' live neighbours (the reference's candidate set, repairConnectionsForDeletion hnsw.h:965-1060;
+    // the build's own neighbour heuristic when they exceed the list), the entry point is replaced if it died, the last live nodes
+    // move into the holes (swapWithLast, hnsw.h:1766-1786: rows, labels, links renumbered, the GPU table's rows moved), and the
+    // arrays shrink.  So dead nodes cost searches at most ~6 % of their evaluations, not an ever-growing share.
+    void maybeCompact();
+    int compactDeleted();
     std::vector<char> preprocess(const void *blob) const;
+    friend class HnswWalk;
+    std::atomic<int> walkers_{0};   // live batch iterators (they hold node ids across calls: no compaction under them)
 
     VecSimType type_ = VecSimType_FLOAT32;
     VecSimMetric metric_ = VecSimMetric_L2;

@@ -30,7 +30,9 @@ public:
         ef_ = (qp && qp->hnswRuntimeParams.efRuntime > 0) ? qp->hnswRuntimeParams.efRuntime : ix_->ef_;
         if (const char *e = std::getenv("VECSIM_HNSW_ITER_AHEAD")) ahead_ = (size_t)std::max(0, std::atoi(e));
         visited_.assign(ix_->n_, 0);
+        ix_->walkers_++;
     }
+    ~HnswWalk() override { ix_->walkers_--; }
 
     VecSimQueryReply *next(size_t n_res, VecSimQueryReply_Order order) override {
         std::lock_guard<std::recursive_mutex> gpu_lock(ix_->gpu_mu_);
