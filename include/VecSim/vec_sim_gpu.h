@@ -174,7 +174,8 @@ void VecSimGpu_SQ8_QueryBlobCentered(const float *vector, const float *mean, siz
  * returns the number of vectors written (0: unknown label, -1: cap_bytes too small / device error); with
  * out == NULL only *blob_bytes is filled. */
 long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, size_t cap_bytes, size_t *blob_bytes);
-/* Flat indexes: the stored blobs of internal ids [first_id, first_id + n) in one go (n, or -1); measurement / test hook */
+/* Flat and HNSW indexes: the stored blobs of internal ids [first_id, first_id + n) in one go (n, or -1); measurement / test hook
+ * (HNSW: the graph's own node order, VecSimGpu_HnswGraphCopy's -- deletes renumber it when dead nodes are removed) */
 long VecSimGpu_ReadStoredRows(VecSimIndex *index, size_t first_id, size_t n, void *out, size_t cap_bytes);
 
 /* device selection for indexes created afterwards on this thread/process (default: $VECSIM_GPU_DEVICE or 0) */

@@ -43,11 +43,9 @@ while time.time() < t_end:
     for lab in rng.choice(np.unique(labels), size=int(rng.integers(0, 6)), replace=False):
         ix.delete_vector(int(lab))
     g = ix.graph()
-    srows = rows
-    if metric == VecSim.VecSimMetric_Cosine:
-        srows = rows.copy()
-        for i in range(n):
-            vso.normalize(srows[i], dim, 0)
+    # the rows in the graph's own node order, as stored (Cosine: normalised at ingest) -- a batch of deletes may have removed dead
+    # nodes and moved the last live ones into the holes (round 5), so insertion order is not node order
+    srows = ix.stored_rows(0, g["n"]).view(np.float32).reshape(g["n"], dim).copy() if g["n"] else rows[:0]
     km = 0 if metric == VecSim.VecSimMetric_L2 else 1
     for _ in range(3):
         q = (rng.integers(-2, 3, dim).astype(np.float32) if coarse else rng.uniform(-1, 1, dim).astype(np.float32))

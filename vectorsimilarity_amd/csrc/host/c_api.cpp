@@ -445,6 +445,10 @@ extern "C" long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, voi
     return out ? index->storedVectors(label, out, cap_bytes) : 0;
 }
 extern "C" long VecSimGpu_ReadStoredRows(VecSimIndex *index, size_t first_id, size_t n, void *out, size_t cap_bytes) {
+    if (auto *h = dynamic_cast<vsa::HnswIndex *>(index)) {   // the graph's own row order (host copy)
+        if (!out || cap_bytes < n * h->storedBlobBytes()) return -1;
+        return h->readRows(first_id, n, out) ? -1 : (long)n;
+    }
     auto *f = dynamic_cast<vsa::FlatIndex *>(index);
     if (!f || !out || cap_bytes < n * f->storedBlobBytes()) return -1;
     return f->readRows((uint32_t)first_id, n, out) ? -1 : (long)n;

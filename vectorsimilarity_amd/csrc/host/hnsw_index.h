@@ -9,6 +9,7 @@
 // (hnsw.h:743-797), mutual linking with re-selection on overflow -- with its own host distance
 // routine (hnsw_index.cpp:build_distance).  That routine is never reached from a query entry point.
 #pragma once
+#include <cstring>
 #include <atomic>
 #include <cstdint>
 #include <memory>
@@ -55,6 +56,12 @@ public:
     long addSynthetic(size_t, uint64_t) override { return -1; }
     long storedVectors(size_t label, void *out, size_t cap_bytes) override;
     size_t storedBlobBytes() const override { return blob_bytes_; }
+    // stored blobs of internal ids [first, first + n) (tests / tools: the graph's own row order, which compaction changes)
+    int readRows(size_t first, size_t n, void *out) const {
+        if (first + n > n_) return -1;
+        std::memcpy(out, raw_.data() + first * blob_bytes_, n * blob_bytes_);
+        return 0;
+    }
     vsgpu_ctx *gpu() override { return ctx_; }
     int distanceTier() const override { return tier_; }
     void setLastMode(VecSearchMode m) override { last_mode_ = m; }
