@@ -403,6 +403,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         if (LK != LP_SQ8 && arow >= P.n_rows) arow = P.n_rows - 1;
         ap = abase + (size_t)(arow & P.slab_mask) * (SQ8 ? 4 : 1);
     };
+    // Rows whose stride is not a multiple of the 128-byte line (SQ8: dim + 12 / 16; int8 Cosine: dim + 4; odd 16-bit dims) are requested
+    // in column-block segments that START AND END inside lines: the neighbouring segment -- another stage, about a unit later --
+    // touches the same line again.  Marked non-temporal the line is gone by then and crosses HBM twice (round 5, rocprofv3 PMC on
+    // the SQ8 filter, 4 M x 784 B: 1.26 x the algorithmic bytes); with the default policy L2 keeps it.  Aligned rows stay non-temporal.
+    const bool keep_lines = (P.row_stride & 127u) != 0;
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
                      uint32_t abuf_i) {
         if (!issuer) return;
@@ -416,12 +421,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);   // (uniform already: keeps it in SGPRs)
                     uint32_t lo32 = st_lane[i];
                     asm volatile("" : "+v"(lo32));   // (keeps the zero-extension in this block: hoisted, the scalar-base form is not selected)
-                    if (pair_map) glds16<0>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
+                    if (pair_map || keep_lines) glds16<0>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
                     else glds16<2>(reinterpret_cast<const char *>(pu) + lo32, base + i * 1024, lds);
                     continue;
                 }
                 // paired query tiles want the row to stay in L2 for the partner: default cache policy there
-                if (pair_map) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
+                if (pair_map || keep_lines) glds16<0>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
                 else glds16<2>(rpt[i] + (size_t)kc * SEG, base + i * 1024, lds);
             }
         }
