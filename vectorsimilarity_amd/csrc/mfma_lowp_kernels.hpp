@@ -403,11 +403,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void k_mfma_filter_lowp(LowpPara
         if (LK != LP_SQ8 && arow >= P.n_rows) arow = P.n_rows - 1;
         ap = abase + (size_t)(arow & P.slab_mask) * (SQ8 ? 4 : 1);
     };
-    // Rows whose stride is not a multiple of the 128-byte line (SQ8: dim + 12 / 16; int8 Cosine: dim + 4; odd 16-bit dims) are requested
-    // in column-block segments that START AND END inside lines: the neighbouring segment -- another stage, about a unit later --
-    // touches the same line again.  Marked non-temporal the line is gone by then and crosses HBM twice (round 5, rocprofv3 PMC on
-    // the SQ8 filter, 4 M x 784 B: 1.26 x the algorithmic bytes); with the default policy L2 keeps it.  Aligned rows stay non-temporal.
-    const bool keep_lines = (P.row_stride & 127u) != 0;
+    // SQ8 rows (dim + 12 / 16 bytes: never a multiple of the 128-byte line at the compiled widths) are requested in column-block
+    // segments that START AND END inside lines: the neighbouring segment -- another stage, about a unit later -- touches the same line
+    // again.  Marked non-temporal the line is gone by then and crosses HBM twice (round 5, rocprofv3 PMC on the SQ8 filter, 4 M x 784 B:
+    // 1.26 x the algorithmic bytes); with the default policy L2 keeps it (1.03 x).  A compile-time property of the kind on purpose: the
+    // same test at run time (any stride % 128 != 0) put a branch around every request of the bf16 filter and cost config 4 5 %.
+    constexpr bool keep_lines = (LK == LP_SQ8);
     auto issue = [&](const char *const (&rpt)[IPW], const uint32_t *apt, int kc, uint32_t slot, bool with_aux,
                      uint32_t abuf_i) {
         if (!issuer) return;
