@@ -59,7 +59,9 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     static_assert(!SHIFT || X32_D <= X32_NS - 2, "SHIFT: the late waves read a unit's slot half a period past its barrier");
     static_assert(!SHIFT || (VAR & 32768), "SHIFT: the late waves must not request rows (they would have to wait for them at their barrier)");
     static_assert(LK == LP_I8 || LK == LP_U8, "int8 / uint8 rows with 4-byte aux values");
-    // FREE (VAR bit 1024): no s_barrier in the loop at all.  The stamps of the lock-step kernel (profiles/r05_c3_batch1.txt) show
+    // FREE (VAR bit 1024; TUNING BUILD ONLY, kept as the record of an experiment: no gain, and WRONG replies at small sizes -- an LDS-DMA
+    // write is not ordered behind the requesting wave's ds_add the way it is behind a barrier, profiles/r05_c3_batches.txt): no s_barrier
+    // in the loop at all.  The stamps of the lock-step kernel (profiles/r05_c3_batch1.txt) show
     // every wave 720-1140 of its ~4000 cycles per unit inside the ring barrier: eight waves whose unit times vary (request issue
     // blocked by the memory pipeline, arbitration for the matrix pipe, a candidate to queue) wait for the slowest of the eight,
     // every unit.  Two monotonic LDS counters carry what the barrier carried:
@@ -73,6 +75,9 @@ __global__ __launch_bounds__(X32_NW * 64, 2) void k_i8_filter_x32(LowpParams P) 
     // No deadlock: the wave that is furthest behind (unit m) waits only for `landed`, i.e. for requesting waves to reach their
     // publication point in iteration m, and those wait only for done(m - 2), which every wave at or past unit m has signalled.
     constexpr bool FREE = (VAR & 1024) != 0;
+#ifndef VSGPU_TUNING
+    static_assert(!FREE, "FREE is a tuning-build experiment");
+#endif
     static_assert(!FREE || ((VAR & 1) && (VAR & 32768) && !(VAR & 4) && !(VAR & 2)), "FREE: EARLY + requests by waves 0-3, no SHIFT / SPREAD");
     static_assert(!FREE || X32_D <= X32_NS - 2, "FREE: one slot of slack for laggards");
     constexpr bool EARLY = (VAR & 1) != 0;
