@@ -158,7 +158,7 @@ def cpu_baseline(args, VecSim, synth):
     # the index follows the host's CPUID like the reference's choosers do (bf16 IP: vdpbf16ps on avx512_bf16 hosts): same tier here
     from vectorsimilarity_amd import _capi
     tier_name = _capi.load().VecSimGpu_HostTier().decode()
-    tier = {"AVX512": vso.TIER_AVX512, "SCALAR": vso.TIER_SCALAR, "AVX512_BF16": vso.TIER_AVX512_BF16}[tier_name]
+    tier = {"AVX512": vso.TIER_AVX512, "SCALAR": vso.TIER_SCALAR, "AVX512_BF16": vso.TIER_AVX512_BF16, "AVX512_FP16": vso.TIER_AVX512_FP16}[tier_name]
     vso.flat_topk_batch_fast(vt, km, rows[:2000], queries[:1], args.topk, args.dim, 1, tier)
 
     def best_of(nq, th, reps):

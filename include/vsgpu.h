@@ -35,7 +35,9 @@ enum { VSGPU_F32 = 0, VSGPU_F64 = 1, VSGPU_BF16 = 2, VSGPU_F16 = 3, VSGPU_I8 = 4
        VSGPU_SQ8H = 7 };
 enum { VSGPU_L2 = 0, VSGPU_IP = 1, VSGPU_COSINE = 2 };
 /* which reference ISA tier's summation order the kernels reproduce */
-enum { VSGPU_TIER_AVX512 = 0, VSGPU_TIER_SCALAR = 1, VSGPU_TIER_AVX512_BF16 = 2 };
+/* AVX512_FP16: as AVX512_BF16, and fp16 rows of dim >= 32 in the order of the half-ACCUMULATING kernels a gcc >= 12 build runs on an
+ * avx512_fp16 host (IP_AVX512FP16_VL_FP16.h:16-51, L2_AVX512FP16_VL_FP16.h:16-58): exact kernels only, no MFMA filter */
+enum { VSGPU_TIER_AVX512 = 0, VSGPU_TIER_SCALAR = 1, VSGPU_TIER_AVX512_BF16 = 2, VSGPU_TIER_AVX512_FP16 = 3 };
 
 enum {
     VSGPU_OK = 0,

@@ -478,6 +478,100 @@ double vso_f16c_distance(int metric, size_t dim, const void *a, const void *b) {
     return dim < 8 ? NAN : f16_f16c(a, b, dim, metric == VSO_L2);
 }
 
+/* ------------------------------------------------------------------ AVX512-FP16 tier (fp16 rows, fp16 ACCUMULATORS)
+ * Builds by gcc >= 12 / clang >= 14 define OPT_AVX512_FP16_VL (cmake/x86_64InstructionFlags.cmake:13,61) and, on hosts with
+ * avx512_fp16 && avx512vl, run fp16 rows of dim >= 32 on IP_AVX512FP16_VL_FP16.h:16-51 / L2_AVX512FP16_VL_FP16.h:16-58
+ * (choosers IP_space.cpp:649-658, L2_space.cpp:388-397): ONE 32-lane accumulator of HALF precision -- the dim % 32 head by a
+ * zero-masked vmulph (L2: zero-masked vsubph, then vmulph), 32 elements per round by vfmadd...ph (L2: vsubph first, rounded to
+ * half), _mm512_reduce_add_ph, and for IP `_Float16(1) - res` rounded to half; the float returned is that half widened.
+ * _mm512_reduce_add_ph: gcc's avx512fp16intrin.h (_MM512_REDUCE_OP) folds 512 -> 256 -> 128 bits, then the shuffles
+ * {4,5,6,7,..}, {2,3,..} and [0] + [1]; clang's (the header is in this image: __builtin_ia32_reduce_fadd_ph512 = a reassociable
+ * llvm.vector.reduce.fadd) is expanded by the same halving shuffles: lanes (i, i + 16), (i, i + 8), (i, i + 4), (i, i + 2), 0 + 1.
+ * PARITY UNPINNED for this tier: the gcc-11 toolchain of this image cannot emit it, no host here or on the GPU box executes it,
+ * and the reference's own test (test_spaces.cpp:1418-1590) holds only "within 1 % of a sequential half-precision sum".
+ * Half arithmetic is done exactly: operands as integers in units of 2^-24 (products: 2^-48), one round-to-nearest-even. */
+typedef __int128 vso_fx;
+static int h_special(uint16_t h) { return (h & 0x7C00) == 0x7C00; }
+static vso_fx h_units24(uint16_t h) {
+    const int e = (h >> 10) & 31;
+    const int64_t m = h & 1023;
+    const int64_t v = e ? ((m | 1024) << (e - 1)) : m;   /* (1024 + m) 2^(e - 25) = ((1024 + m) << (e - 1)) 2^-24 */
+    return (h & 0x8000) ? -(vso_fx)v : (vso_fx)v;
+}
+/* v units of 2^-unit_log2 -> nearest half, ties to even; an exact zero takes the sign the caller derived */
+static uint16_t h_round(vso_fx v, int unit_log2, int zero_negative) {
+    if (v == 0) return zero_negative ? 0x8000 : 0;
+    const int neg = v < 0;
+    unsigned __int128 m = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    int p = 0;
+    for (unsigned __int128 t = m; t >>= 1;) p++;          /* msb index: |value| in [2^(p - unit), 2^(p - unit + 1)) */
+    const int e = p - unit_log2;
+    const int qe = e < -14 ? -24 : e - 10;               /* the result's quantum: 2^qe (subnormals: 2^-24) */
+    const int q = qe + unit_log2;                         /* its bit index in v; >= 0 for units of 2^-24 and 2^-48 */
+    if (q > 0) {
+        const unsigned __int128 half = (unsigned __int128)1 << (q - 1), rem = m & (((unsigned __int128)1 << q) - 1);
+        m >>= q;
+        if (rem > half || (rem == half && (m & 1))) m++;
+    }
+    /* value = m 2^qe, m <= 2048: bits = ((E - 1) << 10) + m with E = qe + 25 (a carry into the exponent adds itself) */
+    const unsigned bits = ((unsigned)(qe + 24) << 10) + (unsigned)m;
+    return (uint16_t)((neg ? 0x8000u : 0u) | (bits >= 0x7C00u ? 0x7C00u : bits));
+}
+static uint16_t h_from_special(double r) {   /* a result with an inf / NaN operand, computed in double */
+    if (r != r) return 0x7E00;
+    if (r == INFINITY) return 0x7C00;
+    if (r == -INFINITY) return 0xFC00;
+    return vso_f32_to_f16((float)r);   /* (finite: only inf / NaN operands come here, so not reached) */
+}
+uint16_t vso_h_fma(uint16_t a, uint16_t b, uint16_t c) {
+    if (h_special(a) || h_special(b) || h_special(c))
+        return h_from_special(fma((double)vso_f16_to_f32(a), (double)vso_f16_to_f32(b), (double)vso_f16_to_f32(c)));
+    const vso_fx prod = h_units24(a) * h_units24(b);
+    const int prod_neg_zero = prod == 0 && (((a ^ b) & 0x8000) != 0);
+    return h_round(prod + h_units24(c) * ((vso_fx)1 << 24), 48, prod_neg_zero && c == 0x8000);
+}
+uint16_t vso_h_mul(uint16_t a, uint16_t b) {
+    if (h_special(a) || h_special(b)) return h_from_special((double)vso_f16_to_f32(a) * (double)vso_f16_to_f32(b));
+    return h_round(h_units24(a) * h_units24(b), 48, ((a ^ b) & 0x8000) != 0);
+}
+uint16_t vso_h_add(uint16_t a, uint16_t b) {
+    if (h_special(a) || h_special(b)) return h_from_special((double)vso_f16_to_f32(a) + (double)vso_f16_to_f32(b));
+    return h_round(h_units24(a) + h_units24(b), 24, (a & 0x8000) && (b & 0x8000));
+}
+uint16_t vso_h_sub(uint16_t a, uint16_t b) { return vso_h_add(a, (uint16_t)(b ^ 0x8000)); }
+
+static float f16_fp16acc(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+    uint16_t s[32];
+    for (int j = 0; j < 32; j++) s[j] = 0;
+    const size_t residual = d % 32;
+    size_t pos = 0;
+    if (residual) {   /* zero-masked head: the other lanes stay +0 */
+        for (size_t j = 0; j < residual; j++) {
+            if (l2) {
+                const uint16_t t = vso_h_sub(a[j], b[j]);
+                s[j] = vso_h_mul(t, t);
+            } else {
+                s[j] = vso_h_mul(a[j], b[j]);
+            }
+        }
+        pos = residual;
+    }
+    do {   /* (dim >= 32: at least one whole block) */
+        for (int j = 0; j < 32; j++) {
+            if (l2) {
+                const uint16_t t = vso_h_sub(a[pos + j], b[pos + j]);
+                s[j] = vso_h_fma(t, t, s[j]);
+            } else {
+                s[j] = vso_h_fma(a[pos + j], b[pos + j], s[j]);
+            }
+        }
+        pos += 32;
+    } while (pos < d);
+    for (int o = 16; o >= 1; o >>= 1)
+        for (int j = 0; j < o; j++) s[j] = vso_h_add(s[j], s[j + o]);
+    return vso_f16_to_f32(l2 ? s[0] : vso_h_sub(0x3C00, s[0]));
+}
+
 /* ------------------------------------------------------------------ tier choosers */
 
 /* Mirrors the x86 branch of L2_space.cpp / IP_space.cpp for a gcc-11 build (no AVX512FP16 tier):
@@ -511,12 +605,14 @@ double vso_distance(int type, int metric, int tier, size_t dim, const void *a, c
             return l2 ? h16_l2_scalar(a, b, dim, vso_f16_to_f32)
                       : h16_ip_scalar(a, b, dim, vso_f16_to_f32);
         if (dim < 16) return f16_f16c(a, b, dim, l2);
+        if (tier == VSO_TIER_AVX512_FP16 && dim >= 32) return f16_fp16acc(a, b, dim, l2);
         return l2 ? f16_l2_lanes(a, b, dim) : f16_ip_lanes(a, b, dim);
     case VSO_BF16:
         if (scalar)
             return l2 ? h16_l2_scalar(a, b, dim, vso_bf16_to_f32)
                       : h16_ip_scalar(a, b, dim, vso_bf16_to_f32);
-        if (!l2 && tier == VSO_TIER_AVX512_BF16) return bf16_ip_dpbf16(a, b, dim);
+        /* (every x86 CPU with avx512_fp16 has avx512_bf16: the FP16 tier includes the vdpbf16ps kernel) */
+        if (!l2 && (tier == VSO_TIER_AVX512_BF16 || tier == VSO_TIER_AVX512_FP16)) return bf16_ip_dpbf16(a, b, dim);
         return bf16_vbmi2(a, b, dim, l2);
     case VSO_I8: {
         if (l2) return (float)i8_l2(a, b, dim);

@@ -39,8 +39,15 @@ enum { VSO_L2 = 0, VSO_IP = 1, VSO_COSINE = 2 };
 enum {
     VSO_TIER_AVX512 = 0, /* gcc-11 build on an AVX-512F/BW/VL/VNNI/VBMI2 host, avx512_bf16 masked off */
     VSO_TIER_SCALAR = 1, /* "no optimisation" kernels */
-    VSO_TIER_AVX512_BF16 = 2 /* as AVX512 plus the vdpbf16ps tier for bf16 IP */
+    VSO_TIER_AVX512_BF16 = 2, /* as AVX512 plus the vdpbf16ps tier for bf16 IP */
+    VSO_TIER_AVX512_FP16 = 3 /* as AVX512_BF16 plus the half-accumulating kernels for fp16 rows of dim >= 32 (gcc >= 12 builds on
+                                avx512_fp16 hosts); parity UNPINNED: restated from the source alone, see vso.c */
 };
+/* IEEE half arithmetic, one rounding to nearest-even each (what vfmadd...ph / vmulph / vaddph / vsubph compute) */
+uint16_t vso_h_fma(uint16_t a, uint16_t b, uint16_t c);
+uint16_t vso_h_mul(uint16_t a, uint16_t b);
+uint16_t vso_h_add(uint16_t a, uint16_t b);
+uint16_t vso_h_sub(uint16_t a, uint16_t b);
 
 size_t vso_elem_size(int type);
 /* bytes of one stored row / query blob: dim*elem (+4 for int8/uint8 Cosine)   vec_utils.cpp:296-302 */

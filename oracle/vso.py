@@ -14,7 +14,7 @@ _LIB = os.path.join(_HERE, "libvso.so")
 
 F32, F64, BF16, F16, I8, U8 = range(6)
 L2, IP, COSINE = range(3)
-TIER_AVX512, TIER_SCALAR, TIER_AVX512_BF16 = range(3)
+TIER_AVX512, TIER_SCALAR, TIER_AVX512_BF16, TIER_AVX512_FP16 = range(4)
 
 NP_DTYPE = {F32: np.float32, F64: np.float64, BF16: np.uint16, F16: np.uint16, I8: np.int8,
             U8: np.uint8}
@@ -66,6 +66,10 @@ def lib():
         L.vso_f32_to_f16.argtypes = [C.c_float]
         L.vso_f16_to_f32.restype = C.c_float
         L.vso_f16_to_f32.argtypes = [C.c_uint16]
+        for name, n_args in (("vso_h_fma", 3), ("vso_h_mul", 2), ("vso_h_add", 2), ("vso_h_sub", 2)):
+            fn = getattr(L, name)
+            fn.restype = C.c_uint16
+            fn.argtypes = [C.c_uint16] * n_args
         L.vso_topk_replay.restype = sz
         L.vso_topk_replay.argtypes = [vp, vp, sz, sz, vp, vp]
         L.vso_topk_replay_multi.restype = sz
@@ -147,6 +151,23 @@ def _ptr(a):
 
 def blob_size(vtype, metric, dim):
     return lib().vso_blob_size(vtype, metric, dim)
+
+
+def h_fma(a, b, c):
+    """IEEE half fused multiply-add on bit patterns (one rounding, ties to even): the AVX512-FP16 tier's vfmadd...ph"""
+    return int(lib().vso_h_fma(int(a), int(b), int(c)))
+
+
+def h_mul(a, b):
+    return int(lib().vso_h_mul(int(a), int(b)))
+
+
+def h_add(a, b):
+    return int(lib().vso_h_add(int(a), int(b)))
+
+
+def h_sub(a, b):
+    return int(lib().vso_h_sub(int(a), int(b)))
 
 
 def distance(vtype, metric, a, b, dim=None, tier=TIER_AVX512):

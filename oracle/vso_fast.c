@@ -342,10 +342,12 @@ int vso_fast_available(int type, int metric, int tier, size_t dim) {
     switch (type) {
     case VSO_F32: return dim >= 8 && vso_has_avx512();
     case VSO_F64: return dim >= 4 && vso_has_avx512();
-    case VSO_F16: return dim >= 16 && vso_has_avx512();
+    case VSO_F16:
+        if (tier == VSO_TIER_AVX512_FP16 && dim >= 32) return 0;   /* half accumulators: no host here executes avx512_fp16 */
+        return dim >= 16 && vso_has_avx512();
     case VSO_BF16:
         if (dim < 32) return 0;
-        if (tier == VSO_TIER_AVX512_BF16 && metric != VSO_L2) return has_all(0, 0, 1);
+        if ((tier == VSO_TIER_AVX512_BF16 || tier == VSO_TIER_AVX512_FP16) && metric != VSO_L2) return has_all(0, 0, 1);
         return has_all(1, 0, 0);
     case VSO_I8: return dim >= 32 && has_all(0, 1, 0);
     case VSO_U8: return dim >= 32 && dim <= 33025 && has_all(0, 1, 0);
@@ -362,7 +364,7 @@ double vso_distance_fast_tier(int type, int metric, int tier, size_t dim, const 
     case VSO_F64: return f64_avx512(a, b, dim, l2);
     case VSO_F16: return f16_avx512(a, b, dim, l2);
     case VSO_BF16:
-        if (tier == VSO_TIER_AVX512_BF16 && !l2) return bf16_ip_dpbf16_hw(a, b, dim);
+        if ((tier == VSO_TIER_AVX512_BF16 || tier == VSO_TIER_AVX512_FP16) && !l2) return bf16_ip_dpbf16_hw(a, b, dim);
         return bf16_vbmi2_hw(a, b, dim, l2);
     case VSO_I8: return i8_vnni(a, b, dim, metric, 0);
     case VSO_U8: return i8_vnni(a, b, dim, metric, 1);

@@ -68,13 +68,19 @@ def test_all_scores_bit_exact(vso, typ, metric, dim):
 
 TIER_CASES = [("scalar", t, m, d) for t in ("f32", "f16", "bf16", "f64", "i8") for m in ("L2", "IP") for d in (17, 64, 100)]
 TIER_CASES += [("avx512_bf16", "bf16", m, d) for m in ("IP", "Cosine", "L2") for d in (32, 33, 47, 64, 100, 768)]
+# AVX512-FP16 tier (gcc >= 12 builds on avx512_fp16 hosts): fp16 rows of dim >= 32 accumulate in HALF precision; below 32 the
+# AVX512F / F16C kernels as on every AVX-512 host; bf16 IP as on the avx512_bf16 tier
+TIER_CASES += [("avx512_fp16", "f16", m, d) for m in ("IP", "Cosine", "L2") for d in (16, 31, 32, 33, 47, 63, 64, 100, 768, 1000)]
+TIER_CASES += [("avx512_fp16", "bf16", "IP", 100), ("avx512_fp16", "f32", "L2", 100)]
 
 
 @pytest.mark.parametrize("tier,typ,metric,dim", TIER_CASES)
 def test_all_scores_bit_exact_other_tiers(vso, monkeypatch, tier, typ, metric, dim):
     """VECSIM_GPU_TIER selects which reference ISA tier's summation order the kernels reproduce: `scalar` (hosts without
     SIMD, L2.cpp:76-133 / IP.cpp:185-238) and `avx512_bf16` (vdpbf16ps, what IP_space.cpp:586-590 picks first on any
-    avx512_bf16 host -- bf16 IP/Cosine only, L2 stays on the VBMI2 kernel).  0 ulp against the oracle's model of that tier."""
+    avx512_bf16 host -- bf16 IP/Cosine only, L2 stays on the VBMI2 kernel) and `avx512_fp16` (half-precision accumulators for fp16 rows,
+    IP_AVX512FP16_VL_FP16.h:16-51, L2 twin; the oracle's half arithmetic is exact integer arithmetic with one rounding, the GPU's is
+    v_fma_f16 / v_sub_f16 / v_add_f16: two independent implementations of IEEE half).  0 ulp against the oracle's model of that tier."""
     from util import TIERS
     monkeypatch.setenv("VECSIM_GPU_TIER", tier)
     rng = np.random.default_rng(dim * 3 + len(typ) + len(tier))
@@ -124,7 +130,8 @@ def test_default_tier_of_this_host_matches_the_oracles_same_tier(vso, monkeypatc
     ix.reset_stats()
     labels, dists = ix.knn_query(q, k)
     stt = ix.stats()
-    assert stt["fallbacks"] == 0 and ("mfma" in stt["scan_kernel"] or "i8" in stt["scan_kernel"] or dim == 100), stt
+    # (fp16 rows on an avx512_fp16 host accumulate in half precision: exact kernels only)
+    assert stt["fallbacks"] == 0 and ("mfma" in stt["scan_kernel"] or "i8" in stt["scan_kernel"] or dim == 100 or (host == "AVX512_FP16" and typ == "f16")), stt
     st = stored_rows(vso, rows, typ, metric)
     for j in range(0, nq, max(1, nq // 16)):
         qq = stored_rows(vso, q[j][None, :], typ, metric)[0]

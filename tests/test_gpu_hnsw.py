@@ -706,6 +706,20 @@ def test_concurrent_readers_on_one_hnsw_index(vso):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+    # a batch of deletes large enough to compact the graph (nodes renumbered, the device table's rows moved, the snapshot replaced):
+    # the reader lanes' views must follow -- the same concurrent round again against fresh serial replies
+    for lab in range(0, n, 9):
+        assert ix.delete_vector(lab) == 1
+    assert ix.graph()["n"] < n
+    want[:] = [ix.knn_query(q, k) for q in qs]
+    want_r[:] = [ix.range_query(q[0], float(w[1][0][4])) for q, w in zip(qs, want)]
+    assert not any(l % 9 == 0 for w in want for l in w[0].ravel().tolist() if l >= 0)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
 
 
 def test_debug_neighbours_dump_matches_the_exported_graph():

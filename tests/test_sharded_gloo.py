@@ -178,6 +178,48 @@ def test_block_partition_is_a_bijection():
     assert len(seen) == 5000
 
 
+def test_wide_merge_equals_the_sequential_heap_loop():
+    """a wide and deep batch (merged on several host threads, the no-tie shortcut for most queries) against the plain loop of
+    brute_force.h:264-281 over the union in gid order, restated here: queries with distinct scores, queries full of ties at the k-th
+    score, queries with fewer candidates than k"""
+    from vectorsimilarity_amd.sharded import merge_topk
+    rng = np.random.default_rng(77)
+    nq, parts, cap, k = 160, 8, 48, 32
+    gids = np.zeros((parts, nq, cap), dtype=np.uint64)
+    labels = np.zeros((parts, nq, cap), dtype=np.uint64)
+    scores = np.zeros((parts, nq, cap), dtype=np.float64)
+    counts = np.zeros((parts, nq), dtype=np.uint32)
+    for q in range(nq):
+        kind = q % 4
+        perm = rng.permutation(parts * cap)
+        for p in range(parts):
+            n = int(rng.integers(0, 4)) if kind == 3 else int(rng.integers(36, cap + 1))
+            counts[p, q] = n
+            g = np.sort(perm[p * cap:p * cap + n])
+            gids[p, q, :n] = g
+            labels[p, q, :n] = (g * 7 + 3) % 1009 + 1000 * g
+            sc = rng.random(n)
+            if kind == 1:
+                sc = np.floor(sc * 6) / 6          # heavy ties, some across the k-th score
+            elif kind == 2:
+                sc = np.floor(sc * 300) / 300      # a few ties
+            scores[p, q, :n] = sc
+    assert int(counts.sum()) >= 32768   # (the threshold of the threaded merge, sharded_index.cpp)
+    l, s = merge_topk(counts, gids, labels, scores, k)
+    for q in range(nq):
+        cands = sorted((int(gids[p, q, i]), int(labels[p, q, i]), float(scores[p, q, i])) for p in range(parts) for i in range(counts[p, q]))
+        heap = []   # (score, label), the largest evicted
+        for _, lab, sc in cands:
+            if len(heap) < k or sc < max(heap)[0]:
+                heap.append((sc, lab))
+                if len(heap) > k:
+                    heap.remove(max(heap))
+        heap.sort()
+        got = [(float(s[q, i]), int(l[q, i])) for i in range(len(heap))]
+        assert got == heap, q
+        assert all(int(x) == -1 for x in l[q, len(heap):])
+
+
 def test_merge_replays_ties_like_the_reference():
     """VecSimGpu_MergeTopK on hand-made partials == sequential heap over the union in gid order"""
     from vectorsimilarity_amd.sharded import merge_topk

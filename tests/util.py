@@ -3,7 +3,7 @@ import numpy as np
 
 TYPES = {"f32": 0, "f64": 1, "bf16": 2, "f16": 3, "i8": 4, "u8": 5}
 METRICS = {"L2": 0, "IP": 1, "Cosine": 2}
-TIERS = {"avx512": 0, "scalar": 1, "avx512_bf16": 2}
+TIERS = {"avx512": 0, "scalar": 1, "avx512_bf16": 2, "avx512_fp16": 3}
 
 
 def encode(vso, values, typ):

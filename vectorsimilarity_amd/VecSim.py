@@ -262,7 +262,7 @@ class VecSimIndex:
         return out
 
     def distance_tier(self):
-        """which reference ISA tier's summation order this index answers in: 'AVX512' | 'AVX512_BF16' | 'SCALAR'"""
+        """which reference ISA tier's summation order this index answers in: 'AVX512' | 'AVX512_BF16' | 'AVX512_FP16' | 'SCALAR'"""
         return self._lib.VecSimGpu_IndexTier(self._h).decode()
 
     def index_type(self):

@@ -12,13 +12,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 // never let the compiler fuse or re-associate: the summation order IS the contract
 #pragma clang fp contract(off)
 
 namespace vsg {
 
 enum ElemKind { EK_F32 = 0, EK_F64 = 1, EK_BF16 = 2, EK_F16 = 3, EK_I8 = 4, EK_U8 = 5, EK_SQ8 = 6, EK_SQ8H = 7 };
-enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3, OP_IP_DPBF16 = 4 };
+enum OpKind { OP_L2_FMA = 0, OP_IP_FMA = 1, OP_L2_MULADD = 2, OP_IP_MULADD = 3, OP_IP_DPBF16 = 4,
+              // AVX512-FP16 tier, fp16 rows: the accumulator is a HALF (carried in a float, every half is one): vsubph + vfmadd...ph
+              OP_L2_F16ACC = 5, OP_IP_F16ACC = 6 };
 enum ScanMode { MODE_DENSE = 0, MODE_FILTER = 1 };
 // how the reduced accumulator becomes a score
 enum Epilogue {
@@ -30,7 +34,8 @@ enum Epilogue {
     // SQ8 storage x FP32 query: acc = sum(code_i * y_i);  ip = min * y_sum + delta * acc  (IP.cpp:60-70; fused into
     // fma(min, y_sum, delta * acc) by gcc in the AVX-512 translation unit, see oracle/vso_sq8.c)
     EPI_SQ8_IP = 5,     // score = 1 - ip                                    (IP.cpp:72-80)
-    EPI_SQ8_L2 = 6      // score = (x_sum_sq + y_sum_sq) - 2 ip               (L2.cpp:30-45)
+    EPI_SQ8_L2 = 6,     // score = (x_sum_sq + y_sum_sq) - 2 ip               (L2.cpp:30-45)
+    EPI_ONE_MINUS_H16 = 7   // score = float(half(1) - half(acc))               (IP_AVX512FP16_VL_FP16.h:49-50)
 };
 
 template <int EK> struct Elem;
@@ -89,7 +94,14 @@ __device__ inline float ftz_f32(float v) {
     return (u & 0x7f800000u) ? v : __uint_as_float(u & 0x80000000u);
 }
 // one accumulation step; explicit rounding intrinsics so no contraction flag can change it
+// half-precision steps on values carried as floats: v_sub_f16 / v_fma_f16 / v_add_f16 round to nearest-even and keep subnormals
+// (the kernels' default mode for 16- and 64-bit operations), as the AVX512-FP16 instructions do
+__device__ inline float h16_fma(float a, float b, float c) { return (float)__builtin_fmaf16((_Float16)a, (_Float16)b, (_Float16)c); }
+__device__ inline float h16_sub(float a, float b) { return (float)((_Float16)a - (_Float16)b); }
+__device__ inline float h16_add(float a, float b) { return (float)((_Float16)a + (_Float16)b); }
 template <int OPK> __device__ inline float acc_step(float x, float q, float acc) {
+    if (OPK == OP_L2_F16ACC) { float t = h16_sub(x, q); return h16_fma(t, t, acc); }
+    if (OPK == OP_IP_F16ACC) { return h16_fma(x, q, acc); }
     if (OPK == OP_IP_DPBF16) { return ftz_f32(__fmaf_rn(ftz_f32(x), ftz_f32(q), ftz_f32(acc))); }
     if (OPK == OP_L2_FMA) { float t = __fsub_rn(x, q); return __fmaf_rn(t, t, acc); }
     if (OPK == OP_IP_FMA) { return __fmaf_rn(x, q, acc); }
@@ -124,6 +136,13 @@ template <> struct Reduced<int> { using type = long long; };
 //   kind 1: the fp16 F16C kernel (dims 8..15): (lane j + lane j+8) + 0 for j < 8, then the eight sums left to right
 //           (L2_F16C_FP16.h:81-82, AVX_utils.h:32-37)
 template <int VL, typename T> __device__ inline T lane_reduce(T v, int kind) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (kind == 2) {   // _mm512_reduce_add_ph: the halving tree in half precision
+#pragma unroll
+            for (int o = VL / 2; o >= 1; o >>= 1) v = h16_add(v, __shfl_down(v, o, VL));
+            return v;
+        }
+    }
     if (kind == 0) {
 #pragma unroll
         for (int o = VL / 2; o >= 1; o >>= 1) v = add_rn(v, __shfl_down(v, o, VL));
@@ -177,6 +196,7 @@ template <typename S> __device__ inline S epilogue_score(long long acc, int epi,
     return (S)__fsub_rn(1.0f, __fdiv_rn(ip, __fmul_rn(nrow, nq)));
 }
 template <typename S> __device__ inline S epilogue_score(float acc, int epi, float, float) {
+    if (epi == EPI_ONE_MINUS_H16) return (S)h16_sub(1.0f, acc);
     return (epi == EPI_ONE_MINUS) ? (S)__fsub_rn(1.0f, acc) : (S)acc;
 }
 __device__ inline float load_f32_unaligned(const char *p) {

@@ -304,7 +304,7 @@ VecSim_InfoField f64_field(const char *name, double v) {
     return f;
 }
 }  // namespace
-// the tier a new index would get on this host (VECSIM_GPU_TIER override, else CPUID): "AVX512" | "AVX512_BF16" | "SCALAR"
+// the tier a new index would get on this host (VECSIM_GPU_TIER override, else CPUID): "AVX512" | "AVX512_BF16" | "AVX512_FP16" | "SCALAR"
 extern "C" const char *VecSimGpu_HostTier(void) { return vsa::tier_name(vsa::resolve_tier()); }
 // what this host lacks for its own reference build to run the restated order for `type` ("" = nothing; host_tier.h)
 extern "C" const char *VecSimGpu_HostTierNote(VecSimType type) {

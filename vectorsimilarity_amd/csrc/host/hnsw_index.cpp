@@ -51,7 +51,8 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     ix->log_ctx_ = logCtx;
     ix->ctx_ = ctx;
     // (the search kernel scores rows with the lane program of the host's tier as well; the scalar tier is not wired into it)
-    ix->tier_ = resolve_tier((int)p.type) == VSGPU_TIER_AVX512_BF16 ? VSGPU_TIER_AVX512_BF16 : VSGPU_TIER_AVX512;
+    ix->tier_ = resolve_tier((int)p.type);
+    if (ix->tier_ == VSGPU_TIER_SCALAR) ix->tier_ = VSGPU_TIER_AVX512;
     ix->table_ = vsgpu_table_create(ctx, (int)p.type, (int)p.metric, ix->tier_, p.dim, ix->blob_bytes_);
     ix->graph_ = ix->table_ ? vsgpu_graph_create(ix->table_, M) : nullptr;
     if (!ix->table_ || !ix->graph_) {

@@ -13,8 +13,12 @@
 //                                               filters (the scalar order turns them off: 10-50x slower) and is the order
 //                                               the same index gives on any AVX-512 host.  The scalar kernels' order
 //                                               (VSGPU_TIER_SCALAR) is an explicit choice only.
-// -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | scalar overrides it.  Also not restated: the AVX512-FP16 tier of gcc >= 12
-// builds (fp16 accumulate).  The reference asks for more than avx512f per type (bf16: avx512bw && avx512vbmi2,
+//   ... && avx512_fp16 && avx512vl           -> fp16 rows of dim >= 32 in HALF-precision accumulators, what a reference built by
+//                                               gcc >= 12 / clang >= 14 (OPT_AVX512_FP16_VL) runs there (IP_space.cpp:649-658,
+//                                               L2_space.cpp:388-397); everything else as AVX512_BF16 (VSGPU_TIER_AVX512_FP16).
+//                                               A gcc-11 build of the reference has no such kernels: VECSIM_GPU_TIER=avx512_bf16
+//                                               gives its order on such a host.
+// -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | avx512_fp16 | scalar overrides it.  The reference asks for more than avx512f per type (bf16: avx512bw && avx512vbmi2,
 // L2_space.cpp:332-337; int8 / uint8: avx512bw && avx512vl && avx512vnni, L2_space.cpp:451-455; fp16: avx512bw && avx512vl):
 // reference_order_missing() names what the host lacks for its own reference build to run the order this library restates for
 // a type; index creation prints it once per type (VecSimGpu_HostTierNote returns the same text to callers and tests).
@@ -24,6 +28,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#if defined(__x86_64__)
+#include <cpuid.h>
+#endif
 
 #include "vsgpu.h"
 
@@ -32,6 +39,7 @@ namespace vsa {
 struct HostFeatures {
     bool avx512f = false, avx512bw = false, avx512vl = false, avx512vbmi2 = false, avx512vnni = false, avx512_bf16 = false;
     bool f16c = false, fma3 = false, avx = false;
+    bool avx512_fp16 = false;
 };
 
 inline HostFeatures host_features() {
@@ -42,6 +50,7 @@ inline HostFeatures host_features() {
         f.avx512f = has("avx512f"), f.avx512bw = has("avx512bw"), f.avx512vl = has("avx512vl");
         f.avx512vbmi2 = has("avx512vbmi2"), f.avx512vnni = has("avx512vnni"), f.avx512_bf16 = has("avx512_bf16");
         f.f16c = has("f16c"), f.fma3 = has("fma3"), f.avx = has("avx");
+        f.avx512_fp16 = has("avx512_fp16");
         return f;
     }
 #if defined(__x86_64__)
@@ -50,11 +59,16 @@ inline HostFeatures host_features() {
     f.avx512vl = __builtin_cpu_supports("avx512vl"), f.avx512vbmi2 = __builtin_cpu_supports("avx512vbmi2");
     f.avx512vnni = __builtin_cpu_supports("avx512vnni"), f.avx512_bf16 = __builtin_cpu_supports("avx512bf16");
     f.f16c = __builtin_cpu_supports("f16c"), f.fma3 = __builtin_cpu_supports("fma"), f.avx = __builtin_cpu_supports("avx");
+    {   // CPUID.(EAX=7,ECX=0):EDX[23] (gcc 11's __builtin_cpu_supports does not know the name); the OS state check is avx512f's
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (f.avx512f && __get_cpuid_count(7, 0, &a, &b, &c, &d)) f.avx512_fp16 = (d >> 23) & 1u;
+    }
 #endif
     return f;
 }
 
 inline int tier_from_features(const HostFeatures &f) {
+    if (f.avx512f && f.avx512_fp16 && f.avx512vl) return VSGPU_TIER_AVX512_FP16;   // (every such CPU has avx512_bf16 as well)
     if (f.avx512f && f.avx512_bf16 && f.avx512vl) return VSGPU_TIER_AVX512_BF16;
     return VSGPU_TIER_AVX512;
 }
@@ -79,6 +93,7 @@ inline int resolve_tier(int type = -1) {
     if (const char *e = std::getenv("VECSIM_GPU_TIER")) {
         if (!std::strcmp(e, "scalar")) return VSGPU_TIER_SCALAR;
         if (!std::strcmp(e, "avx512_bf16")) return VSGPU_TIER_AVX512_BF16;
+        if (!std::strcmp(e, "avx512_fp16")) return VSGPU_TIER_AVX512_FP16;
         if (!std::strcmp(e, "avx512")) return VSGPU_TIER_AVX512;
     }
     const HostFeatures f = host_features();
@@ -103,7 +118,7 @@ inline int resolve_tier(int type = -1) {
 }
 
 inline const char *tier_name(int tier) {
-    return tier == VSGPU_TIER_SCALAR ? "SCALAR" : tier == VSGPU_TIER_AVX512_BF16 ? "AVX512_BF16" : "AVX512";
+    return tier == VSGPU_TIER_SCALAR ? "SCALAR" : tier == VSGPU_TIER_AVX512_BF16 ? "AVX512_BF16" : tier == VSGPU_TIER_AVX512_FP16 ? "AVX512_FP16" : "AVX512";
 }
 
 }  // namespace vsa

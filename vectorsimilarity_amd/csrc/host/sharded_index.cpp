@@ -71,53 +71,123 @@ std::unique_ptr<ShardOps> make_flat_shard(const BFParams &p, void *logCtx, int d
 }
 }  // namespace
 
-int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
-               const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row) {
-    struct Cand {
-        uint64_t gid;
-        size_t label;
-        double score;
-    };
+// One query of the merge: the parts' candidates with a score at or below the union's k-th smallest, in gid order, through the
+// reference's heap loop.  part_stride: distance between two parts' arrays in 8-byte words (nq * cap when they are contiguous; the
+// exchange records are merged where the collective wrote them).
+namespace {
+struct MergeCand {
+    uint64_t gid;
+    size_t label;
+    double score;
+};
+struct MergeScratch {
+    std::vector<MergeCand> c;
+    std::vector<double> tmp;
+    std::vector<std::pair<double, size_t>> store;
+};
+void merge_one_query(size_t q, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels, const double *scores,
+                     const uint32_t *counts, size_t nq, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row,
+                     MergeScratch &S) {
+    auto &c = S.c;
+    c.clear();
+    for (size_t p = 0; p < parts; p++) {
+        const size_t base = p * part_stride + q * cap;
+        const uint32_t n = counts[p * nq + q];
+        for (uint32_t i = 0; i < n; i++) c.push_back(MergeCand{gids[base + i], labels[base + i], scores[base + i]});
+    }
+    if (!every_row && c.size() > k) {   // (every_row: scores may be NaN -- no order to select by; the heap loop below is the reference's)
+        auto &tmp = S.tmp;
+        tmp.resize(c.size());
+        for (size_t i = 0; i < c.size(); i++) tmp[i] = c[i].score;
+        std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(k - 1), tmp.end());
+        const double T = tmp[k - 1];
+        size_t w = 0;
+        for (size_t i = 0; i < c.size(); i++)
+            if (c[i].score <= T) c[w++] = c[i];
+        c.resize(w);
+    }
+    // std::priority_queue<.., RefPairLess> spelled out over the scratch's storage (push_back + push_heap, pop_heap + pop_back: the
+    // container's definition), so that a query allocates nothing
+    auto &h = S.store;
+    h.clear();
+    const RefPairLess less{};
+    if (!every_row && c.size() <= k) {
+        // at most k rows at or below the k-th score (no tie across it): the heap loop ends holding exactly these whatever the order
+        // they arrive in -- each finds the heap short of k or topped by a score above the k-th -- and pops them from the largest
+        // (score, label) down: the reply is the set in ascending heap order, no replay needed
+        bool ordered = true;
+        for (const MergeCand &x : c) {
+            ordered = ordered && x.score == x.score;
+            h.emplace_back(x.score, x.label);
+        }
+        if (ordered) {
+            std::sort(h.begin(), h.end(), less);
+            out_counts[q] = (uint32_t)h.size();
+            for (size_t i = 0; i < h.size(); i++) out_labels[q * k + i] = h[i].second, out_scores[q * k + i] = h[i].first;
+            return;
+        }
+        h.clear();
+    }
+    std::sort(c.begin(), c.end(), [](const MergeCand &a, const MergeCand &b) { return a.gid < b.gid; });
+    double upper = std::numeric_limits<double>::lowest();
+    for (const MergeCand &x : c) {
+        if (x.score < upper || h.size() < k) {
+            h.emplace_back(x.score, x.label);
+            std::push_heap(h.begin(), h.end(), less);
+            if (h.size() > k) {
+                std::pop_heap(h.begin(), h.end(), less);
+                h.pop_back();
+            }
+            upper = h.front().first;
+        }
+    }
+    out_counts[q] = (uint32_t)h.size();
+    for (size_t i = h.size(); i-- > 0;) {
+        out_labels[q * k + i] = h.front().second;
+        out_scores[q * k + i] = h.front().first;
+        std::pop_heap(h.begin(), h.end(), less);
+        h.pop_back();
+    }
+}
+}  // namespace
+
+int merge_topk_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels, const double *scores,
+                       const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row) {
     for (size_t i = 0; i < parts * nq; i++)
         if (counts[i] == 0xFFFFFFFFu) return -1;
     for (size_t q = 0; q < nq; q++) out_counts[q] = 0;
     if (k == 0) return 0;
-    std::vector<Cand> c;
-    std::vector<double> tmp;
-    for (size_t q = 0; q < nq; q++) {
-        c.clear();
-        for (size_t p = 0; p < parts; p++) {
-            const size_t base = (p * nq + q) * cap;
-            for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
-        }
-        if (!every_row && c.size() > k) {   // (every_row: scores may be NaN -- no order to select by; the heap loop below is the reference's)
-            tmp.resize(c.size());
-            for (size_t i = 0; i < c.size(); i++) tmp[i] = c[i].score;
-            std::nth_element(tmp.begin(), tmp.begin() + (std::ptrdiff_t)(k - 1), tmp.end());
-            const double T = tmp[k - 1];
-            size_t w = 0;
-            for (size_t i = 0; i < c.size(); i++)
-                if (c[i].score <= T) c[w++] = c[i];
-            c.resize(w);
-        }
-        std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
-        RefMaxHeap<> heap;
-        double upper = std::numeric_limits<double>::lowest();
-        for (const Cand &x : c) {
-            if (x.score < upper || heap.size() < k) {
-                heap.emplace(x.score, x.label);
-                if (heap.size() > k) heap.pop();
-                upper = heap.top().first;
-            }
-        }
-        out_counts[q] = (uint32_t)heap.size();
-        for (size_t i = heap.size(); i-- > 0;) {
-            out_labels[q * k + i] = heap.top().second;
-            out_scores[q * k + i] = heap.top().first;
-            heap.pop();
-        }
+    auto range = [&](size_t q0, size_t q1) {
+        MergeScratch S;
+        for (size_t q = q0; q < q1; q++)
+            merge_one_query(q, parts, cap, part_stride, gids, labels, scores, counts, nq, k, out_labels, out_scores, out_counts, every_row, S);
+    };
+    // queries are independent: wide AND deep batches (config 3: 256 queries x top-100 from 8 shards = 800 candidates each, 4.7 ms on one
+    // host thread) merge on a few threads, as the single index's replay does (flat_index.cpp); spawning them costs ~0.3 ms
+    size_t total = 0;
+    for (size_t i = 0; i < parts * nq; i++) total += counts[i];
+    static const size_t max_workers = [] {   // VECSIM_GPU_MERGE_THREADS: 1 = merge on the calling thread
+        const char *e = std::getenv("VECSIM_GPU_MERGE_THREADS");
+        const long v = e ? std::atol(e) : 0;
+        return v > 0 ? (size_t)std::min<long>(v, 64) : std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
+    }();
+    const size_t workers = (!every_row && nq >= 16 && total >= 32768) ? max_workers : 1;
+    if (workers > 1) {
+        std::vector<std::thread> pool;
+        const size_t per = (nq + workers - 1) / workers;
+        for (size_t w = 1; w < workers; w++)
+            if (w * per < nq) pool.emplace_back(range, w * per, std::min(nq, (w + 1) * per));
+        range(0, std::min(nq, per));
+        for (auto &th : pool) th.join();
+    } else {
+        range(0, nq);
     }
     return 0;
+}
+
+int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
+               const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row) {
+    return merge_topk_strided(nq, parts, cap, nq * cap, gids, labels, scores, counts, k, out_labels, out_scores, out_counts, every_row);
 }
 
 // Multi-value merge (brute_force_multi.h:108-277, utils/updatable_heap.h:20-113): the union of the shards' rows in gid order
@@ -125,6 +195,12 @@ int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const 
 // evicting the largest (score, label) on overflow; same procedure as FlatIndex::replayMulti on a single index.
 int merge_topk_multi(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
                      const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts) {
+    return merge_topk_multi_strided(nq, parts, cap, nq * cap, gids, labels, scores, counts, k, out_labels, out_scores, out_counts);
+}
+
+int merge_topk_multi_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels,
+                             const double *scores, const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores,
+                             uint32_t *out_counts) {
     struct Cand {
         uint64_t gid;
         size_t label;
@@ -138,7 +214,7 @@ int merge_topk_multi(size_t nq, size_t parts, size_t cap, const uint64_t *gids, 
         if (k == 0) continue;
         c.clear();
         for (size_t p = 0; p < parts; p++) {
-            const size_t base = (p * nq + q) * cap;
+            const size_t base = p * part_stride + q * cap;
             for (uint32_t i = 0; i < counts[p * nq + q]; i++) c.push_back(Cand{gids[base + i], labels[base + i], scores[base + i]});
         }
         std::sort(c.begin(), c.end(), [](const Cand &a, const Cand &b) { return a.gid < b.gid; });
@@ -497,16 +573,12 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
         all = gathered.data();
     }
     const double t2 = now_ms();
-    // repack for the merge: [part][nq][cap] arrays
+    // the merge reads the records where the collective wrote them (parts rec / 8 words apart); only the counts are repacked
     std::vector<uint32_t> counts(G * nq);
-    std::vector<uint64_t> gids(G * nq * cap);
-    std::vector<size_t> labels(G * nq * cap);
-    std::vector<double> scores(G * nq * cap);
     bool failed = false;
     uint64_t min_nan = ~0ull;
     for (size_t p = 0; p < G; p++) {
-        const char *r = all + p * rec;
-        const uint64_t *hdr = reinterpret_cast<const uint64_t *>(r);
+        const uint64_t *hdr = reinterpret_cast<const uint64_t *>(all + p * rec);
         const uint64_t *cnt = hdr + 4;
         if (hdr[0] & 1) failed = true;
         if (hdr[0] & 2) pass->timed_out = true;
@@ -515,10 +587,10 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
             counts[p * nq + q] = (uint32_t)cnt[q];
             if ((uint32_t)cnt[q] == 0xFFFFFFFFu) pass->overflow = true;
         }
-        std::memcpy(gids.data() + p * nq * cap, cnt + nq, nq * cap * 8);
-        std::memcpy(labels.data() + p * nq * cap, cnt + nq + nq * cap, nq * cap * 8);
-        std::memcpy(scores.data() + p * nq * cap, cnt + nq + 2 * nq * cap, nq * cap * 8);
     }
+    const uint64_t *rec_gids = reinterpret_cast<const uint64_t *>(all) + 4 + nq;
+    const size_t *rec_labels = reinterpret_cast<const size_t *>(rec_gids + nq * cap);
+    const double *rec_scores = reinterpret_cast<const double *>(rec_gids + 2 * nq * cap);
     pass->nan_rows_at_head = !all_rows && !params_.multi && min_nan < (uint64_t)k;   // (multi-value: as on a single index, no NaN-aware replay)
     // every process knows by now whether this batch exchanges again (ties beyond cap, NaN-aware passes): if not, the turn
     // goes to the next batch before the merge
@@ -529,10 +601,10 @@ int ShardedIndex::queryOnce(const void *queries, size_t nq, size_t stride, size_
         out_labels.assign(nq * k, 0);
         out_scores.assign(nq * k, 0.0);
         out_counts.assign(nq, 0);
-        rc = params_.multi ? merge_topk_multi(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k,
-                                              out_labels.data(), out_scores.data(), out_counts.data())
-                           : merge_topk(nq, G, cap, gids.data(), labels.data(), scores.data(), counts.data(), k, out_labels.data(),
-                                        out_scores.data(), out_counts.data(), all_rows);
+        rc = params_.multi ? merge_topk_multi_strided(nq, G, cap, rec / 8, rec_gids, rec_labels, rec_scores, counts.data(), k,
+                                                      out_labels.data(), out_scores.data(), out_counts.data())
+                           : merge_topk_strided(nq, G, cap, rec / 8, rec_gids, rec_labels, rec_scores, counts.data(), k, out_labels.data(),
+                                                out_scores.data(), out_counts.data(), all_rows);
     }
     const double t3 = now_ms();
     {

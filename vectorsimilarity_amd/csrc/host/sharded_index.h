@@ -155,6 +155,14 @@ private:
 int merge_topk(size_t nq, size_t parts, size_t cap, const uint64_t *gids, const size_t *labels, const double *scores,
                const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts,
                bool every_row = false);
+// the same over parts whose arrays lie part_stride 8-byte words apart (the exchange records as the collective wrote them); wide and
+// deep batches are merged on a few host threads (queries are independent)
+int merge_topk_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels,
+                       const double *scores, const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores,
+                       uint32_t *out_counts, bool every_row = false);
+int merge_topk_multi_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels,
+                             const double *scores, const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores,
+                             uint32_t *out_counts);
 std::unique_ptr<Exchange> make_rccl_exchange(vsgpu_ctx *ctx, int rank, int world, const void *id128);
 }  // namespace vsa
 

@@ -29,10 +29,14 @@ struct LaneProgram {
     int elem_bytes = 4;
     bool scalar_tier = false;
     // how the vl accumulator lanes become one number: 0 = halving tree (offsets vl/2 .. 1), 1 = the F16C kernel's
-    // (lane j + lane j+8) + 0, j < 8, then the eight sums added left to right (AVX_utils.h:32-37)
+    // (lane j + lane j+8) + 0, j < 8, then the eight sums added left to right (AVX_utils.h:32-37), 2 = the halving tree in HALF
+    // precision (_mm512_reduce_add_ph)
     int reduce = 0;
     // vdpbf16ps step (avx512_bf16 tier, bf16 IP): inputs and result of every fma flushed to zero when subnormal
     bool dpbf16 = false;
+    // AVX512-FP16 tier, fp16 rows: ONE 32-lane accumulator of HALF precision (vfmadd...ph; L2: vsubph first), reduced by the
+    // halving tree in half precision (reduce = 2), IP finished by a half-precision 1 - x
+    bool f16acc = false;
     std::vector<int32_t> offs;  // steps * vl
     // [full_from, full_to): the longest run of steps in which every lane is active (residual handling makes
     // the first step(s) partial for float kernels, the last one partial for the integer striding)
@@ -153,6 +157,24 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
         return p;
     }
 
+    if (type == VSGPU_F16 && tier == VSGPU_TIER_AVX512_FP16 && dim >= 32) {
+        // IP_AVX512FP16_VL_FP16.h:27-51, L2_AVX512FP16_VL_FP16.h:29-58 (choosers IP_space.cpp:649-658, L2_space.cpp:388-397):
+        // the dim % 32 head through a zero mask (a multiply there; an fma onto +0 gives the same value), then 32 elements per round
+        p.f16acc = true;
+        p.reduce = 2;
+        const size_t residual = dim % 32;
+        size_t pos = 0;
+        if (residual) {
+            int s = new_step();
+            for (size_t j = 0; j < residual; j++) put(s, (int)j, j);
+            pos = residual;
+        }
+        for (; pos < dim; pos += 32) {
+            int s = new_step();
+            for (size_t j = 0; j < 32; j++) put(s, (int)j, pos + j);
+        }
+        return p;
+    }
     if (type == VSGPU_F16 && dim < 16) {
         // F16C tier at dims 8..15 (L2_F16C_FP16.h:28-83, IP_F16C_FP16.h:27-81): the first dim-8 elements go through a
         // zero blend into sum0 (lanes 0..7), the remaining 8-block into sum1 (lanes 8..15); sum2 and sum3 stay zero.
@@ -191,7 +213,7 @@ inline LaneProgram build_lane_program(int type, int kernel_metric, int tier, siz
     // bf16, 16 fp32 lanes, one accumulator
     const size_t residual = dim % 32;
     size_t pos = 0;
-    if (tier == VSGPU_TIER_AVX512_BF16 && !p.is_l2) {
+    if ((tier == VSGPU_TIER_AVX512_BF16 || tier == VSGPU_TIER_AVX512_FP16) && !p.is_l2) {   // (every avx512_fp16 CPU has avx512_bf16)
         // vdpbf16ps (IP_AVX512_BF16_VL_BF16.h:14-47): lane j takes the pair (2j, 2j+1), the odd
         // element first, each accumulated with its own rounding (characterised on hardware, see
         // oracle/vso.c).

@@ -223,12 +223,14 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
     t->opk = t->prog.fused ? (l2 ? OP_L2_FMA : OP_IP_FMA) : (l2 ? OP_L2_MULADD : OP_IP_MULADD);
     // bf16 IP on the avx512_bf16 tier: the vdpbf16ps step (odd element, then even, each with FTZ)
     if (t->prog.dpbf16) t->opk = OP_IP_DPBF16;
+    // fp16 rows on the AVX512-FP16 tier: half-precision accumulators (exact kernels only: prog.reduce = 2 keeps the MFMA filters off)
+    if (t->prog.f16acc) t->opk = l2 ? OP_L2_F16ACC : OP_IP_F16ACC;
     if (is_int) t->epi = l2 ? EPI_INT_L2 : (metric == VSGPU_IP ? EPI_INT_IP : EPI_INT_COS);
     else if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) {
         t->epi = l2 ? EPI_SQ8_L2 : EPI_SQ8_IP;
         t->sq8_centred = metric == VSGPU_IP && row_bytes == dim + 16;
     }
-    else t->epi = l2 ? EPI_L2 : EPI_ONE_MINUS;
+    else t->epi = l2 ? EPI_L2 : (t->prog.f16acc ? EPI_ONE_MINUS_H16 : EPI_ONE_MINUS);
     // SQ8 accumulates the code dot product in the IP order whatever the metric (L2 is algebraic: L2.cpp:30-45)
     if (type == VSGPU_SQ8 || type == VSGPU_SQ8H) t->opk = t->prog.fused ? OP_IP_FMA : OP_IP_MULADD;
     // LDS budget: offs + BT query images.  A CU has 160 KiB; up to 152 KiB go to one workgroup when a wide row needs them (the
@@ -819,6 +821,12 @@ template <int EK> static void launch_scan_op(int opk, int bt, const ScanParams &
     case OP_L2_MULADD: launch_scan_t<EK, OP_L2_MULADD, 1>(P, grid, lds, s); break;
     case OP_IP_DPBF16:
         if constexpr (EK == EK_BF16) launch_scan_t<EK, OP_IP_DPBF16, 1>(P, grid, lds, s);
+        break;
+    case OP_L2_F16ACC:
+        if constexpr (EK == EK_F16) launch_scan_bt<EK, OP_L2_F16ACC>(bt, P, grid, lds, s);
+        break;
+    case OP_IP_F16ACC:
+        if constexpr (EK == EK_F16) launch_scan_bt<EK, OP_IP_F16ACC>(bt, P, grid, lds, s);
         break;
     default: launch_scan_t<EK, OP_IP_MULADD, 1>(P, grid, lds, s); break;
     }
@@ -1551,6 +1559,9 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
         else if (t->opk == OP_IP_DPBF16) hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_DPBF16>), grid, dim3(256), 0, c->stream, S);
         else hipLaunchKernelGGL((k_exact_pairs<EK_BF16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);
+    } else if (t->prog.f16acc) {   // AVX512-FP16 tier: half-precision accumulators
+        if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_F16ACC>), grid, dim3(256), 0, c->stream, S);
+        else hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_IP_F16ACC>), grid, dim3(256), 0, c->stream, S);
     } else {
         if (l2) hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_L2_FMA>), grid, dim3(256), 0, c->stream, S);
         else hipLaunchKernelGGL((k_exact_pairs<EK_F16, OP_IP_FMA>), grid, dim3(256), 0, c->stream, S);

@@ -93,6 +93,12 @@ template <int EK> static void launch_hnsw_ek(int opk, const HnswParams &P, dim3 
     else if (opk == OP_IP_DPBF16) {
         if constexpr (EK == EK_BF16) hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_DPBF16>), grid, dim3(64), lds, s, P);
     }
+    else if (opk == OP_L2_F16ACC) {
+        if constexpr (EK == EK_F16) hipLaunchKernelGGL((k_hnsw_search<EK, OP_L2_F16ACC>), grid, dim3(64), lds, s, P);
+    }
+    else if (opk == OP_IP_F16ACC) {
+        if constexpr (EK == EK_F16) hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_F16ACC>), grid, dim3(64), lds, s, P);
+    }
     else hipLaunchKernelGGL((k_hnsw_search<EK, OP_IP_MULADD>), grid, dim3(64), lds, s, P);
 }
 
