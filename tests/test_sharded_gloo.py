@@ -184,7 +184,7 @@ def test_wide_merge_equals_the_sequential_heap_loop():
     score, queries with fewer candidates than k"""
     from vectorsimilarity_amd.sharded import merge_topk
     rng = np.random.default_rng(77)
-    nq, parts, cap, k = 160, 8, 48, 32
+    nq, parts, cap, k = 224, 8, 48, 32
     gids = np.zeros((parts, nq, cap), dtype=np.uint64)
     labels = np.zeros((parts, nq, cap), dtype=np.uint64)
     scores = np.zeros((parts, nq, cap), dtype=np.float64)
@@ -204,7 +204,7 @@ def test_wide_merge_equals_the_sequential_heap_loop():
             elif kind == 2:
                 sc = np.floor(sc * 300) / 300      # a few ties
             scores[p, q, :n] = sc
-    assert int(counts.sum()) >= 32768   # (the threshold of the threaded merge, sharded_index.cpp)
+    assert int(counts.sum()) + nq * k * 8 >= 100000   # (the work estimate past which the merge runs on threads, sharded_index.cpp)
     l, s = merge_topk(counts, gids, labels, scores, k)
     for q in range(nq):
         cands = sorted((int(gids[p, q, i]), int(labels[p, q, i]), float(scores[p, q, i])) for p in range(parts) for i in range(counts[p, q]))

@@ -162,16 +162,19 @@ int merge_topk_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, 
         for (size_t q = q0; q < q1; q++)
             merge_one_query(q, parts, cap, part_stride, gids, labels, scores, counts, nq, k, out_labels, out_scores, out_counts, every_row, S);
     };
-    // queries are independent: wide AND deep batches (config 3: 256 queries x top-100 from 8 shards = 800 candidates each, 4.7 ms on one
-    // host thread) merge on a few threads, as the single index's replay does (flat_index.cpp); spawning them costs ~0.3 ms
+    // queries are independent: wide AND deep batches merge on a few threads, as the single index's replay does (flat_index.cpp).  On the GPU
+    // box's host (tools/merge_time.py, profiles/r05_merge_time.txt): config 3 from 8 shards -- 256 queries x 800 candidates, k = 100 -- 2.26 ms
+    // on one thread, 0.65 on four, 0.46 on eight; configs 2 / 4 (k = 10) take 0.02-0.035 ms and stay on the caller's thread.  The work is
+    // roughly one step per candidate plus the k-deep selection and ordering per query
     size_t total = 0;
     for (size_t i = 0; i < parts * nq; i++) total += counts[i];
+    const size_t work = total + nq * std::min(k, total / std::max<size_t>(nq, 1) + 1) * 8;
     static const size_t max_workers = [] {   // VECSIM_GPU_MERGE_THREADS: 1 = merge on the calling thread
         const char *e = std::getenv("VECSIM_GPU_MERGE_THREADS");
         const long v = e ? std::atol(e) : 0;
         return v > 0 ? (size_t)std::min<long>(v, 64) : std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency()));
     }();
-    const size_t workers = (!every_row && nq >= 16 && total >= 32768) ? max_workers : 1;
+    const size_t workers = (!every_row && nq >= 16 && work >= 100000) ? max_workers : 1;
     if (workers > 1) {
         std::vector<std::thread> pool;
         const size_t per = (nq + workers - 1) / workers;

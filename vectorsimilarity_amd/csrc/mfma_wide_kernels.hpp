@@ -44,8 +44,10 @@ __device__ static inline void mfw_wait_vmcnt(int n) {
 
 // NQ = 2: 32 queries per workgroup -- every fragment read from LDS feeds two MFMAs and a batch needs half the query tiles, i.e.
 // half the passes over the rows (the tiles of a row tile share it through L2 only in part); 2 x KMINE fragments per wave.
-// NS = ring slots (3 in production: 6 slots for a workgroup alone on its CU measured no faster, profiles/r03_wide_dims.txt).
-template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
+// NS = ring slots, U = stages per unit (one ring barrier per unit).  Round 3 measured 6 slots no faster than 3 -- but then one wave worked per
+// unit; since every wave works in every unit (round 4) the workgroup that is alone on its CU is bound by the bytes it has in flight: 5 slots
+// (4 stages = 64 KiB requested ahead) are 4-21 % faster than 3 at every width and kind (profiles/r05_wide_ring_depth.txt).
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3, int U = 1>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RT = 16;
     constexpr bool INT8 = EK >= 3;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int KPW = KSUB / 4;                    // k-steps per wave per stage: 2 (fp32) or 4
     static_assert(KSUB % 4 == 0, "a stage's k-steps are dealt over the four waves");
     constexpr int KMINE = KCH * KPW;                 // k-steps (= fragments per query block) of one wave
-    static_assert(NS - 1 <= KCH && (NS - 2) * 4 + 2 <= 33, "requests reach into the next tile at most");
+    static_assert(NS - U <= KCH && NS >= 2 * U && (NS - 2 * U) * 4 + 2 <= 33 && KCH % U == 0, "requests reach into the next tile at most");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     make_ptrs(tile + step, rp_nxt, np_nxt);
     uint32_t slot_c = 0, parity = 0;
 #pragma unroll
-    for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
+    for (int u = 0; u < NS - U; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
 
     const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS, EK) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
@@ -193,70 +195,76 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
         for (int nt = 0; nt < NQ; nt++) acc[nt] = acc_v{0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < KCH; c++) {
-            {   // unit (tile, c) landed; the NS - 2 younger units (4 loads each, + the norm load of a unit that opens a tile) may be in flight
+        for (int c = 0; c < KCH; c += U) {
+            {   // the unit's stages (tile, c .. c + U - 1) landed; the NS - 2 U younger stages (4 loads each, + the norm load of a stage that opens a tile) may be in flight
                 int n_norm = 0;
 #pragma unroll
-                for (int j = 1; j < NS - 1; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
-                if (norm_loader) mfw_wait_vmcnt((NS - 2) * 4 + n_norm);
-                else mfw_wait_vmcnt((NS - 2) * 4);
+                for (int j = U; j < NS - U; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
+                if (norm_loader) mfw_wait_vmcnt((NS - 2 * U) * 4 + n_norm);
+                else mfw_wait_vmcnt((NS - 2 * U) * 4);
             }
             mf_ring_barrier();
             if (MODE == MF_FILTER && c == 0) {
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
             }
-            {
-                constexpr int D = NS - 1;
-                uint32_t slot_p = slot_c + D;
+#pragma unroll
+            for (int u = 0; u < U; u++) {   // the slots of the unit every wave has just left take the stages NS - U ahead
+                constexpr int D = NS - U;
+                uint32_t slot_p = slot_c + D + u;
                 if (slot_p >= NS) slot_p -= NS;
-                const int cc = c + D;
+                const int cc = c + D + u;
                 if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
                 else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, parity ^ 1u);
             }
-            {   // this wave's k-steps of the stage
-                const char *sbase = lds + slot_c * MF_STAGE_BYTES;
 #pragma unroll
-                for (int jj = 0; jj < KPW; jj++) {
-                    const int j = jj * 4 + wave;
-                    const int fi = c * KPW + jj;   // the fragment of (stage c, k-step j)
-                    if constexpr (INT8) {
-                        // 8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride
-                        // the signed MFMA re-centred by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
-                        const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
-                        const int p = (4 * (j % 4) + kq) ^ m16;
-                        mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-                        if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+            for (int u = 0; u < U; u++) {
+                uint32_t slot_u = slot_c + u;
+                if (slot_u >= NS) slot_u -= NS;
+                {   // this wave's k-steps of the stage
+                    const char *sbase = lds + slot_u * MF_STAGE_BYTES;
 #pragma unroll
-                        for (int nt = 0; nt < NQ; nt++)
-                            acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
-                    } else if constexpr (EK == 0) {
-                        const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
-                        const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
-                        const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
-                        f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
-                        f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
-                        f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
+                    for (int jj = 0; jj < KPW; jj++) {
+                        const int j = jj * 4 + wave;
+                        const int fi = (c + u) * KPW + jj;   // the fragment of (stage c + u, k-step j)
+                        if constexpr (INT8) {
+                            // 8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride
+                            // the signed MFMA re-centred by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
+                            const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
+                            const int p = (4 * (j % 4) + kq) ^ m16;
+                            mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+                            if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
-                        for (int nt = 0; nt < NQ; nt++)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][fi], acc[nt], 0, 0, 0);
-                    } else {
-                        // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
-                        // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
-                        const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
-                        const int p = (4 * (j % 4) + kq) ^ m16;
-                        const mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+                            for (int nt = 0; nt < NQ; nt++)
+                                acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
+                        } else if constexpr (EK == 0) {
+                            const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
+                            const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
+                            const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
+                            f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+                            f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+                            f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
 #pragma unroll
-                        for (int nt = 0; nt < NQ; nt++) {
-                            if constexpr (EK == 1)
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][fi], acc[nt], 0, 0, 0);
-                            else
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][fi]), acc[nt], 0, 0, 0);
+                            for (int nt = 0; nt < NQ; nt++)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][fi], acc[nt], 0, 0, 0);
+                        } else {
+                            // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
+                            // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
+                            const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
+                            const int p = (4 * (j % 4) + kq) ^ m16;
+                            const mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+#pragma unroll
+                            for (int nt = 0; nt < NQ; nt++) {
+                                if constexpr (EK == 1)
+                                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][fi], acc[nt], 0, 0, 0);
+                                else
+                                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][fi]), acc[nt], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
-            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            slot_c = slot_c + U >= NS ? slot_c + U - NS : slot_c + U;
         }
         // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS; wave 0 goes on ----
         if (wave != 0) {

@@ -171,6 +171,7 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "lowp_variant") c->opt_lowp_variant = value;
     else if (n == "lowp_dbg") c->opt_lowp_dbg = value;
     else if (n == "wide_blocks") c->opt_wide_blocks = value;
+    else if (n == "wide_gx") c->opt_wide_gx = value;
     else if (n == "lowp_wg_per_cu") c->opt_lowp_wg_per_cu = std::max(1L, value);
     else if (n == "lowp_ksplit") c->opt_lowp_ksplit = value;
     else if (n == "lowp_x32") c->opt_lowp_x32 = value;

@@ -55,6 +55,7 @@ struct vsgpu_ctx {
     long opt_lowp_variant = 0;
     long opt_hnsw_slots = 16;  // resident search waves (= visited-tag slots) per CU: 8 -> 264 K QPS, 12-32 -> 314-319 K (200 K x 768)
     long opt_wide_blocks = 0;  // k_mfma_filter_wide: 0 = as many 16-query column blocks per workgroup as the registers hold (4 at width 96 k-steps, 2 up to 192), 1 = always one, 2 = at most two
+    long opt_wide_gx = 0;      // k_mfma_filter_wide: workgroups per query tile (diagnosis); 0 = every query tile of a row tile resident at once
     long opt_sq8_block = 1;    // (rounds 1-2: the SQ8 filter's block pre-screen; accepted, without effect since round 3)
     // timing events in the batch's stream (each costs the GPU's timeline 3-5 us, profiles/r04_event_cost.txt): bit 0 = around the
     // scan kernel (stats.scan_ms: what bench.py's roofline reads), bit 1 = around probe + threshold (stats.other_ms)

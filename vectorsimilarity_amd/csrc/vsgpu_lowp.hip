@@ -285,7 +285,10 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
 
 // bf16 / fp16 rows of 2049 .. 8192 elements on k_mfma_filter_wide (mfma_wide_kernels.hpp): same records, same bound
 #ifndef WIDE_NS_ALONE
-#define WIDE_NS_ALONE 3
+#define WIDE_NS_ALONE 5
+#endif
+#ifndef WIDE_U_ALONE
+#define WIDE_U_ALONE 1
 #endif
 template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     auto go = [&](auto kern, int nqb, int ns) {
@@ -295,16 +298,16 @@ template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blo
         hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
     };
     // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave);
-    // WIDE_NS_ALONE: see vsgpu_mfma.hip (a deeper ring for a workgroup alone on its CU measured no faster)
-    constexpr int NA = WIDE_NS_ALONE;
+    // WIDE_NS_ALONE / WIDE_U_ALONE: see vsgpu_mfma.hip and k_mfma_filter_wide (ring depth of a workgroup alone on its CU)
+    constexpr int NA = WIDE_NS_ALONE, UA = WIDE_U_ALONE;
     switch (ksteps) {
     case 96:   // (four column blocks -- 64 queries in ONE pass over the rows -- fit a wave's 512 registers at this width: half of them AGPRs)
-        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA>, 4, NA);
-        else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
+        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA, UA>, 4, NA);
+        else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
         break;
-    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
-    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
-    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA>, 1, NA); break;
+    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
+    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA, UA>, 1, NA); break;
     }
 }
 static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const LowpParams &L, dim3 grid, hipStream_t s) {
@@ -695,7 +698,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         } else if (t->lp_wide) {
             // gridDim.x a multiple of 8: the query tiles of a row tile (blockIdx.y) land on one XCD and share its L2 (vsgpu_mfma.hip)
             const uint32_t per_cu = (wide_blocks >= 2 || KS > 192) ? 1u : 2u;   // (workgroups resident per CU)
-            const uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
+            if (c->opt_wide_gx > 0) gx = (uint32_t)c->opt_wide_gx;
             launch_wide_h16(t, MF_FILTER, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
         } else if (qsplit) launch_lowp_i8_split(t, MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
         else if (hsplit && t->lp_kind == LP_BF16) launch_lowp_h16_split<LP_BF16>(MF_FILTER, Q, dim3(std::min(total_tiles, fw), (unsigned)q_tiles), c->stream);
