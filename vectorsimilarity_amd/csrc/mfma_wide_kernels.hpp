@@ -6,11 +6,11 @@
 // IP_AVX512F_BW_VL_VNNI_UINT8.h:12-106 -- in the 16-byte aux records of the narrower uint8 Cosine path, k_row_aux_u8c).
 //
 // k_mfma_filter keeps the bf16 fragments of 64 queries in registers (16 per wave); at dim 4096 those alone are the whole
-// register file of a CU.  This variant keeps 16 queries per WORKGROUP and splits the row's k range over the four waves by
-// ring stage: wave w multiplies the stages c with c % 4 == w (one stage = 16 rows x 1 KiB = 256 elements of k), so a wave holds
-// KSTEPS / 4 fragments -- 128 registers at dim 4096, 256 at dim 8192 --, and the four partial dot products of a tile meet in
-// LDS (3 KiB) before the epilogue, which wave 0 runs.  Ring, swizzle, counted vmcnt, candidate queue and the bound E are
-// k_mfma_filter's (mfma_kernels.hpp).  A batch of 64 queries is four query tiles (blockIdx.y): the rows are
+// register file of a CU.  This variant keeps 16 queries per column block of a WORKGROUP (one to four blocks) and splits the row's k
+// range over the four waves: of every ring stage (16 rows x 1 KiB = 256 fp32 elements of k) wave w multiplies the quarter it
+// requested itself (256 bytes of each row), so a wave holds KSTEPS / 4 fragments per block -- 128 registers at dim 4096, 256 at dim
+// 8192 --, and the four partial dot products of a tile meet in LDS before the epilogue, which the waves share by column block.
+// Swizzle, counted vmcnt, candidate queue and the bound E are k_mfma_filter's (mfma_kernels.hpp).  A batch of 64 queries is four query tiles (blockIdx.y): the rows are
 // requested with the default cache policy, not non-temporal, so that the other three tiles' reads of a row hit L2 / the
 // Infinity Cache (workgroups x, x + gridDim.x, ... share an XCD when gridDim.x is a multiple of 8).
 #pragma once
@@ -25,10 +25,10 @@ namespace vsg {
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int MFW_QTILE = 16;               // queries per column block; a workgroup holds NQ of them (1 or 2)
-constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block
-constexpr int mfw_norm_bytes(int ek) { return ek == 5 ? 2048 : 512; }   // two parities of 64 aux values (4 B) / records (16 B)
-constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3, int ek = 0) {
-    return ns * MF_STAGE_BYTES + mfw_norm_bytes(ek) + MF_EQ_BYTES + nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
+constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block: the three other waves' partial sums
+constexpr int mfw_norm_bytes(int ek) { return ek == 5 ? 3072 : 768; }   // three tiles of 64 aux values (4 B) / records (16 B)
+constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3, int ek = 0) {   // (two tiles' partial sums)
+    return ns * MF_STAGE_BYTES + mfw_norm_bytes(ek) + MF_EQ_BYTES + 2 * nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
 }
 // s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
 __device__ static inline void mfw_wait_vmcnt(int n) {
@@ -44,15 +44,23 @@ __device__ static inline void mfw_wait_vmcnt(int n) {
 
 // NQ = 2: 32 queries per workgroup -- every fragment read from LDS feeds two MFMAs and a batch needs half the query tiles, i.e.
 // half the passes over the rows (the tiles of a row tile share it through L2 only in part); 2 x KMINE fragments per wave.
-// NS = ring slots, U = stages per unit (one ring barrier per unit).  Round 3 measured 6 slots no faster than 3 -- but then one wave worked per
-// unit; since every wave works in every unit (round 4) the workgroup that is alone on its CU is bound by the bytes it has in flight: 5 slots
-// (4 stages = 64 KiB requested ahead) are 4-21 % faster than 3 at every width and kind (profiles/r05_wide_ring_depth.txt).
-template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3, int U = 1>
+// NS = ring slots.  Round 3 measured 6 slots no faster than 3 -- but then one wave worked per unit; since every wave works in every
+// unit (round 4) the workgroup that is alone on its CU is bound by the bytes it has in flight: 5 slots (4 stages = 64 KiB requested
+// ahead) are 4-21 % faster than 3 at every width and kind (profiles/r05_wide_ring_depth.txt, _depth2.txt).
+//
+// Round 5, late: NO BARRIER IN THE K LOOP.  A lone workgroup of four column blocks ran at 31.5 GB/s whatever the memory system had to
+// spare (profiles/r05_wide_workgroup_rate.txt: 32, 64 or 128 workgroups on the chip, the same rate each) -- half of its unit period was
+// not MFMA time but the ring barrier, the LDS latency behind it, and wave 0's epilogue with three waves waiting.  Now wave w owns a
+// QUARTER OF EVERY ROW: bytes [256 w, 256 w + 256) of each row's 1 KiB stage segment -- its KPW consecutive k-steps -- are requested by
+// wave w (four LDS-DMA instructions of 4 rows x 256 B), land in wave w's 4 KiB of the ring slot and are read by wave w alone.  What a
+// wave waits for is its own vmcnt; a slot's refill follows the wave's own reads of it; the waves meet once per row tile, where the
+// partial dot products are exchanged, and the epilogue is dealt over the waves by column block (wave nt owns block nt).
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
 __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RT = 16;
     constexpr bool INT8 = EK >= 3;
     constexpr bool U8C = EK == 5;                      // uint8 Cosine: 16-byte aux records {norm, sum (x - 128), 0, 0}
-    constexpr int NORM_BYTES = mfw_norm_bytes(EK), NORM_PAR = NORM_BYTES / 2;
+    constexpr int NORM_BYTES = mfw_norm_bytes(EK), NORM_PAR = NORM_BYTES / 3;   // three tiles' aux values (see the tile-end barrier)
     constexpr int EB = EK == 0 ? 4 : (INT8 ? 1 : 2);   // bytes per stored element
     constexpr int KC = (MF_STAGE_BYTES / EB) / RT;   // 256 (fp32) / 512 (bf16, fp16) / 1024 (int8, uint8) elements per row per stage
     constexpr int SEG = KC * EB;                     // 1 KiB
@@ -61,14 +69,11 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     using acc_v = typename std::conditional<INT8, i32x4w_t, f32x4_t>::type;
     static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
     constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
-    // Which k-steps a wave multiplies.  Round 3 dealt whole STAGES (wave w took the stages c with c % 4 == w): one wave worked
-    // per unit while three sat in the barrier, and the unit period -- that wave's 8-16 k-steps -- bounded a workgroup at
-    // ~21 GB/s.  Now every wave works in every unit: wave w takes the k-steps j with j % 4 == w of each stage, a quarter of
-    // the unit's work each, the same number of fragments per wave (KSTEPS / 4, no short last quadruple).
-    constexpr int KPW = KSUB / 4;                    // k-steps per wave per stage: 2 (fp32) or 4
+    constexpr int KPW = KSUB / 4;                    // k-steps per wave per stage: 2 (fp32) or 4 -- 256 bytes of the row
     static_assert(KSUB % 4 == 0, "a stage's k-steps are dealt over the four waves");
     constexpr int KMINE = KCH * KPW;                 // k-steps (= fragments per query block) of one wave
-    static_assert(NS - U <= KCH && NS >= 2 * U && (NS - 2 * U) * 4 + 2 <= 33 && KCH % U == 0, "requests reach into the next tile at most");
+    static_assert(NS - 1 <= KCH && (NS - 2) * 4 + 2 <= 33, "requests reach into the next tile at most");
+    static_assert(NQ <= 4, "one epilogue wave per column block");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     const int kq = lane >> 4;
     const int qtile = blockIdx.y;
 
-    // this wave's fragments: the k-steps of stages wave, wave + 4, ...
+    // this wave's fragments: k-steps wave * KPW .. wave * KPW + KPW - 1 of every stage
     bf16x8_t qf[NQ][KMINE];
     int qidx[NQ];
     float nq2[NQ], tau[NQ], qnorm[NQ];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         const uint4 *src = P.qfrag + ((size_t)(qtile * NQ + nt) * KSTEPS) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
-            const int s = (i / KPW) * KSUB + (i % KPW) * 4 + wave;   // stage i / KPW, its k-step (i % KPW) * 4 + wave
+            const int s = (i / KPW) * KSUB + wave * KPW + (i % KPW);   // stage i / KPW, its k-step wave * KPW + i % KPW
             uint4 v = src[(size_t)s * 64];
             qf[nt][i] = __builtin_bit_cast(bf16x8_t, v);
         }
@@ -108,21 +113,23 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]), "+v"(qnorm[nt]));
     }
 
+    // request t of this wave: rows 4 t .. 4 t + 3 of the tile, 256 bytes each (16 lanes x 16 B); lane l -> row 4 t + l / 16, LDS slot
+    // l % 16 of the row's 256-byte block, which takes the 16 bytes at slot ^ (row % 16) of the block in memory (the fragment reads of 16
+    // rows 256 B apart then spread over the banks)
     uint32_t st_row[4], st_off[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const uint32_t L = 1024u * (uint32_t)(4 * wave + t) + 16u * (uint32_t)lane;
-        const uint32_t row = L / SEG, slot = (L % SEG) / 16;
+        const uint32_t row = 4u * (uint32_t)t + (uint32_t)(lane >> 4), slot = (uint32_t)lane & 15u;
         st_row[t] = row;
-        st_off[t] = (slot / 16) * 256 + (((slot % 16) ^ (row & 15)) * 16);
+        st_off[t] = 256u * (uint32_t)wave + ((slot ^ (row & 15u)) * 16u);
     }
-    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
+    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);   // this wave's quarter of a ring slot: 16 rows x 256 B
     char *norm_lds = lds + NS * MF_STAGE_BYTES;
     const bool norm_loader = wave == 0;
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + NORM_BYTES);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + NS * MF_STAGE_BYTES + NORM_BYTES + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
-    const uint32_t red_off = mf_lds_offset(lds + NS * MF_STAGE_BYTES + NORM_BYTES + MF_EQ_BYTES);
+    const uint32_t red_off = mf_lds_offset(lds + NS * MF_STAGE_BYTES + NORM_BYTES + MF_EQ_BYTES);   // two tiles' partial sums
     if (MODE == MF_FILTER && tid == 0) *eq_n = 0;
 
     const uint32_t step = gridDim.x;
@@ -158,127 +165,138 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         if (nrow >= P.n_rows) nrow = P.n_rows - 1;
         np = nbase + (size_t)(nrow & P.slab_mask) * (U8C ? 4 : 1);
     };
-    auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_parity) {
+    auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_buf) {
         const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
 #pragma unroll
         for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
         if (with_norm && norm_loader) {
-            if constexpr (U8C) glds16<0>(np, norm_parity * NORM_PAR, norm_lds);   // 64 records of 16 bytes (the tile's 16 in front)
-            else glds4(np, norm_parity * 256, norm_lds);
+            if constexpr (U8C) glds16<0>(np, norm_buf * NORM_PAR, norm_lds);   // 64 records of 16 bytes (the tile's 16 in front)
+            else glds4(np, norm_buf * NORM_PAR, norm_lds);
         }
     };
 
     uint32_t tile = blockIdx.x;
     make_ptrs(tile, rp_cur, np_cur);
     make_ptrs(tile + step, rp_nxt, np_nxt);
-    uint32_t slot_c = 0, parity = 0;
+    uint32_t slot_c = 0, nbuf = 0, rpar = 0;   // ring slot of the current stage; aux buffer (of three) and partial-sum buffer (of two) of the current tile
 #pragma unroll
-    for (int u = 0; u < NS - U; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
+    for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
 
     const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS, EK) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
-    auto flush_probe_minima = [&]() {   // (wave 0 only)
+    auto flush_probe_minima = [&](int nt) {   // (the wave that owns column block nt)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
-#pragma unroll
-            for (int nt = 0; nt < NQ; nt++) {
-                float v;
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (it * NQ + nt) * 64u) : "memory");
-                P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
-            }
+            float v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (it * NQ + nt) * 64u) : "memory");
+            P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pm_n = 0;
     };
+    // One k-step's A operand from this wave's quarter of a ring slot, and its MFMAs.
+    //   8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride the signed MFMA re-centred
+    //               by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
+    //   fp32 rows:  a k-step is 32 elements = 128 bytes, lane (m16, kq) converts its 8
+    //   16-bit rows: a k-step is 64 bytes of the row, lane (m16, kq) reads its 16 (slot (4 jj + kq) ^ m16 of the row's block)
+    using a_t = typename std::conditional<EK == 0, bf16x8_t, mf_u32x4>::type;
+    auto load_a = [&](uint32_t slot, int jj) -> a_t {
+        const char *rowp = lds + slot * MF_STAGE_BYTES + lds_stage_wave_off + m16 * 256;
+        if constexpr (EK == 0) {
+            const int p0 = (8 * jj + 2 * kq) ^ m16;
+            const int p1 = (8 * jj + 2 * kq + 1) ^ m16;
+            f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
+            f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
+            f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_convertvector(x, bf16x8_t);
+        } else {
+            const int p = (4 * jj + kq) ^ m16;
+            mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
+            if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+            return a;
+        }
+    };
+    // PF fragments of the NEXT stage are read while this stage's MFMAs run (nothing but the wave's own vmcnt says when a stage is
+    // there), so a unit starts multiplying at once instead of behind an LDS round trip
+    constexpr int PF = KPW >= 4 ? 2 : 1;
+    constexpr int NPF = PF * (EK == 0 ? 2 : 1);   // LDS reads behind PF operands
+    a_t apf[PF];
+    mfw_wait_vmcnt((NS - 2) * 4);   // stage 0 (and, wave 0, its aux values): NS - 2 younger stages in flight
+#pragma unroll
+    for (int j = 0; j < PF; j++) apf[j] = load_a(0, j);
     for (; tile < P.n_tiles; tile += step) {
         acc_v acc[NQ];
 #pragma unroll
         for (int nt = 0; nt < NQ; nt++) acc[nt] = acc_v{0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < KCH; c += U) {
-            {   // the unit's stages (tile, c .. c + U - 1) landed; the NS - 2 U younger stages (4 loads each, + the norm load of a stage that opens a tile) may be in flight
-                int n_norm = 0;
-#pragma unroll
-                for (int j = U; j < NS - U; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
-                if (norm_loader) mfw_wait_vmcnt((NS - 2 * U) * 4 + n_norm);
-                else mfw_wait_vmcnt((NS - 2 * U) * 4);
-            }
-            mf_ring_barrier();
-            if (MODE == MF_FILTER && c == 0) {
-                if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {   // the slots of the unit every wave has just left take the stages NS - U ahead
-                constexpr int D = NS - U;
-                uint32_t slot_p = slot_c + D + u;
-                if (slot_p >= NS) slot_p -= NS;
-                const int cc = c + D + u;
-                if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
-                else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, parity ^ 1u);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint32_t slot_u = slot_c + u;
-                if (slot_u >= NS) slot_u -= NS;
-                {   // this wave's k-steps of the stage
-                    const char *sbase = lds + slot_u * MF_STAGE_BYTES;
-#pragma unroll
-                    for (int jj = 0; jj < KPW; jj++) {
-                        const int j = jj * 4 + wave;
-                        const int fi = (c + u) * KPW + jj;   // the fragment of (stage c + u, k-step j)
-                        if constexpr (INT8) {
-                            // 8-bit rows: a k-step is 64 elements = 64 bytes of the row, read like a 16-bit k-step; uint8 rows ride
-                            // the signed MFMA re-centred by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
-                            const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
-                            const int p = (4 * (j % 4) + kq) ^ m16;
-                            mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-                            if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-#pragma unroll
-                            for (int nt = 0; nt < NQ; nt++)
-                                acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
-                        } else if constexpr (EK == 0) {
-                            const char *rowp = sbase + m16 * SEG + (j / 2) * 256;
-                            const int p0 = (8 * (j % 2) + 2 * kq) ^ m16;
-                            const int p1 = (8 * (j % 2) + 2 * kq + 1) ^ m16;
-                            f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
-                            f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
-                            f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                            bf16x8_t a = __builtin_convertvector(x, bf16x8_t);
-#pragma unroll
-                            for (int nt = 0; nt < NQ; nt++)
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[nt][fi], acc[nt], 0, 0, 0);
-                        } else {
-                            // 16-bit rows: k-step j of the stage is 64 bytes of the row, lane (m16, kq) reads its 16 (the swizzle of
-                            // k_mfma_filter_lowp: 256-byte block j / 4, slot (4 (j % 4) + kq) ^ m16)
-                            const char *rowp = sbase + m16 * SEG + (j / 4) * 256;
-                            const int p = (4 * (j % 4) + kq) ^ m16;
-                            const mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-#pragma unroll
-                            for (int nt = 0; nt < NQ; nt++) {
-                                if constexpr (EK == 1)
-                                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][fi], acc[nt], 0, 0, 0);
-                                else
-                                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][fi]), acc[nt], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
-            slot_c = slot_c + U >= NS ? slot_c + U - NS : slot_c + U;
-        }
-        // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS; wave 0 goes on ----
-        if (wave != 0) {
+        auto mma = [&](a_t a, int fi) {
 #pragma unroll
             for (int nt = 0; nt < NQ; nt++) {
+                if constexpr (INT8)
+                    acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4w_t, a), __builtin_bit_cast(i32x4w_t, qf[nt][fi]), acc[nt], 0, 0, 0);
+                else if constexpr (EK == 2)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, qf[nt][fi]), acc[nt], 0, 0, 0);
+                else
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qf[nt][fi], acc[nt], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            {   // the slot this wave finished with the previous stage takes the stage NS - 1 ahead.  Its reads of that slot must be complete
+                // (hipcc may have left their wait next to the MFMAs that consume them, and those may sit below this point): LDS operations
+                // return in order, and the only ones issued since are the NPF reads that fetched THIS stage's first operands
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NPF) : "memory");
+                constexpr int D = NS - 1;
+                uint32_t slot_p = slot_c + D;
+                if (slot_p >= NS) slot_p -= NS;
+                const int cc = c + D;
+                const uint32_t nb1 = nbuf + 1 >= 3 ? 0 : nbuf + 1;
+                if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
+                else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, nb1);
+            }
+            // this wave's k-steps of the stage, from its own quarter of the slot: the first PF operands are in registers
+            a_t a[KPW];
+#pragma unroll
+            for (int jj = 0; jj < KPW; jj++) a[jj] = jj < PF ? apf[jj] : load_a(slot_c, jj);
+            mma(a[0], c * KPW);
+            {   // this wave's part of stage c + 1 landed?  Its NS - 2 younger stages (4 loads each, + the aux load of a stage that opens a
+                // tile) may be in flight.  Then its first operands, under the MFMAs just issued
+                int n_norm = 0;
+#pragma unroll
+                for (int j = 2; j < NS; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
+                if (norm_loader) mfw_wait_vmcnt((NS - 2) * 4 + n_norm);
+                else mfw_wait_vmcnt((NS - 2) * 4);
+                const uint32_t slot_n = slot_c + 1 == NS ? 0 : slot_c + 1;
+#pragma unroll
+                for (int j = 0; j < PF; j++) apf[j] = load_a(slot_n, j);
+            }
+#pragma unroll
+            for (int jj = 1; jj < KPW; jj++) mma(a[jj], c * KPW + jj);
+            slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+        }
+        // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS: wave nt collects column block nt ----
+        const uint32_t red_tile = red_off + rpar * (uint32_t)(NQ * MFW_RED_BYTES);
+#pragma unroll
+        for (int nt = 0; nt < NQ; nt++) {
+            if (wave != nt) {
+                const int k3 = wave < nt ? wave : wave - 1;   // which of the three partials of block nt this wave writes
                 const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc[nt]);
-                asm volatile("ds_write_b128 %0, %1" ::"v"(red_off + (uint32_t)(nt * MFW_RED_BYTES + (wave - 1) * 1024 + lane * 16)), "v"(v) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(red_tile + (uint32_t)(nt * MFW_RED_BYTES + k3 * 1024 + lane * 16)), "v"(v) : "memory");
             }
         }
+        // The one barrier of a row tile.  Behind it every wave has left the previous tile's epilogue, so: the queue length is final and
+        // uniform (flush decision), the other partial-sum buffer may be written again by the next tile, and the aux buffer this tile's
+        // successor will have refilled two tiles on is no longer read (three aux buffers: wave 0 requests tile t + 1's values during
+        // tile t, i.e. possibly while other waves are still in the epilogue of tile t - 1).
         mf_ring_barrier();
+        if (MODE == MF_FILTER) {
+            if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+        }
         const uint32_t r0 = tile_row0(tile);
         bool emitted = false;
-        if (wave == 0) {
-            const float *nrm = reinterpret_cast<const float *>(norm_lds + parity * NORM_PAR);
+#pragma unroll
+        for (int nt = 0; nt < NQ; nt++) {
+            if (wave != nt) continue;
+            const float *nrm = reinterpret_cast<const float *>(norm_lds + nbuf * NORM_PAR);
             mf_u32x4 nbits, sxbits = {0u, 0u, 0u, 0u};
             if constexpr (U8C) {   // rows kq * 4 + i: the record's first two words
                 u32x2_t r2[4];
@@ -292,73 +310,68 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
             }
             const f32x4_t n4 = __builtin_bit_cast(f32x4_t, nbits);
+            mf_u32x4 p1, p2, p3;
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                         : "v"(red_tile + (uint32_t)(nt * MFW_RED_BYTES + lane * 16))
+                         : "memory");
+            acc_v a4 = acc[nt];
+            a4 += __builtin_bit_cast(acc_v, p1);
+            a4 += __builtin_bit_cast(acc_v, p2);
+            a4 += __builtin_bit_cast(acc_v, p3);
+            float tmin = INFINITY;
 #pragma unroll
-            for (int nt = 0; nt < NQ; nt++) {
-                mf_u32x4 p1, p2, p3;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(p1), "=&v"(p2), "=&v"(p3)
-                             : "v"(red_off + (uint32_t)(nt * MFW_RED_BYTES + lane * 16))
-                             : "memory");
-                acc_v a4 = acc[nt];
-                a4 += __builtin_bit_cast(acc_v, p1);
-                a4 += __builtin_bit_cast(acc_v, p2);
-                a4 += __builtin_bit_cast(acc_v, p3);
-                float tmin = INFINITY;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t row = r0 + kq * 4 + i;
-                    float low, up;
-                    bool pass;
-                    if constexpr (INT8) {
-                        // exact integer dot: the reference's own score (mfma_lowp_kernels.hpp has the same four epilogues); aux =
-                        // sum x^2 (L2; of the re-centred bytes for uint8), sum x' (uint8 IP) or the stored float norm (Cosine)
-                        int dot = (int)a4[i];
-                        const uint32_t av = nbits[i];
-                        uint32_t qa = __float_as_uint(nq2[nt]);
-                        if constexpr (U8C) {   // sum x q = sum x'q' + 128 sum x' + (128 sum q' + 128^2 dim); the score from the two stored norms
-                            dot += 128 * (int)sxbits[i] + (int)qa;
-                            qa = __float_as_uint(qnorm[nt]);
-                        }
-                        float sc;
-                        if (P.iepi == 2) sc = (float)((int)av + (int)qa - 2 * dot);
-                        else if (P.iepi == 3) sc = (float)(1 - dot);
-                        else if (P.iepi == 5) sc = (float)(1 - (dot + 128 * (int)av + (int)qa));
-                        else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qa))));
-                        low = up = sc;
-                        pass = sc <= tau[nt];
-                    } else {
-                        const float ssum = n4[i] + nq2[nt];
-                        const float dot = (float)a4[i];
-                        const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
-                        const float E = P.cE * ssum + P.absE;
-                        low = a - E;
-                        up = a + E;
-                        pass = !(low > tau[nt]);
+            for (int i = 0; i < 4; i++) {
+                const uint32_t row = r0 + kq * 4 + i;
+                float low, up;
+                bool pass;
+                if constexpr (INT8) {
+                    // exact integer dot: the reference's own score (mfma_lowp_kernels.hpp has the same four epilogues); aux =
+                    // sum x^2 (L2; of the re-centred bytes for uint8), sum x' (uint8 IP) or the stored float norm (Cosine)
+                    int dot = (int)a4[i];
+                    const uint32_t av = nbits[i];
+                    uint32_t qa = __float_as_uint(nq2[nt]);
+                    if constexpr (U8C) {   // sum x q = sum x'q' + 128 sum x' + (128 sum q' + 128^2 dim); the score from the two stored norms
+                        dot += 128 * (int)sxbits[i] + (int)qa;
+                        qa = __float_as_uint(qnorm[nt]);
                     }
-                    if (MODE == MF_PROBE) {
-                        if (row < P.n_rows && up < tmin) tmin = up;
-                    } else {
-                        if (row < P.n_rows && pass) {
-                            const uint32_t pos = mf_queue_reserve(eq_n_off);
-                            if (pos < MF_EQ_CAP) {
-                                mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
-                            } else {
-                                uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
-                                if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                                emitted = true;
-                            }
-                        }
-                    }
+                    float sc;
+                    if (P.iepi == 2) sc = (float)((int)av + (int)qa - 2 * dot);
+                    else if (P.iepi == 3) sc = (float)(1 - dot);
+                    else if (P.iepi == 5) sc = (float)(1 - (dot + 128 * (int)av + (int)qa));
+                    else sc = __fsub_rn(1.0f, __fdiv_rn((float)dot, __fmul_rn(__uint_as_float(av), __uint_as_float(qa))));
+                    low = up = sc;
+                    pass = sc <= tau[nt];
+                } else {
+                    const float ssum = n4[i] + nq2[nt];
+                    const float dot = (float)a4[i];
+                    const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
+                    const float E = P.cE * ssum + P.absE;
+                    low = a - E;
+                    up = a + E;
+                    pass = !(low > tau[nt]);
                 }
                 if (MODE == MF_PROBE) {
-                    tmin = fminf(tmin, __shfl_xor(tmin, 16));
-                    tmin = fminf(tmin, __shfl_xor(tmin, 32));
-                    if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + (pm_n * NQ + nt) * 64u), "v"(tmin) : "memory");
+                    if (row < P.n_rows && up < tmin) tmin = up;
+                } else {
+                    if (row < P.n_rows && pass) {
+                        const uint32_t pos = mf_queue_reserve(eq_n_off);
+                        if (pos < MF_EQ_CAP) {
+                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx[nt], __float_as_uint(low));
+                        } else {
+                            uint32_t s = atomicAdd(&P.counts[qidx[nt]], 1u);
+                            if (s < P.cap) P.cand[(size_t)qidx[nt] * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                            emitted = true;
+                        }
+                    }
                 }
             }
             if (MODE == MF_PROBE) {
+                tmin = fminf(tmin, __shfl_xor(tmin, 16));
+                tmin = fminf(tmin, __shfl_xor(tmin, 32));
+                if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + (pm_n * NQ + nt) * 64u), "v"(tmin) : "memory");
                 if (pm_n == 0) pm_tile0 = tile;
-                if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
+                if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima(nt);
             }
         }
         if (MODE == MF_FILTER) {
@@ -369,9 +382,14 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         for (int i = 0; i < 4; i++) rp_cur[i] = rp_nxt[i];
         np_cur = np_nxt;
         make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
-        parity ^= 1u;
+        nbuf = nbuf + 1 >= 3 ? 0 : nbuf + 1;
+        rpar ^= 1u;
     }
-    if (MODE == MF_PROBE && wave == 0 && pm_n) flush_probe_minima();
+    if (MODE == MF_PROBE && pm_n) {
+#pragma unroll
+        for (int nt = 0; nt < NQ; nt++)
+            if (wave == nt) flush_probe_minima(nt);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER) {
         __builtin_amdgcn_s_barrier();

@@ -287,9 +287,6 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
 #ifndef WIDE_NS_ALONE
 #define WIDE_NS_ALONE 5
 #endif
-#ifndef WIDE_U_ALONE
-#define WIDE_U_ALONE 1
-#endif
 template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     auto go = [&](auto kern, int nqb, int ns) {
         const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns, EK);
@@ -298,16 +295,16 @@ template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blo
         hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
     };
     // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave);
-    // WIDE_NS_ALONE / WIDE_U_ALONE: see vsgpu_mfma.hip and k_mfma_filter_wide (ring depth of a workgroup alone on its CU)
-    constexpr int NA = WIDE_NS_ALONE, UA = WIDE_U_ALONE;
+    // WIDE_NS_ALONE: see vsgpu_mfma.hip and k_mfma_filter_wide (ring depth of a workgroup alone on its CU)
+    constexpr int NA = WIDE_NS_ALONE;
     switch (ksteps) {
     case 96:   // (four column blocks -- 64 queries in ONE pass over the rows -- fit a wave's 512 registers at this width: half of them AGPRs)
-        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA, UA>, 4, NA);
-        else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
+        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA>, 4, NA);
+        else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
         break;
-    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
-    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA, UA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
-    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA, UA>, 1, NA); break;
+    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
+    default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA>, 1, NA); break;
     }
 }
 static void launch_wide_h16(const vsgpu_table *t, int mode, int nq_blocks, const LowpParams &L, dim3 grid, hipStream_t s) {

@@ -144,42 +144,39 @@ static void launch_probe(int ksteps, const MfmaParams &P, dim3 grid, hipStream_t
 }
 
 // rows wider than 3072 elements: 16 queries per workgroup, the k range split over the waves (mfma_wide_kernels.hpp)
-template <int KS, int MODE, int NQ, int NS, int U = 1> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
+template <int KS, int MODE, int NQ, int NS> static void launch_wide_ks(const MfmaParams &P, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, NQ, NS);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
 #ifdef VSGPU_TUNING
     if (getenv("VSGPU_WIDE_NT")) {
-        auto k2 = k_mfma_filter_wide<KS, MODE, 2, 0, NQ, NS, U>;
+        auto k2 = k_mfma_filter_wide<KS, MODE, 2, 0, NQ, NS>;
         if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         hipLaunchKernelGGL(k2, grid, dim3(256), lds_bytes, s, P);
         return;
     }
 #endif
-    auto kern = k_mfma_filter_wide<KS, MODE, 0, 0, NQ, NS, U>;
+    auto kern = k_mfma_filter_wide<KS, MODE, 0, 0, NQ, NS>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
 }
 // nq_blocks: 16-query column blocks per workgroup (2 up to width 6144: the fragments of 32 queries fit the registers of a wave).
-// WIDE_NS_ALONE / WIDE_U_ALONE: ring slots and stages per unit of a workgroup that is alone on its CU (two blocks, or width 8192): see
-// k_mfma_filter_wide (profiles/r05_wide_ring_depth.txt)
+// WIDE_NS_ALONE: ring slots of a workgroup that is alone on its CU (two blocks, or width 8192): see k_mfma_filter_wide
+// (profiles/r05_wide_ring_depth.txt; two stages per ring barrier, while the loop still had one, measured no faster: _depth2.txt)
 #ifndef WIDE_NS_ALONE
 #define WIDE_NS_ALONE 5
-#endif
-#ifndef WIDE_U_ALONE
-#define WIDE_U_ALONE 1
 #endif
 template <int MODE> static void launch_wide(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     switch (ksteps) {
     case 128:
-        if (nq_blocks == 2) launch_wide_ks<128, MODE, 2, WIDE_NS_ALONE, WIDE_U_ALONE>(P, grid, s);
+        if (nq_blocks == 2) launch_wide_ks<128, MODE, 2, WIDE_NS_ALONE>(P, grid, s);
         else launch_wide_ks<128, MODE, 1, 3>(P, grid, s);
         break;
     case 192:
-        if (nq_blocks == 2) launch_wide_ks<192, MODE, 2, WIDE_NS_ALONE, WIDE_U_ALONE>(P, grid, s);
+        if (nq_blocks == 2) launch_wide_ks<192, MODE, 2, WIDE_NS_ALONE>(P, grid, s);
         else launch_wide_ks<192, MODE, 1, 3>(P, grid, s);
         break;
-    default: launch_wide_ks<256, MODE, 1, WIDE_NS_ALONE, WIDE_U_ALONE>(P, grid, s); break;
+    default: launch_wide_ks<256, MODE, 1, WIDE_NS_ALONE>(P, grid, s); break;
     }
 }
 
