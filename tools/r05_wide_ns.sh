@@ -9,8 +9,8 @@ cp vectorsimilarity_amd/libvsgpu.so vectorsimilarity_amd/ab/libvsgpu_cur.so
 {
 for v in ${VERSIONS:-base ns4 ns5 base}; do
   cp vectorsimilarity_amd/ab/libvsgpu_$v.so vectorsimilarity_amd/libvsgpu.so
-  for spec in "bf16 IP 3072 64" "bf16 IP 3072 128" "bf16 IP 4096 64" "bf16 IP 6144 64" "bf16 IP 8192 64" "i8 L2 6144 128" "i8 L2 8192 64" \
-              "i8 L2 16384 64" "u8 Cosine 8192 64" "f32 L2 4096 64" "f32 L2 6144 64" "f32 L2 8192 64"; do
+  IFS=';' read -ra LIST <<< "${SPECS:-bf16 IP 3072 64;bf16 IP 3072 128;bf16 IP 4096 64;bf16 IP 6144 64;bf16 IP 8192 64;i8 L2 6144 128;i8 L2 8192 64;i8 L2 16384 64;u8 Cosine 8192 64;f32 L2 4096 64;f32 L2 6144 64;f32 L2 8192 64}"
+  for spec in "${LIST[@]}"; do
     set -- $spec
     echo "$v $(python tools/bench_dims.py --type $1 --metric $2 --batch $4 $3 2>&1 | tail -1)"
   done

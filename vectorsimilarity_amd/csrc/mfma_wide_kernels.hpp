@@ -25,10 +25,10 @@ namespace vsg {
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int MFW_QTILE = 16;               // queries per column block; a workgroup holds NQ of them (1 or 2)
-constexpr int MFW_RED_BYTES = 3 * 64 * 16;   // per column block: the three other waves' partial sums
+constexpr int mfw_red_bytes(int nw) { return (nw - 1) * 64 * 16; }   // per column block: the other waves' partial sums
 constexpr int mfw_norm_bytes(int ek) { return ek == 5 ? 3072 : 768; }   // three tiles of 64 aux values (4 B) / records (16 B)
-constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3, int ek = 0) {   // (two tiles' partial sums)
-    return ns * MF_STAGE_BYTES + mfw_norm_bytes(ek) + MF_EQ_BYTES + 2 * nq * MFW_RED_BYTES + (probe ? nq * MF_PM_TILES * 64 : 0);
+constexpr int mfw_lds_bytes(bool probe, int nq = 1, int ns = 3, int ek = 0, int nw = 4) {   // (two tiles' partial sums)
+    return ns * MF_STAGE_BYTES + mfw_norm_bytes(ek) + MF_EQ_BYTES + 2 * nq * mfw_red_bytes(nw) + (probe ? nq * MF_PM_TILES * 64 : 0);
 }
 // s_waitcnt needs an immediate: after unrolling, n is a constant and the switch folds to one instruction
 __device__ static inline void mfw_wait_vmcnt(int n) {
@@ -55,8 +55,15 @@ __device__ static inline void mfw_wait_vmcnt(int n) {
 // wave w (four LDS-DMA instructions of 4 rows x 256 B), land in wave w's 4 KiB of the ring slot and are read by wave w alone.  What a
 // wave waits for is its own vmcnt; a slot's refill follows the wave's own reads of it; the waves meet once per row tile, where the
 // partial dot products are exchanged, and the epilogue is dealt over the waves by column block (wave nt owns block nt).
-template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3>
-__global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
+// NW = 8 (tuning only): EIGHT waves, an eighth of every row each (128 B per stage, two requests of 8 rows x 128 B).  With four waves
+// of 512 registers a SIMD has one wave, and whatever that wave waits for -- above all the issue of its LDS-DMA requests, 60-185 cycles
+// apiece -- the matrix pipe waits for too (a lone workgroup of four column blocks: 43 GB/s, a third of it MFMA time); eight waves would
+// give every SIMD a second wave to multiply meanwhile.  Built and measured for four column blocks at 96 k-steps: bit-identical replies,
+// but 192 registers of fragments + 16 accumulators + ~90 others do not fit a wave's 256 -- 50-80 spilled, some inside the k loop --
+// and the filter ran at HALF the rate (bf16 3072, batch 128: 1.77 against 4.8 TB/s; profiles/r05_wide_eight_waves.txt).  Two column
+// blocks per workgroup would fit, and then a batch crosses the rows twice as often: not built.
+template <int KSTEPS, int MODE, int AUX = 0, int EK = 0, int NQ = 1, int NS = 3, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RT = 16;
     constexpr bool INT8 = EK >= 3;
     constexpr bool U8C = EK == 5;                      // uint8 Cosine: 16-byte aux records {norm, sum (x - 128), 0, 0}
@@ -69,10 +76,17 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     using acc_v = typename std::conditional<INT8, i32x4w_t, f32x4_t>::type;
     static_assert(KSTEPS % KSUB == 0, "the row is a whole number of stages");
     constexpr int KCH = KSTEPS / KSUB;               // stages per row tile
-    constexpr int KPW = KSUB / 4;                    // k-steps per wave per stage: 2 (fp32) or 4 -- 256 bytes of the row
-    static_assert(KSUB % 4 == 0, "a stage's k-steps are dealt over the four waves");
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    constexpr int KPW = KSUB / NW;                   // k-steps per wave per stage: 2 (fp32) or 4 with four waves -- BW bytes of the row
+    static_assert(KSUB % NW == 0, "a stage's k-steps are dealt over the waves");
+    constexpr int BW = SEG / NW;                     // bytes of a row's stage segment per wave: 256 / 128
+    constexpr int LPR = BW / 16;                     // lanes (16-byte slots) per row of a request: 16 / 8
+    constexpr int RPP = 64 / LPR;                    // rows per request: 4 / 8
+    constexpr int PP = RT / RPP;                     // requests per wave and stage: 4 / 2
+    constexpr int WREG = RT * BW;                    // a wave's share of a ring slot: 4 KiB / 2 KiB
+    constexpr int RED_BYTES = mfw_red_bytes(NW);
     constexpr int KMINE = KCH * KPW;                 // k-steps (= fragments per query block) of one wave
-    static_assert(NS - 1 <= KCH && (NS - 2) * 4 + 2 <= 33, "requests reach into the next tile at most");
+    static_assert(NS - 1 <= KCH && (NS - 2) * PP + 2 <= 33, "requests reach into the next tile at most");
     static_assert(NQ <= 4, "one epilogue wave per column block");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -106,24 +120,28 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
             // more than ~220 registers of fragments (four column blocks at KSTEPS 96): the upper half is parked in AGPRs, which the
-            // MFMA reads directly (one wave per SIMD owns all 512 registers of a lane); left to hipcc they are spilled
-            if (NQ * KMINE * 4 > 224 && nt >= NQ / 2) asm volatile("" : "+a"(qf[nt][i]));
+            // MFMA reads directly (one wave per SIMD owns all 512 registers of a lane, one of two 256); left to hipcc they are spilled
+            if (NQ * KMINE * 4 > (NW == 8 ? 100 : 224) && nt >= NQ / 2) asm volatile("" : "+a"(qf[nt][i]));
             else asm volatile("" : "+v"(qf[nt][i]));
         }
         asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]), "+v"(qnorm[nt]));
     }
 
-    // request t of this wave: rows 4 t .. 4 t + 3 of the tile, 256 bytes each (16 lanes x 16 B); lane l -> row 4 t + l / 16, LDS slot
-    // l % 16 of the row's 256-byte block, which takes the 16 bytes at slot ^ (row % 16) of the block in memory (the fragment reads of 16
-    // rows 256 B apart then spread over the banks)
-    uint32_t st_row[4], st_off[4];
+    // request t of this wave: rows RPP t .. RPP t + RPP - 1 of the tile, BW bytes each (LPR lanes x 16 B); lane l -> row RPP t + l / LPR,
+    // LDS slot l % LPR of the row's block, which takes the 16 bytes at slot ^ swz(row) of the block in memory (the fragment reads of 16
+    // rows BW bytes apart then spread over the banks: swz = row % 16 for 16 slots; for 8 slots row % 8 ^ row / 8 -- rows r and r + 8 lie
+    // 1 KiB apart, on the same banks)
+    // The request's address is a wave-uniform base in SGPRs -- the tile's first row, the stage's column -- plus this constant 32-bit offset
+    // of the lane (`global_load_lds_dwordx4 v, s[..]`: no 64-bit VGPR address per request, none to rebuild per tile).  Rows past the
+    // table's end are not clamped: a tile never leaves its slab, slabs are allocated whole, the epilogue masks such rows.
+    auto swz = [](uint32_t row) -> uint32_t { return NW == 4 ? (row & 15u) : ((row & 7u) ^ (row >> 3)); };
+    uint32_t voff[PP];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint32_t row = 4u * (uint32_t)t + (uint32_t)(lane >> 4), slot = (uint32_t)lane & 15u;
-        st_row[t] = row;
-        st_off[t] = 256u * (uint32_t)wave + ((slot ^ (row & 15u)) * 16u);
+    for (int t = 0; t < PP; t++) {
+        const uint32_t row = (uint32_t)(RPP * t) + (uint32_t)lane / (uint32_t)LPR, slot = (uint32_t)lane % (uint32_t)LPR;
+        voff[t] = row * P.row_stride + (uint32_t)BW * (uint32_t)wave + ((slot ^ swz(row)) * 16u);
     }
-    const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);   // this wave's quarter of a ring slot: 16 rows x 256 B
+    const uint32_t lds_stage_wave_off = (uint32_t)(wave * WREG);   // this wave's share of a ring slot: 16 rows x BW bytes
     char *norm_lds = lds + NS * MF_STAGE_BYTES;
     const bool norm_loader = wave == 0;
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + NS * MF_STAGE_BYTES + NORM_BYTES);
@@ -136,11 +154,11 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
         return (P.tile_first + (t >> P.tile_run_shift) * (P.tile_step << P.tile_run_shift) + (t & ((1u << P.tile_run_shift) - 1u))) * RT;
     };
-    const char *rp_cur[4], *rp_nxt[4];
+    uint64_t rb_cur, rb_nxt;   // (scalar) address of the tile's first row
     const float *np_cur, *np_nxt;
     uint32_t cur_slab = 0xFFFFFFFFu;
     uint64_t cur_sbase = 0, cur_nbase = 0;
-    auto make_ptrs = [&](uint32_t t, const char *(&rp)[4], const float *&np) {
+    auto make_ptrs = [&](uint32_t t, uint64_t &rb, const float *&np) {
         uint32_t tt = t < P.n_tiles ? t : P.n_tiles - 1;
         const uint32_t r0 = tile_row0(tt);
         const uint32_t sidx = __builtin_amdgcn_readfirstlane(r0 >> P.slab_shift);
@@ -153,22 +171,24 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                          : "s"(sp), "s"(npp)
                          : "memory");
         }
-        const char *sbase = reinterpret_cast<const char *>(cur_sbase);
         const float *nbase = reinterpret_cast<const float *>(cur_nbase);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t row = r0 + st_row[i];
-            if (row >= P.n_rows) row = P.n_rows - 1;
-            rp[i] = sbase + (size_t)(row & P.slab_mask) * P.row_stride + st_off[i];
-        }
+        const uint32_t rs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r0 & P.slab_mask));
+        rb = cur_sbase + (uint64_t)rs * (uint64_t)P.row_stride;
         uint32_t nrow = r0 + lane;
         if (nrow >= P.n_rows) nrow = P.n_rows - 1;
         np = nbase + (size_t)(nrow & P.slab_mask) * (U8C ? 4 : 1);
     };
-    auto issue = [&](const char *const (&rp)[4], const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_buf) {
-        const uint32_t base = slot * MF_STAGE_BYTES + lds_stage_wave_off;
+    const uint32_t lds_ring_off = mf_lds_offset(lds) + lds_stage_wave_off;
+    auto issue = [&](uint64_t rb, const float *np, int kc, uint32_t slot, bool with_norm, uint32_t norm_buf) {
+        const uint32_t base = lds_ring_off + slot * MF_STAGE_BYTES;
+        const uint64_t sb = rb + (uint64_t)(kc * SEG);
 #pragma unroll
-        for (int i = 0; i < 4; i++) glds16<AUX>(rp[i] + (size_t)kc * SEG, base + i * 1024, lds);
+        for (int i = 0; i < PP; i++) {   // LDS address = M0 + the lane's 16 bytes
+            if constexpr (AUX == 2)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff[i]), "s"(sb), "s"(base + i * 1024) : "memory", "m0");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(sb), "s"(base + i * 1024) : "memory", "m0");
+        }
         if (with_norm && norm_loader) {
             if constexpr (U8C) glds16<0>(np, norm_buf * NORM_PAR, norm_lds);   // 64 records of 16 bytes (the tile's 16 in front)
             else glds4(np, norm_buf * NORM_PAR, norm_lds);
@@ -176,11 +196,11 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     };
 
     uint32_t tile = blockIdx.x;
-    make_ptrs(tile, rp_cur, np_cur);
-    make_ptrs(tile + step, rp_nxt, np_nxt);
+    make_ptrs(tile, rb_cur, np_cur);
+    make_ptrs(tile + step, rb_nxt, np_nxt);
     uint32_t slot_c = 0, nbuf = 0, rpar = 0;   // ring slot of the current stage; aux buffer (of three) and partial-sum buffer (of two) of the current tile
 #pragma unroll
-    for (int u = 0; u < NS - 1; u++) issue(rp_cur, np_cur, u, u, u == 0, 0);
+    for (int u = 0; u < NS - 1; u++) issue(rb_cur, np_cur, u, u, u == 0, 0);
 
     const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS, EK) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
@@ -199,31 +219,48 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     //               by 128 (the query fragments were re-centred on the host: DESIGN.md 5.5)
     //   fp32 rows:  a k-step is 32 elements = 128 bytes, lane (m16, kq) converts its 8
     //   16-bit rows: a k-step is 64 bytes of the row, lane (m16, kq) reads its 16 (slot (4 jj + kq) ^ m16 of the row's block)
+    // The operand reads are inline asm with COUNTED waits: behind the asm waits of this loop hipcc's own scoreboard starts from "unknown"
+    // and put a full lgkmcnt(0) in front of the first MFMA after every fresh pair of reads -- the matrix pipe idle for an LDS round trip
+    // twice per unit.  LDS operations return in order, so "all but the newest n" is exact.
     using a_t = typename std::conditional<EK == 0, bf16x8_t, mf_u32x4>::type;
-    auto load_a = [&](uint32_t slot, int jj) -> a_t {
-        const char *rowp = lds + slot * MF_STAGE_BYTES + lds_stage_wave_off + m16 * 256;
+    constexpr int RD = EK == 0 ? 2 : 1;   // LDS reads per operand
+    struct araw {
+        mf_u32x4 lo, hi;   // (hi: fp32 rows only)
+    };
+    const uint32_t rd_base = mf_lds_offset(lds) + lds_stage_wave_off + (uint32_t)m16 * (uint32_t)BW;
+    const uint32_t rd_sw = swz((uint32_t)m16);
+    auto read_a = [&](uint32_t slot, int jj) -> araw {   // issues the reads; wait_a() before finish_a()
+        araw r;
+        const uint32_t rowp = rd_base + slot * MF_STAGE_BYTES;
         if constexpr (EK == 0) {
-            const int p0 = (8 * jj + 2 * kq) ^ m16;
-            const int p1 = (8 * jj + 2 * kq + 1) ^ m16;
-            f32x4_t lo = *reinterpret_cast<const f32x4_t *>(rowp + p0 * 16);
-            f32x4_t hi = *reinterpret_cast<const f32x4_t *>(rowp + p1 * 16);
-            f32x8_t x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_convertvector(x, bf16x8_t);
+            const uint32_t p0 = (uint32_t)(8 * jj + 2 * kq) ^ rd_sw, p1 = (uint32_t)(8 * jj + 2 * kq + 1) ^ rd_sw;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(r.lo), "=&v"(r.hi) : "v"(rowp + p0 * 16u), "v"(rowp + p1 * 16u) : "memory");
         } else {
-            const int p = (4 * jj + kq) ^ m16;
-            mf_u32x4 a = *reinterpret_cast<const mf_u32x4 *>(rowp + p * 16);
-            if constexpr (EK >= 4) a ^= mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-            return a;
+            const uint32_t p = (uint32_t)(4 * jj + kq) ^ rd_sw;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(r.lo) : "v"(rowp + p * 16u) : "memory");
+            r.hi = r.lo;
+        }
+        return r;
+    };
+    auto finish_a = [&](const araw &r) -> a_t {
+        if constexpr (EK == 0) {
+            f32x8_t x = __builtin_shufflevector(__builtin_bit_cast(f32x4_t, r.lo), __builtin_bit_cast(f32x4_t, r.hi), 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_convertvector(x, bf16x8_t);
+        } else if constexpr (EK >= 4) {
+            return r.lo ^ mf_u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+        } else {
+            return r.lo;
         }
     };
-    // PF fragments of the NEXT stage are read while this stage's MFMAs run (nothing but the wave's own vmcnt says when a stage is
+    // PF operands of the NEXT stage are read while this stage's MFMAs run (nothing but the wave's own vmcnt says when a stage is
     // there), so a unit starts multiplying at once instead of behind an LDS round trip
     constexpr int PF = KPW >= 4 ? 2 : 1;
-    constexpr int NPF = PF * (EK == 0 ? 2 : 1);   // LDS reads behind PF operands
-    a_t apf[PF];
-    mfw_wait_vmcnt((NS - 2) * 4);   // stage 0 (and, wave 0, its aux values): NS - 2 younger stages in flight
+    constexpr int NPF = PF * RD;             // LDS reads behind the prefetched operands
+    constexpr int NREST = (KPW - PF) * RD;   // ... behind the stage's other operands
+    araw apf[PF];
+    mfw_wait_vmcnt((NS - 2) * PP);   // stage 0 (and, wave 0, its aux values): NS - 2 younger stages in flight
 #pragma unroll
-    for (int j = 0; j < PF; j++) apf[j] = load_a(0, j);
+    for (int j = 0; j < PF; j++) apf[j] = read_a(0, j);
     for (; tile < P.n_tiles; tile += step) {
         acc_v acc[NQ];
 #pragma unroll
@@ -241,46 +278,53 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         };
 #pragma unroll
         for (int c = 0; c < KCH; c++) {
-            {   // the slot this wave finished with the previous stage takes the stage NS - 1 ahead.  Its reads of that slot must be complete
-                // (hipcc may have left their wait next to the MFMAs that consume them, and those may sit below this point): LDS operations
-                // return in order, and the only ones issued since are the NPF reads that fetched THIS stage's first operands
+            {   // the slot this wave finished with the previous stage takes the stage NS - 1 ahead.  Its reads of that slot are complete: the
+                // only LDS operations issued since they were waited for are the NPF reads that fetched THIS stage's first operands
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NPF) : "memory");
                 constexpr int D = NS - 1;
                 uint32_t slot_p = slot_c + D;
                 if (slot_p >= NS) slot_p -= NS;
                 const int cc = c + D;
                 const uint32_t nb1 = nbuf + 1 >= 3 ? 0 : nbuf + 1;
-                if (cc < KCH) issue(rp_cur, np_cur, cc, slot_p, false, 0);
-                else issue(rp_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, nb1);
+                if (cc < KCH) issue(rb_cur, np_cur, cc, slot_p, false, 0);
+                else issue(rb_nxt, np_nxt, cc - KCH, slot_p, cc == KCH, nb1);
             }
-            // this wave's k-steps of the stage, from its own quarter of the slot: the first PF operands are in registers
-            a_t a[KPW];
+            // this wave's k-steps of the stage, from its own quarter of the slot: the first PF operands were requested a unit ago
+            araw ar[KPW];
 #pragma unroll
-            for (int jj = 0; jj < KPW; jj++) a[jj] = jj < PF ? apf[jj] : load_a(slot_c, jj);
-            mma(a[0], c * KPW);
-            {   // this wave's part of stage c + 1 landed?  Its NS - 2 younger stages (4 loads each, + the aux load of a stage that opens a
+            for (int jj = 0; jj < KPW; jj++) ar[jj] = jj < PF ? apf[jj] : read_a(slot_c, jj);
+#pragma unroll
+            for (int jj = 0; jj < PF; jj++)   // all but the NREST reads just issued have returned
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ar[jj].lo), "+v"(ar[jj].hi) : "n"(NREST) : "memory");
+            mma(finish_a(ar[0]), c * KPW);
+            {   // this wave's part of stage c + 1 landed?  Its NS - 2 younger stages (PP loads each, + the aux load of a stage that opens a
                 // tile) may be in flight.  Then its first operands, under the MFMAs just issued
                 int n_norm = 0;
 #pragma unroll
                 for (int j = 2; j < NS; j++) n_norm += ((c + j) % KCH == 0) ? 1 : 0;
-                if (norm_loader) mfw_wait_vmcnt((NS - 2) * 4 + n_norm);
-                else mfw_wait_vmcnt((NS - 2) * 4);
+                if (norm_loader) mfw_wait_vmcnt((NS - 2) * PP + n_norm);
+                else mfw_wait_vmcnt((NS - 2) * PP);
                 const uint32_t slot_n = slot_c + 1 == NS ? 0 : slot_c + 1;
 #pragma unroll
-                for (int j = 0; j < PF; j++) apf[j] = load_a(slot_n, j);
+                for (int j = 0; j < PF; j++) apf[j] = read_a(slot_n, j);
             }
 #pragma unroll
-            for (int jj = 1; jj < KPW; jj++) mma(a[jj], c * KPW + jj);
+            for (int jj = 1; jj < PF; jj++) mma(finish_a(ar[jj]), c * KPW + jj);
+#pragma unroll
+            for (int jj = PF; jj < KPW; jj++) {   // all but the NPF reads of the next stage have returned
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ar[jj].lo), "+v"(ar[jj].hi) : "n"(NPF) : "memory");
+                mma(finish_a(ar[jj]), c * KPW + jj);
+            }
             slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
         }
         // ---- the four waves' partial dot products of (row kq*4 + i, query m16) meet in LDS: wave nt collects column block nt ----
-        const uint32_t red_tile = red_off + rpar * (uint32_t)(NQ * MFW_RED_BYTES);
+        const uint32_t red_tile = red_off + rpar * (uint32_t)(NQ * RED_BYTES);
 #pragma unroll
         for (int nt = 0; nt < NQ; nt++) {
             if (wave != nt) {
-                const int k3 = wave < nt ? wave : wave - 1;   // which of the three partials of block nt this wave writes
+                const int k3 = wave < nt ? wave : wave - 1;   // which of the NW - 1 partials of block nt this wave writes
                 const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc[nt]);
-                asm volatile("ds_write_b128 %0, %1" ::"v"(red_tile + (uint32_t)(nt * MFW_RED_BYTES + k3 * 1024 + lane * 16)), "v"(v) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(red_tile + (uint32_t)(nt * RED_BYTES + k3 * 1024 + lane * 16)), "v"(v) : "memory");
             }
         }
         // The one barrier of a row tile.  Behind it every wave has left the previous tile's epilogue, so: the queue length is final and
@@ -289,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
         // tile t, i.e. possibly while other waves are still in the epilogue of tile t - 1).
         mf_ring_barrier();
         if (MODE == MF_FILTER) {
-            if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+            if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<64 * NW>(eq_n, eq, P.counts, P.cand, P.cap);
         }
         const uint32_t r0 = tile_row0(tile);
         bool emitted = false;
@@ -310,15 +354,24 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nbits) : "v"(mf_lds_offset(nrm) + (uint32_t)(kq * 16)) : "memory");
             }
             const f32x4_t n4 = __builtin_bit_cast(f32x4_t, nbits);
-            mf_u32x4 p1, p2, p3;
-            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(p1), "=&v"(p2), "=&v"(p3)
-                         : "v"(red_tile + (uint32_t)(nt * MFW_RED_BYTES + lane * 16))
-                         : "memory");
             acc_v a4 = acc[nt];
-            a4 += __builtin_bit_cast(acc_v, p1);
-            a4 += __builtin_bit_cast(acc_v, p2);
-            a4 += __builtin_bit_cast(acc_v, p3);
+#pragma unroll
+            for (int g = 0; g + 3 <= NW - 1; g += 3) {   // the other waves' partials, three at a time, in wave order
+                mf_u32x4 p1, p2, p3;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(p1), "=&v"(p2), "=&v"(p3)
+                             : "v"(red_tile + (uint32_t)(nt * RED_BYTES + g * 1024 + lane * 16))
+                             : "memory");
+                a4 += __builtin_bit_cast(acc_v, p1);
+                a4 += __builtin_bit_cast(acc_v, p2);
+                a4 += __builtin_bit_cast(acc_v, p3);
+            }
+            if constexpr ((NW - 1) % 3 == 1) {   // (eight waves: the seventh)
+                mf_u32x4 p1;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(p1) : "v"(red_tile + (uint32_t)(nt * RED_BYTES + (NW - 2) * 1024 + lane * 16)) : "memory");
+                a4 += __builtin_bit_cast(acc_v, p1);
+            }
+            static_assert((NW - 1) % 3 != 2, "partials are read in threes, plus one");
             float tmin = INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -378,10 +431,9 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
             if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) rp_cur[i] = rp_nxt[i];
+        rb_cur = rb_nxt;
         np_cur = np_nxt;
-        make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
+        make_ptrs(tile + 2 * step, rb_nxt, np_nxt);
         nbuf = nbuf + 1 >= 3 ? 0 : nbuf + 1;
         rpar ^= 1u;
     }
@@ -393,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_filter_wide(MfmaParams P) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER) {
         __builtin_amdgcn_s_barrier();
-        mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
+        mf_flush_queue<64 * NW>(eq_n, eq, P.counts, P.cand, P.cap);
     }
 }
 

@@ -287,19 +287,22 @@ static void launch_lowp_i8_split(const vsgpu_table *t, int mode, const LowpParam
 #ifndef WIDE_NS_ALONE
 #define WIDE_NS_ALONE 5
 #endif
+#ifndef WIDE_NW4
+#define WIDE_NW4 4   // waves of the four-column-block workgroup (8: measured at half the rate, see k_mfma_filter_wide)
+#endif
 template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
-    auto go = [&](auto kern, int nqb, int ns) {
-        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns, EK);
+    auto go = [&](auto kern, int nqb, int ns, int nw = 4) {
+        const int lds_bytes = mfw_lds_bytes(MODE == MF_PROBE, nqb, ns, EK, nw);
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, P);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, s, P);
     };
     // two 16-query column blocks per workgroup up to width 6144 (the fragments of 32 queries fit the registers of a wave);
     // WIDE_NS_ALONE: see vsgpu_mfma.hip and k_mfma_filter_wide (ring depth of a workgroup alone on its CU)
     constexpr int NA = WIDE_NS_ALONE;
     switch (ksteps) {
     case 96:   // (four column blocks -- 64 queries in ONE pass over the rows -- fit a wave's 512 registers at this width: half of them AGPRs)
-        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA>, 4, NA);
+        if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA, WIDE_NW4>, 4, NA, WIDE_NW4);
         else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
         break;
     case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
