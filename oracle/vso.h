@@ -17,12 +17,15 @@
  *   - Flat top-K / range scans    algorithms/brute_force/brute_force.h:242-326
  *
  * Parity pin: checked against the reference's own known-answer tests (tests/unit/test_spaces.cpp,
- * test_bruteforce.cpp, test_int8.cpp ... restated as data in tests/golden/) by tests/test_oracle*.py.
- * The reference itself cannot be compiled in the build image without writing stand-in headers for
- * the un-vendored cpu_features dependency (every kernel header includes it through
- * spaces/space_includes.h:13-16), so there is no oracle/_ref; the "AVX-512 order" variants are
- * restated from the source lines above and cross-checked against an independent AVX-512
- * intrinsics implementation of the same published algorithm (vso_fast.c) on the host CPU.
+ * test_bruteforce.cpp, test_int8.cpp ... restated as data in tests/golden/) by tests/test_oracle*.py, and -- the scalar
+ * kernels, the conversions, normalisation, scalar SQ8, the top-k containers and heaps -- against bits the reference ITSELF
+ * produced: oracle/_ref is the reference's own scalar translation units compiled where they lie (oracle/build_ref.sh,
+ * tests/golden/ref_scalar_random.json).  The SIMD kernel headers cannot be compiled in the build image without writing
+ * stand-in headers for the un-vendored cpu_features dependency (every one includes it through
+ * spaces/space_includes.h:13-16): the "AVX-512 order" variants are restated from the source lines above and cross-checked
+ * against an independent AVX-512 intrinsics implementation of the same published algorithm (vso_fast.c) on the host CPU.
+ * PARITY UNPINNED for one tier: VSO_TIER_AVX512_FP16 (half-precision accumulators, gcc >= 12 builds on avx512_fp16 hosts) --
+ * no toolchain or CPU within reach emits or executes it; see vso.c.
  */
 #ifndef VSO_H
 #define VSO_H
