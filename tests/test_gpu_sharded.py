@@ -130,6 +130,32 @@ def test_config4_shape_bf16_ip_shards(vso):
         assert "lowp" in st["scan_kernel"] and st["fallbacks"] == 0, st
 
 
+def test_config3_shape_int8_cosine_top100_across_eight_shards(vso):
+    """BASELINE config 3's shape per query batch: int8 Cosine, d = 1024, 256 queries, top-100 -- every shard on the 32 x 32 x 32 filter,
+    and the exchange at ITS size: 1.27 MB of records per shard, 800 candidates per query for the merge, which reads them where the
+    collective wrote them and runs on several host threads (host/sharded_index.cpp merge_topk_strided).  int8 scores tie in droves: the
+    merge's global-id order decides."""
+    rng = np.random.default_rng(303)
+    dim, n, nq, k, G = 1024, 40_000, 256, 100, 8
+    rows = random_vectors(rng, n, dim, "i8", vso)
+    queries = random_vectors(rng, nq, dim, "i8", vso)
+    labels = rng.permutation(n) + 5
+    sx = ShardedFlatIndex(params("i8", "Cosine", dim, 512), shards=G)
+    one = VecSim.BFIndex(params("i8", "Cosine", dim, 512))
+    sx.add_vectors(rows, labels)
+    one.add_vectors(rows, labels)
+    for s in range(G):
+        sx.local_index(s).set_option("dense_pairs", 0)
+        sx.local_index(s).reset_stats()
+    one.set_option("dense_pairs", 0)
+    check_equal(vso, sx, one, "i8", "Cosine", rows, labels, queries, k, oracle_queries=range(0, nq, 37))
+    for s in range(G):
+        st = sx.local_index(s).stats()
+        assert "x32" in st["scan_kernel"] and st["fallbacks"] == 0, st
+    # a second batch with fewer candidates than k in some shards' lists and a short last tile of queries
+    check_equal(vso, sx, one, "i8", "Cosine", rows, labels, queries[:131], k, oracle_queries=(0, 130))
+
+
 @pytest.mark.parametrize("typ,metric,dim", [("i8", "Cosine", 128), ("f32", "Cosine", 100), ("u8", "L2", 64), ("f16", "IP", 96)])
 def test_other_types_shard_identically(vso, typ, metric, dim):
     rng = np.random.default_rng(dim)
