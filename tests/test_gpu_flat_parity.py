@@ -98,6 +98,58 @@ def test_all_scores_bit_exact_other_tiers(vso, monkeypatch, tier, typ, metric, d
         assert np.array_equal(dists[j], es), (tier, typ, metric, dim, j)
 
 
+def test_avx512_fp16_tier_batches_range_iterator_and_hnsw(vso, monkeypatch):
+    """the half-accumulating tier beyond one small dense pass: a batch wide enough for the 8-query exact-scan tile, a table large enough
+    that a batch would otherwise go to the MFMA filter (it must not: no filter models half-precision accumulation), range queries,
+    getDistanceFrom, the batch iterator, and the HNSW search kernel scoring its candidates in the same order"""
+    from util import TIERS
+    monkeypatch.setenv("VECSIM_GPU_TIER", "avx512_fp16")
+    rng = np.random.default_rng(1616)
+    dim, n, nq, k = 96, 30_000, 19, 10
+    rows = random_vectors(rng, n, dim, "f16", vso)
+    q = random_vectors(rng, nq, dim, "f16", vso)
+    for metric in ("L2", "IP"):
+        ix = make_index("f16", metric, dim)
+        assert ix.distance_tier() == "AVX512_FP16"
+        ix.add_vectors(rows, np.arange(n))
+        ix.set_option("dense_pairs", 0)
+        ix.reset_stats()
+        labels, dists = ix.knn_query(q, k)
+        stt = ix.stats()
+        assert "mfma" not in stt["scan_kernel"], stt
+        st = stored_rows(vso, rows, "f16", metric)
+        km = kernel_metric("f16", metric)
+        for j in range(nq):
+            el, es = vso.flat_topk(TYPES["f16"], km, st, q[j], k, dim, tier=TIERS["avx512_fp16"])
+            assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (metric, j)
+        # scores have 11 significant bits: many rows tie at the k-th score, the replay's id order decides -- checked above; range:
+        sc = vso.scan(TYPES["f16"], km, st, q[0], dim, tier=TIERS["avx512_fp16"])
+        radius = float(np.sort(sc[sc >= 0])[40])   # (a negative radius is refused like the reference refuses it; IP scores can be negative)
+        rl, rd = ix.range_query(q[0], radius, order=VecSim.BY_ID)
+        want = np.nonzero(sc <= radius)[0]
+        assert np.array_equal(rl[0][:len(want)], want) and np.array_equal(rd[0][:len(want)], sc[want])
+        assert ix.get_distance_from(123, q[0]) == sc[123]
+        it = ix.create_batch_iterator(q[0])
+        got = []
+        while it.has_next() and len(got) < 300:
+            l, d = it.get_next_results(100, VecSim.BY_SCORE)
+            got += d[0].tolist()
+        assert got[:300] == np.sort(sc)[:300].tolist()
+    # HNSW: the search kernel scores its candidates in the same order -- its replies against the oracle's loops on the exported graph
+    hp = VecSim.HNSWParams()
+    hp.type, hp.dim, hp.metric, hp.M, hp.efConstruction, hp.efRuntime = VecSim.VecSimType_FLOAT16, 64, VecSim.VecSimMetric_L2, 8, 60, 40
+    hx = VecSim.HNSWIndex(hp)
+    hrows = random_vectors(rng, 3000, 64, "f16", vso)
+    hx.add_vectors(hrows, np.arange(3000))
+    assert hx.distance_tier() == "AVX512_FP16"
+    g = hx.graph()
+    qh = random_vectors(rng, 6, 64, "f16", vso)
+    l, d = hx.knn_query(qh, 10)
+    for j in range(6):
+        el, es, _ = vso.hnsw_search(TYPES["f16"], vso.L2, hrows, g, qh[j], 10, 40, 64, tier=TIERS["avx512_fp16"])
+        assert np.array_equal(l[j][:len(el)], el.astype(np.int64)) and np.array_equal(d[j][:len(es)], es), j
+
+
 DEFAULT_TIER_CASES = [
     ("f32", "L2", 768, 60_000, 64, 10),       # BASELINE config 2's query tile
     ("i8", "Cosine", 1024, 60_000, 256, 100),  # config 3's
