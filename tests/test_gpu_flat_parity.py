@@ -710,6 +710,8 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
     ("L2", 8192, 3_000, 17, 10),
     ("L2", 5000, 6_000, 70, 100),
     ("IP", 4096, 4_000, 9, 10),        # at most 16 queries: one column block per workgroup
+    ("L2", 4096, 5_000, 100, 10),      # three column blocks per workgroup (width 128 k-steps): 48 + 48 + 4 queries
+    ("IP", 4000, 4_000, 40, 10),       # ... one 48-query tile instead of two of 32
 ])
 def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
     """rows beyond 3072 elements: 16 queries per workgroup, the k range split over the waves by ring stage, partial dot products
@@ -732,9 +734,12 @@ def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
         assert np.array_equal(l1[j], el.astype(np.int64)) and np.array_equal(d1[j], es), (metric, dim, j)
 
 
-@pytest.mark.parametrize("typ,dim,blocks", [("bf16", 3072, 2), ("f16", 4096, 2), ("bf16", 6144, 1), ("f32", 4096, 1), ("f32", 6144, 1)])
+@pytest.mark.parametrize("typ,dim,blocks", [("bf16", 3072, 2), ("f16", 4096, 2), ("bf16", 6144, 1), ("f32", 4096, 1), ("f32", 6144, 1),
+                                             ("bf16", 4096, 2), ("i8", 8192, 2), ("u8", 8192, 2), ("f32", 4096, 2), ("bf16", 3600, 1)])
 def test_wide_rows_both_workgroup_shapes(vso, typ, dim, blocks):
-    """k_mfma_filter_wide with 16 and with 32 queries per workgroup (option wide_blocks) where production picks the other one"""
+    """k_mfma_filter_wide with 16 and with 32 queries per workgroup (option wide_blocks) where production picks the other one -- at width
+    128 k-steps (16-bit rows of 3073 .. 4096 elements, 8-bit rows of 6145 .. 8192, fp32 rows up to 4096) production takes 40 queries as one
+    tile of THREE column blocks"""
     rng = np.random.default_rng(dim + blocks)
     n, nq, k = 3_001, 40, 10
     rows = random_vectors(rng, n, dim, typ, vso)

@@ -119,9 +119,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
     for (int nt = 0; nt < NQ; nt++) {
 #pragma unroll
         for (int i = 0; i < KMINE; i++) {
-            // more than ~220 registers of fragments (four column blocks at KSTEPS 96): the upper half is parked in AGPRs, which the
-            // MFMA reads directly (one wave per SIMD owns all 512 registers of a lane, one of two 256); left to hipcc they are spilled
-            if (NQ * KMINE * 4 > (NW == 8 ? 100 : 224) && nt >= NQ / 2) asm volatile("" : "+a"(qf[nt][i]));
+            // more than ~220 registers of fragments (four column blocks at KSTEPS 96, three at 128: 384): the upper half -- by fragment,
+            // not by block -- is parked in AGPRs, which the MFMA reads directly (one wave per SIMD owns all 512 registers of a lane, one
+            // of two 256); left to hipcc they are spilled
+            if (NQ * KMINE * 4 > (NW == 8 ? 100 : 224) && 2 * (nt * KMINE + i) >= NQ * KMINE) asm volatile("" : "+a"(qf[nt][i]));
             else asm volatile("" : "+v"(qf[nt][i]));
         }
         asm volatile("" : "+v"(nq2[nt]), "+v"(tau[nt]), "+v"(qnorm[nt]));

@@ -305,7 +305,10 @@ template <int EK, int MODE> static void launch_wide_h16_m(int ksteps, int nq_blo
         if (nq_blocks == 4) go(k_mfma_filter_wide<96, MODE, 0, EK, 4, NA, WIDE_NW4>, 4, NA, WIDE_NW4);
         else nq_blocks == 2 ? go(k_mfma_filter_wide<96, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<96, MODE, 0, EK, 1, 3>, 1, 3);
         break;
-    case 128: nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3); break;
+    case 128:   // (three column blocks are the same 384 registers of fragments as four at width 96)
+        if (nq_blocks == 3) go(k_mfma_filter_wide<128, MODE, 0, EK, 3, NA>, 3, NA);
+        else nq_blocks == 2 ? go(k_mfma_filter_wide<128, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<128, MODE, 0, EK, 1, 3>, 1, 3);
+        break;
     case 192: nq_blocks == 2 ? go(k_mfma_filter_wide<192, MODE, 0, EK, 2, NA>, 2, NA) : go(k_mfma_filter_wide<192, MODE, 0, EK, 1, 3>, 1, 3); break;
     default: go(k_mfma_filter_wide<256, MODE, 0, EK, 1, NA>, 1, NA); break;
     }
@@ -374,7 +377,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     // (round 4, late) at kernel width 96 k-steps -- 16-bit rows up to 3072 elements, 8-bit rows up to 6144 -- FOUR column blocks fit: 384
     // registers of fragments per wave, half of them AGPRs, one wave per SIMD; a batch of 64 then crosses the rows once instead of twice
     // (bf16 3072, batch 64: 4.18 -> 6.05 TB/s; int8 6144: 3.74 -> 4.91; profiles/r04_wide_blocks4.txt); option wide_blocks = 2: at most 32
+    // (round 5) at kernel width 128 k-steps THREE column blocks fit the same way: used where 48-query tiles cross the rows less often than
+    // 32-query tiles do -- 33 .. 48 queries (once instead of twice), 65 .. 96 (2 / 3), 97 .. 128 (3 / 4) ...
+    const bool three = t->lp_wide && KS == 128 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 3) && (nq + 47) / 48 < (nq + 31) / 32;
     const int wide_blocks = (t->lp_wide && nq > 32 && KS == 96 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 4)) ? 4
+                            : three ? 3
                             : ((t->lp_wide && nq > 16 && c->opt_wide_blocks != 1 && KS <= 192) ? 2 : 1);
     const size_t QT = t->lp_wide ? (size_t)16 * wide_blocks : hsplit ? 64 : (narrow ? lowp_narrow_qtile(t) : (qsplit ? 128 : (size_t)t->lp_qtile));
     const size_t q_tiles = (nq + QT - 1) / QT, nqp = q_tiles * QT;
@@ -395,6 +402,11 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     std::vector<uint32_t> qaux(nqp, 0);
     std::vector<float> tau0(nqp, -INFINITY);
     std::vector<float> qmeta((is_sq8 || is_u8c) ? nqp * 8 : 0, 0.0f);
+    // uint8 Cosine: a padding query (threshold -inf) with norm 0 would score -inf on every row whose re-centred sum is positive -- and
+    // -inf <= -inf passes: the tile's padding columns flooded the candidate queue (same replies, a third of the rate; found with the
+    // 48-query tiles, present in every padded batch before).  Norm +inf makes their score 1.
+    if (is_u8c)
+        for (size_t q = nq; q < nqp; q++) qmeta[q * 8] = INFINITY;
     std::vector<signed char> yq(is_sq8 ? dim : 0);
     for (size_t q = 0; q < nq; q++) {
         const unsigned char *src = (const unsigned char *)queries + q * qstride;

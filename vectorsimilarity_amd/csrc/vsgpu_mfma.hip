@@ -169,7 +169,8 @@ template <int KS, int MODE, int NQ, int NS> static void launch_wide_ks(const Mfm
 template <int MODE> static void launch_wide(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
     switch (ksteps) {
     case 128:
-        if (nq_blocks == 2) launch_wide_ks<128, MODE, 2, WIDE_NS_ALONE>(P, grid, s);
+        if (nq_blocks == 3) launch_wide_ks<128, MODE, 3, WIDE_NS_ALONE>(P, grid, s);
+        else if (nq_blocks == 2) launch_wide_ks<128, MODE, 2, WIDE_NS_ALONE>(P, grid, s);
         else launch_wide_ks<128, MODE, 1, 3>(P, grid, s);
         break;
     case 192:
@@ -186,10 +187,13 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const size_t n = t->n, dim = t->dim;
     const int KS = t->ksteps;
     const bool wide = KS > 96;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
-    const int wide_blocks = (wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1;
+    // (three column blocks at width 128 k-steps -- 4096 elements -- where 48-query tiles cross the rows less often than 32-query tiles: vsgpu_lowp.hip)
+    const bool three = wide && KS == 128 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 3) && (nq + 47) / 48 < (nq + 31) / 32;
+    const int wide_blocks = three ? 3 : ((wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1);
     const bool rt16 = !wide && probe_rt16(c, KS);
     const size_t QT = wide ? (size_t)MFW_QTILE * wide_blocks : (size_t)MF_QTILE, TILE_ROWS = (wide || rt16) ? 16 : (size_t)MF_TILE_ROWS;
-    const size_t q_tiles = (nq + QT - 1) / QT, nqp = (nq + MF_QTILE - 1) / MF_QTILE * MF_QTILE;
+    // (padded queries: whole 64-query tiles, and whole 48-query tiles where three column blocks run: 128 queries are three of those = 144)
+    const size_t q_tiles = (nq + QT - 1) / QT, nqp = std::max((nq + MF_QTILE - 1) / MF_QTILE * MF_QTILE, q_tiles * QT);
     const bool l2 = (t->metric == VSGPU_L2);
 
     // (1) bf16 B-operand fragments + |q|^2 for the filter, (2) exact-order query images for the re-rank -- staged behind the
@@ -327,7 +331,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             // tiles of a row tile (blockIdx.y) land on one XCD and share its L2
             // (as many workgroups as are resident at once -- two per CU while a wave's fragments leave room for it, else one --
             // so that the query tiles of a row tile run at the same time)
-            const uint32_t per_cu = (wide_blocks == 2 || KS > 192) ? 1u : 2u;
+            const uint32_t per_cu = (wide_blocks >= 2 || KS > 192) ? 1u : 2u;
             uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
             if (c->opt_wide_gx > 0) gx = (uint32_t)c->opt_wide_gx;   // (diagnosis: option wide_gx)
             launch_wide<MF_FILTER>(KS, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
