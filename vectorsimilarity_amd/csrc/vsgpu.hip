@@ -339,6 +339,9 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lp_ksteps = dim <= 2048 ? 32 : (dim <= 3072 ? 48 : 64);
             t->lp_rt = 16;
             t->lp_qtile = dim <= 3072 ? 128 : 64;
+            // (uint8 Cosine at width 3072: the 8-wave kernel -- 192 registers of fragments + the two-value epilogue in a wave's 256 --
+            // spilled 60 registers and ran at 1.8 TB/s where int8 Cosine runs 4.9: the 4-wave shape of width 4096, fragments in AGPRs)
+            if (t->lp_kind == LP_U8C && t->lp_ksteps == 48) t->lp_qtile = 64;
         }
         if ((type == VSGPU_I8 || type == VSGPU_U8) && dim <= 1024) {
             t->lowp_ok = true;

@@ -59,8 +59,27 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
         case 8: bf ? launch_lowp_narrow<LP_BF16, 8, 64>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 8, 64>(mode, P, grid, s); return true;
         case 16: bf ? launch_lowp_narrow<LP_BF16, 16, 32>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 16, 32>(mode, P, grid, s); return true;
         case 24: bf ? launch_lowp_narrow<LP_BF16, 24, 32>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 24, 32>(mode, P, grid, s); return true;
+        case 32: bf ? launch_lowp_narrow<LP_BF16, 32, 16>(mode, P, grid, s) : launch_lowp_narrow<LP_F16, 32, 16>(mode, P, grid, s); return true;   // (round 5: 1024 elements)
         default: return false;
         }
+    }
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || t->lp_kind == LP_U8C) && (t->lp_ksteps == 8 || t->lp_ksteps == 12) && t->lp_rt == 64) {
+        // int8 / uint8 rows of at most 768 elements, at most 128 queries (round 5): the 16-wave, 256-query workgroup these widths had
+        // -- one per CU, half of it padding at 128 queries -- streamed 1.6-2.0 TB/s at every batch size (profiles/r05_anomaly_scan.txt);
+        // 8 waves x 16 queries at <= 128 VGPRs, two workgroups per CU, four ring slots: the SQ8 filter's shape
+        auto go = [&](auto ks_tag, auto lk_tag) {
+            constexpr int KS = decltype(ks_tag)::value, LK = decltype(lk_tag)::value;
+            if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, 64, 8, 1, 4, 3>(P, grid, s);
+            else launch_lowp_k<LK, KS, MF_FILTER, 64, 8, 1, 4, 4>(P, grid, s);
+        };
+        auto by_kind = [&](auto ks_tag) {
+            if (t->lp_kind == LP_I8) go(ks_tag, std::integral_constant<int, LP_I8>{});
+            else if (t->lp_kind == LP_U8) go(ks_tag, std::integral_constant<int, LP_U8>{});
+            else go(ks_tag, std::integral_constant<int, LP_U8C>{});
+        };
+        if (t->lp_ksteps == 8) by_kind(std::integral_constant<int, 8>{});
+        else by_kind(std::integral_constant<int, 12>{});
+        return true;
     }
     if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) {
         // int8 / uint8, width 1024, at most 128 queries: 8 waves x 16 queries at <= 128 VGPRs, two workgroups resident per CU
@@ -78,8 +97,10 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
 // query-tile width of the narrow-batch kernels (0: none for this table)
 static size_t lowp_narrow_qtile(const vsgpu_table *t) {
     if (t->lp_kind == LP_SQ8) return 64;
-    if ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps <= 24) return 64;
+    if ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps <= 32) return 64;
     if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
+    // int8 / uint8 (every metric) up to 768 elements: the same 8-wave shape the SQ8 filter runs on (rows of 768 + 16 bytes there)
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || t->lp_kind == LP_U8C) && (t->lp_ksteps == 8 || t->lp_ksteps == 12) && t->lp_rt == 64) return 128;
     return 0;
 }
 template <int KS, int RT, int LK = LP_I8> static void launch_lowp_i8(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
@@ -117,6 +138,11 @@ template <int LK> static void launch_lowp_w2048(int mode, const LowpParams &P, d
     else launch_lowp_k<LK, 32, MF_FILTER, 16, 8, 1, 1, 3>(P, grid, s);
 }
 template <int LK> static void launch_lowp_w3072(int mode, const LowpParams &P, dim3 grid, hipStream_t s) {
+    if constexpr (LK == LP_U8C) {   // 4 waves x 16 queries, one wave per SIMD (vsgpu.hip: lp_qtile 64)
+        if (mode == MF_PROBE) launch_lowp_k<LK, 48, MF_PROBE, 16, 4, 1, 1, 3>(P, grid, s);
+        else launch_lowp_k<LK, 48, MF_FILTER, 16, 4, 1, 1, 3>(P, grid, s);
+        return;
+    }
     if (mode == MF_PROBE) launch_lowp_k<LK, 48, MF_PROBE, 16, 8, 1, 1, 3>(P, grid, s);
     else launch_lowp_k<LK, 48, MF_FILTER, 16, 8, 1, 1, 3>(P, grid, s);
 }
