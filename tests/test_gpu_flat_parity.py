@@ -861,6 +861,12 @@ def test_reply_objects_and_array_entry_points_agree():
     ("i8", "L2", 2048, 12_000, 140, 10),        # rows of 1025 .. 2048 elements: 8 waves x 16 queries, 16-row tiles
     ("i8", "Cosine", 2000, 9_000, 70, 10),
     ("u8", "IP", 1500, 10_000, 33, 5),
+    ("i8", "L2", 1536, 10_000, 128, 10),        # width 1536 (round 5): 24 k-steps on 32-row tiles
+    ("i8", "Cosine", 1100, 9_000, 70, 10),
+    ("u8", "Cosine", 1300, 8_000, 129, 10),
+    ("u8", "Cosine", 2600, 5_000, 100, 10),     # width 3072, uint8 Cosine: the 4-wave shape, two 64-query tiles
+    ("i8", "Cosine", 768, 20_000, 128, 10),     # at most 768 elements, at most 128 queries: the 8-wave shape
+    ("u8", "L2", 500, 20_000, 100, 10),
     ("u8", "Cosine", 2048, 8_000, 128, 10),
     ("i8", "IP", 3072, 6_000, 130, 10),
     ("u8", "L2", 2500, 6_000, 64, 10),

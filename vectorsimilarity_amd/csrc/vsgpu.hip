@@ -336,8 +336,10 @@ extern "C" vsgpu_table *vsgpu_table_create(vsgpu_ctx *c, int type, int metric, i
             t->lowp_ok = true;
             t->lp_kind = type == VSGPU_I8 ? LP_I8 : (metric == VSGPU_COSINE ? LP_U8C : LP_U8);
             if (t->lp_kind == LP_U8C) t->aux_bytes = 16;
-            t->lp_ksteps = dim <= 2048 ? 32 : (dim <= 3072 ? 48 : 64);
-            t->lp_rt = 16;
+            // (round 5: width 1536 -- 24 k-steps on 32-row tiles of 512-byte stage segments, the shape 16-bit rows of 768 elements use;
+            // before, 1025 .. 1536 elements ran at width 2048, a quarter of every row image the next row's bytes)
+            t->lp_ksteps = dim <= 1536 ? 24 : (dim <= 2048 ? 32 : (dim <= 3072 ? 48 : 64));
+            t->lp_rt = t->lp_ksteps == 24 ? 32 : 16;
             t->lp_qtile = dim <= 3072 ? 128 : 64;
             // (uint8 Cosine at width 3072: the 8-wave kernel -- 192 registers of fragments + the two-value epilogue in a wave's 256 --
             // spilled 60 registers and ran at 1.8 TB/s where int8 Cosine runs 4.9: the 4-wave shape of width 4096, fragments in AGPRs)

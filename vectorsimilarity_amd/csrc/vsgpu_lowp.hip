@@ -156,6 +156,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
     else if (t->lp_kind == LP_F16) launch_lowp_h16<LP_F16>(t->lp_ksteps, mode, P, grid, s);
     else if (t->lp_kind == LP_U8C) {
         switch (t->lp_ksteps) {
+        case 24: launch_lowp_t<LP_U8C, 24, 32, 1>(mode, P, grid, s); break;   // width 1536
         case 32: launch_lowp_w2048<LP_U8C>(mode, P, grid, s); break;
         case 48: launch_lowp_w3072<LP_U8C>(mode, P, grid, s); break;
         case 64: launch_lowp_w4096<LP_U8C>(mode, P, grid, s); break;
@@ -182,6 +183,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         }
     } else if (t->lp_kind == LP_U8) {
         switch (t->lp_ksteps) {
+        case 24: launch_lowp_t<LP_U8, 24, 32, 1>(mode, P, grid, s); break;   // width 1536
         case 32: launch_lowp_w2048<LP_U8>(mode, P, grid, s); break;
         case 48: launch_lowp_w3072<LP_U8>(mode, P, grid, s); break;
         case 64: launch_lowp_w4096<LP_U8>(mode, P, grid, s); break;
@@ -197,6 +199,7 @@ static void launch_lowp(const vsgpu_table *t, int mode, const LowpParams &P, dim
         // barrier per 32 KiB): 3.54 TB/s against 3.24 for 16 KiB half-row slots, 3.1 for 8 waves x 32 queries and
         // 2.5 for 4 waves x 64 queries (profiles/r01_tuning_lowp.txt)
         switch (t->lp_ksteps) {
+        case 24: launch_lowp_t<LP_I8, 24, 32, 1>(mode, P, grid, s); break;   // width 1536
         case 32: launch_lowp_w2048<LP_I8>(mode, P, grid, s); break;
         case 48: launch_lowp_w3072<LP_I8>(mode, P, grid, s); break;
         case 64: launch_lowp_w4096<LP_I8>(mode, P, grid, s); break;
