@@ -69,8 +69,12 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
         // 8 waves x 16 queries at <= 128 VGPRs, two workgroups per CU, four ring slots: the SQ8 filter's shape
         auto go = [&](auto ks_tag, auto lk_tag) {
             constexpr int KS = decltype(ks_tag)::value, LK = decltype(lk_tag)::value;
-            if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, 64, 8, 1, 4, 3>(P, grid, s);
-            else launch_lowp_k<LK, KS, MF_FILTER, 64, 8, 1, 4, 4>(P, grid, s);
+            // (registers: at 12 k-steps the int8 / uint8 L2 / IP kernel needs more than the 128 that two workgroups per CU leave a wave
+            // -- 42-54 spilled -- and runs better alone on its CU with 256: int8 L2 768 3.2 -> 4.35 TB/s, Cosine 4.6 -> 4.45; the 8 k-step
+            // kernels and uint8 Cosine fit and lose 12-19 % alone: profiles/r05_anomaly_fixes.txt)
+            constexpr int MW = (KS == 12 && LK != LP_U8C) ? 2 : 4;
+            if (mode == MF_PROBE) launch_lowp_k<LK, KS, MF_PROBE, 64, 8, 1, MW, 3>(P, grid, s);
+            else launch_lowp_k<LK, KS, MF_FILTER, 64, 8, 1, MW, 4>(P, grid, s);
         };
         auto by_kind = [&](auto ks_tag) {
             if (t->lp_kind == LP_I8) go(ks_tag, std::integral_constant<int, LP_I8>{});
@@ -81,11 +85,15 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
         else by_kind(std::integral_constant<int, 12>{});
         return true;
     }
-    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) {
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || t->lp_kind == LP_U8C) && t->lp_ksteps == 16 && t->lp_rt == 32) {
         // int8 / uint8, width 1024, at most 128 queries: 8 waves x 16 queries at <= 128 VGPRs, two workgroups resident per CU
+        // (uint8 Cosine joined in round 5: on the 16-wave workgroup it ran 2.1 TB/s between 3.8 at 768 and 3.9 at 2048 elements)
         if (t->lp_kind == LP_I8) {
             if (mode == MF_PROBE) launch_lowp_k<LP_I8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
             else launch_lowp_k<LP_I8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
+        } else if (t->lp_kind == LP_U8C) {
+            if (mode == MF_PROBE) launch_lowp_k<LP_U8C, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
+            else launch_lowp_k<LP_U8C, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
         } else {
             if (mode == MF_PROBE) launch_lowp_k<LP_U8, 16, MF_PROBE, 32, 8, 1, 4, 3>(P, grid, s);
             else launch_lowp_k<LP_U8, 16, MF_FILTER, 32, 8, 1, 4, 3>(P, grid, s);
@@ -98,7 +106,7 @@ static bool launch_lowp_narrow_any(const vsgpu_table *t, int mode, const LowpPar
 static size_t lowp_narrow_qtile(const vsgpu_table *t) {
     if (t->lp_kind == LP_SQ8) return 64;
     if ((t->lp_kind == LP_BF16 || t->lp_kind == LP_F16) && t->lp_ksteps <= 32) return 64;
-    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8) && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
+    if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || t->lp_kind == LP_U8C) && t->lp_ksteps == 16 && t->lp_rt == 32) return 128;
     // int8 / uint8 (every metric) up to 768 elements: the same 8-wave shape the SQ8 filter runs on (rows of 768 + 16 bytes there)
     if ((t->lp_kind == LP_I8 || t->lp_kind == LP_U8 || t->lp_kind == LP_U8C) && (t->lp_ksteps == 8 || t->lp_ksteps == 12) && t->lp_rt == 64) return 128;
     return 0;
