@@ -712,6 +712,10 @@ def test_narrow_batches_run_on_half_size_workgroups(vso, typ, metric, dim, nq):
     ("IP", 4096, 4_000, 9, 10),        # at most 16 queries: one column block per workgroup
     ("L2", 4096, 5_000, 100, 10),      # three column blocks per workgroup (width 128 k-steps): 48 + 48 + 4 queries
     ("IP", 4000, 4_000, 40, 10),       # ... one 48-query tile instead of two of 32
+    ("L2", 768, 30_000, 128, 10),      # more than 64 queries at widths 512 / 768 / 1024: eight column blocks, 128 queries per pass
+    ("IP", 700, 20_000, 100, 10),
+    ("Cosine", 1024, 20_000, 200, 5),
+    ("L2", 400, 40_000, 65, 10),
 ])
 def test_wide_rows_on_the_k_split_filter(vso, metric, dim, n, nq, k):
     """rows beyond 3072 elements: 16 queries per workgroup, the k range split over the waves by ring stage, partial dot products

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
     constexpr int RED_BYTES = mfw_red_bytes(NW);
     constexpr int KMINE = KCH * KPW;                 // k-steps (= fragments per query block) of one wave
     static_assert(NS - 1 <= KCH && (NS - 2) * PP + 2 <= 33, "requests reach into the next tile at most");
-    static_assert(NQ <= 4, "one epilogue wave per column block");
+    static_assert(NQ <= 4 || (NW == 4 && NQ % 4 == 0), "column block nt is collected by wave nt % NW");
+    constexpr int OWN = NW == 4 ? 4 : NQ;   // the waves that collect column blocks (block nt: wave nt % OWN); eight waves: NQ <= 4
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int tid = threadIdx.x;
@@ -205,12 +206,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
 
     const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mfw_lds_bytes(false, NQ, NS, EK) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
-    auto flush_probe_minima = [&](int nt) {   // (the wave that owns column block nt)
+    auto flush_probe_minima = [&]() {   // (a wave that collects column blocks: the buffered minima of its blocks)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
-            float v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (it * NQ + nt) * 64u) : "memory");
-            P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
+#pragma unroll
+        for (int nt = 0; nt < NQ; nt++) {
+            if (wave != nt % OWN) continue;
+            for (uint32_t it = (uint32_t)kq; it < pm_n; it += 4) {
+                float v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pm_off + (it * NQ + nt) * 64u) : "memory");
+                P.tilemin[(size_t)qidx[nt] * P.tilemin_stride + pm_tile0 + it * step] = v;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pm_n = 0;
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
         const uint32_t red_tile = red_off + rpar * (uint32_t)(NQ * RED_BYTES);
 #pragma unroll
         for (int nt = 0; nt < NQ; nt++) {
-            if (wave != nt) {
-                const int k3 = wave < nt ? wave : wave - 1;   // which of the NW - 1 partials of block nt this wave writes
+            if (wave != nt % OWN) {
+                const int k3 = wave < nt % OWN ? wave : wave - 1;   // which of the NW - 1 partials of block nt this wave writes
                 const mf_u32x4 v = __builtin_bit_cast(mf_u32x4, acc[nt]);
                 asm volatile("ds_write_b128 %0, %1" ::"v"(red_tile + (uint32_t)(nt * RED_BYTES + k3 * 1024 + lane * 16)), "v"(v) : "memory");
             }
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
         bool emitted = false;
 #pragma unroll
         for (int nt = 0; nt < NQ; nt++) {
-            if (wave != nt) continue;
+            if (wave != nt % OWN) continue;
             const float *nrm = reinterpret_cast<const float *>(norm_lds + nbuf * NORM_PAR);
             mf_u32x4 nbits, sxbits = {0u, 0u, 0u, 0u};
             if constexpr (U8C) {   // rows kq * 4 + i: the record's first two words
@@ -424,9 +429,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
                 tmin = fminf(tmin, __shfl_xor(tmin, 16));
                 tmin = fminf(tmin, __shfl_xor(tmin, 32));
                 if (kq == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pm_off + (pm_n * NQ + nt) * 64u), "v"(tmin) : "memory");
-                if (pm_n == 0) pm_tile0 = tile;
-                if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima(nt);
             }
+        }
+        if (MODE == MF_PROBE && wave < (NQ < OWN ? NQ : OWN)) {   // (once per tile, whatever the number of blocks the wave collects)
+            if (pm_n == 0) pm_tile0 = tile;
+            if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
         }
         if (MODE == MF_FILTER) {
             if (__any(emitted)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -438,11 +445,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mfma_filter_wide(MfmaParams P) {
         nbuf = nbuf + 1 >= 3 ? 0 : nbuf + 1;
         rpar ^= 1u;
     }
-    if (MODE == MF_PROBE && pm_n) {
-#pragma unroll
-        for (int nt = 0; nt < NQ; nt++)
-            if (wave == nt) flush_probe_minima(nt);
-    }
+    if (MODE == MF_PROBE && pm_n) flush_probe_minima();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (MODE == MF_FILTER) {
         __builtin_amdgcn_s_barrier();

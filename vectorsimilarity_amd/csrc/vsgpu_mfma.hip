@@ -167,6 +167,14 @@ template <int KS, int MODE, int NQ, int NS> static void launch_wide_ks(const Mfm
 #define WIDE_NS_ALONE 5
 #endif
 template <int MODE> static void launch_wide(int ksteps, int nq_blocks, const MfmaParams &P, dim3 grid, hipStream_t s) {
+    if (nq_blocks == 8) {   // 128 queries per workgroup at widths 512 / 768 / 1024 (ring depth: at most one row tile ahead)
+        switch (ksteps) {
+        case 16: launch_wide_ks<16, MODE, 8, 3>(P, grid, s); break;
+        case 24: launch_wide_ks<24, MODE, 8, 4>(P, grid, s); break;
+        default: launch_wide_ks<32, MODE, 8, 5>(P, grid, s); break;
+        }
+        return;
+    }
     switch (ksteps) {
     case 128:
         if (nq_blocks == 3) launch_wide_ks<128, MODE, 3, WIDE_NS_ALONE>(P, grid, s);
@@ -186,10 +194,14 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n, dim = t->dim;
     const int KS = t->ksteps;
-    const bool wide = KS > 96;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
+    // (round 5, late) fp32 rows of 257 .. 1024 elements (kernel widths 512 / 768 / 1024), MORE THAN 64 QUERIES: k_mfma_filter holds 64 queries per workgroup, so a batch of 128
+    // crosses the rows twice (3.4 TB/s effective at any dim).  The k-split filter holds EIGHT column blocks at these widths -- 8 x KS registers
+    // of fragments per wave, 128-256 (at width 1536 the 384 + two blocks' epilogue spill) -- i.e. 128 queries per pass.  Option wide_blocks = 8 / 0 allow it, any other value keeps the 64-query tiles.
+    const bool k8 = t->type == VSGPU_F32 && (KS == 16 || KS == 24 || KS == 32) && nq > 64 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 8);
+    const bool wide = KS > 96 || k8;   // (fp32 only: vsgpu_table_create offers fp64 rows no width beyond 64)
     // (three column blocks at width 128 k-steps -- 4096 elements -- where 48-query tiles cross the rows less often than 32-query tiles: vsgpu_lowp.hip)
     const bool three = wide && KS == 128 && (c->opt_wide_blocks == 0 || c->opt_wide_blocks == 3) && (nq + 47) / 48 < (nq + 31) / 32;
-    const int wide_blocks = three ? 3 : ((wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1);
+    const int wide_blocks = k8 ? 8 : three ? 3 : ((wide && KS <= 192 && nq > (size_t)MFW_QTILE && c->opt_wide_blocks != 1) ? 2 : 1);
     const bool rt16 = !wide && probe_rt16(c, KS);
     const size_t QT = wide ? (size_t)MFW_QTILE * wide_blocks : (size_t)MF_QTILE, TILE_ROWS = (wide || rt16) ? 16 : (size_t)MF_TILE_ROWS;
     // (padded queries: whole 64-query tiles, and whole 48-query tiles where three column blocks run: 128 queries are three of those = 144)
