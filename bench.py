@@ -87,6 +87,9 @@ def parse():
                          "c4: weak: the line's value / scaling), the other kind under \"also\"")
     ap.add_argument("--no-shard-curve", dest="shard_curve", action="store_false",
                     help="one GPU, c2: skip measuring the rows / G shards (G = 2, 4, 8) the strong-scaling estimate is built from")
+    ap.add_argument("--no-full-parity", dest="full_parity", action="store_false",
+                    help="one GPU: skip comparing the timed table's last reply with the oracle's scan of all its rows (streams the "
+                         "table back to the host once: ~10 s at 30 GB)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning: VecSimGpu_SetOption on the index (e.g. probe_div=64); not used by the default run")
     a = ap.parse_args()
@@ -189,6 +192,43 @@ def cpu_baseline(args, VecSim, synth):
                           n, args.rows, args.batch, nq1, args.topk,
                           "AVX-512 intrinsics (oracle/vso_fast.c twin of the reference kernel)" if fast else "portable reference-order lanes",
                           tier_name, same)}
+
+
+def full_table_parity(args, ix, n, queries, reply, which):
+    """checker leg (the other place bench.py touches oracle/): the TIMED index's own reply to its last timed batch, compared for the
+    queries `which` with the oracle's reference-order scan of the whole table -- the stored rows streamed back in 1 GiB pieces
+    and scored on the host cores (oracle.vso.StreamTopK = brute_force.h:242-291 over a running candidate set).  Labels, order
+    and scores must be bit-equal.  Returns the verdict and what it cost."""
+    from oracle import vso
+    from vectorsimilarity_amd import _capi
+    vso.build()
+    t0 = time.perf_counter()
+    vt = getattr(vso, {"FLOAT32": "F32", "INT8": "I8", "BFLOAT16": "BF16"}[args.type_name])
+    tier_name = _capi.load().VecSimGpu_HostTier().decode()
+    tier = {"AVX512": vso.TIER_AVX512, "SCALAR": vso.TIER_SCALAR, "AVX512_BF16": vso.TIER_AVX512_BF16, "AVX512_FP16": vso.TIER_AVX512_FP16}[tier_name]
+    qsel = np.ascontiguousarray(queries[which])
+    if args.metric_name == "Cosine":                         # int8 Cosine: query blob = elements + float norm
+        qb = np.zeros((len(which), args.dim + 4), dtype=np.uint8)
+        qb[:, :args.dim] = qsel.view(np.uint8)
+        for i in range(len(which)):
+            vso.normalize(qb[i], args.dim, vt)
+        qsel, km = qb, vso.COSINE
+    else:
+        km = vso.L2 if args.metric_name == "L2" else vso.IP
+    threads = min(64, os.cpu_count() or 1)
+    st = vso.StreamTopK(vt, km, qsel, args.topk, args.dim, threads=threads, tier=tier)
+    rb = ix.stored_rows(0, 1).shape[1]
+    per = max(1, (1 << 30) // rb)
+    buf = np.empty(per * rb, dtype=np.uint8)
+    for r0 in range(0, n, per):
+        st.feed(ix.stored_rows(r0, min(per, n - r0), out=buf), r0)
+    el, es = st.result()
+    labels, scores = reply
+    same = all(bool(np.array_equal(labels[qi], el[j]) and np.array_equal(scores[qi], es[j])) for j, qi in enumerate(which))
+    return {"same": bool(same and st.rows_seen == n), "rows": int(st.rows_seen), "queries": [int(x) for x in which], "host_threads": threads,
+            "tier": tier_name, "seconds": time.perf_counter() - t0,
+            "how": "the timed index's reply to its last timed batch vs the oracle's reference-order scan of ALL its stored rows "
+                   "(streamed back in 1 GiB pieces), labels + order + scores bit for bit"}
 
 
 def run_c5(args):
@@ -493,6 +533,10 @@ def main():
         ix, local, transport = build_index(args, p, my_rows, rank, world, local_rank, dist, distributed, VecSim, ShardedFlatIndex)
         ph = timed_phase(args, ix, local, transport, my_rows, args.steps, qsets, rank, world, dist, distributed, readers, nwarm)
         ph.update(kind=kind, my_rows=my_rows, total_rows=total_rows, transport=transport)
+        if world == 1 and not distributed and args.full_parity and not phases:
+            # the table that was just timed, against the oracle (first, middle and last query of the last timed batch)
+            ph["full_table_parity"] = full_table_parity(args, local, my_rows, qsets[(args.warmup + args.steps - 1) % nb_distinct], ph["last"],
+                                                        sorted({0, args.batch // 2, args.batch - 1}))
         phases.append(ph)
         del ix, local                          # (the next phase's rows need the room)
     ph = phases[0]
@@ -597,6 +641,9 @@ def main():
         # size-independent property at full size: replies are ascending in score
         labels, scores = ph["last"]
         out["sorted"] = bool(np.all(np.diff(scores, axis=1) >= 0) and np.all(labels >= 0))
+        if "full_table_parity" in ph:
+            out["full_table_parity"] = ph["full_table_parity"]["same"]
+            out["full_table_parity_detail"] = ph["full_table_parity"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

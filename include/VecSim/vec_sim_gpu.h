@@ -188,8 +188,8 @@ const char *VecSimGpu_LastError(void);
 /* Which reference ISA tier's summation order a new index reproduces on this host: "AVX512" | "AVX512_BF16" | "AVX512_FP16" | "SCALAR".
  * Chosen like the reference chooses its kernels -- from the host CPU's features at run time (spaces.h:68-78,
  * IP_space.cpp:554-615, L2_space.cpp:185-241): avx512f -> the AVX-512 kernels' order, avx512_bf16 && avx512vl on top ->
- * vdpbf16ps for bf16 IP / Cosine, avx512_fp16 && avx512vl on top -> half-precision accumulators for fp16 rows of dim >= 32 (what
- * a reference built by gcc >= 12 runs there; $VECSIM_GPU_TIER=avx512_bf16 for a gcc-11 build's order).  A host without AVX-512 also gets "AVX512" (its reference build would run AVX2 / SSE
+ * vdpbf16ps for bf16 IP / Cosine.  "AVX512_FP16" (half-precision accumulators for fp16 rows of dim >= 32, what a reference built by
+ * gcc >= 12 runs on an avx512_fp16 host) is never chosen from CPUID: $VECSIM_GPU_TIER=avx512_fp16 opts in (unpinned order).  A host without AVX-512 also gets "AVX512" (its reference build would run AVX2 / SSE
  * kernels, whose orders are not restated; one line on stderr says so).  $VECSIM_GPU_TIER = avx512 | avx512_bf16 | avx512_fp16 |
  * scalar overrides.  VecSimGpu_IndexTier: the tier an existing index answers in (VecSimIndex_DebugInfoIterator carries exactly the
  * reference's fields). */

@@ -174,6 +174,9 @@ int vso_flat_topk_batch_fast(int type, int metric, size_t dim, const void *rows,
 int vso_flat_topk_batch_fast_tier(int type, int metric, int tier, size_t dim, const void *rows, size_t n,
                                   size_t stride, const void *queries, size_t nq, size_t qstride,
                                   size_t k, int threads, size_t *out_labels, double *out_scores);
+/* scores of nq queries x n rows (out[q * n + i]), row blocks dealt over `threads` threads: the full-size checker's leg */
+int vso_scan_batch_fast_tier(int type, int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride,
+                             const void *queries, size_t nq, size_t qstride, int threads, double *out);
 int vso_fast_available(int type, int metric, int tier, size_t dim);
 double vso_distance_fast(int type, int metric, size_t dim, const void *a, const void *b);   /* tier AVX512 */
 double vso_distance_fast_tier(int type, int metric, int tier, size_t dim, const void *a, const void *b);

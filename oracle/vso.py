@@ -52,6 +52,8 @@ def lib():
         L.vso_fast_available.argtypes = [i, i, i, sz]
         L.vso_flat_topk_batch_fast_tier.restype = i
         L.vso_flat_topk_batch_fast_tier.argtypes = [i, i, i, sz, vp, sz, sz, vp, sz, sz, sz, i, vp, vp]
+        L.vso_scan_batch_fast_tier.restype = i
+        L.vso_scan_batch_fast_tier.argtypes = [i, i, i, sz, vp, sz, sz, vp, sz, sz, i, vp]
         L.vso_uses_scalar.restype = i
         L.vso_uses_scalar.argtypes = [i, i, i, sz]
         L.vso_scan.restype = None
@@ -366,6 +368,57 @@ def flat_topk_batch_fast(vtype, metric, rows, queries, k, dim, threads=1, tier=T
                                                rows.strides[0], _ptr(queries), nq, queries.strides[0],
                                                k, threads, _ptr(ol), _ptr(osc))
     return ol, osc, bool(fast)
+
+
+def scan_batch(vtype, metric, rows, queries, dim, threads=1, tier=TIER_AVX512):
+    """scores[nq, n] (f64) of every query against every row, row blocks dealt over `threads` threads"""
+    rows = np.ascontiguousarray(rows)
+    queries = np.ascontiguousarray(queries)
+    n, nq = rows.shape[0], queries.shape[0]
+    out = np.empty((nq, n), dtype=np.float64)
+    lib().vso_scan_batch_fast_tier(vtype, metric, tier, dim, _ptr(rows), n, rows.strides[0], _ptr(queries), nq,
+                                   queries.strides[0], threads, _ptr(out))
+    return out
+
+
+class StreamTopK:
+    """brute_force.h:242-291 over a table too large to hold on the host: feed() the stored rows piece by piece in internal-id
+    order; the running set keeps every row whose score is <= the k-th smallest seen so far (a superset of what the sequential
+    heap can ever hold: SURVEY.md 8a A10), result() replays the reference's heap over that set in id order."""
+
+    def __init__(self, vtype, metric, queries, k, dim, threads=1, tier=TIER_AVX512):
+        self.vtype, self.metric, self.k, self.dim, self.threads, self.tier = vtype, metric, k, dim, threads, tier
+        self.queries = np.ascontiguousarray(queries)
+        nq = self.queries.shape[0]
+        self.ids = [np.empty(0, dtype=np.uint64) for _ in range(nq)]
+        self.scores = [np.empty(0, dtype=np.float64) for _ in range(nq)]
+        self.bound = [np.inf] * nq
+        self.rows_seen = 0
+
+    def feed(self, rows, first_id):
+        sc = scan_batch(self.vtype, self.metric, rows, self.queries, self.dim, self.threads, self.tier)
+        assert not np.isnan(sc).any()
+        for q in range(len(self.ids)):
+            keep = np.nonzero(sc[q] <= self.bound[q])[0]
+            ids = np.concatenate([self.ids[q], keep.astype(np.uint64) + np.uint64(first_id)])
+            scs = np.concatenate([self.scores[q], sc[q][keep]])
+            if len(scs) > self.k:
+                t = np.partition(scs, self.k - 1)[self.k - 1]
+                m = scs <= t
+                ids, scs, self.bound[q] = ids[m], scs[m], t
+            self.ids[q], self.scores[q] = ids, scs
+        self.rows_seen += rows.shape[0]
+
+    def result(self):
+        nq = len(self.ids)
+        labels = np.full((nq, self.k), -1, dtype=np.int64)
+        scores = np.full((nq, self.k), np.nan)
+        for q in range(nq):
+            o = np.argsort(self.ids[q], kind="stable")
+            l, s = topk_replay(self.scores[q][o], self.k, self.ids[q][o])
+            labels[q, :len(l)] = l.astype(np.int64)
+            scores[q, :len(s)] = s
+        return labels, scores
 
 
 def synth_rows_f32(seed, first_row, nrows, dim):

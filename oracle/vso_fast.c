@@ -438,6 +438,32 @@ int vso_flat_topk_batch_fast_tier(int type, int metric, int tier, size_t dim, co
     return fast;
 }
 
+/* Full-size checker leg: the scores of nq queries against n rows, rows dealt over `threads` OpenMP threads in blocks (each
+ * block is read once for all queries).  out[q * n + i] = the same value vso_distance / vso_distance_fast_tier gives for
+ * (row i, query q) -- brute_force.h:264-281 calls that function once per stored row; the order of the calls does not enter
+ * a score.  Returns 1 if the intrinsics twin ran. */
+int vso_scan_batch_fast_tier(int type, int metric, int tier, size_t dim, const void *rows, size_t n, size_t stride,
+                             const void *queries, size_t nq, size_t qstride, int threads, double *out) {
+    const int fast = vso_fast_available(type, metric, tier, dim);
+    const long blk = 128, nblk = (long)((n + blk - 1) / blk);
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
+#endif
+    for (long b = 0; b < nblk; b++) {
+        const size_t i0 = (size_t)b * blk, i1 = i0 + blk < n ? i0 + blk : n;
+        for (size_t q = 0; q < nq; q++) {
+            const char *qp = (const char *)queries + q * qstride;
+            for (size_t i = i0; i < i1; i++) {
+                const char *rp = (const char *)rows + i * stride;
+                out[q * n + i] = fast ? vso_distance_fast_tier(type, metric, tier, dim, rp, qp)
+                                      : vso_distance(type, metric, tier, dim, rp, qp);
+            }
+        }
+    }
+    return fast;
+}
+
 int vso_flat_topk_batch_fast(int type, int metric, size_t dim, const void *rows, size_t n,
                              size_t stride, const void *queries, size_t nq, size_t qstride,
                              size_t k, int threads, size_t *out_labels, double *out_scores) {

@@ -233,12 +233,15 @@ class VecSimIndex:
             return rows[:, :dim].copy().view(np.int8).astype(np.float32)
         return rows[:, :dim].copy().astype(np.float32)
 
-    def stored_rows(self, first_id, n):
+    def stored_rows(self, first_id, n, out=None):
         """the stored blobs of internal ids [first_id, first_id + n) as a uint8 array [n, blob bytes] (Flat indexes; Cosine rows
-        as normalised at ingest, int8 / uint8 Cosine with the trailing float norm)"""
+        as normalised at ingest, int8 / uint8 Cosine with the trailing float norm); `out`: a uint8 buffer to reuse"""
         bb = C.c_size_t(0)
         self._lib.VecSimGpu_GetStoredVectors(self._h, 0, None, 0, C.byref(bb))
-        out = np.empty((n, bb.value), dtype=np.uint8)
+        if out is None:
+            out = np.empty((n, bb.value), dtype=np.uint8)
+        else:
+            out = out.reshape(-1)[: n * bb.value].reshape(n, bb.value)
         got = self._lib.VecSimGpu_ReadStoredRows(self._h, int(first_id), int(n), out.ctypes.data_as(C.c_void_p), out.nbytes)
         if got != n:
             raise RuntimeError("stored_rows failed")

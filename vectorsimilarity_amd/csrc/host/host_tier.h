@@ -13,11 +13,12 @@
 //                                               filters (the scalar order turns them off: 10-50x slower) and is the order
 //                                               the same index gives on any AVX-512 host.  The scalar kernels' order
 //                                               (VSGPU_TIER_SCALAR) is an explicit choice only.
-//   ... && avx512_fp16 && avx512vl           -> fp16 rows of dim >= 32 in HALF-precision accumulators, what a reference built by
-//                                               gcc >= 12 / clang >= 14 (OPT_AVX512_FP16_VL) runs there (IP_space.cpp:649-658,
-//                                               L2_space.cpp:388-397); everything else as AVX512_BF16 (VSGPU_TIER_AVX512_FP16).
-//                                               A gcc-11 build of the reference has no such kernels: VECSIM_GPU_TIER=avx512_bf16
-//                                               gives its order on such a host.
+//   ... && avx512_fp16 && avx512vl           -> STILL AVX512_BF16 (one line on stderr for fp16 indexes).  A reference built by gcc >= 12 /
+//                                               clang >= 14 (OPT_AVX512_FP16_VL) accumulates fp16 rows of dim >= 32 in HALF precision
+//                                               there (IP_space.cpp:649-658, L2_space.cpp:388-397); that order is restated
+//                                               (VSGPU_TIER_AVX512_FP16) but OPT-IN: VECSIM_GPU_TIER=avx512_fp16 -- it is unpinned (no
+//                                               host here executes it), a gcc-11 build has no such kernels, and it runs on the exact
+//                                               kernels only.
 // -- and VECSIM_GPU_TIER = avx512 | avx512_bf16 | avx512_fp16 | scalar overrides it.  The reference asks for more than avx512f per type (bf16: avx512bw && avx512vbmi2,
 // L2_space.cpp:332-337; int8 / uint8: avx512bw && avx512vl && avx512vnni, L2_space.cpp:451-455; fp16: avx512bw && avx512vl):
 // reference_order_missing() names what the host lacks for its own reference build to run the order this library restates for
@@ -68,7 +69,9 @@ inline HostFeatures host_features() {
 }
 
 inline int tier_from_features(const HostFeatures &f) {
-    if (f.avx512f && f.avx512_fp16 && f.avx512vl) return VSGPU_TIER_AVX512_FP16;   // (every such CPU has avx512_bf16 as well)
+    // avx512_fp16 hosts are NOT promoted to VSGPU_TIER_AVX512_FP16 on their own (round 6, advisor): that order is the one tier whose
+    // parity is unpinned (nothing here executes avx512_fp16), it only equals reference builds made by gcc >= 12 / clang >= 14, and it
+    // turns the MFMA filters off for fp16 rows.  VECSIM_GPU_TIER=avx512_fp16 opts in; resolve_tier says so once on such a host.
     if (f.avx512f && f.avx512_bf16 && f.avx512vl) return VSGPU_TIER_AVX512_BF16;
     return VSGPU_TIER_AVX512;
 }
@@ -105,6 +108,14 @@ inline int resolve_tier(int type = -1) {
                                  "orders are not restated); set VECSIM_GPU_TIER=scalar for the scalar kernels' order\n");
         }
     } else if (type >= 0 && type < 16) {
+        static bool said_fp16 = false;
+        if (type == VSGPU_F16 && f.avx512_fp16 && f.avx512vl && !said_fp16) {
+            said_fp16 = true;
+            std::fprintf(stderr, "vecsim_amd: host CPU has avx512_fp16: a reference built by gcc >= 12 / clang >= 14 accumulates fp16 rows of "
+                                 "dim >= 32 in half precision here; this library keeps the AVX512F fp32-accumulate order (what a gcc-11 build "
+                                 "runs) unless VECSIM_GPU_TIER=avx512_fp16 is set (that order is restated but unpinned, and runs without the "
+                                 "MFMA filters)\n");
+        }
         static bool said_for[16] = {};
         const std::string miss = reference_order_missing(f, type);
         if (!miss.empty() && !said_for[type]) {

@@ -154,7 +154,7 @@ void merge_one_query(size_t q, size_t parts, size_t cap, size_t part_stride, con
 int merge_topk_strided(size_t nq, size_t parts, size_t cap, size_t part_stride, const uint64_t *gids, const size_t *labels, const double *scores,
                        const uint32_t *counts, size_t k, size_t *out_labels, double *out_scores, uint32_t *out_counts, bool every_row) {
     for (size_t i = 0; i < parts * nq; i++)
-        if (counts[i] == 0xFFFFFFFFu) return -1;
+        if (counts[i] == 0xFFFFFFFFu || counts[i] > cap) return -1;   // (overflow marker; a count beyond the record's room is a corrupt record)
     for (size_t q = 0; q < nq; q++) out_counts[q] = 0;
     if (k == 0) return 0;
     auto range = [&](size_t q0, size_t q1) {

@@ -1045,7 +1045,15 @@ static __global__ __launch_bounds__(256) void k_row_aux_i8(const char *rows, uin
         if (lane == 0) {
             const unsigned char *np = reinterpret_cast<const unsigned char *>(p + dim);
             out[row] = (uint32_t)np[0] | ((uint32_t)np[1] << 8) | ((uint32_t)np[2] << 16) | ((uint32_t)np[3] << 24);
-            note(out[row]);
+            // the extremes are kept in the signed order of the bit patterns, which is the floats' order for non-negative, non-NaN
+            // norms only.  The norm is whatever the blob's tail holds (IP.cpp:264-271 reads it verbatim): a negative or NaN one
+            // poisons the pair to {-inf, +inf}, so that x32l_threshold's product is -inf / NaN and EVERY value takes the exact test
+            if ((int)out[row] < 0 || out[row] > 0x7F800000u) {
+                note(0xFF800000u);
+                note(0x7F800000u);
+            } else {
+                note(out[row]);
+            }
         }
         return;
     }

@@ -6,7 +6,9 @@
 // libvsgpu.so carry no RCCL dependency and a process that already holds an RCCL (e.g. torch's) shares it.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
 
 #include "vsgpu_internal.hpp"
 
@@ -79,14 +81,19 @@ struct vsgpu_comm {
     // A collective that failed on this rank (RCCL error, HIP error, the peers not arriving within the time limit) ABORTS the
     // communicator: a rank that merely returned an error would leave its peers inside the collective for ever.  Their kernels see
     // the abort (or their own time limit) and every rank comes back with an error.  A dead communicator refuses further calls.
-    bool dead = false;
+    // Threads: `mu` is held for the whole of a collective (one in flight per communicator).  vsgpu_comm_abort from ANOTHER thread
+    // only raises `abort_req` and then waits for `mu`: the thread inside the collective sees the flag in comm_wait and performs the
+    // abort itself (ncclCommAbort frees the communicator, so nobody may still be inside ncclCommGetAsyncError with it); a collective
+    // that had already left comm_wait completes, and the abort runs behind it.
+    std::atomic<bool> dead{false};
+    std::atomic<bool> abort_req{false};
+    std::mutex mu;
     long timeout_ms = 0;         // VECSIM_GPU_EXCHANGE_TIMEOUT_MS (default 120 s; 0 = wait for ever)
     uint64_t collectives = 0;    // issued so far
     long fail_at = -1;           // VECSIM_GPU_EXCHANGE_FAIL_AT = n: the n-th collective reports an RCCL failure (test hook)
 };
 static int comm_abort(vsgpu_comm *c, const char *why) {
-    if (!c->dead) {
-        c->dead = true;
+    if (!c->dead.exchange(true)) {
         Rccl *r = rccl();
         if (c->comm && r && r->CommAbort) {
             (void)r->CommAbort(c->comm);   // frees the communicator and releases kernels waiting inside it
@@ -102,9 +109,12 @@ static int comm_wait(vsgpu_comm *c) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 1;; spin++) {
         const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipSuccess) return VSGPU_OK;
+        // (a stream that drained because the communicator was aborted under it also reports success: the receive block then holds
+        // whatever was there before -- never hand that back as a result)
+        if (e == hipSuccess) return (c->dead || c->abort_req) ? comm_abort(c, "aborted while the exchange was in flight") : VSGPU_OK;
         if (e != hipErrorNotReady) return comm_abort(c, hipGetErrorString(e));
         if ((spin & 0x3FF) != 0) continue;
+        if (c->abort_req) return comm_abort(c, "aborted by the caller");
         int async = kRcclSuccess;
         if (r->CommGetAsyncError && c->comm && r->CommGetAsyncError(c->comm, &async) == kRcclSuccess && async != kRcclSuccess)
             return comm_abort(c, rccl_err(async));
@@ -197,6 +207,8 @@ extern "C" void vsgpu_comm_destroy(vsgpu_comm *c) {
 }
 extern "C" int vsgpu_comm_abort(vsgpu_comm *c) {
     if (!c) return VSGPU_OK;
+    c->abort_req = true;                       // an exchange in flight sees it in comm_wait and aborts on its own thread
+    std::lock_guard<std::mutex> lk(c->mu);     // ... and has left the communicator when this lock is granted
     (void)hipSetDevice(c->ctx->device);
     (void)comm_abort(c, "aborted by the caller");
     return VSGPU_OK;
@@ -237,6 +249,7 @@ static int comm_reserve(vsgpu_comm *c, size_t send_bytes, size_t recv_bytes) {
 
 // entry of every collective: a dead communicator refuses; the test hook's chosen collective fails the way an RCCL call would
 static int comm_enter(vsgpu_comm *c) {
+    if (c->abort_req && !c->dead) return comm_abort(c, "aborted by the caller");
     if (c->dead) return fail(VSGPU_ERR_HIP, "shard exchange: the communicator of rank %d was aborted by an earlier failure", c->rank);
     if (c->fail_at >= 0 && (long)c->collectives == c->fail_at) {
         c->collectives++;
@@ -248,6 +261,7 @@ static int comm_enter(vsgpu_comm *c) {
 
 extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t bytes, void *recv) {
     if (bytes == 0) return VSGPU_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->ctx->device));
     int rc = comm_enter(c);
     if (rc) return rc;
@@ -264,6 +278,7 @@ extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t byte
     }
     rc = comm_wait(c);
     if (rc) return rc;
+    if (c->dead) return fail(VSGPU_ERR_HIP, "shard exchange: the communicator of rank %d was aborted", c->rank);
     memcpy(recv, c->h_recv, total);
     return VSGPU_OK;
 }
@@ -271,6 +286,7 @@ extern "C" int vsgpu_comm_allgather(vsgpu_comm *c, const void *send, size_t byte
 extern "C" int vsgpu_comm_broadcast(vsgpu_comm *c, void *buf, size_t bytes, int root) {
     if (bytes == 0) return VSGPU_OK;
     if (root < 0 || root >= c->world) return fail(VSGPU_ERR_ARG, "broadcast root %d of %d", root, c->world);
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->ctx->device));
     int rc = comm_enter(c);
     if (rc) return rc;
