@@ -466,7 +466,7 @@ def timed_phase(args, ix, local, transport, my_rows, steps, qsets, rank, world, 
         nb = max(1, sst["batches"])
         mine = torch.tensor([st["scan_ms"] / max(1, st["scan_launches"]), sst["scan_ms"] / nb, sst["turn_wait_ms"] / nb,
                              sst["exchange_ms"] / nb, sst["merge_ms"] / nb, sst["exchange_bytes"] / nb, float(ix._lib.VecSimGpu_ShardedWorld(ix._h)),
-                             my_dt / steps * 1e3, float(my_rows)],
+                             my_dt / steps * 1e3, float(my_rows), float(local._lib.VecSimGpu_IndexDevice(local._h))],
                             dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -475,10 +475,10 @@ def timed_phase(args, ix, local, transport, my_rows, steps, qsets, rank, world, 
         per_rank = [{"rank": r, "rows": int(t[8]), "ms_per_batch": float(t[7]), "scan_kernel_ms": float(t[0]),
                      "fixed_ms_per_batch": float(t[7] - t[0]), "shard_scan_call_ms": float(t[1]), "turn_wait_ms": float(t[2]),
                      "exchange_ms": float(t[3]), "merge_ms": float(t[4]), "exchange_bytes": float(t[5]),
-                     "rccl_world": int(t[6])} for r, t in enumerate(allr)]
+                     "rccl_world": int(t[6]), "device": int(t[9])} for r, t in enumerate(allr)]
         assert transport != "rccl" or all(q["rccl_world"] == world for q in per_rank), per_rank   # every communicator spans all N ranks
     launches = max(1, st["scan_launches"])
-    return {"dt": dt, "steps": steps, "st": st, "per_rank": per_rank, "last": last, "avg_kernel_ms": st["scan_ms"] / launches,
+    return {"device": int(local._lib.VecSimGpu_IndexDevice(local._h)), "dt": dt, "steps": steps, "st": st, "per_rank": per_rank, "last": last, "avg_kernel_ms": st["scan_ms"] / launches,
             "ms_per_step": dt / steps * 1e3, "fixed_ms_per_batch": dt / steps * 1e3 - st["scan_ms"] / launches,
             "candidates_per_query": st["candidates"] / max(1, steps * args.batch)}
 
@@ -536,7 +536,7 @@ def main():
         if world == 1 and not distributed and args.full_parity and not phases:
             # the table that was just timed, against the oracle (first, middle and last query of the last timed batch)
             ph["full_table_parity"] = full_table_parity(args, local, my_rows, qsets[(args.warmup + args.steps - 1) % nb_distinct], ph["last"],
-                                                        sorted({0, args.batch // 2, args.batch - 1}))
+                                                        sorted(set(range(0, args.batch, max(1, args.batch // 8))) | {args.batch - 1}))
         phases.append(ph)
         del ix, local                          # (the next phase's rows need the room)
     ph = phases[0]
@@ -604,6 +604,10 @@ def main():
                        "sharding": "rows x %d" % world if world > 1 else "single GPU",
                        "reader_threads": readers,
                        "exchange_buffers": getattr(args, "exchange_mode", None),
+                       # self-diagnosis of a multi-GPU run: the size every rank's RCCL communicator reports, and which device each rank drove
+                       "rccl_world": ([q["rccl_world"] for q in ph["per_rank"]] if ph["per_rank"] else None),
+                       "rank_devices": ([q["device"] for q in ph["per_rank"]] if ph["per_rank"] else [ph["device"]]),
+                       "exchange_transport": args.exchange_transport,
                        "exchange": (("rccl ncclAllGather" if args.exchange_transport == "rccl" else args.exchange_transport) +
                                     " of per-shard candidate records over %d rank(s), sequence-ordered, + exact host "
                                     "merge (C++ host library)" % world) if distributed else "none (plain VecSimIndex_TopKQueryBatch)"},

@@ -199,6 +199,9 @@ const char *VecSimGpu_HostTier(void);
  * lower tier, L2_space.cpp:332-337).  Index creation prints the same once per type on stderr.  Valid until the thread's next call. */
 const char *VecSimGpu_HostTierNote(VecSimType type);
 const char *VecSimGpu_IndexTier(VecSimIndex *index);
+/* The HIP device ordinal the index's rows live on (-1: none); a multi-rank job prints it per rank so that a first run on an
+ * 8-GPU node shows at a glance that every rank drove its own device. */
+int VecSimGpu_IndexDevice(VecSimIndex *index);
 
 /* HIP-event timing of the dominant scan kernel since the last reset (bench.py roofline leg) */
 typedef struct {

@@ -409,13 +409,16 @@ class StreamTopK:
             self.ids[q], self.scores[q] = ids, scs
         self.rows_seen += rows.shape[0]
 
-    def result(self):
+    def result(self, label_of=None):
+        """label_of: ids (uint64 array) -> labels, for tables whose labels are not their internal ids (the heap's eviction rule reads
+        the label: utils/vecsim_stl.h:63-83)"""
         nq = len(self.ids)
         labels = np.full((nq, self.k), -1, dtype=np.int64)
         scores = np.full((nq, self.k), np.nan)
         for q in range(nq):
             o = np.argsort(self.ids[q], kind="stable")
-            l, s = topk_replay(self.scores[q][o], self.k, self.ids[q][o])
+            ids = self.ids[q][o]
+            l, s = topk_replay(self.scores[q][o], self.k, ids if label_of is None else np.asarray(label_of(ids), dtype=np.uint64))
             labels[q, :len(l)] = l.astype(np.int64)
             scores[q, :len(s)] = s
         return labels, scores

@@ -22,7 +22,7 @@ def _tier(vso):
             "avx512_fp16": vso.TIER_AVX512_FP16}[os.environ.get("VECSIM_GPU_TIER", "avx512")]
 
 
-def stream_oracle(vso, ix, typ, metric, dim, n, qblobs, k, threads):
+def stream_oracle(vso, ix, typ, metric, dim, n, qblobs, k, threads, label_of=None):
     """the oracle's reply for the query blobs `qblobs` over the n stored rows of `ix`, streamed back piece by piece"""
     km = METRICS["IP"] if (metric == "Cosine" and typ not in ("i8", "u8")) else METRICS[metric]
     st = vso.StreamTopK(TYPES[typ], km, qblobs, k, dim, threads=threads, tier=_tier(vso))
@@ -33,7 +33,7 @@ def stream_oracle(vso, ix, typ, metric, dim, n, qblobs, k, threads):
         c = min(per, n - r0)
         st.feed(ix.stored_rows(r0, c, out=buf), r0)
     assert st.rows_seen == n
-    return st.result()
+    return st.result(label_of)
 
 
 # (typ, metric, dim, rows, batch, k, generator): BASELINE.json configs 2, 3, 4 (4: one GPU's shard of the 100 M rows)
@@ -63,7 +63,8 @@ def test_full_size_table_matches_oracle(vso, typ, metric, dim, n, nq, k, gen):
         q[qi] = g(47, row, 1, dim)[0]
     labels, dists = ix.knn_query(q, k)
     assert ix.stats()["scan_kernel"] != ""
-    check = sorted({0, nq // 3, nq - 2} | set(plant))
+    # config 2: every query of the batch; the others: a spread of them (the host scan is 7 M distances / s / core at 1 KiB rows)
+    check = list(range(nq)) if typ == "f32" else sorted(set(range(0, nq, nq // 16)) | {nq - 2} | set(plant))
     qblobs = stored_rows(vso, q[check], typ, metric)
     threads = min(64, os.cpu_count() or 1)
     el, es = stream_oracle(vso, ix, typ, metric, dim, n, qblobs, k, threads)
@@ -75,3 +76,21 @@ def test_full_size_table_matches_oracle(vso, typ, metric, dim, n, nq, k, gen):
     # a single query goes down a different path (no batch): same reply for the planted last row
     l1, d1 = ix.knn_query(q[nq - 1], k)
     assert np.array_equal(l1[0], labels[nq - 1]) and np.array_equal(d1[0], dists[nq - 1])
+    if typ != "f32":
+        return
+    # mutation at full size (brute_force.h:196-224): deleting label 5 moves the LAST row (label N-1) into internal id 5 -- a D2D
+    # copy from the last slab into the first; the table is one row shorter and the planted query must still find label N-1 first
+    assert ix.delete_vector(5) == 1 and ix.index_size() == n - 1
+    labels2, dists2 = ix.knn_query(q, k)
+    assert labels2[nq - 1][0] == n - 1 and dists2[nq - 1][0] == dists[nq - 1][0]
+    moved = ix.stored_rows(5, 1)
+    assert np.array_equal(moved[0, :eb], g(47, n - 1, 1, dim).view(np.uint8).reshape(-1)[:eb])
+
+    def label_of(ids):
+        out = ids.copy()
+        out[ids == 5] = n - 1
+        return out
+    sub = [0, 1, nq // 2, nq - 1]
+    el2, es2 = stream_oracle(vso, ix, typ, metric, dim, n - 1, stored_rows(vso, q[sub], typ, metric), k, threads, label_of)
+    for j, qi in enumerate(sub):
+        assert np.array_equal(labels2[qi], el2[j]) and np.array_equal(dists2[qi], es2[j]), ("after delete", qi)

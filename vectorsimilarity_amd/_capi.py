@@ -142,7 +142,7 @@ EXPORTS = [
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
-    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_HostTierNote", "VecSimGpu_IndexTier", "VecSimGpu_ResetStats",
+    "VecSimGpu_SetDevice", "VecSimGpu_DeviceCount", "VecSimGpu_DeviceSynchronize", "VecSimGpu_LastError", "VecSimGpu_HostTier", "VecSimGpu_HostTierNote", "VecSimGpu_IndexTier", "VecSimGpu_IndexDevice", "VecSimGpu_ResetStats",
     "VecSimGpu_GetStats", "VecSimGpu_SetOption",
     "VecSimGpu_ShardedGetUniqueId", "VecSimGpu_ShardedNew", "VecSimGpu_ShardedNewWithTransport",
     "VecSimGpu_ShardedNewExternal", "VecSimGpu_ShardedNewLocal", "VecSimGpu_ShardedFree", "VecSimGpu_ShardedAddVector",
@@ -312,6 +312,8 @@ def load():
     L.VecSimGpu_HostTierNote.argtypes = [C.c_int]
     L.VecSimGpu_IndexTier.restype = C.c_char_p
     L.VecSimGpu_IndexTier.argtypes = [C.c_void_p]
+    L.VecSimGpu_IndexDevice.restype = C.c_int
+    L.VecSimGpu_IndexDevice.argtypes = [C.c_void_p]
     L.VecSimGpu_ResetStats.restype = None
     L.VecSimGpu_ResetStats.argtypes = [vp]
     L.VecSimGpu_GetStats.restype = None

@@ -313,6 +313,11 @@ extern "C" const char *VecSimGpu_HostTierNote(VecSimType type) {
     return note.c_str();
 }
 extern "C" const char *VecSimGpu_IndexTier(VecSimIndex *index) { return index ? vsa::tier_name(index->distanceTier()) : ""; }
+extern "C" int VecSimGpu_IndexDevice(VecSimIndex *index) {
+    if (!index) return -1;
+    const auto g = index->gpus();
+    return g.empty() ? -1 : vsgpu_ctx_device(g[0]);
+}
 extern "C" VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
     const VecSimIndexDebugInfo info = index->debugInfo();
     const CommonInfo &ci = info.commonInfo;
