@@ -162,6 +162,13 @@ size_t vso_hnsw_iterate(int type, int metric, int tier, size_t dim, const void *
                         int *depleted_out);
 
 
+/* ---- HNSW insert path (vso_hnsw.c; hnsw.h:418-422, 743-963, 1567-1610, 1857-1946): serial inserts in id order.  Pinned by the
+ * reference-built graphs of tests/golden/ref_hnsw_graphs.npz.  Layout of the outputs: the index's graph export. */
+void vso_hnsw_levels(uint32_t n, uint32_t M, uint32_t seed, uint8_t *levels);
+uint64_t vso_hnsw_build(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n, uint32_t M, uint32_t efc,
+                        uint32_t seed, int fast, uint32_t *links0, uint16_t *cnt0, uint8_t *levels, uint32_t *upper_off, uint32_t *upper,
+                        uint32_t *entry_out, int *max_level_out);
+
 /* ---- timing leg (bench.py cpu_baseline, kind "port") ----
  * Same arithmetic as VSO_TIER_AVX512, written with AVX-512 intrinsics when the host has them
  * (falls back to the portable lanes code otherwise).  nq queries, `threads` OpenMP threads, one

@@ -411,3 +411,277 @@ size_t vso_hnsw_iterate(int type, int metric, int tier, size_t dim, const void *
     return b;
 #undef IDIST
 }
+
+/*
+ * ---- the INSERT path (round 6) -------------------------------------------------------------------------------------------
+ *   getRandomLevel                                   hnsw.h:418-422   (std::default_random_engine seed 100, hnsw.h:230)
+ *   storeNewElement / indexVector / appendVector     hnsw.h:1857-1946 (entry point and max level move at STORE time)
+ *   insertElementToGraph                             hnsw.h:1567-1610
+ *   greedySearchLevel<false>                         hnsw.h:1210-1258
+ *   searchLayer + processCandidate                   hnsw.h:680-720, 530-613
+ *   getNeighborsByHeuristic2 (+ _internal)           hnsw.h:720-797
+ *   mutuallyConnectNewElement                        hnsw.h:889-963
+ *   revisitNeighborConnections                       hnsw.h:800-886
+ * Serial inserts in id order, no deletions.  PINNED: tests/golden/ref_hnsw_graphs.npz holds two graphs the REFERENCE built and
+ * serialized (its unit tests' own data files, tests/unit/data/ *.v3: 1001 x 4 fp32, L2, M 8, efConstruction 10); re-inserting
+ * their vectors here reproduces every level, every link list IN ORDER, the entry point and the unidirectional-edge sets
+ * (tests/test_oracle_hnsw_build.py).
+ *
+ * What is library-defined in the reference and how it is restated:
+ *  - the level generator is libstdc++'s minstd_rand0 (x <- 16807 x mod 2^31-1) through generate_canonical<double, 53>: two
+ *    draws a, b -> ((a - 1) + (b - 1) R) / R^2 with R = 2^31 - 2, in double (the 1001 golden levels check it);
+ *  - candidate_set / top_candidates are std::priority_queue<pair<dist, id>>: pairs are totally ordered (ids are unique), so
+ *    WHICH element is on top never depends on the heap's layout.  The layout matters in one place: a candidate list shorter
+ *    than M is linked in the container's order (mutuallyConnectNewElement iterates it unsorted).  Such a heap has never
+ *    popped (it would hold ef >= M entries otherwise), so its layout is that of push_heap's sift-up alone -- canonical;
+ *  - getNeighborsByHeuristic2 sorts by distance ONLY with std::sort ("we don't mind the secondary order"): among EXACTLY equal
+ *    distances the reference's order is introsort's.  Here: a stable sort of the container order.  Identical whenever no two
+ *    candidates of one list tie exactly (random float data); integer-valued data can differ there -- the host builder
+ *    (csrc/host/hnsw_index.cpp) calls the same std::sort on the same sequence, which is what a gcc-built reference runs.
+ */
+typedef struct { double d; uint32_t id; } pr_t;                       /* pair<DistType, idType> */
+static int pr_less(pr_t a, pr_t b) { return a.d < b.d || (!(b.d < a.d) && a.id < b.id); }   /* std::less<pair> */
+typedef struct { pr_t *v; size_t n, cap; } heap_t;                    /* max-heap under pr_less, array = container order */
+static void heap_push(heap_t *h, pr_t x) {
+    if (h->n == h->cap) { h->cap = h->cap ? 2 * h->cap : 64; h->v = realloc(h->v, h->cap * sizeof(pr_t)); }
+    size_t i = h->n++;
+    while (i > 0) {                                                   /* __push_heap: sift the hole up */
+        size_t p = (i - 1) / 2;
+        if (!pr_less(h->v[p], x)) break;
+        h->v[i] = h->v[p];
+        i = p;
+    }
+    h->v[i] = x;
+}
+static void heap_pop(heap_t *h) {
+    pr_t x = h->v[--h->n];
+    size_t i = 0, n = h->n;
+    if (!n) return;
+    for (;;) {
+        size_t c = 2 * i + 1;
+        if (c >= n) break;
+        if (c + 1 < n && pr_less(h->v[c], h->v[c + 1])) c++;
+        if (!pr_less(x, h->v[c])) break;
+        h->v[i] = h->v[c];
+        i = c;
+    }
+    h->v[i] = x;
+}
+
+typedef struct {
+    int type, metric, tier, fast;
+    size_t dim, stride;
+    const char *rows;
+    uint32_t n, M, M0, efc;
+    uint32_t *links0; uint16_t *cnt0; uint8_t *levels; uint32_t *upper_off; uint32_t *upper;
+    uint32_t *tag, epoch;
+    uint64_t evals;
+} bld_t;
+static double bdist(bld_t *b, uint32_t x, uint32_t y) {
+    b->evals++;
+    const void *px = b->rows + (size_t)x * b->stride, *py = b->rows + (size_t)y * b->stride;
+    double d = b->fast ? vso_distance_fast_tier(b->type, b->metric, b->tier, b->dim, px, py) : vso_distance(b->type, b->metric, b->tier, b->dim, px, py);
+    return NARROW(b->type, d);
+}
+static uint32_t *blinks(bld_t *b, uint32_t node, int level, uint32_t *cnt, uint32_t **cnt_word, uint16_t **cnt0_word) {
+    if (level == 0) {
+        *cnt = b->cnt0[node];
+        if (cnt0_word) *cnt0_word = &b->cnt0[node];
+        if (cnt_word) *cnt_word = NULL;
+        return b->links0 + (size_t)node * b->M0;
+    }
+    uint32_t *blk = b->upper + ((size_t)b->upper_off[node] + (size_t)(level - 1)) * (b->M + 1);
+    *cnt = blk[0];
+    if (cnt_word) *cnt_word = blk;
+    if (cnt0_word) *cnt0_word = NULL;
+    return blk + 1;
+}
+static void bset_count(bld_t *b, uint32_t node, int level, uint32_t cnt) {
+    if (level == 0) b->cnt0[node] = (uint16_t)cnt;
+    else b->upper[((size_t)b->upper_off[node] + (size_t)(level - 1)) * (b->M + 1)] = cnt;
+}
+/* searchLayer (hnsw.h:680-720): the top_candidates heap, container order kept */
+static void bsearch_layer(bld_t *b, uint32_t ep, uint32_t q, int level, size_t ef, heap_t *top, heap_t *cand) {
+    top->n = cand->n = 0;
+    if (++b->epoch == 0) { memset(b->tag, 0, (size_t)b->n * 4); b->epoch = 1; }
+    const uint32_t tg = b->epoch;
+    double d = bdist(b, ep, q), lower = d;                           /* (no deleted nodes on this path) */
+    heap_push(top, (pr_t){d, ep});
+    heap_push(cand, (pr_t){-d, ep});
+    b->tag[ep] = tg;
+    while (cand->n) {
+        pr_t c = cand->v[0];
+        if (-c.d > lower && top->n >= ef) break;
+        heap_pop(cand);
+        uint32_t cnt;
+        const uint32_t *lk = blinks(b, c.id, level, &cnt, NULL, NULL);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t nb = lk[j];
+            if (b->tag[nb] == tg) continue;
+            b->tag[nb] = tg;
+            const double dd = bdist(b, nb, q);
+            if (lower > dd || top->n < ef) {
+                heap_push(cand, (pr_t){-dd, nb});
+                heap_push(top, (pr_t){dd, nb});
+                if (top->n > ef) heap_pop(top);
+                lower = top->v[0].d;
+            }
+        }
+    }
+}
+/* getNeighborsByHeuristic2_internal (hnsw.h:743-797): list -> the kept candidates, in order; removed[] gets the others */
+static size_t bheuristic(bld_t *b, pr_t *list, size_t n, size_t M, uint32_t *removed, size_t *n_removed) {
+    if (n_removed) *n_removed = 0;
+    if (n < M) return n;
+    for (size_t i = 1; i < n; i++) {                                  /* stable insertion sort by distance only */
+        pr_t x = list[i];
+        size_t j = i;
+        while (j > 0 && x.d < list[j - 1].d) { list[j] = list[j - 1]; j--; }
+        list[j] = x;
+    }
+    pr_t *kept = malloc((M + 1) * sizeof(pr_t));
+    size_t nk = 0, i = 0;
+    for (; i < n && nk < M; i++) {
+        int good = 1;
+        for (size_t s = 0; s < nk; s++)
+            if (bdist(b, kept[s].id, list[i].id) < list[i].d) { good = 0; break; }
+        if (good) kept[nk++] = list[i];
+        else if (removed) removed[(*n_removed)++] = list[i].id;
+    }
+    if (removed) for (; i < n; i++) removed[(*n_removed)++] = list[i].id;
+    memcpy(list, kept, nk * sizeof(pr_t));
+    free(kept);
+    return nk;
+}
+/* mutuallyConnectNewElement + revisitNeighborConnections (hnsw.h:800-963), serial: returns the next entry point */
+static uint32_t bconnect(bld_t *b, uint32_t node, const heap_t *top, int level) {
+    const uint32_t maxM = level ? b->M : b->M0;
+    size_t n = top->n;
+    pr_t *list = malloc((n + 1) * sizeof(pr_t));
+    memcpy(list, top->v, n * sizeof(pr_t));
+    uint32_t next;
+    if (n < b->M) {                                                   /* std::min_element by distance: the first smallest */
+        size_t bi = 0;
+        for (size_t i = 1; i < n; i++) if (list[i].d < list[bi].d) bi = i;
+        next = list[bi].id;
+    } else {
+        n = bheuristic(b, list, n, b->M, NULL, NULL);
+        next = list[0].id;
+    }
+    pr_t *cands = malloc(((size_t)maxM + 2) * sizeof(pr_t));
+    uint32_t *removed = malloc(((size_t)maxM + 2) * sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t nb = list[i].id;
+        uint32_t mycnt, nbcnt;
+        uint32_t *mine = blinks(b, node, level, &mycnt, NULL, NULL);
+        if (mycnt == maxM) break;
+        uint32_t *nl = blinks(b, nb, level, &nbcnt, NULL, NULL);
+        if (nbcnt < maxM) {
+            mine[mycnt] = nb;
+            bset_count(b, node, level, mycnt + 1);
+            nl[nbcnt] = node;
+            bset_count(b, nb, level, nbcnt + 1);
+            continue;
+        }
+        size_t nc = 0, nrem = 0;
+        cands[nc++] = (pr_t){list[i].d, node};
+        for (uint32_t j = 0; j < nbcnt; j++) cands[nc++] = (pr_t){bdist(b, nl[j], nb), nl[j]};
+        bheuristic(b, cands, nc, maxM, removed, &nrem);
+        int chosen = 1;
+        for (size_t r = 0; r < nrem; r++) chosen &= removed[r] != node;
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < nbcnt; j++) {
+            int gone = 0;
+            for (size_t r = 0; r < nrem; r++) gone |= removed[r] == nl[j];
+            if (!gone) nl[w++] = nl[j];
+        }
+        if (mycnt < maxM) {
+            mine[mycnt] = nb;
+            bset_count(b, node, level, mycnt + 1);
+            if (chosen && w < maxM) nl[w++] = node;
+        }
+        bset_count(b, nb, level, w);
+    }
+    free(list); free(cands); free(removed);
+    return next;
+}
+typedef struct { uint64_t x; } minstd_t;
+static uint32_t minstd_next(minstd_t *g) { g->x = (g->x * 16807ull) % 2147483647ull; return (uint32_t)g->x; }
+static double minstd_canonical(minstd_t *g) {
+    const double R = 2147483646.0;
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; k++) { sum += (double)(minstd_next(g) - 1u) * tmp; tmp *= R; }
+    double r = sum / tmp;
+    return r >= 1.0 ? nextafter(1.0, 0.0) : r;
+}
+/* levels of n nodes inserted in id order into an index created with M (hnsw.h:418-422; mult = 1 / log(M), hnsw.h:1644) */
+void vso_hnsw_levels(uint32_t n, uint32_t M, uint32_t seed, uint8_t *levels) {
+    minstd_t g = {seed % 2147483647ull ? seed % 2147483647ull : 1};
+    const double mult = 1.0 / log(1.0 * M);
+    for (uint32_t i = 0; i < n; i++) {
+        const double r = -log(minstd_canonical(&g)) * mult;
+        const size_t l = (size_t)r;
+        levels[i] = (uint8_t)(l > 255 ? 255 : l);
+    }
+}
+/* Builds the graph of rows 0..n-1 inserted in id order.  Outputs in the index's export layout (VecSimGpu_HnswGraphCopy):
+ * links0 [n][2M], cnt0 [n], upper_off [n] (block number or 0xFFFFFFFF), upper: blocks of {count, links[M]} per level >= 1 in id
+ * order, levels [n].  upper must hold (sum of levels) * (M + 1) words (vso_hnsw_levels gives the levels first).  fast != 0: the
+ * intrinsics twins of the kernels (bit-identical, tests/test_oracle_kats.py).  Returns the number of distance evaluations. */
+uint64_t vso_hnsw_build(int type, int metric, int tier, size_t dim, const void *rows, size_t stride, uint32_t n, uint32_t M, uint32_t efc,
+                        uint32_t seed, int fast, uint32_t *links0, uint16_t *cnt0, uint8_t *levels, uint32_t *upper_off, uint32_t *upper,
+                        uint32_t *entry_out, int *max_level_out) {
+    bld_t b = {0};
+    b.type = type; b.metric = metric; b.tier = tier; b.dim = dim; b.stride = stride; b.rows = rows; b.n = n;
+    b.fast = fast && vso_fast_available(type, metric, tier, dim);
+    b.M = M; b.M0 = 2 * M; b.efc = efc < M ? M : efc;
+    b.links0 = links0; b.cnt0 = cnt0; b.levels = levels; b.upper_off = upper_off; b.upper = upper;
+    b.tag = calloc(n ? n : 1, 4);
+    vso_hnsw_levels(n, M, seed, levels);
+    size_t blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        cnt0[i] = 0;
+        upper_off[i] = levels[i] ? (uint32_t)blocks : 0xFFFFFFFFu;
+        blocks += levels[i];
+    }
+    memset(upper, 0, blocks * (M + 1) * 4);
+    memset(links0, 0, (size_t)n * b.M0 * 4);
+    heap_t top = {0}, cand = {0};
+    uint32_t entry = 0xFFFFFFFFu;
+    int max_level = -1;
+    for (uint32_t id = 0; id < n; id++) {
+        const int level = levels[id];
+        if (entry == 0xFFFFFFFFu) { entry = id; max_level = level; continue; }
+        const uint32_t prev_entry = entry;
+        const int prev_max = max_level;
+        if (level > prev_max) { entry = id; max_level = level; }      /* storeNewElement */
+        uint32_t cur = prev_entry;
+        int common;
+        if (level < prev_max) {
+            double cd = bdist(&b, cur, id);
+            for (int l = prev_max; l > level; l--) {
+                int changed = 1;
+                while (changed) {
+                    changed = 0;
+                    uint32_t cnt;
+                    const uint32_t *lk = blinks(&b, cur, l, &cnt, NULL, NULL);   /* the ORIGINAL node's list to its end */
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        const double d = bdist(&b, lk[i], id);
+                        if (d < cd) { cd = d; cur = lk[i]; changed = 1; }
+                    }
+                }
+            }
+            common = level;
+        } else {
+            common = prev_max;
+        }
+        for (int l = common; l >= 0; l--) {
+            bsearch_layer(&b, cur, id, l, b.efc, &top, &cand);
+            if (top.n) cur = bconnect(&b, id, &top, l);
+        }
+    }
+    *entry_out = entry;
+    *max_level_out = max_level;
+    free(top.v); free(cand.v); free(b.tag);
+    return b.evals;
+}

@@ -350,16 +350,33 @@ def test_hnsw_batch_iterator_protocol():
     ix.add_vectors(rows, np.arange(n))
     q = rng.random((1, dim), dtype=np.float32)
     it = ix.create_batch_iterator(q)
-    seen, total, last = set(), 0, -np.inf
+    seen, total = set(), 0
     d = truth(rows, q[0], F32, L2)
     first = None
     for _ in range(10):
         assert it.has_next()
         l, s = it.get_next_results(100, VecSim.BY_SCORE)
         first = l[0] if first is None else first
-        assert np.all(np.diff(s[0]) >= 0) and s[0][0] >= last and not (seen & set(l[0]))
-        last = s[0][-1]
+        # (a graph walk is approximate: a later batch may hold a row closer than an earlier batch's last -- the reference's HNSW
+        # iterator gives no such guarantee either, its flow test measures recall per batch; no row ever comes back twice)
+        assert np.all(np.diff(s[0]) >= 0) and not (seen & set(l[0]))
         seen |= set(l[0])
         total += l.shape[1]
     assert total == 1000
     assert len(set(first) & set(np.argsort(d)[:100])) >= 90  # the first batch is (nearly) the true top 100
+
+
+def test_batch_iterator_may_outlive_its_index():
+    """query_results.cpp:77-82: a batch iterator keeps what it needs alive; freeing the index first and the iterator later is legal"""
+    rng = np.random.default_rng(5)
+    rows = rng.random((5000, 32), dtype=np.float32)
+    for make in (lambda: fill(flat(F32, L2, 32), rows), lambda: fill(hnsw(F32, L2, 32, 16, 100, 50), rows)):
+        ix = make()
+        it = ix.create_batch_iterator(rows[:1])
+        l, _ = it.get_next_results(10, VecSim.BY_SCORE)
+        assert l[0][0] == 0
+        lib, h = ix._lib, ix._h
+        ix._h = None                      # (the Python object no longer owns the handle)
+        it._index = None
+        lib.VecSimIndex_Free(h)           # index first ...
+        del it                            # ... iterator afterwards

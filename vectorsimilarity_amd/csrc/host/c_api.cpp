@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <queue>
 #include <stdexcept>
 #include <unordered_map>
@@ -45,7 +46,18 @@ extern "C" VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
     if (!ix) std::fprintf(stderr, "vecsim_amd: cannot create GPU index: %s\n", vsgpu_last_error());
     return ix;
 }
-extern "C" void VecSimIndex_Free(VecSimIndex *index) { delete index; }
+static std::mutex g_lifetime_mu;   // (index / iterator lifetime bookkeeping: flat_index.h live_iterators_)
+extern "C" void VecSimIndex_Free(VecSimIndex *index) {
+    if (!index) return;
+    {
+        std::lock_guard<std::mutex> lk(g_lifetime_mu);
+        if (index->live_iterators_ > 0) {   // freed under its batch iterators: the last of them destroys it
+            index->orphaned_ = true;
+            return;
+        }
+    }
+    delete index;
+}
 
 // ---- SQ8 storage (vec_sim_gpu.h): the reference has the spaces and the preprocessor (types/sq8.h, preprocessors.h:259-649,
 // IP.cpp:34-183, L2.cpp:30-45,185-201) but no RAM index factory that selects them, so the constructor is an extension
@@ -660,7 +672,12 @@ extern "C" void VecSimQueryReply_IteratorFree(VecSimQueryReply_Iterator *it) { d
 // either a bounded max-heap pass (few results out of many remaining) or an nth_element partition.
 extern "C" VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *queryBlob,
                                                         VecSimQueryParams *queryParams) {
-    return index->newBatchIterator(queryBlob, queryParams);
+    VecSimBatchIterator *it = index->newBatchIterator(queryBlob, queryParams);
+    if (it) {
+        std::lock_guard<std::mutex> lk(g_lifetime_mu);
+        index->live_iterators_++;
+    }
+    return it;
 }
 
 using ScoredLabel = std::pair<double, size_t>;
@@ -881,8 +898,16 @@ extern "C" bool VecSimBatchIterator_HasNext(VecSimBatchIterator *it) {
     return it->walker ? !it->walker->depleted() : it->returned < it->label_count;
 }
 extern "C" void VecSimBatchIterator_Free(VecSimBatchIterator *it) {
-    if (it->dev) it->index->iteratorDeviceEnd(it->dev);
+    if (!it) return;
+    VecSimIndexInterface *index = it->index;
+    if (it->dev) index->iteratorDeviceEnd(it->dev);
     delete it;
+    bool last_of_orphan;
+    {
+        std::lock_guard<std::mutex> lk(g_lifetime_mu);
+        last_of_orphan = --index->live_iterators_ == 0 && index->orphaned_;
+    }
+    if (last_of_orphan) delete index;
 }
 extern "C" void VecSimBatchIterator_Reset(VecSimBatchIterator *it) {
     if (it->walker) {

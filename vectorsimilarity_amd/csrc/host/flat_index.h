@@ -89,6 +89,11 @@ struct VecSimIndexInterface {
     virtual std::vector<vsgpu_ctx *> gpus() { return {gpu()}; }
     virtual void setLastMode(VecSearchMode m) = 0;
     virtual int distanceTier() const { return VSGPU_TIER_AVX512; }   // which reference ISA tier's order the scores follow (host_tier.h)
+    // Lifetime (c_api.cpp): the reference lets a batch iterator outlive its index (it keeps the allocator alive: query_results.cpp:77-82;
+    // only freeing it is legal then).  Here an iterator holds device state and node ids of its index, so VecSimIndex_Free of an index
+    // with live iterators only marks it; the last VecSimBatchIterator_Free destroys it.
+    int live_iterators_ = 0;
+    bool orphaned_ = false;
 };
 
 namespace vsa {

@@ -89,6 +89,23 @@ int ensure_pin_up(vsgpu_ctx *c, size_t bytes) {
     c->pin_up_cap = want;
     return VSGPU_OK;
 }
+// 16 bytes per thread from pinned host memory (read over PCIe, uncached) into device memory
+typedef unsigned int upload_u32x4 __attribute__((ext_vector_type(4)));
+static __global__ __launch_bounds__(256) void k_upload_block(upload_u32x4 *__restrict__ dst, const upload_u32x4 *__restrict__ src, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+int upload_block(vsgpu_ctx *c, void *dev, const void *pinned_src, size_t bytes) {
+    if (bytes == 0) return VSGPU_OK;
+    if (!c->opt_upload_kernel || bytes > ((size_t)4 << 20) || (bytes & 15) || ((uintptr_t)dev & 15) || ((uintptr_t)pinned_src & 15)) {
+        HIPCHK(hipMemcpyAsync(dev, pinned_src, bytes, hipMemcpyHostToDevice, c->stream));
+        return VSGPU_OK;
+    }
+    const uint32_t n16 = (uint32_t)(bytes / 16);
+    hipLaunchKernelGGL(k_upload_block, dim3(std::min<uint32_t>((n16 + 255) / 256, 512)), dim3(256), 0, c->stream, (upload_u32x4 *)dev,
+                       (const upload_u32x4 *)pinned_src, n16);
+    HIPCHK(hipGetLastError());
+    return VSGPU_OK;
+}
 int ensure_pinned(vsgpu_ctx *c, size_t bytes) {
     if (bytes <= c->pinned_cap) return VSGPU_OK;
     if (c->pinned) {
@@ -123,8 +140,13 @@ extern "C" vsgpu_ctx *vsgpu_ctx_create(int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess ||
-        hipEventCreate(&c->ev_c) != hipSuccess || hipEventCreate(&c->ev_d) != hipSuccess) {
+        // timing events WITHOUT the system-scope release a default event performs (a cache write-back so that the HOST sees device
+        // writes: nothing reads through these events, the stream's own synchronisation orders the download): a pair around a kernel
+        // costs its stream 2.8 us instead of 6.7 (tools/stream/event_cost.hip, profiles/r06_event_cost.txt)
+        hipEventCreateWithFlags(&c->ev_a, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_b, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_c, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_d, hipEventDisableSystemFence) != hipSuccess) {
         fail(VSGPU_ERR_HIP, "stream/event creation failed on device %d", device);
         delete c;
         return nullptr;
@@ -179,6 +201,8 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;
     else if (n == "chain_early") c->opt_chain_early = value;
+    else if (n == "upload_kernel") c->opt_upload_kernel = value;
+    else if (n == "sel_mapped") c->opt_sel_mapped = value;
     else if (n == "events") c->opt_events = value & 3;
     else if (n == "probe_rt16") c->opt_probe_rt16 = value;
     else if (n == "sq8_block") c->opt_sq8_block = value;
@@ -1346,11 +1370,16 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     const size_t ocap = cap;
     // one block {selected counts [nq], raw counts [nq], records [nq][ocap]}: one download
     const size_t hdr = (nq * 8 + 15) & ~(size_t)15;
-    int rc = ensure(c, c->sel, hdr + nq * ocap * sizeof(uint2));
+    // (round 6) the select kernel writes its block straight into the pinned reply block -- host memory the device sees at the same
+    // address -- so the batch has no download operation (a blit kernel + its queue hop: 9 us of every batch); only the records a
+    // query kept cross PCIe.  Option sel_mapped = 0: device block + hipMemcpyAsync as before.
+    const bool mapped = c->opt_sel_mapped != 0;
+    int rc = mapped ? ensure_pinned(c, hdr + nq * ocap * sizeof(uint2)) : ensure(c, c->sel, hdr + nq * ocap * sizeof(uint2));
     if (rc) return rc;
+    char *selblk = mapped ? (char *)c->pinned : (char *)c->sel.p;
     hipLaunchKernelGGL(k_select_upto_kth, dim3((unsigned)nq), dim3(256), 0, c->stream, (const uint2 *)c->cand.p,
-                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)((char *)c->sel.p + hdr),
-                       (uint32_t *)c->sel.p, (uint32_t)ocap);
+                       (const uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)std::min(k, n), (uint2 *)(selblk + hdr),
+                       (uint32_t *)selblk, (uint32_t)ocap);
     HIPCHK(hipGetLastError());
     // the last kernel of this batch is in the stream: the next reader lane's kernels may follow (its probe and scan then
     // overlap with this lane's downloads and host replay, not with its kernels -- a re-rank or select kernel sharing the
@@ -1360,7 +1389,7 @@ int collect_candidates(vsgpu_table *t, const void *queries, size_t nq, size_t qs
     if (rc) return rc;
     uint32_t *hsel = (uint32_t *)c->pinned;
     uint2 *hrec = (uint2 *)((char *)c->pinned + hdr);
-    HIPCHK(hipMemcpyAsync(c->pinned, c->sel.p, hdr + nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    if (!mapped) HIPCHK(hipMemcpyAsync(c->pinned, c->sel.p, hdr + nq * ocap * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     WallMarks wm;
     HIPCHK(hipStreamSynchronize(c->stream));
     wm.mark("wait_gpu");

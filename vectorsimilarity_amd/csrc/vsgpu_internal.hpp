@@ -61,6 +61,12 @@ struct vsgpu_ctx {
     // scan kernel (stats.scan_ms: what bench.py's roofline reads), bit 1 = around probe + threshold (stats.other_ms)
     long opt_events = 1;
     long opt_probe_rt16 = 1;   // fp32 / fp64 probe on 16-row tiles where the filter uses them
+    // round 6 (the seven stream operations of a batch): 1 = the batch's query block reaches the device through a copy KERNEL reading the
+    // pinned staging block (a kernel behind a kernel starts 0 us later; a kernel behind an SDMA copy 8 us later, profiles/r06_timelines.txt),
+    // 0 = hipMemcpyAsync.  Blocks beyond 4 MiB always take hipMemcpyAsync.
+    long opt_upload_kernel = 1;
+    // 1 = the select kernel writes the batch's records straight into the pinned (device-visible) reply block: no download operation
+    long opt_sel_mapped = 1;
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
@@ -242,6 +248,8 @@ struct ScanChainGuard {
 int stage_queries(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, void *host_dst = nullptr, void *dev_dst = nullptr);
 size_t staged_query_bytes(const vsgpu_table *t, size_t nq);
 int ensure_pin_up(vsgpu_ctx *c, size_t bytes);
+// the batch's staged block (pinned host memory, device-visible) -> device, on the batch's stream: a copy kernel or hipMemcpyAsync
+int upload_block(vsgpu_ctx *c, void *dev, const void *pinned_src, size_t bytes);
 void alias_into(DevBuf &b, void *p, size_t bytes);
 int tile_rows_of(int ek);
 int run_scan(vsgpu_table *t, vsg::ScanParams &P, size_t nq, bool timed);

@@ -584,7 +584,8 @@ int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         alias_into(c->tau, db + o_tau, al(nqp * 4));
         alias_into(c->counts, db + o_cnt, al(nqp * 4));
         alias_into(c->qmeta, db + o_meta, al(qmeta.size() * 4));
-        HIPCHK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, c->stream));
+        rc = upload_block(c, db, hb, total);
+        if (rc) return rc;
     }
     if (!is_int) {   // exact-order images for the re-rank, uploaded ahead of the scan (vsgpu_mfma.hip)
         rc = stage_queries(t, queries, nq, qstride);

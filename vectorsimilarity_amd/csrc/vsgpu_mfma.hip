@@ -272,7 +272,8 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     rc = stage_queries(t, queries, nq, qstride, (char *)c->pin_up + fb + 3 * ab, (char *)c->qblock.p + fb + 3 * ab);
     if (rc) return rc;
     wm0.mark("stage_queries");
-    HIPCHK(hipMemcpyAsync(c->qblock.p, c->pin_up, fb + 3 * ab + qb, hipMemcpyHostToDevice, c->stream));
+    rc = upload_block(c, c->qblock.p, c->pin_up, fb + 3 * ab + qb);
+    if (rc) return rc;
     wm0.mark("uploads");
 
     // rigorous |a - s_ref| <= cE*(|x|^2+|q|^2) + absE   (derivation: DESIGN.md §5.2)
