@@ -137,6 +137,10 @@ long VecSimIndex_AddSyntheticVectors(VecSimIndex *index, size_t n, uint64_t seed
 int VecSimGpu_HnswGraphInfo(VecSimIndex *index, uint64_t info[6]);
 int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0, uint32_t *upper_off, uint32_t *upper,
                             uint8_t *deleted, uint64_t *labels);
+/* Per-node top level (n bytes; NULL: none wanted).  Returns 1 when single VecSimIndex_AddVector calls on this index follow the
+ * reference's insert path with the tier's own distances (hnsw.h:1567-1610, 889-963; $VECSIM_GPU_HNSW_BUILD = reference | fast,
+ * default reference), 0 when the fast builder runs, -1 when `index` is not an HNSW index. */
+int VecSimGpu_HnswLevels(VecSimIndex *index, uint8_t *levels);
 uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
 
 /* ---- SQ8 storage: scalar-quantised 8-bit rows (uint8 codes + FP32 metadata) scored against FP32 queries.

@@ -343,27 +343,46 @@ def test_hnsw_multi_value_recall_and_unique_labels():
 
 
 def test_hnsw_batch_iterator_protocol():
+    """test_hnsw.py:119-215: batches by id / by score, at most two results of the second batch that belonged in the first, the
+    runtime ef reaches the iterator, 1000 results gathered in ten batches hold >= 89 % of the true top 1000, and a drained iterator
+    has returned >= 95 % of the index without ever repeating a label"""
     rng = np.random.default_rng(47)
-    n, dim = 20_000, 100
+    n, dim = 100_000, 100
     rows = rng.random((n, dim), dtype=np.float32)
     ix = hnsw(F32, L2, dim, 26, 180, 180)
     ix.add_vectors(rows, np.arange(n))
     q = rng.random((1, dim), dtype=np.float32)
     it = ix.create_batch_iterator(q)
-    seen, total = set(), 0
-    d = truth(rows, q[0], F32, L2)
-    first = None
-    for _ in range(10):
-        assert it.has_next()
-        l, s = it.get_next_results(100, VecSim.BY_SCORE)
-        first = l[0] if first is None else first
-        # (a graph walk is approximate: a later batch may hold a row closer than an earlier batch's last -- the reference's HNSW
-        # iterator gives no such guarantee either, its flow test measures recall per batch; no row ever comes back twice)
-        assert np.all(np.diff(s[0]) >= 0) and not (seen & set(l[0]))
+    l1, d1 = it.get_next_results(10, VecSim.BY_ID)
+    assert np.all(np.diff(l1[0]) > 0)
+    l2, d2 = it.get_next_results(10, VecSim.BY_SCORE)
+    assert np.all(np.diff(d2[0]) >= 0)
+    assert sum(1 for x in d2[0] if np.any(d1[0] > x)) <= 2
+    qp = VecSim.VecSimQueryParams()
+    qp.hnswRuntimeParams.efRuntime = 5
+    lo, dlo = ix.create_batch_iterator(q, qp).get_next_results(10, VecSim.BY_ID)
+    assert d1[0].sum() < dlo[0].sum()                      # a smaller ef finds a worse first batch
+    qp.hnswRuntimeParams.efRuntime = 180
+    same_l, same_d = ix.create_batch_iterator(q, qp).get_next_results(10, VecSim.BY_ID)
+    assert np.array_equal(same_l, l1) and np.array_equal(same_d, d1)
+    for qv in rng.random((10, dim), dtype=np.float32):
+        it = ix.create_batch_iterator(qv)
+        got, calls = [], 0
+        while it.has_next() and len(got) < 1000:
+            l, s = it.get_next_results(100, VecSim.BY_SCORE)
+            assert np.all(np.diff(s[0]) >= 0)
+            got.extend(l[0])
+            calls += 1
+        assert calls == 10 and len(set(got)) == 1000
+        want = np.argsort(truth(rows, qv, F32, L2))[:1000]
+        assert len(set(got) & set(want)) / 1000 >= 0.89
+    it = ix.create_batch_iterator(q)
+    seen = set()
+    while it.has_next():
+        l, _ = it.get_next_results(1000, VecSim.BY_SCORE)
+        assert not (seen & set(l[0]))
         seen |= set(l[0])
-        total += l.shape[1]
-    assert total == 1000
-    assert len(set(first) & set(np.argsort(d)[:100])) >= 90  # the first batch is (nearly) the true top 100
+    assert len(seen) >= 0.95 * n
 
 
 def test_batch_iterator_may_outlive_its_index():

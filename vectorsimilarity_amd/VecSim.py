@@ -458,6 +458,8 @@ class HNSWIndex(VecSimIndex):
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._lib.VecSimGpu_HnswGraphCopy(self._h, p(g["links0"]), p(g["cnt0"]), p(g["upper_off"]), p(g["upper"]),
                                           p(g["deleted"]), p(g["labels"]))
+        g["levels"] = np.zeros(n, dtype=np.uint8)
+        g["reference_order_build"] = self._lib.VecSimGpu_HnswLevels(self._h, p(g["levels"])) == 1
         return g
 
     def last_distance_evals(self):

@@ -457,6 +457,14 @@ extern "C" int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uin
     std::memcpy(labels, e.labels, (size_t)e.n * 8);
     return 0;
 }
+// per-node top level [n] (with the arrays of VecSimGpu_HnswGraphCopy the whole graph); returns 1 when single AddVector calls follow the
+// reference's insert path in the tier's distance order (hnsw_ref_build.cpp), 0 when the fast builder runs, -1: not an HNSW index
+extern "C" int VecSimGpu_HnswLevels(VecSimIndex *index, uint8_t *levels) {
+    auto *h = dynamic_cast<vsa::HnswIndex *>(index);
+    if (!h) return -1;
+    if (levels) std::memcpy(levels, h->levels(), h->exportGraph().n);
+    return h->referenceOrderBuild() ? 1 : 0;
+}
 extern "C" long VecSimGpu_GetStoredVectors(VecSimIndex *index, size_t label, void *out, size_t cap_bytes, size_t *blob_bytes) {
     if (blob_bytes) *blob_bytes = index->storedBlobBytes();
     return out ? index->storedVectors(label, out, cap_bytes) : 0;

@@ -61,6 +61,16 @@ HnswIndex *HnswIndex::create(const HNSWParams &p, void *logCtx) {
     }
     ix->multi_ = p.multi;
     vsgpu_graph_set_multi(ix->graph_, p.multi ? 1 : 0);
+    {   // build mode (hnsw_index.h)
+        const char *e = std::getenv("VECSIM_GPU_HNSW_BUILD");
+        const bool want_fast = e && !std::strcmp(e, "fast");
+        const bool have = ix->ref_eval_.init((int)p.type, (int)p.metric, ix->tier_, p.dim);
+        ix->ref_add_ = have && !want_fast;
+        ix->ref_bulk_ = have && e && !std::strcmp(e, "reference");
+        if (e && !std::strcmp(e, "reference") && !have)
+            std::fprintf(stderr, "vecsim_amd: VECSIM_GPU_HNSW_BUILD=reference: no host walker for this type / tier (AVX512-FP16 half "
+                                 "accumulators); building with the fast routine\n");
+    }
     size_t n_lanes = 2;   // the index's own context + one reader lane; VECSIM_GPU_READER_LANES as for the Flat index
     if (const char *e = std::getenv("VECSIM_GPU_READER_LANES")) n_lanes = (size_t)std::max(1, std::min(8, std::atoi(e)));
     for (size_t i = 1; i < n_lanes; i++) {   // best effort: without lanes readers take turns
@@ -493,7 +503,8 @@ int HnswIndex::addVector(const void *blob, size_t label) {
     std::vector<char> pv = preprocess(blob);
     const uint32_t id = allocNode(pv.data(), label, drawLevel());
     main_ctx_.locked = false;
-    insertNode(id, vec(id), main_ctx_);
+    if (ref_add_) insertNodeRef(id);
+    else insertNode(id, vec(id), main_ctx_);
     graph_dirty_ = true;
     if (!is_new) maybeCompact();   // (an overwrite leaves a dead node behind)
     return is_new;
@@ -534,7 +545,7 @@ long HnswIndex::addBulk(const void *blobs, const size_t *labels, size_t n) {
     // at 300 K rows -- measured, not kept)
     // default: at most 64 linking threads; VECSIM_HNSW_BUILD_THREADS may ask for up to 256
     threads = std::max<size_t>(1, std::min<size_t>(threads, std::getenv("VECSIM_HNSW_BUILD_THREADS") ? 256 : 64));
-    if (n < 2048 || threads == 1) {
+    if (n < 2048 || threads == 1 || ref_bulk_) {
         host_vecs_.reserve(host_vecs_.size() + n * dim_);
         for (size_t i = 0; i < n; i++) addVector((const char *)blobs + i * dim_ * elem_bytes_, labels[i]);
         return (long)n;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "flat_index.h"
+#include "host_lane_eval.h"
 
 namespace vsa {
 
@@ -80,6 +81,8 @@ public:
     };
     Export exportGraph();
     uint64_t lastDistanceEvals() const { return last_dist_evals_.load(); }
+    const uint8_t *levels() const { return level_.data(); }
+    bool referenceOrderBuild() const { return ref_add_; }
     // labels of `label`'s neighbours, level by level (VecSimDebug_GetElementNeighborsInHNSWGraph); -1: unknown label, -2: multi-value
     int neighborLabels(size_t label, std::vector<std::vector<size_t>> &out);
     std::vector<vsgpu_ctx *> gpus() override;
@@ -104,6 +107,9 @@ private:
     uint32_t allocNode(const char *stored_blob, size_t label, int level);
     void widen(const char *stored_blob, float *out) const;
     int drawLevel();
+    // the reference's insert path with the tier's own distances, serial (hnsw_ref_build.cpp)
+    void insertNodeRef(uint32_t id);
+    double refDistance(uint32_t a, uint32_t b) const;
     void insertNode(uint32_t id, const float *v, BuildCtx &bc);
     void searchLayer(const float *q, uint32_t ep, float ep_dist, int level, size_t ef,
                      std::vector<std::pair<float, uint32_t>> &out, BuildCtx &bc);
@@ -163,6 +169,13 @@ private:
     std::unordered_map<size_t, std::vector<uint32_t>> label_to_ids_;
     uint32_t entry_ = 0xFFFFFFFFu;
     int max_level_ = -1;
+    // Build modes ($VECSIM_GPU_HNSW_BUILD).  VecSimIndex_AddVector follows the REFERENCE's insert path -- same level generator,
+    // same candidate order, distances in the tier's own summation order (host_lane_eval.h) -- whenever the tier has a host walker
+    // ("reference"; the default), so that N AddVector calls leave the graph the reference would hold; "fast" = the round 1-5
+    // builder (any-order AVX-512 distances on widened rows).  The bulk entry point builds in parallel with the fast routine
+    // unless the variable says "reference" (then serial, reference order).
+    HostLaneEval ref_eval_;
+    bool ref_add_ = false, ref_bulk_ = false;
     BuildCtx main_ctx_;                               // single-threaded inserts
     std::unique_ptr<std::atomic_flag[]> node_lock_;  // per-node link-list locks (parallel bulk build only)
     size_t node_lock_n_ = 0;
