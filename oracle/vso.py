@@ -22,7 +22,7 @@ NP_DTYPE = {F32: np.float32, F64: np.float64, BF16: np.uint16, F16: np.uint16, I
 
 def build(force=False):
     """Compile oracle/libvso.so from the C restatement (gcc + make)."""
-    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso_hnsw.c", "vso_sq8.c", "vso.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("vso.c", "vso_fast.c", "vso_hnsw.c", "vso_sq8.c", "vso_stdsort.cpp", "vso.h", "Makefile")]
     if (not force and os.path.exists(_LIB)
             and os.path.getmtime(_LIB) >= max(os.path.getmtime(s) for s in srcs)):
         return _LIB

@@ -435,10 +435,10 @@ size_t vso_hnsw_iterate(int type, int metric, int tier, size_t dim, const void *
  *    than M is linked in the container's order (mutuallyConnectNewElement iterates it unsorted).  Such a heap has never
  *    popped (it would hold ef >= M entries otherwise), so its layout is that of push_heap's sift-up alone -- canonical;
  *  - getNeighborsByHeuristic2 sorts by distance ONLY with std::sort ("we don't mind the secondary order"): among EXACTLY equal
- *    distances the reference's order is introsort's.  Here: a stable sort of the container order.  Identical whenever no two
- *    candidates of one list tie exactly (random float data); integer-valued data can differ there -- the host builder
- *    (csrc/host/hnsw_index.cpp) calls the same std::sort on the same sequence, which is what a gcc-built reference runs.
+ *    distances the reference's order is libstdc++'s introsort's.  That one step is not restated: vso_stdsort.cpp hands the list to
+ *    the same std::sort with the same comparator (ties do occur: ~1 % of the lists of a 30 K x 32 fp32 build hold one).
  */
+void vso_std_sort_by_distance(void *pairs, size_t n);   /* vso_stdsort.cpp: std::sort by .d */
 typedef struct { double d; uint32_t id; } pr_t;                       /* pair<DistType, idType> */
 static int pr_less(pr_t a, pr_t b) { return a.d < b.d || (!(b.d < a.d) && a.id < b.id); }   /* std::less<pair> */
 typedef struct { pr_t *v; size_t n, cap; } heap_t;                    /* max-heap under pr_less, array = container order */
@@ -533,12 +533,7 @@ static void bsearch_layer(bld_t *b, uint32_t ep, uint32_t q, int level, size_t e
 static size_t bheuristic(bld_t *b, pr_t *list, size_t n, size_t M, uint32_t *removed, size_t *n_removed) {
     if (n_removed) *n_removed = 0;
     if (n < M) return n;
-    for (size_t i = 1; i < n; i++) {                                  /* stable insertion sort by distance only */
-        pr_t x = list[i];
-        size_t j = i;
-        while (j > 0 && x.d < list[j - 1].d) { list[j] = list[j - 1]; j--; }
-        list[j] = x;
-    }
+    vso_std_sort_by_distance(list, n);                                /* std::sort, distance only (vso_stdsort.cpp) */
     pr_t *kept = malloc((M + 1) * sizeof(pr_t));
     size_t nk = 0, i = 0;
     for (; i < n && nk < M; i++) {

@@ -7,9 +7,9 @@
     walk) against the oracle's independent restatement (oracle/vso_hnsw.c vso_hnsw_build, distances from the pinned kernel
     oracle) on 3 K - 30 K-node cases of several types / metrics / dims: graphs equal edge for edge, and a top-k query on the
     index equals the oracle's search loop on the oracle's graph -- AddVector x N -> TopKQuery end to end.
-Tolerance: none.  (Exactly tied build distances: the reference's own order is libstdc++'s std::sort there; the host path calls
-the same std::sort, the oracle sorts stably -- the random float cases below have no ties; the int8 case checks the host path
-against the oracle only where no list holds a tie, and says how many lists that excluded.)"""
+Tolerance: none -- exactly tied build distances included: the reference orders them by libstdc++'s std::sort (hnsw.h:763), the host
+path and the oracle (oracle/vso_stdsort.cpp) both hand that step to the same library routine; ties are common (about 1 % of the
+candidate lists of the 30 K x 32 fp32 case hold one, nearly every list of the int8 case)."""
 import os
 
 import numpy as np
@@ -75,16 +75,9 @@ def test_add_vector_graph_equals_the_oracle_insert_path(vso, typ, metric, dim, n
     assert np.array_equal(got["levels"], ref["levels"])
     have, want = vso.graph_lists(got), vso.graph_lists(ref)
     diff = [k for k in want if have[k] != want[k]]
-    if typ == "i8":
-        # exactly tied build distances order by the sort algorithm (module docstring): the graphs may part ways at the first such
-        # list; every list must still hold the right NUMBER of links and the graphs agree up to the first divergent node
-        first = min((k[0] for k in diff), default=n)
-        assert first > n // 50, (len(diff), first)
-        print("int8 Cosine: %d of %d lists differ, first at node %d (exact distance ties)" % (len(diff), len(want), first))
-    else:
-        assert not diff, (typ, metric, len(diff), diff[:4], [have[k] for k in diff[:2]], [want[k] for k in diff[:2]])
+    assert not diff, (typ, metric, len(diff), diff[:4], [have[k] for k in diff[:2]], [want[k] for k in diff[:2]])
     # end to end: AddVector x N -> TopKQuery equals the oracle's search loop over the ORACLE's graph
-    if typ != "i8":
+    if True:
         q = random_vectors(rng, 6, dim, typ, vso)
         sq = stored_rows(vso, q, typ, metric)
         l, d = ix.knn_query(q, 10)
