@@ -76,9 +76,13 @@ def parse():
     ap.add_argument("--readers", type=int, default=2,
                     help="threads submitting batches (the reference's readers: bindings.cpp:250-283 knn_parallel); 2 lets one "
                          "batch's upload / probe / re-rank / download / host replay overlap with the next batch's scan kernel")
-    ap.add_argument("--data", default="lowrank", choices=["uniform", "lowrank"],
-                    help="c5 only.  uniform: BASELINE's i.i.d. U[-1,1) rows (intrinsic dimension = d: no graph index finds neighbours "
-                         "there); lowrank: 32 latent factors mixed into d dims + 5%% noise (embedding-like)")
+    ap.add_argument("--data", default=None, choices=["uniform", "lowrank", "clustered"],
+                    help="row distribution.  uniform: BASELINE's i.i.d. U[-1,1) rows (the default of the Flat configs; intrinsic dimension "
+                         "= d: no graph index finds neighbours there); lowrank: 32 latent factors mixed into d dims + 5%% noise "
+                         "(embedding-like; the default of c5); clustered (c2 / c4): uniform rows, 1%% of them within 1e-3 of one of 64 centres, "
+                         "half of the queries next to a centre -- what the filter's candidate lists look like on non-uniform data "
+                         "(profiles/r06_selectivity.json).  Non-uniform Flat runs generate on the host (numpy, seeded per 200 K-row chunk) "
+                         "and carry no cpu_baseline")
     ap.add_argument("--ef", type=int, default=128, help="c5: efRuntime")
     ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
                     help="N > 1.  strong: the job holds --rows vectors, rank r holds its share of them (BASELINE's headline reads N = 10 M "
@@ -100,6 +104,12 @@ def parse():
     a.batch = a.batch or batch
     a.topk = a.topk or k
     a.cpu_sample_rows = a.cpu_sample_rows or cpu_rows
+    if a.data is None:
+        a.data = "lowrank" if a.config == "c5" else "uniform"
+    if a.config != "c5" and a.data != "uniform":
+        if a.config not in ("c2", "c4") or a.gpus != 1:
+            ap.error("--data lowrank / clustered: c2, c4 (one GPU) and c5 only")
+        a.no_cpu_baseline = True
     return a
 
 
@@ -231,6 +241,44 @@ def full_table_parity(args, ix, n, queries, reply, which):
                    "(streamed back in 1 GiB pieces), labels + order + scores bit for bit"}
 
 
+# ---- non-uniform rows for the Flat configs (--data lowrank | clustered): host-generated, seeded per chunk
+def _nu_shared(args):
+    rng = np.random.default_rng([args.seed, 7])
+    return {"mix": rng.standard_normal((32, args.dim), dtype=np.float32) / np.float32(np.sqrt(32.0)),
+            "centres": rng.random((64, args.dim), dtype=np.float32) * 2 - 1}
+
+
+def _nu_rows(args, shared, chunk_id, cnt, queries=False):
+    """float32 rows of chunk `chunk_id` (queries: the batch's own stream)"""
+    rng = np.random.default_rng([args.seed, 11 if queries else 13, chunk_id])
+    u = rng.random((cnt, args.dim), dtype=np.float32) * 2 - 1
+    if args.data == "lowrank":
+        return (rng.standard_normal((cnt, 32), dtype=np.float32) @ shared["mix"] + np.float32(0.05) * u).astype(np.float32)
+    # clustered: 1 % of the rows (half of the queries) within 1e-3 of one of 64 centres
+    near = (np.arange(cnt) % 2 == 0) if queries else (rng.random(cnt) < 0.01)
+    c = rng.integers(0, 64, int(near.sum()))
+    u[near] = shared["centres"][c] + np.float32(1e-3) * u[near]
+    return u
+
+
+def _nu_encode(args, rows):
+    if args.type_name == "BFLOAT16":
+        u = np.ascontiguousarray(rows, dtype=np.float32).view(np.uint32)
+        return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    return rows
+
+
+def fill_nonuniform(args, ix, n):
+    from concurrent.futures import ThreadPoolExecutor
+    shared = _nu_shared(args)
+    step = 200_000
+    chunks = [(i, r0, min(step, n - r0)) for i, r0 in enumerate(range(0, n, step))]
+    with ThreadPoolExecutor(8) as pool:     # generation on a few host threads, ingest in order
+        for (i, r0, cnt), rows in zip(chunks, pool.map(lambda c: _nu_encode(args, _nu_rows(args, shared, c[0], c[2])), chunks)):
+            ix.add_vectors(rows, np.arange(r0, r0 + cnt))
+    return shared
+
+
 def run_c5(args):
     """config 5: HNSW fp32 L2 (graph built on the host cores, queries on the GPU: k_hnsw_search).  One step = one batch of
     `batch` queries answered end to end.  value = queries/s; roofline = the gathered row bytes (distance evaluations x
@@ -355,7 +403,10 @@ def build_index(args, p, my_rows, rank, world, local_rank, dist, distributed, Ve
     rank's communicator fail to come up; the line then says so"""
     if not distributed:
         ix = VecSim.BFIndex(p)
-        ix.add_synthetic(my_rows, args.seed)
+        if args.data == "uniform":
+            ix.add_synthetic(my_rows, args.seed)
+        else:
+            args.nu_shared = fill_nonuniform(args, ix, my_rows)
         ix.set_option("mfma", args.mfma)
         for o in args.opt:
             name, val = o.split("=", 1)
@@ -521,7 +572,10 @@ def main():
     kinds = [head] if (world == 1 or args.scaling != "both") else [head, "weak" if head == "strong" else "strong"]
     gen = getattr(synth, args.gen)
     nb_distinct = min(args.warmup + args.steps, 8)                       # host-side query sets, cycled
-    qsets = [gen(args.seed + 1 + b, 0, args.batch, args.dim) for b in range(nb_distinct)]
+    if args.data == "uniform":
+        qsets = [gen(args.seed + 1 + b, 0, args.batch, args.dim) for b in range(nb_distinct)]
+    else:
+        qsets = [_nu_encode(args, _nu_rows(args, _nu_shared(args), b, args.batch, queries=True)) for b in range(nb_distinct)]
     readers = max(1, min(args.readers, args.steps))
     # (the reader lanes' scratch is sized on their first batches; the low-precision filters' first launches run 15-30 % slow --
     # profiles/r04c_c4_kernel_stats.txt: 3726 4200 3702 3582 us, then 3150 -- so their steady state needs ten warm-up batches)
@@ -617,6 +671,10 @@ def main():
             "per_rank_ms_per_batch": ph["per_rank"],
             "candidates_per_query": st["candidates"] / max(1, args.steps * args.batch),
             "fallbacks": int(st["fallbacks"]),
+            "retries": int(st["retries"]),     # queries that took a second filter pass (candidate list overflow: near-duplicate clusters)
+            "rows_kind": {"uniform": "i.i.d. U[-1,1) (BASELINE's generator, device-generated)",
+                          "lowrank": "32 latent factors mixed into %d dims + 5%% noise (host-generated, numpy PCG64 seeded per chunk)" % args.dim,
+                          "clustered": "U[-1,1) rows, 1%% within 1e-3 of one of 64 centres; every second query next to a centre"}[args.data],
         }
         if len(phases) > 1:
             o = phases[1]

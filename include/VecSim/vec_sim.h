@@ -2,10 +2,14 @@
  * VecSim/vec_sim.h -- the index C API (drop-in boundary).
  *
  * Same symbols and signatures as the reference's src/VecSim/vec_sim.h:28-331.  Behind it, Flat
- * (VecSimAlgo_BF, single- and multi-label) and HNSW (VecSimAlgo_HNSWLIB, single-label) indexes keep
- * their vector blocks in MI355X HBM and every query-time distance is evaluated by the gfx950 kernels
- * reached through include/vsgpu.h; there is no CPU distance path.  VecSimIndex_New returns NULL for
- * algorithms this build does not construct (tiered, SVS, multi-label / fp64 HNSW) and when no GPU is
+ * (VecSimAlgo_BF, single- and multi-label) and HNSW (VecSimAlgo_HNSWLIB, single- and multi-label) indexes keep
+ * their vector blocks in MI355X HBM and every distance a QUERY needs (top-k, range, batch iterator,
+ * GetDistanceFrom) is evaluated by the gfx950 kernels reached through include/vsgpu.h; no query entry point
+ * has a CPU distance path and none falls back to one.  The one place host code evaluates distances is HNSW
+ * INGEST: the graph an AddVector call leaves depends on the build-time distances (hnsw.h:1567-1610), so the
+ * insert path ranks its candidates on the host -- in the index's own tier order (csrc/host/host_lane_eval.h)
+ * for single adds, with a fast any-order routine for the parallel bulk build (csrc/host/hnsw_index.cpp).
+ * VecSimIndex_New returns NULL for algorithms this build does not construct (tiered, SVS) and when no GPU is
  * visible.
  */
 #pragma once

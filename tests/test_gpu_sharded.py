@@ -477,3 +477,107 @@ def test_torchrun_one_rank_bench_uses_rccl():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["sorted"] and out["n_gpus"] == 1 and out["config"]["exchange"].startswith("rccl"), out
+
+
+class _ThreadBus:
+    """an all-gather between `world` rank THREADS of one process: what MPI / RCCL do between processes, for the in-process test
+    below (the callbacks have _capi.ALLGATHER_FN's shape: user, send, nbytes, recv)"""
+
+    def __init__(self, world, timeout):
+        import threading
+        self.world, self.slots = world, [b""] * world
+        self.barrier = threading.Barrier(world, timeout=timeout)
+        self.fail_rank, self.fail_at, self.calls = -1, -1, [0] * world
+
+    def callbacks(self, rank):
+        import ctypes as C
+        import threading
+
+        def allgather(_user, send, nbytes, recv):
+            try:
+                n = self.calls[rank]
+                self.calls[rank] += 1
+                if rank == self.fail_rank and n >= self.fail_at:
+                    return -1                                   # this rank's transport fails: it never shows up
+                self.slots[rank] = C.string_at(send, nbytes)
+                self.barrier.wait()
+                out = b"".join(self.slots)
+                self.barrier.wait()
+                C.memmove(recv, out, len(out))
+                return 0
+            except threading.BrokenBarrierError:
+                return -1                                       # a peer never arrived within the time limit
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def broadcast(_user, buf, nbytes, root):
+            return -1                                           # (append-only index: no delete, no broadcast)
+        return allgather, broadcast
+
+
+def test_eight_ranks_in_one_process_two_readers_each_then_one_rank_fails(vso):
+    """Round-5 review item 8.  The DISTRIBUTED code path (VecSimGpu_ShardedNewWithTransport: one ShardedIndex per rank, turn-ordered
+    exchanges, merge of 8 records on every rank) at G = 8 and config 4's per-shard shape / 10 (1.25 M x 768 bf16 IP rows per rank,
+    128 queries, top-10), all eight ranks as threads of this process on one GPU, two reader threads per rank submitting numbered
+    batches.  (RCCL itself refuses a second rank on the same device, and the local 8-shard index has no exchange at all, so the
+    records travel through a thread barrier with the transport callbacks' exact shape; the RCCL staged / mapped buffers are
+    exercised on a communicator of one above.)  Every rank's every reply must equal the local 8-shard index's -- which the
+    oracle check pins for three queries -- and when one rank's transport fails, every rank comes back with an error within the
+    time limit instead of hanging."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vectorsimilarity_amd import synth
+    G, per, dim, nq, k, nb = 8, 1_250_000, 768, 128, 10, 8
+    p = params("bf16", "IP", dim, 1024)
+    bus = _ThreadBus(G, timeout=20.0)
+    ranks = [ShardedFlatIndex(p, rank=r, world=G, device=0, transport=bus.callbacks(r)) for r in range(G)]
+    local = ShardedFlatIndex(p, shards=G)
+    with ThreadPoolExecutor(G) as pool:
+        list(pool.map(lambda ix: ix.add_synthetic_local(per, 47), ranks))
+    local.add_synthetic_local(per, 47)
+    assert all(ix.index_size() == G * per for ix in ranks) and local.index_size() == G * per
+    qsets = [synth.rows_bf16(48 + b, 0, nq, dim) for b in range(nb)]
+    want = [local.knn_query(qs, k) for qs in qsets]
+    # oracle: the equivalent single index is the concatenation of the shards (gid = shard * per + local id, label = gid)
+    check = [0, 77, 127]
+    st = vso.StreamTopK(TYPES["bf16"], METRICS["IP"], qsets[0][check], k, dim, threads=min(64, os.cpu_count() or 1))
+    buf = np.empty(per * dim * 2, dtype=np.uint8)
+    for s in range(G):
+        st.feed(local.local_index(s).stored_rows(0, per, out=buf), s * per)
+    el, es = st.result()
+    for j, qi in enumerate(check):
+        assert np.array_equal(want[0][0][qi], el[j]) and np.array_equal(want[0][1][qi], es[j]), qi
+
+    def rank_job(r):
+        ix = ranks[r]
+
+        def reader(t):
+            return [(b, ix.knn_query(qsets[b], k, seq=b)) for b in range(t, nb, 2)]
+        with ThreadPoolExecutor(2) as rp:
+            return [x for part in rp.map(reader, range(2)) for x in part]
+    with ThreadPoolExecutor(G) as pool:
+        for r, replies in enumerate(pool.map(rank_job, range(G))):
+            assert len(replies) == nb
+            for b, (gl, gs) in replies:
+                assert np.array_equal(gl, want[b][0]) and np.array_equal(gs, want[b][1]), (r, b)
+    for ix in ranks:
+        stt = ix.stats()
+        assert stt["batches"] == nb and stt["exchange_bytes"] > 0
+    # rank 5's transport dies at its next exchange: nobody hangs, everybody reports
+    bus.fail_rank, bus.fail_at = 5, bus.calls[5]
+    for ix in ranks:
+        ix.reset_seq()
+
+    def failing(r):
+        try:
+            ranks[r].knn_query(qsets[0], k, seq=0)
+            return None
+        except RuntimeError as e:
+            return str(e)
+    import time
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(G) as pool:
+        errs = list(pool.map(failing, range(G)))
+    assert all(e is not None for e in errs), errs
+    assert time.perf_counter() - t0 < 60
