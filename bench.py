@@ -578,7 +578,7 @@ def main():
         qsets = [_nu_encode(args, _nu_rows(args, _nu_shared(args), b, args.batch, queries=True)) for b in range(nb_distinct)]
     readers = max(1, min(args.readers, args.steps))
     # (the reader lanes' scratch is sized on their first batches; the low-precision filters' first launches run 15-30 % slow --
-    # profiles/r04c_c4_kernel_stats.txt: 3726 4200 3702 3582 us, then 3150 -- so their steady state needs ten warm-up batches)
+    # profiles/r06_warmup_cliff.txt: the shader clock ramps over the first ~25 ms of load after any idle half second -- so their steady state needs ten warm-up batches)
     nwarm = max(args.warmup, 2 * readers if readers > 1 else 0, 10 if args.dtype in ("i8", "bf16") else 0)
     phases = []
     for kind in kinds:
@@ -636,7 +636,7 @@ def main():
                 "warmup_batches": nwarm,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 # probe + threshold kernels by their own pair of events: off by default (an event record costs the stream 3-5 us,
-                # profiles/r04_event_cost.txt; the scan kernel's pair stays, it is what this object is computed from): --opt events=3
+                # profiles/r06_event_cost.txt; the scan kernel's pair stays, it is what this object is computed from): --opt events=3
                 "other_kernels_ms_per_step": (st["other_ms"] / max(1, args.steps)) if st["other_ms"] > 0 else None}
         if args.dtype == "i8" and avg_ms > 0:
             rows_per_launch = st["scan_rows"] / launches

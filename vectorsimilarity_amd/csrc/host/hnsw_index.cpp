@@ -619,6 +619,7 @@ int HnswIndex::compactDeleted() {
     std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mu_);
     std::vector<std::unique_lock<std::mutex>> lane_locks;
     for (auto &l : lanes_) lane_locks.emplace_back(l->mu);
+    if (walkers_.load() != 0) return 0;   // (an iterator created between maybeCompact's look and the locks: it holds node ids)
     const size_t n = n_, n_new = n - n_deleted_;
     // 1. every live node that points at a dead one: a new list, level by level
     std::vector<uint32_t> mark(n, 0xFFFFFFFFu);
@@ -674,6 +675,9 @@ int HnswIndex::compactDeleted() {
     // 3. the last live nodes move into the holes
     std::vector<uint32_t> new_id(n - n_new, 0xFFFFFFFFu);   // for ids >= n_new
     const bool rows_on_device = uploaded_rows_ == n;
+    // (the device's row moves are carried out AFTER the host state is whole again -- round-5 advisor: a move that failed half way
+    // used to leave labels, links and rows rewritten for some holes only)
+    std::vector<std::pair<uint32_t, uint32_t>> device_moves;
     {
         size_t t = n;
         for (size_t h = 0; h < n_new; h++) {
@@ -692,7 +696,7 @@ int HnswIndex::compactDeleted() {
                 for (uint32_t &v : label_to_ids_.at((size_t)labels_[h]))
                     if (v == (uint32_t)t) v = (uint32_t)h;
             } else label_to_id_[(size_t)labels_[h]] = (uint32_t)h;
-            if (rows_on_device && vsgpu_table_move(table_, h, t)) return -1;
+            if (rows_on_device) device_moves.emplace_back((uint32_t)h, (uint32_t)t);
         }
     }
     auto remap = [&](uint32_t v) { return v >= n_new ? new_id[v - n_new] : v; };
@@ -726,15 +730,19 @@ int HnswIndex::compactDeleted() {
     deleted_.resize(n_new);
     n_ = n_new;
     n_deleted_ = 0;
-    if (rows_on_device) {
-        if (vsgpu_table_truncate(table_, n_new)) return -1;
-        uploaded_rows_ = n_new;
-    } else {   // rows were still pending: start the device table over (the next query appends every row)
-        if (vsgpu_table_truncate(table_, 0)) return -1;
-        uploaded_rows_ = 0;
-    }
     graph_dirty_ = true;
-    return 0;
+    // the host graph is consistent from here on; now the device table.  Any failure: drop the device rows altogether -- the next
+    // query re-appends every row from raw_ (syncDevice) -- and report
+    bool dev_ok = rows_on_device;
+    for (size_t i = 0; dev_ok && i < device_moves.size(); i++) dev_ok = vsgpu_table_move(table_, device_moves[i].first, device_moves[i].second) == 0;
+    if (dev_ok) dev_ok = vsgpu_table_truncate(table_, n_new) == 0;
+    if (dev_ok) {
+        uploaded_rows_ = n_new;
+        return 0;
+    }
+    const int rc = vsgpu_table_truncate(table_, 0);   // (also the path of rows that were still pending)
+    uploaded_rows_ = 0;
+    return (rows_on_device || rc) ? -1 : 0;
 }
 
 int HnswIndex::syncDevice() {
