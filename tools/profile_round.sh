@@ -10,9 +10,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-shard-curve > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shard-curve > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shard-curve > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o r1 -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-shard-curve --no-full-parity > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shard-curve --no-full-parity > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o r1 -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shard-curve --no-full-parity > $OUT/pmc_write.log 2>&1
 python $R/profiles/summarize.py $OUT $OUT/summary || true
 if [ "$ALL" = "all" ]; then
   for c in c1 c3 c4; do
@@ -23,9 +23,9 @@ if [ "$ALL" = "all" ]; then
   timeout 600 python $R/bench.py --config c5 --rows 200000 --data uniform --steps 5 --warmup 1 > $OUT/bench_c5_uniform.json 2> $OUT/bench_c5_uniform.err
   for c in c3 c4; do
     mkdir -p $OUT/cfg_$c
-    rocprofv3 --kernel-trace --stats -d $OUT/cfg_$c/trace -o r1 -- python $R/bench.py --config $c --steps 10 --warmup 10 --no-cpu-baseline > $OUT/cfg_$c/trace.log 2>&1
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_fetch -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $OUT/cfg_$c/pmc_fetch.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_write -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $OUT/cfg_$c/pmc_write.log 2>&1
+    rocprofv3 --kernel-trace --stats -d $OUT/cfg_$c/trace -o r1 -- python $R/bench.py --config $c --steps 10 --warmup 10 --no-cpu-baseline --no-full-parity > $OUT/cfg_$c/trace.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_fetch -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-full-parity > $OUT/cfg_$c/pmc_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cfg_$c/pmc_write -o r1 -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-full-parity > $OUT/cfg_$c/pmc_write.log 2>&1
     python $R/profiles/summarize.py $OUT/cfg_$c $OUT/cfg_$c/summary || true
   done
 fi
