@@ -141,6 +141,10 @@ int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uint16_t *cnt0
  * reference's insert path with the tier's own distances (hnsw.h:1567-1610, 889-963; $VECSIM_GPU_HNSW_BUILD = reference | fast,
  * default reference), 0 when the fast builder runs, -1 when `index` is not an HNSW index. */
 int VecSimGpu_HnswLevels(VecSimIndex *index, uint8_t *levels);
+/* Test hook, needs no GPU: the distance of two STORED blobs as the reference-order HNSW insert path evaluates it on the host
+ * (the lane program of (type, metric, tier, dim) walked by csrc/host/host_lane_eval.h).  tier: 0 AVX512, 2 AVX512_BF16, -1 the host's.
+ * NaN where the tier has no host walker (AVX512-FP16 half accumulators). */
+double VecSimGpu_HostLaneDistance(int type, int metric, int tier, size_t dim, const void *a, const void *b);
 uint64_t VecSimGpu_HnswLastDistanceEvals(VecSimIndex *index);
 
 /* ---- SQ8 storage: scalar-quantised 8-bit rows (uint8 codes + FP32 metadata) scored against FP32 queries.

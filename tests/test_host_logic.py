@@ -204,3 +204,30 @@ def test_host_tier_probe_matches_proc_cpuinfo(monkeypatch):
                 break
     expect = "AVX512_BF16" if {"avx512f", "avx512_bf16", "avx512vl"} <= flags else "AVX512"
     assert lib.VecSimGpu_HostTier().decode() == expect
+
+
+HL_DIMS = {"f32": list(range(1, 100)) + [128, 500, 768, 1024], "f64": list(range(1, 50)) + [128, 768], "f16": list(range(1, 100)) + [128, 768],
+           "bf16": list(range(1, 130)) + [768, 1024], "i8": list(range(1, 140)) + [768, 1024], "u8": list(range(1, 140)) + [1024]}
+
+
+@pytest.mark.parametrize("typ", list(HL_DIMS))
+def test_host_lane_walker_equals_the_oracle_for_every_residual_class(vso, typ):
+    """csrc/host/host_lane_eval.h -- what the reference-order HNSW insert path ranks its candidates by -- against the pinned kernel
+    oracle, bit for bit: every dim's residual class, L2 / IP / Cosine, the AVX-512 tier (+ the vdpbf16ps tier for bf16), stored blobs
+    (Cosine: normalised, int8 / uint8 with the norm behind the elements); no GPU involved"""
+    import ctypes as C
+    from util import METRICS, TYPES, random_vectors, stored_rows
+    lib = _capi.load()
+    rng = np.random.default_rng(11)
+    t = TYPES[typ]
+    for d in HL_DIMS[typ]:
+        v = random_vectors(rng, 2, d, typ, vso)
+        for metric in ("L2", "IP", "Cosine"):
+            st = stored_rows(vso, v, typ, metric)
+            a, b = np.ascontiguousarray(st[0]), np.ascontiguousarray(st[1])
+            km = METRICS["IP"] if (metric == "Cosine" and typ not in ("i8", "u8")) else METRICS[metric]
+            for tier in [0] + ([2] if typ == "bf16" else []):
+                got = lib.VecSimGpu_HostLaneDistance(t, METRICS[metric], tier, d, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+                want = vso.distance(t, km, a, b, dim=d, tier=tier)
+                assert got == want or (got != got and want != want), (typ, metric, d, tier, got, want)
+    assert np.isnan(lib.VecSimGpu_HostLaneDistance(TYPES["f16"], 0, 3, 64, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))) or typ != "f16"

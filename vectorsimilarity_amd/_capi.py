@@ -138,7 +138,7 @@ EXPORTS = [
     "VecSimBatchIterator_HasNext", "VecSimBatchIterator_Free", "VecSimBatchIterator_Reset",
     "VecSimIndex_TopKQueryBatch", "VecSimIndex_TopKQueryBatchArrays", "VecSimIndex_TopKCandidatesBatch", "VecSimGpu_MergeTopK",
     "VecSimIndex_AddVectorsBulk", "VecSimIndex_AddSyntheticVectors",
-    "VecSimDebug_GetElementNeighborsInHNSWGraph", "VecSimDebug_ReleaseElementNeighborsInHNSWGraph", "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLevels", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors", "VecSimGpu_ReadStoredRows",
+    "VecSimDebug_GetElementNeighborsInHNSWGraph", "VecSimDebug_ReleaseElementNeighborsInHNSWGraph", "VecSimGpu_HnswGraphInfo", "VecSimGpu_HnswGraphCopy", "VecSimGpu_HnswLevels", "VecSimGpu_HostLaneDistance", "VecSimGpu_HnswLastDistanceEvals", "VecSimGpu_GetStoredVectors", "VecSimGpu_ReadStoredRows",
     "VecSimGpu_NewFlatSQ8", "VecSimGpu_SQ8_StoredDistance", "VecSimGpu_SQ8_StorageBlobSize", "VecSimGpu_SQ8_QueryBlobSize",
     "VecSimGpu_SQ8_Quantize", "VecSimGpu_SQ8_QueryBlob", "VecSimGpu_NewFlatSQ8Centered", "VecSimGpu_SQ8_StorageBlobSizeCentered",
     "VecSimGpu_SQ8_QueryBlobSizeCentered", "VecSimGpu_SQ8_QuantizeCentered", "VecSimGpu_SQ8_QueryBlobCentered",
@@ -301,6 +301,8 @@ def load():
     L.VecSimGpu_HnswGraphCopy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.VecSimGpu_HnswLevels.restype = i
     L.VecSimGpu_HnswLevels.argtypes = [vp, vp]
+    L.VecSimGpu_HostLaneDistance.restype = C.c_double
+    L.VecSimGpu_HostLaneDistance.argtypes = [i, i, i, C.c_size_t, vp, vp]
     L.VecSimGpu_HnswLastDistanceEvals.restype = C.c_uint64
     L.VecSimGpu_HnswLastDistanceEvals.argtypes = [vp]
     L.VecSimGpu_SetDevice.restype = i

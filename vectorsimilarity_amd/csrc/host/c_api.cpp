@@ -22,6 +22,7 @@
 #include "ref_heap.h"
 #include "flat_index.h"
 #include "host_tier.h"
+#include "host_lane_eval.h"
 #include "sq8_prep.h"
 #include "hnsw_index.h"
 #include "sharded_index.h"
@@ -456,6 +457,33 @@ extern "C" int VecSimGpu_HnswGraphCopy(VecSimIndex *index, uint32_t *links0, uin
     std::memcpy(deleted, e.deleted, e.n);
     std::memcpy(labels, e.labels, (size_t)e.n * 8);
     return 0;
+}
+// Test hook (CPU, no GPU needed): the distance of two STORED blobs as the HNSW reference-order insert path computes it on the host
+// (csrc/host/host_lane_eval.h walking csrc/lane_program.h).  type / metric: VecSimType / VecSimMetric of the index; tier: VSGPU_TIER_*
+// (-1: the host's).  NaN when this (type, tier) has no host walker (the AVX512-FP16 tier's half accumulators).
+extern "C" double VecSimGpu_HostLaneDistance(int type, int metric, int tier, size_t dim, const void *a, const void *b) {
+    vsa::HostLaneEval ev;
+    if (tier < 0) tier = vsa::resolve_tier(-1);
+    if (tier == VSGPU_TIER_SCALAR) tier = VSGPU_TIER_AVX512;   // (as HnswIndex::create: small dims take the scalar order by themselves)
+    if (!ev.init(type, metric, tier, dim)) return std::numeric_limits<double>::quiet_NaN();
+    std::vector<float> wa, wb;
+    if (type == VecSimType_FLOAT32 || type == VecSimType_BFLOAT16 || type == VecSimType_FLOAT16) {
+        wa.resize(dim);
+        wb.resize(dim);
+        for (size_t i = 0; i < dim; i++) {
+            if (type == VecSimType_FLOAT32) {
+                std::memcpy(&wa[i], (const char *)a + 4 * i, 4);
+                std::memcpy(&wb[i], (const char *)b + 4 * i, 4);
+            } else {
+                uint16_t ha, hb;
+                std::memcpy(&ha, (const char *)a + 2 * i, 2);
+                std::memcpy(&hb, (const char *)b + 2 * i, 2);
+                wa[i] = type == VecSimType_BFLOAT16 ? vsa::bf16_widen(ha) : vsa::fp16_widen(ha);
+                wb[i] = type == VecSimType_BFLOAT16 ? vsa::bf16_widen(hb) : vsa::fp16_widen(hb);
+            }
+        }
+    }
+    return ev.score((const char *)a, (const char *)b, wa.data(), wb.data());
 }
 // per-node top level [n] (with the arrays of VecSimGpu_HnswGraphCopy the whole graph); returns 1 when single AddVector calls follow the
 // reference's insert path in the tier's distance order (hnsw_ref_build.cpp), 0 when the fast builder runs, -1: not an HNSW index
