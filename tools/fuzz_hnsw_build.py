@@ -39,8 +39,17 @@ while time.time() - t0 < a.seconds:
     if mode == 2:                                    # duplicates of earlier rows
         src = rng.integers(0, n, n // 5)
         rows[rng.integers(0, n, n // 5)] = rows[src]
-    if metric == "Cosine" and typ not in ("i8", "u8"):
-        rows[np.all(rows.view(np.uint8).reshape(n, -1) == 0, axis=1)] = random_vectors(rng, 1, dim, typ, vso)[0]   # (no zero vectors)
+    if metric == "Cosine":
+        # no zero vectors (-0.0 included): their normalisation is 0 / 0, every distance to them NaN, and which of two pairs with NaN
+        # scores std::priority_queue moves is a property of the language standard the reference is built with (docs/HISTORY.md 3)
+        if typ in ("bf16", "f16"):
+            zero = np.all((rows & 0x7FFF) == 0, axis=1)
+        else:
+            zero = np.all(rows == 0, axis=1)
+        for i in np.nonzero(zero)[0]:
+            rows[i] = random_vectors(rng, 1, dim, typ, vso)[0]
+            if typ in ("f32", "f64"):
+                rows[i] += 3.0
     p = VecSim.HNSWParams()
     p.type, p.dim, p.metric, p.M, p.efConstruction, p.efRuntime = TYPES[typ], dim, METRICS[metric], M, efc, 10
     ix = VecSim.HNSWIndex(p)
