@@ -1482,3 +1482,44 @@ def test_concurrent_readers_get_the_single_reader_replies(vso, typ, metric, dim,
     allrows = np.concatenate([rows, extra])
     el, es = oracle_topk(vso, typ, metric, allrows, qs[1][3], k)
     assert np.array_equal(alone2[1][0][3], el.astype(np.int64)) and np.array_equal(alone2[1][1][3], es)
+
+
+# ---------------------------------------------------------------- round 6: the sliced dense path (single queries on small tables)
+@pytest.mark.parametrize("typ,metric,dim,n,nq,k", [("f32", "L2", 128, 100_000, 1, 10), ("f32", "L2", 128, 100_000, 1, 100),
+                                                   ("f32", "Cosine", 100, 30_000, 4, 10), ("bf16", "IP", 64, 60_000, 2, 10),
+                                                   ("f16", "L2", 48, 120_000, 1, 7), ("f32", "IP", 16, 9_000, 3, 500)])
+def test_sliced_dense_path_bit_exact(vso, typ, metric, dim, n, nq, k):
+    """vsgpu.hip dense_sliced_topk: upload kernel -> exact scan -> k_select_dense_slices -> final select (BASELINE config 1's shape is
+    the first case): labels, order and scores equal the oracle's sequential scan, and the path is the one that ran"""
+    rng = np.random.default_rng(n + dim + k)
+    rows = random_vectors(rng, n, dim, typ, vso)
+    q = random_vectors(rng, nq, dim, typ, vso)
+    ix = make_index(typ, metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"] == "k_exact_scan(dense)" and st["fallbacks"] == 0, st
+    for j in range(nq):
+        el, es = oracle_topk(vso, typ, metric, rows, q[j], k)
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (typ, metric, j)
+    ix.set_option("dense_sliced_bytes", 0)          # the filter path on the same index gives the same reply
+    l2, d2 = ix.knn_query(q, k)
+    assert np.array_equal(l2, labels) and np.array_equal(d2, dists)
+
+
+def test_sliced_dense_path_massive_ties_take_the_plain_pass(vso):
+    """every slice holds far more than its room of rows tied at the k-th score: the lists run over, the queries fall back to the
+    one-workgroup dense select, the reply is still the reference's (ties resolved by the sequential heap)"""
+    rng = np.random.default_rng(77)
+    n, dim, k = 40_000, 4, 10
+    rows = rng.integers(0, 2, (n, dim)).astype(np.float32)          # 0 / 1 grid in 4 dims: sixteen distinct rows, five distinct scores
+    q = rng.integers(0, 2, (2, dim)).astype(np.float32)
+    ix = make_index("f32", "L2", dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    assert ix.stats()["fallbacks"] >= 1
+    for j in range(2):
+        el, es = oracle_topk(vso, "f32", "L2", rows, q[j], k)
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es)

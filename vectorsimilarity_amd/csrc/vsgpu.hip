@@ -57,11 +57,17 @@ void poison(void *p, size_t bytes) {
     }
 }
 int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
+    if (b.alias) {   // an alias is only good for the call that made it: back to the buffer's own memory
+        b.p = b.own_p;
+        b.cap = b.own_cap;
+        b.alias = false;
+        b.own_p = nullptr;
+        b.own_cap = 0;
+    }
     if (bytes <= b.cap) return VSGPU_OK;
-    if (b.p && !b.alias) HIPCHK(hipFree(b.p));
+    if (b.p) HIPCHK(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-    b.alias = false;
     size_t want = std::max(bytes, (size_t)4096);
     want = (want + 0xFFFF) & ~(size_t)0xFFFF;
     HIPCHK(hipMalloc(&b.p, want));
@@ -71,7 +77,11 @@ int ensure(vsgpu_ctx *c, DevBuf &b, size_t bytes) {
 }
 // b becomes a region of another buffer (its own memory, if any, is released: every call ends with a stream sync, nothing reads it)
 void alias_into(DevBuf &b, void *p, size_t bytes) {
-    if (b.p && !b.alias) (void)hipFree(b.p);
+    if (b.p && !b.alias) {   // park the buffer's own allocation (ensure() takes it back)
+        if (b.own_p && b.own_p != b.p) (void)hipFree(b.own_p);
+        b.own_p = b.p;
+        b.own_cap = b.cap;
+    }
     b.p = p;
     b.cap = bytes;
     b.alias = true;
@@ -158,8 +168,10 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock})
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock}) {
         if (b->p && !b->alias) (void)hipFree(b->p);
+        if (b->own_p && (b->alias || b->own_p != b->p)) (void)hipFree(b->own_p);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
     (void)hipEventDestroy(c->ev_a);
@@ -209,6 +221,8 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "wg_per_cu") c->opt_wg_per_cu = c->opt_lowp_wg_per_cu = std::max(1L, value);   // (both filter families)
     else if (n == "mfma_min_q") c->opt_mfma_min_q = std::max(1L, value);
     else if (n == "dense_pairs") c->opt_dense_pairs = value;
+    else if (n == "dense_sliced_bytes") c->opt_dense_sliced_bytes = std::max(0L, value);
+    else if (n == "dense_small_q") c->opt_dense_small_q = std::max(1L, value);
     else if (n == "probe_div") c->opt_probe_div = std::max(0L, value);
     else if (n == "probe_cap") c->opt_probe_cap = std::min(1L << 20, std::max(64L, value));
     else if (n == "probe_run") c->opt_probe_run = std::min(8L, std::max(-1L, value));
@@ -1298,7 +1312,10 @@ static int fallback_dense_path(vsgpu_table *t, size_t nq, size_t k, size_t cap, 
     vsgpu_ctx *c = t->ctx;
     ScanChainGuard g(t);
     g.before_scan();
+    const bool was_plain = c->dense_plain;
+    c->dense_plain = true;   // (the sliced dense path ends in collect_candidates, whose fallback is this function)
     const int rc = topk_dense_path(t, nq, k, cap, ids, scores, counts, q_first, q_count, queries, qstride);
+    c->dense_plain = was_plain;
     (void)hipStreamSynchronize(c->stream);   // (the pass ends drained on success; an error may have left work queued)
     g.submitted();
     if (c->dense.p && !c->dense.alias && c->dense.cap > DENSE_KEEP_BYTES) {
@@ -1619,10 +1636,58 @@ int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t
 // Exact scores of ALL rows for nq queries in one dense matrix on the device, the k-th smallest per query by radix selection there
 // (k_select_dense_upto_kth), only the rows at or below it to the host.  The small-problem path of vsgpu_topk and the fallback of
 // queries whose candidate lists overflowed twice (collect_candidates).  fp32-scored tables; the caller bounds nq * n.
+static bool dense_sliced_ok(const vsgpu_table *t, size_t nq) {
+    const vsgpu_ctx *c = t->ctx;
+    return !c->dense_plain && c->opt_dense_sliced_bytes > 0 && nq <= (size_t)c->opt_dense_small_q && t->n >= 8192 &&
+           (t->type == VSGPU_F32 || t->type == VSGPU_BF16 || t->type == VSGPU_F16) && t->epi != EPI_INT_COS;
+}
+// The dense path with its selection dealt over slices of the rows (k_select_dense_slices): ONE staged block (zeroed candidate counters +
+// the exact-order query images) uploaded by the copy kernel, the exact scan into the dense score matrix, the slice select appending
+// each slice's rows at or below its own k-th score to the query's candidate list, and collect_candidates' final select + reply.
+static int dense_sliced_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
+                             double *scores, uint32_t *counts) {
+    vsgpu_ctx *c = t->ctx;
+    const size_t n = t->n, kk = std::min(k, n);
+    const size_t S = std::min<size_t>(256, (n + 4095) / 4096), L = (n + S - 1) / S;
+    const size_t ccap = S * (2 * kk + 64);
+    const size_t ab = (nq * 4 + 255) & ~(size_t)255, qb = (staged_query_bytes(t, nq) + 255) & ~(size_t)255;
+    int rc = ensure(c, c->qblock, ab + qb);
+    if (rc) return rc;
+    rc = ensure_pin_up(c, ab + qb);
+    if (rc) return rc;
+    memset(c->pin_up, 0, ab);
+    rc = stage_queries(t, queries, nq, qstride, (char *)c->pin_up + ab, (char *)c->qblock.p + ab);
+    if (rc) return rc;
+    alias_into(c->counts, c->qblock.p, ab);
+    rc = upload_block(c, c->qblock.p, c->pin_up, ab + qb);
+    if (rc) return rc;
+    rc = ensure(c, c->dense, nq * n * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->cand, nq * ccap * sizeof(uint2));
+    if (rc) return rc;
+    ScanParams P{};
+    P.row_ids = nullptr;
+    P.row_begin = 0;
+    P.row_end = (uint32_t)n;
+    P.n_compact = (uint32_t)n;
+    P.tile_step = (uint32_t)tile_rows_of(t->ek);
+    P.mode = MODE_DENSE;
+    P.out = c->dense.p;
+    P.out_stride = n;
+    rc = run_scan(t, P, nq, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_dense_slices, dim3((unsigned)nq, (unsigned)S), dim3(1024), 0, c->stream, (const float *)c->dense.p, n,
+                       (uint32_t)n, (uint32_t)kk, (uint2 *)c->cand.p, (uint32_t *)c->counts.p, (uint32_t)ccap, (uint32_t)L);
+    HIPCHK(hipGetLastError());
+    // final select among the slices' survivors, records into the pinned reply block, host emit; a list that ran over its room (massive
+    // exact ties) or came up short (NaN scores) goes to the plain dense pass (collect_candidates -> fallback_dense_path)
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, "k_exact_scan(dense)", nullptr);
+}
 static int dense_gpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
                           double *scores, uint32_t *counts) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
+    if (dense_sliced_ok(t, nq)) return dense_sliced_topk(t, queries, nq, qstride, k, cap, ids, scores, counts);
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
     ScanParams P{};
@@ -1718,7 +1783,8 @@ extern "C" int vsgpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
 
     // small problems (and fp64 without the MFMA filter: narrow batches, scalar-tier dims): one dense score matrix
     const bool f64_filter = f64 && t->mfma_ok && c->opt_mfma && nq >= (size_t)c->opt_mfma_min_q;
-    if ((f64 && !f64_filter) || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k) {
+    const bool small_sliced = c->opt_dense_pairs > 0 /* (dense_pairs = 0 is how callers ask for the filter path) */ && dense_sliced_ok(t, nq) && (double)n * (double)t->row_bytes * (double)nq <= (double)c->opt_dense_sliced_bytes;
+    if ((f64 && !f64_filter) || (double)n * (double)nq <= (double)c->opt_dense_pairs || n <= 4 * k || small_sliced) {
         if (!f64 && n * nq * 4 <= ((size_t)1 << 28)) return dense_gpu_topk(t, queries, nq, qstride, k, cap, ids, scores, counts);
         if (f64) {
             // fp64: dense double scores per group of queries, 64-bit selection on the GPU, survivors to the host

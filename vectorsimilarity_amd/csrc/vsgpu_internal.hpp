@@ -35,6 +35,11 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     bool alias = false;   // p points into another buffer (vsgpu_ctx::qblock): never freed through this handle
+    // the buffer's OWN allocation while p is an alias (alias_into parks it here, ensure() takes it back): a context whose calls alternate
+    // between a path that aliases (one staged block per batch) and one that does not neither frees and reallocates per call nor --
+    // round 6, found by the sliced dense path's test -- keeps writing through a stale alias into a block the next path lays out anew
+    void *own_p = nullptr;
+    size_t own_cap = 0;
 };
 
 struct vsgpu_ctx {
@@ -84,6 +89,13 @@ struct vsgpu_ctx {
     long opt_mfma_min_q = 1;          // batches narrower than this stay on the exact kernel.  Measured (tools/bench_small_batches.py):
                                       // the MFMA filter wins from one query up (10M x 768: 4.7 ms vs 5.8-8.5 ms for 1-8 queries)
     long opt_dense_pairs = 1L << 16;  // nq*n at or below this: one dense score matrix + one select kernel
+    // (round 6) fp32 / bf16 / fp16 tables, at most opt_dense_small_q queries: the dense path while rows x storedDataSize x queries stays
+    // at or below THIS many bytes, its selection dealt over slices of the rows (k_select_dense_slices) -- upload, exact scan, slice
+    // select, final select: four stream operations instead of the filter path's six, for single queries on small tables (BASELINE
+    // config 1: 100 K x 128 fp32, one query: 51 -> 39 us; 400 K rows 80 -> 71; 800 K rows: the filter path wins, profiles/r06_c1_dense.txt).  0 = off
+    long opt_dense_sliced_bytes = 256L << 20;
+    long opt_dense_small_q = 4;
+    bool dense_plain = false;         // inside the overflow fallback: the one-workgroup select, no slices (it must not come back here)
     long opt_probe_div = 0;           // probe ~ n / probe_div rows; 0 = chosen per call by probe_divisor()
     long opt_probe_cap = 32768;       // ... but at most this many probe tiles
     long opt_probe_run = -1;          // probe tiles per contiguous run, as a shift; -1 = about 2 MiB per run (probe_run_shift())
