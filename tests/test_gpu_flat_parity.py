@@ -1487,7 +1487,9 @@ def test_concurrent_readers_get_the_single_reader_replies(vso, typ, metric, dim,
 # ---------------------------------------------------------------- round 6: the sliced dense path (single queries on small tables)
 @pytest.mark.parametrize("typ,metric,dim,n,nq,k", [("f32", "L2", 128, 100_000, 1, 10), ("f32", "L2", 128, 100_000, 1, 100),
                                                    ("f32", "Cosine", 100, 30_000, 4, 10), ("bf16", "IP", 64, 60_000, 2, 10),
-                                                   ("f16", "L2", 48, 120_000, 1, 7), ("f32", "IP", 16, 9_000, 3, 500)])
+                                                   ("f16", "L2", 48, 120_000, 1, 7), ("f32", "IP", 16, 9_000, 3, 500),
+                                                   ("i8", "Cosine", 128, 80_000, 1, 10), ("i8", "L2", 96, 40_000, 2, 20),
+                                                   ("u8", "IP", 64, 50_000, 1, 10), ("u8", "Cosine", 100, 30_000, 3, 10)])
 def test_sliced_dense_path_bit_exact(vso, typ, metric, dim, n, nq, k):
     """vsgpu.hip dense_sliced_topk: upload kernel -> exact scan -> k_select_dense_slices -> final select (BASELINE config 1's shape is
     the first case): labels, order and scores equal the oracle's sequential scan, and the path is the one that ran"""

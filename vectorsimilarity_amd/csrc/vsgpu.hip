@@ -1639,7 +1639,7 @@ int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t
 static bool dense_sliced_ok(const vsgpu_table *t, size_t nq) {
     const vsgpu_ctx *c = t->ctx;
     return !c->dense_plain && c->opt_dense_sliced_bytes > 0 && nq <= (size_t)c->opt_dense_small_q && t->n >= 8192 &&
-           (t->type == VSGPU_F32 || t->type == VSGPU_BF16 || t->type == VSGPU_F16) && t->epi != EPI_INT_COS;
+           (t->type == VSGPU_F32 || t->type == VSGPU_BF16 || t->type == VSGPU_F16 || t->type == VSGPU_I8 || t->type == VSGPU_U8);
 }
 // The dense path with its selection dealt over slices of the rows (k_select_dense_slices): ONE staged block (zeroed candidate counters +
 // the exact-order query images) uploaded by the copy kernel, the exact scan into the dense score matrix, the slice select appending
@@ -1650,16 +1650,20 @@ static int dense_sliced_topk(vsgpu_table *t, const void *queries, size_t nq, siz
     const size_t n = t->n, kk = std::min(k, n);
     const size_t S = std::min<size_t>(256, (n + 4095) / 4096), L = (n + S - 1) / S;
     const size_t ccap = S * (2 * kk + 64);
+    // the block: {zeroed candidate counters, query norms (int8 / uint8 Cosine: the float behind a query's elements), exact-order images}
     const size_t ab = (nq * 4 + 255) & ~(size_t)255, qb = (staged_query_bytes(t, nq) + 255) & ~(size_t)255;
-    int rc = ensure(c, c->qblock, ab + qb);
+    int rc = ensure(c, c->qblock, 2 * ab + qb);
     if (rc) return rc;
-    rc = ensure_pin_up(c, ab + qb);
+    rc = ensure_pin_up(c, 2 * ab + qb);
     if (rc) return rc;
-    memset(c->pin_up, 0, ab);
-    rc = stage_queries(t, queries, nq, qstride, (char *)c->pin_up + ab, (char *)c->qblock.p + ab);
+    memset(c->pin_up, 0, 2 * ab);
+    if (t->epi == EPI_INT_COS)
+        for (size_t q = 0; q < nq; q++) memcpy((char *)c->pin_up + ab + 4 * q, (const char *)queries + q * qstride + t->dim, 4);
+    rc = stage_queries(t, queries, nq, qstride, (char *)c->pin_up + 2 * ab, (char *)c->qblock.p + 2 * ab);
     if (rc) return rc;
     alias_into(c->counts, c->qblock.p, ab);
-    rc = upload_block(c, c->qblock.p, c->pin_up, ab + qb);
+    alias_into(c->qnorm, (char *)c->qblock.p + ab, ab);
+    rc = upload_block(c, c->qblock.p, c->pin_up, 2 * ab + qb);
     if (rc) return rc;
     rc = ensure(c, c->dense, nq * n * 4);
     if (rc) return rc;
