@@ -1691,7 +1691,8 @@ static int dense_gpu_topk(vsgpu_table *t, const void *queries, size_t nq, size_t
                           double *scores, uint32_t *counts) {
     vsgpu_ctx *c = t->ctx;
     const size_t n = t->n;
-    if (dense_sliced_ok(t, nq)) return dense_sliced_topk(t, queries, nq, qstride, k, cap, ids, scores, counts);
+    // (a k beyond a quarter of a 4 K-row slice would have every slice hand on most of its rows: the one-workgroup select then)
+    if (dense_sliced_ok(t, nq) && std::min(k, n) <= 1024) return dense_sliced_topk(t, queries, nq, qstride, k, cap, ids, scores, counts);
     int rc = stage_queries(t, queries, nq, qstride);
     if (rc) return rc;
     ScanParams P{};
