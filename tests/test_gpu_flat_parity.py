@@ -1525,3 +1525,47 @@ def test_sliced_dense_path_massive_ties_take_the_plain_pass(vso):
     for j in range(2):
         el, es = oracle_topk(vso, "f32", "L2", rows, q[j], k)
         assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es)
+
+
+# ---------------------------------------------------------------- round 6: the streaming threshold (mfma_kernels.hpp MF_STREAM)
+@pytest.mark.parametrize("metric,dim,n,nq,k,order", [("L2", 768, 300_000, 64, 10, "random"), ("IP", 512, 400_000, 40, 10, "random"),
+                                                     ("Cosine", 1024, 200_000, 64, 100, "random"), ("L2", 768, 250_000, 17, 128, "random"),
+                                                     ("L2", 512, 300_000, 8, 10, "far_first"), ("L2", 768, 200_000, 64, 10, "clustered_tail")])
+def test_streaming_threshold_filter_bit_exact(vso, metric, dim, n, nq, k, order):
+    """option stream_tau: a probe of 512 tiles seeds tau and the per-query lists, the filter tightens them while it streams.  The
+    reply must equal the oracle (and the plain filter's) whatever the order of the rows -- `far_first`: rows sorted by DEcreasing
+    closeness to the first query (every tile beats the threshold so far: the worst case, settled by the retry pass);
+    `clustered_tail`: the last 2 % of the table sit next to the queries"""
+    rng = np.random.default_rng(dim + n + k)
+    rows = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    if order == "far_first":
+        d = ((rows - q[0]) ** 2).sum(axis=1)
+        rows = np.ascontiguousarray(rows[np.argsort(-d)])
+    if order == "clustered_tail":
+        m = n // 50
+        rows[-m:] = q[rng.integers(0, nq, m)] + rng.uniform(-0.05, 0.05, (m, dim)).astype(np.float32)
+    ix = make_index("f32", metric, dim)
+    ix.add_vectors(rows, np.arange(n))
+    ix.set_option("dense_pairs", 0)
+    plain = ix.knn_query(q, k)
+    ix.set_option("stream_tau", 1)
+    ix.reset_stats()
+    labels, dists = ix.knn_query(q, k)
+    st = ix.stats()
+    assert st["scan_kernel"] == "k_mfma_filter", st
+    assert np.array_equal(labels, plain[0]) and np.array_equal(dists, plain[1])
+    for j in range(0, nq, max(1, nq // 6)):
+        el, es = oracle_topk(vso, "f32", metric, rows, q[j], k)
+        assert np.array_equal(labels[j], el.astype(np.int64)) and np.array_equal(dists[j], es), (metric, j)
+    # twice more (the candidate sets depend on timing, the replies must not), once under two concurrent readers
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:
+        for l2, d2 in pool.map(lambda _: ix.knn_query(q, k), range(4)):
+            assert np.array_equal(l2, labels) and np.array_equal(d2, dists)
+    # the pace of the threshold re-reads changes the candidate sets, never the reply
+    for refresh, early in ((1, 0), (64, 0), (8, 16)):
+        ix.set_option("stream_refresh", refresh)
+        ix.set_option("stream_early", early)
+        l2, d2 = ix.knn_query(q, k)
+        assert np.array_equal(l2, labels) and np.array_equal(d2, dists), (refresh, early)

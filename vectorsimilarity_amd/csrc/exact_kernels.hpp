@@ -384,9 +384,11 @@ __global__ __launch_bounds__(256) void k_exact_scan(ScanParams P) {
 // Any k distinct rows bound the k-th smallest score of the whole table from above, and minima of
 // disjoint tiles belong to distinct rows, so tau >= T_q (the exact k-th smallest) always holds.
 // One 1024-thread workgroup per query; M <= 8192 (power of two), bitonic sort in LDS.
+// klist != nullptr (the streaming filter, mfma_kernels.hpp MF_STREAM): the k smallest group minima seed the query's list
+// ([queries][klist_stride] order-preserving integer keys, ascending).
 static __global__ __launch_bounds__(1024) void k_probe_threshold(const float *dense, size_t stride,
                                                           uint32_t n0, uint32_t k, uint32_t M,
-                                                          float *tau) {
+                                                          float *tau, uint32_t *klist = nullptr, uint32_t klist_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *v = reinterpret_cast<float *>(smem);
     const float *src = dense + (size_t)blockIdx.x * stride;
@@ -413,10 +415,13 @@ static __global__ __launch_bounds__(1024) void k_probe_threshold(const float *de
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) {
-        // number of non-empty tiles
-        uint32_t tiles = (n0 + ts - 1) / ts;
-        tau[blockIdx.x] = (k >= 1 && k <= tiles) ? v[k - 1] : INFINITY;
+    // number of non-empty tiles
+    const uint32_t tiles = (n0 + ts - 1) / ts;
+    if (threadIdx.x == 0) tau[blockIdx.x] = (k >= 1 && k <= tiles) ? v[k - 1] : INFINITY;
+    if (klist && threadIdx.x < min(k, klist_stride)) {   // ascending keys; +inf where the probe had fewer than k tiles
+        const float f = threadIdx.x < tiles ? v[threadIdx.x] : INFINITY;
+        const uint32_t b = __float_as_uint(f);
+        klist[(size_t)blockIdx.x * klist_stride + threadIdx.x] = b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
     }
 }
 

@@ -34,7 +34,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x8_t __attribute__((ext_vector_type(8)));
 
-enum MfmaMode { MF_PROBE = 0, MF_FILTER = 1 };
+enum MfmaMode { MF_PROBE = 0, MF_FILTER = 1, MF_STREAM = 2 };
+// MF_STREAM (round 6): the filter with a threshold that TIGHTENS while it streams.  tau_q starts as the k-th smallest tile minimum
+// of a SMALL probe (a few hundred tiles instead of n / 48 rows) whose k smallest minima also seed a per-query list in global memory;
+// every workgroup re-reads tau_q once per tile (an L2 hit, beside the slab pointers it loads there anyway) and, whenever one of its
+// tiles' minimum upper bound beats tau_q, enters it into the list (lock-free: mf_stream_insert).  The
+// list always holds upper bounds of k DISTINCT rows (tiles are disjoint; the probe's own tiles never insert again), so tau_q >= T_q
+// at every moment, and a stale tau_q is only looser: the emitted set stays a superset of {s_ref <= T_q}.  Expected survivors per
+// query ~ 2.3 k ln(n / probe rows) whatever the probe's size, which is what lets the probe shrink.
+constexpr int MF_KLIST = 128;         // list entries per query (k beyond this: the plain filter)
 
 constexpr int MF_TILE_ROWS = 64;      // default rows per workgroup tile (4 MFMA M-tiles of 16)
 constexpr int MF_STAGE_BYTES = 16384; // one ring slot: RT rows x (4096/RT) floats
@@ -118,7 +126,62 @@ struct MfmaParams {
     uint2 *cand;                     // [q_tiles*64][cap] {row, lower-bound bits}
     uint32_t cap;
     const float *qmeta;              // k_mfma_filter_wide on uint8 Cosine rows (EK = 5): [queries][8] = {norm_q, bits(int 128 sum q' + 16384 dim), ...}
+    // MF_STREAM: klist [queries][MF_KLIST] order-preserving keys
+    // (a query's slots in cache lines of its own: a slot-major layout -- one 64-byte request for a wave's sixteen thresholds -- put the
+    // atomics of all queries on the same lines and cost 0.1 ms more per 10 M rows, r06_stream_ab.txt) of the k smallest upper bounds seen so far, ascending (seeded by
+    // k_probe_threshold); the query's threshold is slot k - 1, read again every tile.  k = 0xFFFFFFFF: no insertions (measurement)
+    uint32_t *klist;
+    uint32_t klist_stride;   // words between two queries' lists (>= MF_KLIST)
+    uint32_t k;
+    uint32_t refresh_mask, refresh_early;   // re-read tau_q every (mask + 1)-th tile, and after each of a workgroup's first `early` tiles
+    uint32_t probe_shift, probe_tiles;   // tiles t = j << probe_shift, j < probe_tiles, were the probe's: their minima are in the list already
 };
+
+// One lane, one query: `up` -- an upper bound of a row no list entry stands for -- enters the query's list of the k smallest such bounds.
+// LOCK-FREE (the first version took a per-query lock: an unbounded spin hung the GPU -- sixteen lanes of a wave hold sixteen locks --, a
+// bounded one cost 0.7 ms per 10 M rows in stalls).  The list is k slots of order-preserving integer keys, ascending; inserting x is the
+// cascade  x = max(x, atomicMin(&slot[i], x))  from the first slot whose value exceeds x: every atomic step leaves {slot, carry} the
+// same multiset with the smaller one in the slot, so (1) the slots always hold bounds of k DISTINCT rows (what falls off the end is the
+// largest), (2) each slot only ever decreases and slot[i] <= slot[i + 1] holds after every single step, whatever interleaves -- hence
+// tau_q = slot[k - 1], read by a plain load, is at every moment the k-th smallest bound of k distinct rows: >= T_q.  Slots at or below x
+// are skipped without an atomic (they can only have decreased since they were read).
+__device__ __forceinline__ uint32_t mf_key_of(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float mf_float_of(uint32_t key) {
+    return __uint_as_float(key ^ ((key & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// Returns the key of slot k - 1 as last seen: the caller's threshold for free.
+__device__ __forceinline__ uint32_t mf_stream_insert(uint32_t *klist, uint32_t stride, uint32_t k, int q, float up) {
+    uint32_t *lst = klist + (size_t)q * stride;
+    uint32_t x = mf_key_of(up);
+    // the slots as they are now, the last one and eight at a time from the first, all loads in flight together
+    uint32_t last = __hip_atomic_load(lst + k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t i = 0;
+    for (uint32_t i0 = 0; i0 < k; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (i0 + j < k) ? __hip_atomic_load(lst + i0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        if (last <= x) return last;   // (the caller's threshold was stale: nothing to enter)
+        uint32_t below = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) below += (i0 + j < k && v[j] <= x) ? 1u : 0u;
+        i += below;
+        if (below < 8) break;
+    }
+    for (; i < k; i++) {
+        const uint32_t old = atomicMin(lst + i, x);
+        if (i + 1 == k) last = old < x ? old : x;
+        if (old <= x) continue;    // (the slot had come down to x or below meanwhile: x moves on unchanged)
+        x = old;                   // x rests in slot i; what it displaced moves on
+        if (i + 1 < k) {
+            last = __hip_atomic_load(lst + k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last <= x) break;  // the carry is the largest: it falls off
+        }
+    }
+    return last;
+}
 
 template <int AUX>
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_byte_off, char *lds_base) {
@@ -178,7 +241,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     const int qidx = qtile * MF_QTILE + wave * 16 + m16;
     float nq2 = P.qn2[qidx];
     float tau = 0.f;
-    if (MODE == MF_FILTER) tau = P.tau[qidx];
+    if (MODE != MF_PROBE) tau = P.tau[qidx];
     // Pin the completion of these ordinary loads HERE, before any LDS-DMA is issued: an empty asm that
     // consumes the registers makes hipcc place its s_waitcnt now instead of a vmcnt(0) in front of the
     // first MFMA of every tile (which would drain the stages in flight once per tile).
@@ -206,7 +269,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES);
     uint4 *eq = reinterpret_cast<uint4 *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES + 16);
     const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
-    if (MODE == MF_FILTER && tid == 0) *eq_n = 0;  // visible to everyone after the first unit's barrier
+    if (MODE != MF_PROBE && tid == 0) *eq_n = 0;  // visible to everyone after the first unit's barrier
 
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
@@ -267,6 +330,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     };
 
     uint32_t tile = my_first;
+    uint32_t tiles_done = 0;   // (MF_STREAM: paces the threshold re-reads)
     make_ptrs(tile, rp_cur, np_cur);
     make_ptrs(tile + step, rp_nxt, np_nxt);
     uint32_t slot_c = 0;       // slot computed in the current unit
@@ -279,6 +343,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         else issue(rp_nxt, np_nxt, u - KCH, u, u == KCH, 1);
     }
 
+    // MF_STREAM: this wave's threshold mailbox behind the queue, a key per lane (the four lanes of a query hold the same)
+    const uint32_t tau_box = mf_lds_offset(lds) + (uint32_t)mf_lds_bytes(MF_NSTAGE) + (uint32_t)wave * 256u + (uint32_t)lane * 4u;
+    if (MODE == MF_STREAM) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(tau_box), "v"(mf_key_of(tau)) : "memory");
     // MF_PROBE: this wave's buffered tile minima, [MF_PM_TILES][16 queries] floats behind the queue
     const uint32_t pm_off = mf_lds_offset(lds) + (uint32_t)mf_lds_bytes(MF_NSTAGE) + (uint32_t)wave * (MF_PM_TILES * 64) + (uint32_t)m16 * 4u;
     uint32_t pm_n = 0, pm_tile0 = 0;
@@ -315,7 +382,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             }
             mf_ring_barrier();
-            if (MODE == MF_FILTER && c == 0) {
+            if (MODE != MF_PROBE && c == 0) {
                 // every wave has finished the previous tile's epilogue: the queue length is final and uniform
                 if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
             }
@@ -367,7 +434,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         bool emitted = false;
         float tmin = INFINITY;
         bool skip = false;
-        if (PRESCREEN && MODE == MF_FILTER) {
+        if (PRESCREEN && MODE != MF_PROBE) {
             bool any = false;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -393,6 +460,10 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 const float dot = acc[mt][i];
                 const float a = P.is_l2 ? (ssum - 2.0f * dot) : (1.0f - dot);
                 const float E = P.cE * ssum + P.absE;
+                if (MODE == MF_STREAM) {
+                    const float up = a + E;
+                    if (row < P.n_rows && up < tmin) tmin = up;
+                }
                 if (MODE == MF_PROBE) {
                     const float up = a + E;
                     if (row < P.n_rows && up < tmin) tmin = up;
@@ -419,6 +490,25 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
             if (pm_n == 0) pm_tile0 = tile;
             if (++pm_n == (uint32_t)MF_PM_TILES) flush_probe_minima();
         } else {
+            if (MODE == MF_STREAM) {
+                // this tile's minimum upper bound per query (lanes m16, m16+16, m16+32, m16+48 hold the four row quads)
+                tmin = fminf(tmin, __shfl_xor(tmin, 16));
+                tmin = fminf(tmin, __shfl_xor(tmin, 32));
+                const uint32_t tt = tile - P.tile_first;
+                const bool probed = (tt & ((1u << P.probe_shift) - 1u)) == 0 && (tt >> P.probe_shift) < P.probe_tiles;   // (wave-uniform)
+                // (the insertion waits for its own loads and atomics -- nothing of it is in flight afterwards)
+                {   // the mailbox: the threshold's key as of the last re-read
+                    uint32_t kraw;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kraw) : "v"(tau_box) : "memory");
+                    tau = fminf(tau, mf_float_of(kraw));
+                }
+                uint32_t seen = 0xFFFFFFFFu;
+                if (kq == 0 && !probed && tmin < tau && P.k != 0xFFFFFFFFu) seen = mf_stream_insert(P.klist, P.klist_stride, P.k, qidx, tmin);
+                if (__any(seen != 0xFFFFFFFFu)) {   // the four lanes of a query share what the insertion saw of its threshold
+                    const uint32_t s0 = (uint32_t)__shfl((int)seen, m16);
+                    if (s0 != 0xFFFFFFFFu) tau = fminf(tau, mf_float_of(s0));
+                }
+            }
             if (__any(emitted)) {
                 // stores/atomics share the VM counter with the staged loads: drain once so the counted
                 // waits of the next tile see only loads
@@ -432,12 +522,23 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
         for (int i = 0; i < 4; i++) rp_cur[i] = rp_nxt[i];
         np_cur = np_nxt;
         make_ptrs(tile + 2 * step, rp_nxt, np_nxt);
+        // MF_STREAM: the threshold as it stands now (an L2 hit issued beside the slab-pointer loads; used in the next tile's epilogue)
+        // -- every (refresh_mask + 1)-th tile only: a device-scope load is served behind the XCD's own L2 (sc1), and 4096 waves asking
+        // for 16 thresholds each every tile were 1.2 TB/s of requests beside the table's stream (the scan 11 % slower: r06_stream_ab.txt)
+        if (MODE == MF_STREAM && P.k != 0xFFFFFFFFu && ((++tiles_done & P.refresh_mask) == 0 || tiles_done <= P.refresh_early)) {
+            // -- and through the LDS DMA, into this wave's mailbox (lane-linear: lane l's dword): no register waits for it, so no
+            // s_waitcnt vmcnt(0) of the compiler's drains the ring for it (a plain load here stalled the workgroup a round trip per
+            // re-read); it is one more load in flight, which makes the counted waits stricter, never laxer, and it has landed at the
+            // latest when the next tile's slab pointers have
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.klist + (size_t)qidx * P.klist_stride + (P.k - 1)),
+                                             (__attribute__((address_space(3))) void *)(lds + mf_lds_bytes(MF_NSTAGE) + wave * 256), 4, 0, 16 /* sc1 */);
+        }
         parity ^= 1u;
     }
     if (MODE == MF_PROBE && pm_n) flush_probe_minima();
     // drain the stages still in flight before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (MODE == MF_FILTER) {
+    if (MODE != MF_PROBE) {
         __builtin_amdgcn_s_barrier();
         mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
     }

@@ -168,7 +168,7 @@ extern "C" void vsgpu_ctx_destroy(vsgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->qblock}) {
+    for (DevBuf *b : {&c->qperm, &c->qnorm, &c->dense, &c->tau, &c->counts, &c->cand, &c->ids, &c->qfrag, &c->qfrag2, &c->qn2, &c->sel, &c->selcnt, &c->qmeta, &c->klist, &c->qblock}) {
         if (b->p && !b->alias) (void)hipFree(b->p);
         if (b->own_p && (b->alias || b->own_p != b->p)) (void)hipFree(b->own_p);
     }
@@ -213,6 +213,15 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "lowp_qsplit") c->opt_lowp_qsplit = value;
     else if (n == "lowp_narrow") c->opt_lowp_narrow = value;
     else if (n == "chain_early") c->opt_chain_early = value;
+    else if (n == "stream_tau") c->opt_stream_tau = value;
+    else if (n == "stream_probe_tiles") c->opt_stream_probe_tiles = std::max(16L, value);
+    else if (n == "stream_stride") c->opt_stream_stride = std::min(std::max(value, (long)MF_KLIST), 65536L);
+    else if (n == "stream_early") c->opt_stream_early = std::max(0L, value);
+    else if (n == "stream_refresh") {   // tiles between two re-reads of a query's threshold, rounded down to a power of two
+        long r = 1;
+        while (r * 2 <= std::min(std::max(value, 1L), 1024L)) r *= 2;
+        c->opt_stream_refresh = r;
+    }
     else if (n == "upload_kernel") c->opt_upload_kernel = value;
     else if (n == "sel_mapped") c->opt_sel_mapped = value;
     else if (n == "events") c->opt_events = value & 3;
@@ -1621,7 +1630,14 @@ int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap) {
     HIPCHK(hipGetLastError());
     return VSGPU_OK;
 }
-int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M) {
+int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M, bool seed_list) {
+    if (seed_list) {   // the streaming filter's lists (M <= 2048 there: the sorting kernel)
+        hipLaunchKernelGGL(k_probe_threshold, dim3((unsigned)nq), dim3(1024), M * sizeof(float), c->stream,
+                           (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p,
+                           (uint32_t *)c->klist.p, (uint32_t)c->opt_stream_stride);
+        HIPCHK(hipGetLastError());
+        return VSGPU_OK;
+    }
     if (M > 2048)
         hipLaunchKernelGGL(k_probe_threshold_wide, dim3((unsigned)nq), dim3(1024), 0, c->stream,
                            (const float *)c->dense.p, (size_t)probe_tiles, probe_tiles, (uint32_t)k, M, (float *)c->tau.p);

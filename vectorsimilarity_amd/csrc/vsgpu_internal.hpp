@@ -46,7 +46,7 @@ struct vsgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
-    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qfrag2, qn2, sel, selcnt, qmeta;
+    DevBuf qperm, qnorm, dense, tau, counts, cand, ids, qfrag, qfrag2, qn2, sel, selcnt, qmeta, klist;
     // one upload per batch: {query fragments, |q|^2, thresholds, zeroed counters} are regions of qblock, staged in pin_up
     DevBuf qblock;
     void *pin_up = nullptr;
@@ -72,6 +72,13 @@ struct vsgpu_ctx {
     long opt_upload_kernel = 1;
     // 1 = the select kernel writes the batch's records straight into the pinned (device-visible) reply block: no download operation
     long opt_sel_mapped = 1;
+    // (round 6) the streaming threshold of the fp32 / fp64 filter (mfma_kernels.hpp MF_STREAM): a probe of opt_stream_probe_tiles tiles
+    // instead of n / div rows, the filter tightens tau while it streams.  0 = the full probe + fixed thresholds
+    long opt_stream_tau = 0;
+    long opt_stream_stride = 128;  // words between two queries' lists
+    long opt_stream_probe_tiles = 512;
+    long opt_stream_early = 0;     // ... and after each of a workgroup's first this many tiles (the threshold falls fastest at the start)
+    long opt_stream_refresh = 8;   // the filter re-reads a query's threshold every this many tiles (a device-scope load each: behind the XCD's L2)
     long opt_chain_early = 1;  // reader lanes: the next lane's probe may follow this lane's SCAN (1; its scan still waits for the select kernel) or only the select kernel (0)
     long opt_lowp_narrow = 1;  // batches of <= 64 queries on 4-wave workgroups (SQ8, bf16 / fp16 up to 768 elements)
     long opt_lowp_qsplit = 0;  // int8: 1 = two 128-query workgroups per row tile instead of one 256-query one
@@ -290,7 +297,7 @@ size_t candidate_capacity(const vsgpu_ctx *c, size_t k, size_t n, size_t probe_r
 // stage 2 of the filter paths: reference-order exact re-score of the candidate lists in ctx->cand (in place)
 int launch_exact_pairs(vsgpu_table *t, size_t nq, size_t ccap);
 // threshold of every query from the probe's per-tile minima (ctx->dense -> ctx->tau)
-int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M);
+int launch_probe_threshold(vsgpu_ctx *c, size_t nq, uint32_t probe_tiles, size_t k, uint32_t M, bool seed_list = false);
 int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,
               double *scores, uint32_t *counts);
 int topk_lowp(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, size_t k, size_t cap, uint32_t *ids,

@@ -102,6 +102,22 @@ static int launch_mfma_variant(int variant, MfmaParams Q, size_t n, uint32_t wgs
 #else
 static int launch_mfma_variant(int, MfmaParams, size_t, uint32_t, unsigned, hipStream_t) { return 0; }
 #endif
+// the streaming-threshold filter (MF_STREAM): the 16-row x 1-KiB shapes only
+template <int KS, int EB = 4> static void launch_stream_ks(MfmaParams Q, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    Q.n_tiles = (uint32_t)((n + 15) / 16);
+    hipLaunchKernelGGL((k_mfma_filter<KS, MF_STREAM, 3, 2, 1, 16, 0, EB>), dim3(std::min(Q.n_tiles, wgs), q_tiles), dim3(256), mf_lds_bytes(3) + 1024 /* the waves' threshold mailboxes */, s, Q);
+}
+static bool stream_shape(int ksteps) { return ksteps == 16 || ksteps == 24 || ksteps == 32 || ksteps == 48 || ksteps == 64 || ksteps == 96; }
+static void launch_stream(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
+    switch (ksteps) {
+    case 16: launch_stream_ks<16>(P, n, wgs, q_tiles, s); break;
+    case 24: launch_stream_ks<24>(P, n, wgs, q_tiles, s); break;
+    case 32: launch_stream_ks<32>(P, n, wgs, q_tiles, s); break;
+    case 48: launch_stream_ks<48>(P, n, wgs, q_tiles, s); break;
+    case 64: launch_stream_ks<64>(P, n, wgs, q_tiles, s); break;
+    default: launch_stream_ks<96>(P, n, wgs, q_tiles, s); break;
+    }
+}
 static void launch_filter(int ksteps, const MfmaParams &P, size_t n, uint32_t wgs, unsigned q_tiles, hipStream_t s) {
     switch (ksteps) {
     case 4: launch_filter_ks<4>(P, n, wgs, q_tiles, s); break;
@@ -263,7 +279,18 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const uint32_t total_tiles = (uint32_t)((n + TILE_ROWS - 1) / TILE_ROWS);
     uint32_t probe_tiles = std::max<uint32_t>(total_tiles / probe_divisor(c, n, nq, k, true), (uint32_t)(4 * k * MF_TILE_ROWS / TILE_ROWS));   // (at least 256 k rows)
     probe_tiles = std::min<uint32_t>(std::min<uint32_t>(probe_tiles, total_tiles), (uint32_t)(c->opt_probe_cap * (long)(MF_TILE_ROWS / TILE_ROWS)));   // (the cap counts 64-row tiles)
-    const size_t ccap = candidate_capacity(c, k, n, (size_t)probe_tiles * TILE_ROWS);
+    // (round 6) streaming threshold: a SMALL probe seeds tau and the per-query lists, the filter tightens them while it streams
+    // (mfma_kernels.hpp MF_STREAM).  fp32 rows on the 16-row shapes, first passes only (a retry pass brings its thresholds), k <= MF_KLIST
+    const bool stream_kernel_only = c->opt_stream_tau == 4 && !wide && rt16 && t->type == VSGPU_F32 && stream_shape(KS);
+    const bool stream = c->opt_stream_tau != 0 && c->opt_stream_tau != 4 && !wide && rt16 && t->type == VSGPU_F32 && stream_shape(KS) && c->tau_override == nullptr && k <= (size_t)MF_KLIST &&
+                        (size_t)c->opt_stream_probe_tiles * 4 < probe_tiles;
+    const uint32_t full_probe_tiles = probe_tiles;
+    if (stream) probe_tiles = std::max<uint32_t>((uint32_t)c->opt_stream_probe_tiles, (uint32_t)(4 * k * MF_TILE_ROWS / TILE_ROWS));
+    // room per query: the streaming filter lets through ~2.3 k ln(n / probe rows) rows (the harmonic sum of a tightening k-th) -- 6 x that
+    // -- and never less than the full probe's pass is given (clustered rows: many lower bounds within E of the k-th score)
+    const size_t ccap = stream ? std::max<size_t>(candidate_capacity(c, k, n, (size_t)full_probe_tiles * TILE_ROWS),
+                                                  (size_t)(14.0 * (double)k * std::log((double)n / ((double)probe_tiles * TILE_ROWS)) + 256.0))
+                               : candidate_capacity(c, k, n, (size_t)probe_tiles * TILE_ROWS);
     rc = ensure(c, c->cand, nqp * ccap * sizeof(uint2));
     if (rc) return rc;
     const bool have_tau = c->tau_override != nullptr;   // (retry pass: thresholds from the first pass's exact scores, no probe)
@@ -283,7 +310,11 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     const float cE = (float)(((cq + 2.0 * gref) * 1.001 + 16.0 * u) * (1.0 + 1e-6));
     const float absE = l2 ? 1e-30f : 1e-6f;
 
-    const uint32_t tile_step = total_tiles / probe_tiles;
+    uint32_t tile_step = total_tiles / probe_tiles, stream_shift = 0;
+    if (stream) {   // a power-of-two stride: the filter tells the probe's tiles by a mask (the sample then spans more than half the table)
+        while ((2u << stream_shift) <= tile_step) stream_shift++;
+        tile_step = 1u << stream_shift;
+    }
     uint32_t M = 64;  // group minima sorted per query (more probe tiles than that are grouped, see topk_lowp)
     while (M < probe_tiles && M < 8192 && M < 64 * k) M <<= 1;   // (64 k groups: two of the k best rows rarely share one)
 
@@ -291,6 +322,10 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     rc = ensure(c, c->dense, std::max(nqp * (size_t)probe_tiles * 4, f64 ? nqp * ccap * 8 : (size_t)0));
     if (rc) return rc;
 
+    if (stream) {
+        rc = ensure(c, c->klist, nqp * (size_t)c->opt_stream_stride * sizeof(uint32_t));
+        if (rc) return rc;
+    }
     MfmaParams P{};
     P.slabs = t->d_slabs;
     P.norm_slabs = t->d_norm_slabs;
@@ -318,7 +353,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         MfmaParams Q = P;
         Q.tile_first = 0;
         Q.tile_step = tile_step;
-        Q.tile_run_shift = probe_run_shift(c, TILE_ROWS * t->row_bytes, probe_tiles);
+        Q.tile_run_shift = stream ? 0u : probe_run_shift(c, TILE_ROWS * t->row_bytes, probe_tiles);   // (MF_STREAM tells the probe's tiles by their stride)
         Q.n_tiles = probe_tiles;
         Q.tilemin = (float *)c->dense.p;
         Q.tilemin_stride = probe_tiles;
@@ -326,7 +361,7 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
         else if (f64) launch_probe_f64(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream, rt16);
         else launch_probe(KS, Q, dim3(std::min(probe_tiles, wg_cap), (unsigned)q_tiles), c->stream, rt16);
         HIPCHK(hipGetLastError());
-        rc = launch_probe_threshold(c, nq, probe_tiles, k, M);
+        rc = launch_probe_threshold(c, nq, probe_tiles, k, M, stream);
         if (rc) return rc;
     }
     VSG_POLL_POINT(c);
@@ -348,6 +383,17 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             uint32_t gx = std::max<uint32_t>(8, std::min<uint32_t>(total_tiles, (uint32_t)c->n_cu * per_cu / (uint32_t)std::min<size_t>(q_tiles, 4)) / 8 * 8);
             if (c->opt_wide_gx > 0) gx = (uint32_t)c->opt_wide_gx;   // (diagnosis: option wide_gx)
             launch_wide<MF_FILTER>(KS, wide_blocks, Q, dim3(std::min(total_tiles, gx), (unsigned)q_tiles), c->stream);
+        } else if (stream || stream_kernel_only) {
+            // (measurement: 2 = no insertions, tau stays the small probe's; 4 = the full probe's thresholds, this kernel without
+            // insertions and re-reads -- what its epilogue alone costs)
+            Q.klist = (uint32_t *)c->klist.p;
+            Q.klist_stride = (uint32_t)c->opt_stream_stride;
+            Q.k = (c->opt_stream_tau == 2 || stream_kernel_only) ? 0xFFFFFFFFu : (uint32_t)k;
+            Q.probe_shift = stream_shift;
+            Q.refresh_early = (uint32_t)std::max<long>(c->opt_stream_early, 0);
+            Q.refresh_mask = (uint32_t)std::max<long>(c->opt_stream_refresh, 1) - 1;   // (a power of two)
+            Q.probe_tiles = stream ? probe_tiles : 0;
+            launch_stream(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         } else if (f64) launch_filter_f64(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
         else if (!(KS == 24 && launch_mfma_variant((int)c->opt_mfma_variant, Q, n, wgs, (unsigned)q_tiles, c->stream)))
             launch_filter(KS, Q, n, wgs, (unsigned)q_tiles, c->stream);
