@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 6: the probe divisor (rows / probe rows) once more, after the chain changes: config 2, its 1.25 M-row shard, config 4
+cd ${GRAFT_REPO_ROOT:-.}
+line() { python -c 'import json,sys
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); print("%8.4f ms/step  kernel %.4f  fixed %.4f  cand/q %.0f fallbacks %d retries %d" % (d["ms_per_step"], d["roofline"]["avg_kernel_ms"], d["fixed_ms_per_batch"], d["candidates_per_query"], d["fallbacks"], d["retries"]))'; }
+run() { echo "== $*"; timeout 200 python bench.py --no-cpu-baseline --no-shard-curve --no-full-parity "$@" 2>&1 | line; }
+for pd in 0 32 64 96 128 192; do run --config c2 --steps 40 --warmup 5 --opt probe_div=$pd; done
+for pd in 0 12 24 32 48 64; do run --config c2 --rows 1250000 --steps 100 --warmup 10 --opt probe_div=$pd; done
+for pd in 0 32 64 96 128; do run --config c4 --steps 30 --warmup 10 --opt probe_div=$pd; done
+# the streaming threshold's re-reads under other cache policies (stream_aux: 16 = sc1, 2 = nt, 18 = sc1 nt)
+for cfg in "16 8" "2 1" "2 2" "2 8" "18 1" "18 8"; do set -- $cfg
+  o="--opt stream_tau=1 --opt stream_aux=$1 --opt stream_refresh=$2"
+  run --config c2 --steps 40 --warmup 5 $o
+  run --config c2 --rows 1250000 --steps 100 --warmup 10 $o
+done
