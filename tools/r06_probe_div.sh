@@ -9,9 +9,3 @@ run() { echo "== $*"; timeout 200 python bench.py --no-cpu-baseline --no-shard-c
 for pd in 0 32 64 96 128 192; do run --config c2 --steps 40 --warmup 5 --opt probe_div=$pd; done
 for pd in 0 12 24 32 48 64; do run --config c2 --rows 1250000 --steps 100 --warmup 10 --opt probe_div=$pd; done
 for pd in 0 32 64 96 128; do run --config c4 --steps 30 --warmup 10 --opt probe_div=$pd; done
-# the streaming threshold's re-reads under other cache policies (stream_aux: 16 = sc1, 2 = nt, 18 = sc1 nt)
-for cfg in "16 8" "2 1" "2 2" "2 8" "18 1" "18 8"; do set -- $cfg
-  o="--opt stream_tau=1 --opt stream_aux=$1 --opt stream_refresh=$2"
-  run --config c2 --steps 40 --warmup 5 $o
-  run --config c2 --rows 1250000 --steps 100 --warmup 10 $o
-done

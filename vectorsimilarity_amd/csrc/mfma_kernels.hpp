@@ -133,7 +133,6 @@ struct MfmaParams {
     uint32_t *klist;
     uint32_t klist_stride;   // words between two queries' lists (>= MF_KLIST)
     uint32_t k;
-    uint32_t refresh_aux;
     uint32_t refresh_mask, refresh_early;   // re-read tau_q every (mask + 1)-th tile, and after each of a workgroup's first `early` tiles
     uint32_t probe_shift, probe_tiles;   // tiles t = j << probe_shift, j < probe_tiles, were the probe's: their minima are in the list already
 };
@@ -531,13 +530,10 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
             // s_waitcnt vmcnt(0) of the compiler's drains the ring for it (a plain load here stalled the workgroup a round trip per
             // re-read); it is one more load in flight, which makes the counted waits stricter, never laxer, and it has landed at the
             // latest when the next tile's slab pointers have
-            const auto *src = (const __attribute__((address_space(1))) void *)(P.klist + (size_t)qidx * P.klist_stride + (P.k - 1));
-            auto *box = (__attribute__((address_space(3))) void *)(lds + mf_lds_bytes(MF_NSTAGE) + wave * 256);
-            // (refresh_aux, measurement: 2 = nt -- past the L1, served by this XCD's L2, which may hold the line as it was before another
-            // XCD's atomics: a stale threshold is a looser, still valid one)
-            if (P.refresh_aux == 2) __builtin_amdgcn_global_load_lds(src, box, 4, 0, 2 /* nt */);
-            else if (P.refresh_aux == 18) __builtin_amdgcn_global_load_lds(src, box, 4, 0, 18 /* sc1 nt */);
-            else __builtin_amdgcn_global_load_lds(src, box, 4, 0, 16 /* sc1 */);
+            // (sc1: past the L1, served by the L2 while the line is there; `nt` / `sc1 nt` re-reads were measured 0.7-2.1 ms SLOWER per
+            // 10 M rows -- the hint lets the line go, every re-read then comes from memory: r06_stream_ab.txt)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.klist + (size_t)qidx * P.klist_stride + (P.k - 1)),
+                                             (__attribute__((address_space(3))) void *)(lds + mf_lds_bytes(MF_NSTAGE) + wave * 256), 4, 0, 16 /* sc1 */);
         }
         parity ^= 1u;
     }

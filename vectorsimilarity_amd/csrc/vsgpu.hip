@@ -216,7 +216,6 @@ extern "C" int vsgpu_set_option(vsgpu_ctx *c, const char *name, long value) {
     else if (n == "stream_tau") c->opt_stream_tau = value;
     else if (n == "stream_probe_tiles") c->opt_stream_probe_tiles = std::max(16L, value);
     else if (n == "stream_stride") c->opt_stream_stride = std::min(std::max(value, (long)MF_KLIST), 65536L);
-    else if (n == "stream_aux") c->opt_stream_aux = value;
     else if (n == "stream_early") c->opt_stream_early = std::max(0L, value);
     else if (n == "stream_refresh") {   // tiles between two re-reads of a query's threshold, rounded down to a power of two
         long r = 1;

@@ -75,7 +75,6 @@ struct vsgpu_ctx {
     // (round 6) the streaming threshold of the fp32 / fp64 filter (mfma_kernels.hpp MF_STREAM): a probe of opt_stream_probe_tiles tiles
     // instead of n / div rows, the filter tightens tau while it streams.  0 = the full probe + fixed thresholds
     long opt_stream_tau = 0;
-    long opt_stream_aux = 16;      // cache policy of the threshold re-reads (16 = sc1; 2 = nt, 18 = sc1 nt: measurement)
     long opt_stream_stride = 128;  // words between two queries' lists
     long opt_stream_probe_tiles = 512;
     long opt_stream_early = 0;     // ... and after each of a workgroup's first this many tiles (the threshold falls fastest at the start)

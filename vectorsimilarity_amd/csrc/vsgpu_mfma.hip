@@ -390,7 +390,6 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
             Q.klist_stride = (uint32_t)c->opt_stream_stride;
             Q.k = (c->opt_stream_tau == 2 || stream_kernel_only) ? 0xFFFFFFFFu : (uint32_t)k;
             Q.probe_shift = stream_shift;
-            Q.refresh_aux = (uint32_t)c->opt_stream_aux;
             Q.refresh_early = (uint32_t)std::max<long>(c->opt_stream_early, 0);
             Q.refresh_mask = (uint32_t)std::max<long>(c->opt_stream_refresh, 1) - 1;   // (a power of two)
             Q.probe_tiles = stream ? probe_tiles : 0;
