@@ -1550,10 +1550,12 @@ def test_streaming_threshold_filter_bit_exact(vso, metric, dim, n, nq, k, order)
     ix.set_option("dense_pairs", 0)
     plain = ix.knn_query(q, k)
     ix.set_option("stream_tau", 1)
+    ix.set_option("stream_probe_tiles", 64)      # (tables this small engage it only with a seed probe this small)
     ix.reset_stats()
     labels, dists = ix.knn_query(q, k)
     st = ix.stats()
-    assert st["scan_kernel"] == "k_mfma_filter", st
+    # (the name is the LAST scan's: far_first overflows the streaming pass and is settled by a retry pass of the plain kernel)
+    assert st["scan_kernel"] == "k_mfma_filter(stream)" or (order == "far_first" and st["retries"] >= 1), st
     assert np.array_equal(labels, plain[0]) and np.array_equal(dists, plain[1])
     for j in range(0, nq, max(1, nq // 6)):
         el, es = oracle_topk(vso, "f32", metric, rows, q[j], k)

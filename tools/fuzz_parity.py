@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--readers", type=int, default=0, help="> 1: every shape is also queried by this many threads at once (reader lanes)")
+ap.add_argument("--stream", action="store_true", help="fp32 rows up to 3072 elements with the opt-in streaming threshold (option stream_tau) at random re-read paces")
 ap.add_argument("--verbose", action="store_true", help="print every shape before it runs (the last line names the shape a crash happened in)")
 ap.add_argument("--wide", action="store_true", help="only the wide-row kernels' shapes: 16-bit rows of 2049 .. 8192 elements, 8-bit rows of 4097 .. 16384, "
                                                      "fp32 3073 .. 8192, batches above and below the 16 / 32 / 64 queries a workgroup holds")
@@ -55,9 +56,14 @@ while time.time() < t_end:
         typ = rng.choice(["f32", "bf16", "f16", "i8", "u8"])
         lo, hi = {"f32": (3073, 8192), "bf16": (2049, 8192), "f16": (2049, 8192), "i8": (4097, 16384), "u8": (4097, 16384)}[typ]
         dim = int(rng.choice([rng.integers(lo, lo + (hi - lo) // 6), rng.integers(lo, hi + 1)]))   # (half of them in the narrowest kernel width)
+    if a.stream:
+        typ = "f32"
+        dim = int(rng.choice([rng.integers(33, 600), rng.integers(600, 3073)]))
     eb = {"f32": 4, "f64": 8, "bf16": 2, "f16": 2, "i8": 1, "u8": 1, "sq8": 1}[typ]
     budget = int(rng.choice([3e7, 1.5e8, 4e8]))                      # bytes of rows: one slab .. several
     n = max(300, min(400_000, budget // (dim * eb)))
+    if a.stream:
+        n = max(20_000, min(1_000_000, int(rng.choice([4e8, 1.2e9, 2.5e9])) // (dim * eb)))
     nq = int(rng.choice([1, 3, 16, 17, 40, 64, 100, 128, 200, 256]))
     if a.wide:
         nq = int(rng.choice([16, 31, 33, 48, 64, 65, 100, 128]))
@@ -75,6 +81,11 @@ while time.time() < t_end:
     if a.verbose:
         print("shape", runs, typ, metric, "dim", dim, "n", n, "nq", nq, "k", k, "scale", scale, flush=True)
     ix.set_option("dense_pairs", 0)
+    if a.stream:
+        ix.set_option("stream_tau", 1)
+        ix.set_option("stream_probe_tiles", int(rng.choice([16, 64, 512])))
+        ix.set_option("stream_refresh", int(rng.choice([1, 2, 8, 32])))
+        ix.set_option("stream_early", int(rng.choice([0, 0, 16])))
     ix.reset_stats()
     l1, d1 = ix.knn_query(q, k)
     kern = ix.stats()["scan_kernel"]

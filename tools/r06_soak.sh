@@ -10,6 +10,7 @@ cd $R
 echo "## fuzz_parity 240 s"; timeout 400 python tools/fuzz_parity.py --seconds 240 --seed 701 2>&1 | tail -3
 echo "## fuzz_parity --readers 2, 240 s"; timeout 400 python tools/fuzz_parity.py --seconds 240 --seed 702 --readers 2 2>&1 | tail -3
 echo "## fuzz_parity --wide --readers 3, 180 s"; timeout 400 python tools/fuzz_parity.py --seconds 180 --seed 703 --wide --readers 3 2>&1 | tail -3
+echo "## fuzz_parity --stream --readers 2, 240 s"; timeout 500 python tools/fuzz_parity.py --seconds 240 --seed 707 --stream --readers 2 2>&1 | tail -3
 echo "## fuzz_sharded 180 s"; timeout 400 python tools/fuzz_sharded.py --seconds 180 --seed 704 2>&1 | tail -3
 echo "## fuzz_hnsw_iter 180 s"; timeout 400 python tools/fuzz_hnsw_iter.py --seconds 180 --seed 705 2>&1 | tail -3
 echo "## fuzz_hnsw_build 300 s"; timeout 500 python tools/fuzz_hnsw_build.py --seconds 300 --seed 706 2>&1 | tail -6

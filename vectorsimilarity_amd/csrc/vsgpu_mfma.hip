@@ -408,5 +408,5 @@ int topk_mfma(vsgpu_table *t, const void *queries, size_t nq, size_t qstride, si
     wm0.flush("mfma_pre");
     rc = launch_exact_pairs(t, nq, ccap);  // exact re-rank of the survivors, in place
     if (rc) return rc;
-    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, wide ? "k_mfma_filter_wide" : "k_mfma_filter", &chain);
+    return collect_candidates(t, queries, nq, qstride, k, cap, ccap, ids, scores, counts, wide ? "k_mfma_filter_wide" : stream ? "k_mfma_filter(stream)" : "k_mfma_filter", &chain);
 }
