@@ -562,6 +562,18 @@ def main():
         import torch  # noqa: F401
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        # self-diagnosis before anything collective touches a GPU: every rank's device must exist (a rank that fails later would
+        # leave the others inside a communicator's rendezvous, which has no timeout)
+        from vectorsimilarity_amd import _capi
+        ndev = _capi.load().VecSimGpu_DeviceCount()
+        flags = [None] * world
+        dist.all_gather_object(flags, None if local_rank < ndev else "rank %d wants GPU %d, %d visible" % (rank, local_rank, ndev))
+        bad = [f for f in flags if f is not None]
+        if bad:
+            if rank == 0:
+                print("bench.py: " + "; ".join(bad) + " -- one process per GPU; on a one-GPU box pass --same-gpu to exercise the N > 1 path", file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(2)
 
     p = VecSim.BFParams()
     p.type, p.dim, p.metric = getattr(VecSim, "VecSimType_" + args.type_name), args.dim, getattr(VecSim, "VecSimMetric_" + args.metric_name)

@@ -144,6 +144,15 @@ def _worker(rank, world, port, out):
         el, es = vso.flat_topk(0, 0, rows, queries[qi], k, dim, labels.astype(np.uint64))
         ok &= np.array_equal(got_l[qi], el.astype(np.int64)) and np.array_equal(got_s[qi], es)
     owned = len(shard.rows)
+    # the RCCL form's pre-flight: no GPU here, so every rank's device is out of range -- ALL ranks must fail, at once and with the
+    # reason, before anyone enters the communicator's rendezvous (one rank failing alone used to leave the others blocked in it)
+    import time
+    t0 = time.time()
+    try:
+        ShardedFlatIndex(p, rank=rank, world=world, dist=dist, device=rank)
+        ok = False
+    except RuntimeError as e:
+        ok &= "out of range" in str(e) and time.time() - t0 < 20
     dist.barrier()
     dist.destroy_process_group()
     out.put((rank, bool(ok), owned))

@@ -100,6 +100,16 @@ class ShardedFlatIndex:
                 self._keep += [ag, bc]
                 self._h = lib.VecSimGpu_ShardedNewWithTransport(C.byref(p), rank, world, device, ag, bc, None)
             else:
+                # Pre-flight, agreed by all ranks BEFORE anyone enters ncclCommInitRank (which blocks until every rank has joined
+                # and has no timeout): a rank whose device is missing must fail everybody at once, not leave the others waiting
+                if world > 1:
+                    ndev = lib.VecSimGpu_DeviceCount()
+                    mine = None if 0 <= device < ndev else "rank %d: device %d out of range (%d visible)" % (rank, device, ndev)
+                    flags = [None] * world
+                    dist.all_gather_object(flags, mine)
+                    bad = [f for f in flags if f is not None]
+                    if bad:
+                        raise RuntimeError("sharded index: " + "; ".join(bad))
                 uid = [None]
                 if rank == 0:
                     buf = (C.c_char * 128)()
