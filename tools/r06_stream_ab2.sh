@@ -9,8 +9,8 @@ for l in sys.stdin:
 run() { echo "== $*"; timeout 150 python bench.py --config c2 --no-cpu-baseline --no-shard-curve "$@" 2>&1 | line; }
 run --steps 40 --warmup 5 --opt stream_tau=0
 run --rows 1250000 --steps 100 --warmup 10 --opt stream_tau=0
-for cfg in "1 128" "1 1088" "1 2112" "1 4160" "2 1088" "4 1088" "8 1088" "8 4160"; do set -- $cfg
-  o="--opt stream_tau=1 --opt stream_refresh=$1 --opt stream_stride=$2"
+for cfg in "8" "4" "16"; do set -- $cfg
+  o="--opt stream_tau=1 --opt stream_refresh=$1"
   run --steps 40 --warmup 5 $o
   run --rows 1250000 --steps 100 --warmup 10 $o
 done
