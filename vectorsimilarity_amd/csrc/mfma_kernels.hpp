@@ -53,6 +53,7 @@ constexpr int MF_NORM_BYTES = 4 * 2 * 256;  // [wave][parity][64 floats]
 // DMA pipeline is counted on); the queue is flushed to global memory when half full and at kernel end.
 constexpr int MF_EQ_CAP = 384;                     // queued {row, query, score bits} records
 constexpr int MF_EQ_BYTES = 16 + MF_EQ_CAP * 16;
+constexpr int MF_WQ_CAP = MF_EQ_CAP / 4;           // k_mfma_filter: a wave's share of the queue (four waves)
 constexpr int mf_lds_bytes(int nstage) { return nstage * MF_STAGE_BYTES + MF_NORM_BYTES + MF_EQ_BYTES; }
 // MF_PROBE: the (tile, query) minima wait in LDS and leave in batches (a global store per tile shares the VM counter with
 // the ring: one full drain per tile; batching them measured neutral, the probe's rate is set by its short per-workgroup
@@ -266,10 +267,22 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     const uint32_t lds_stage_wave_off = (uint32_t)(wave * 4096);
     char *norm_lds = lds + MF_NSTAGE * MF_STAGE_BYTES + (SNORM ? 0 : wave) * 512;
     const bool norm_loader = !SNORM || wave == 0;
-    uint32_t *eq_n = reinterpret_cast<uint32_t *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES);
-    uint4 *eq = reinterpret_cast<uint4 *>(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES + 16);
-    const uint32_t eq_n_off = mf_lds_offset(eq_n), eq_off = mf_lds_offset(eq);
-    if (MODE != MF_PROBE && tid == 0) *eq_n = 0;  // visible to everyone after the first unit's barrier
+    // survivors wait in a queue of this WAVE's own (MF_WQ_CAP records of the workgroup's MF_EQ_CAP) and leave in batches, wave by wave:
+    // its fill count is a register, nobody else touches it, so neither emission nor flush meets a barrier or a returning LDS atomic
+    const uint32_t wq_off = mf_lds_offset(lds + MF_NSTAGE * MF_STAGE_BYTES + MF_NORM_BYTES + 16) + (uint32_t)wave * (uint32_t)(MF_WQ_CAP * 16);
+    uint32_t wq_n = 0;
+    auto flush_wave_queue = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the queued records have landed
+        const uint32_t n = min(wq_n, (uint32_t)MF_WQ_CAP);
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+            mf_u32x4 r;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(wq_off + i * 16) : "memory");
+            const uint32_t s = atomicAdd(&P.counts[r.y], 1u);
+            if (s < P.cap) P.cand[(size_t)r.y * P.cap + s] = make_uint2(r.x, r.z);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (stores / atomics share the VM counter with the staged loads)
+        wq_n = 0;
+    };
 
     const uint32_t my_first = blockIdx.x;
     const uint32_t step = gridDim.x;
@@ -382,10 +395,6 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             }
             mf_ring_barrier();
-            if (MODE != MF_PROBE && c == 0) {
-                // every wave has finished the previous tile's epilogue: the queue length is final and uniform
-                if (*eq_n >= MF_EQ_CAP / 2) mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
-            }
             // refill the slot read in the previous unit with unit +(NS-1)
             {
                 constexpr int D = NS - 1;
@@ -469,15 +478,23 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                     if (row < P.n_rows && up < tmin) tmin = up;
                 } else {
                     const float low = a - E;
-                    if (row < P.n_rows && !(low > tau)) {  // NaN bounds (NaN/Inf in the data) go on to the exact re-rank
-                        const uint32_t pos = mf_queue_reserve(eq_n_off);
-                        if (pos < MF_EQ_CAP) {
-                            mf_queue_write(eq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));
-                        } else {  // queue full (dense survivors): straight to global memory
-                            uint32_t s = atomicAdd(&P.counts[qidx], 1u);
-                            if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
-                            emitted = true;
+                    const bool pass = row < P.n_rows && !(low > tau);  // NaN bounds (NaN/Inf in the data) go on to the exact re-rank
+                    // the wave's own queue: a slot is this lane's rank among the passing lanes behind the wave's count -- a ballot and a
+                    // fire-and-forget LDS write, no returning LDS atomic to wait for (round 6: the shared queue's ds_add_rtn + wait cost
+                    // a workgroup 0.3-0.6 us per survivor, profiles/r06_wave_queue.txt)
+                    const uint64_t pm = __ballot(pass);
+                    if (pm) {
+                        const uint32_t pos = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                        if (pass) {
+                            if (pos < (uint32_t)MF_WQ_CAP) {
+                                mf_queue_write(wq_off + pos * 16, row, (uint32_t)qidx, __float_as_uint(low));
+                            } else {  // queue full (dense survivors): straight to global memory
+                                uint32_t s = atomicAdd(&P.counts[qidx], 1u);
+                                if (s < P.cap) P.cand[(size_t)qidx * P.cap + s] = make_uint2(row, __float_as_uint(low));
+                                emitted = true;
+                            }
                         }
+                        wq_n += (uint32_t)__popcll(pm);
                     }
                 }
             }
@@ -514,6 +531,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
                 // waits of the next tile see only loads
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (wq_n >= (uint32_t)MF_WQ_CAP / 2) flush_wave_queue();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // queue writes land before the next barrier
         }
 
@@ -540,10 +558,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_filter(MfmaParams P) {
     if (MODE == MF_PROBE && pm_n) flush_probe_minima();
     // drain the stages still in flight before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (MODE != MF_PROBE) {
-        __builtin_amdgcn_s_barrier();
-        mf_flush_queue<256>(eq_n, eq, P.counts, P.cand, P.cap);
-    }
+    if (MODE != MF_PROBE) flush_wave_queue();
 }
 
 // |x|^2 per row in double, rounded once to float (relative error <= 2^-24): feeds the bound E
